@@ -1,0 +1,156 @@
+/*
+ * resr.h -- C-ABI of libresr_hip.so: the MI355X (gfx950) Real-ESRGAN hot path.
+ *
+ * The reference (Lornatang/Real_ESRGAN-PyTorch) has no FFI: its device arithmetic is stock
+ * PyTorch op call sites.  Each entry point below names the reference call site(s) it replaces
+ * (file:line relative to the reference root).  All pointers are raw device pointers owned by the
+ * caller (PyTorch's caching allocator); the library never allocates, frees or retains device
+ * memory, never synchronises the stream, and is graph-capture safe.  Every call enqueues on the
+ * given hipStream_t (passed as void*) of the current device and returns 0 or a negative
+ * resr_status; resr_last_error() returns a thread-local message.  No C++ exception crosses.
+ *
+ * Layouts.  Activations: NHWC ("pixel-major"), element type f16 (fast mode) or f32 (strict mode),
+ * channels padded to a multiple of 32, addressed as base + pixel * pixel_stride + channel; a conv
+ * reads a channel *prefix* of one or two such tensors, which is how the dense-block concat of
+ * model.py:91-94 is served without materialising it.  Weights: packed MFMA A-fragments made by
+ * resr_pack_weights from the module's OIHW fp32 parameters.
+ */
+#ifndef RESR_H_
+#define RESR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RESR_VERSION 1
+
+typedef enum {
+    RESR_OK = 0,
+    RESR_ERR_ARG = -1,      /* bad descriptor / unsupported shape */
+    RESR_ERR_LAUNCH = -2,   /* hipLaunchKernel failed */
+    RESR_ERR_WORKSPACE = -3 /* workspace too small */
+} resr_status;
+
+typedef enum { RESR_F16 = 0, RESR_F32 = 1 } resr_dtype;
+
+/* epilogue / gather flags of resr_conv3x3 */
+enum {
+    RESR_CONV_LRELU = 1 << 0,        /* v = v > 0 ? v : slope*v              (model.py:81,90-93,237,242,248) */
+    RESR_CONV_UPSAMPLE_IN = 1 << 1,  /* input is nearest-upsampled x2 on load (model.py:264-265)            */
+    RESR_CONV_CLAMP01 = 1 << 2,      /* v = min(max(v,0),1)                   (model.py:270)                */
+    RESR_CONV_OUT_NCHW_F32 = 1 << 3, /* write planar fp32 [N,cout,H,W] (+ pass-mask bytes to aux)           */
+    RESR_CONV_MASK = 1 << 4,         /* v *= (mask[p,c] > 0 ? 1 : slope): LeakyReLU backward                */
+    RESR_CONV_NO_BIAS = 1 << 5
+};
+
+/* One 3x3, stride 1, pad 1 convolution pass (forward conv or backward-data conv):
+ *   v = sum_{tap,c} W[co][c][tap] * in[p + tap][c] + bias[co]
+ *   v = mask / lrelu / (v*s0 + t0*res0[p,co]) / (v*s1 + t1*res1[p,co]) / clamp, in that order.
+ * Replaces the F.conv2d + leaky_relu + torch.cat + mul/add call sites of model.py:87-98,
+ * 123-132, 255-272 and their autograd backward-data counterparts. */
+typedef struct {
+    int32_t n, h, w;         /* output batch / height / width (input is h/2 x w/2 when UPSAMPLE_IN) */
+    int32_t cin;             /* input channels, multiple of 32                                        */
+    int32_t cin0;            /* channels [0,cin0) come from in0, [cin0,cin) from in1; multiple of 32  */
+    int32_t in0_stride;      /* pixel strides in elements                                             */
+    int32_t in1_stride;
+    int32_t cout;            /* real output channels (<= cout_pad)                                    */
+    int32_t cout_pad;        /* 32 or 64: rows of the packed weight tile                              */
+    int32_t out_stride;      /* NHWC pixel stride of out (ignored for OUT_NCHW_F32)                   */
+    int32_t res0_stride, res1_stride, mask_stride;
+    int32_t dtype;           /* resr_dtype of activations and packed weights                          */
+    int32_t flags;
+    float s0, t0, s1, t1, slope;
+} ResrConvDesc;
+
+int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const void* w_packed,
+                 const float* bias, const void* res0, const void* res1, const void* mask,
+                 void* out, void* aux_out, void* stream);
+
+/* Weight-gradient of the same convolution: dW[co][ci][tap] = sum_p G[p][co] * X[p + tap][ci]
+ * (autograd backward of F.conv2d wrt weight, all conv call sites of model.py) and
+ * db[co] = sum_p G[p][co].  Two launches: partial sums over pixel splits into `partial`
+ * (fp32, resr_wgrad_partial_bytes), then a deterministic reduce that writes dW (OIHW fp32,
+ * scaled by `scale`) and db. */
+typedef struct {
+    int32_t n, h, w;
+    int32_t cin, cin0, in0_stride, in1_stride; /* X operand, same addressing as ResrConvDesc      */
+    int32_t cin_real;                          /* rows of dW actually written (<= cin)            */
+    int32_t cout, cout_pad, g_stride;          /* G operand: channels [0,cout_pad) of g           */
+    int32_t dtype, flags;                      /* RESR_CONV_UPSAMPLE_IN honoured for X            */
+    int32_t splits;                            /* pixel splits (partial slabs)                    */
+    float scale;
+} ResrWgradDesc;
+
+size_t resr_wgrad_partial_bytes(const ResrWgradDesc* d);
+int resr_conv3x3_wgrad(const ResrWgradDesc* d, const void* x0, const void* x1, const void* g,
+                       float* partial, float* dw, float* db, void* stream);
+
+/* Weight packing: a table of chunk descriptors turns the flat fp32 OIHW parameter arena into
+ * MFMA A-fragment order (forward) or its transposed+flipped form (backward-data). */
+typedef struct {
+    int64_t src_off;     /* element offset of the source conv weight in the fp32 arena            */
+    int64_t dst_off;     /* element offset of this chunk in the packed buffer                     */
+    int32_t src_cout, src_cin;
+    int32_t m_off, m_count; /* first row / number of real rows (rest zero) of this chunk's M      */
+    int32_t k_off, k_count; /* first / number of real K channels of this chunk (<= 32)            */
+    int32_t mt;          /* M tiles (1 or 2)                                                      */
+    int32_t transposed;  /* 0: M = cout, K = cin;  1: M = cin, K = cout, taps flipped             */
+    float scale;
+    int32_t pad_;
+} ResrPackChunk;
+
+int resr_pack_weights(const ResrPackChunk* chunks_dev, int32_t n_chunks, const float* arena,
+                      void* packed, int32_t dtype, void* stream);
+
+/* Layout helpers around the generator (model.py:257 PixelUnshuffle, NCHW fp32 module surface). */
+int resr_nchw_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w,
+                      int32_t unshuffle, int32_t c_pad, int32_t dtype, const uint8_t* mask,
+                      void* stream);
+int resr_nhwc_to_nchw(const void* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w,
+                      int32_t shuffle, int32_t src_stride, int32_t dtype, void* stream);
+/* backward of nearest x2 upsample (+ optional LeakyReLU mask of the producer's output) */
+int resr_sumpool2x2(const void* src, void* dst, const void* mask, int32_t n, int32_t h_out,
+                    int32_t w_out, int32_t c, int32_t dtype, float slope, void* stream);
+
+/* Whole-generator passes (model.py:255-272 and its autograd backward), enqueued natively so the
+ * ~350 / ~1100 launches cost no Python time.  See real_esrgan-pytorch_amd/csrc/generator.hip. */
+typedef struct {
+    int32_t n, h, w;          /* input batch / height / width (before pixel-unshuffle)           */
+    int32_t in_channels, out_channels, upscale; /* Generator(in, out, upscale) ctor args          */
+    int32_t n_blocks;         /* RRDB count (23)                                                  */
+    int32_t dtype;            /* RESR_F16 fast / RESR_F32 strict                                  */
+    int32_t training;         /* keep activations for backward                                    */
+    int32_t wgrad_splits;     /* 0 = auto                                                         */
+} ResrGeneratorDesc;
+
+size_t resr_generator_param_count(const ResrGeneratorDesc* d);
+size_t resr_generator_packed_bytes(const ResrGeneratorDesc* d, int32_t backward);
+size_t resr_generator_workspace_bytes(const ResrGeneratorDesc* d);
+/* fills `chunks` (host memory, capacity in elements) and returns the count; forward table first,
+ * then (if backward) the backward-data table; dst offsets are relative to one packed buffer */
+int64_t resr_generator_pack_table(const ResrGeneratorDesc* d, int32_t backward,
+                                  ResrPackChunk* chunks, int64_t capacity);
+int resr_generator_forward(const ResrGeneratorDesc* d, const float* x_nchw, const float* params,
+                           const void* packed, void* workspace, size_t workspace_bytes,
+                           float* y_nchw, void* stream);
+int resr_generator_backward(const ResrGeneratorDesc* d, const float* gy_nchw, const float* params,
+                            const void* packed, void* workspace, size_t workspace_bytes,
+                            float* grad_params, float* gx_nchw, void* stream, void* side_stream);
+
+/* EMA.update (model.py:43-48) over the flat parameter arena, one launch. */
+int resr_ema_update(float* shadow, const float* params, int64_t count, double decay, void* stream);
+
+/* test probe: lane/element map of ds_read_b64_tr_b16 (256 floats out) */
+int resr_debug_tr_probe(float* out256, void* stream);
+
+const char* resr_last_error(void);
+int resr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RESR_H_ */

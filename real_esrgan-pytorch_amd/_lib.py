@@ -1,0 +1,112 @@
+"""ctypes binding of csrc/libresr_hip.so (C-ABI declared in include/resr.h).
+
+The product path has no CPU or PyTorch fallback: if the shared library is missing, `lib()` raises.
+Structures mirror include/resr.h field for field.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libresr_hip.so")
+
+RESR_F16, RESR_F32 = 0, 1
+CONV_LRELU, CONV_UPSAMPLE_IN, CONV_CLAMP01, CONV_OUT_NCHW_F32, CONV_MASK, CONV_NO_BIAS = 1, 2, 4, 8, 16, 32
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("cin", C.c_int32), ("cin0", C.c_int32), ("in0_stride", C.c_int32), ("in1_stride", C.c_int32),
+                ("cout", C.c_int32), ("cout_pad", C.c_int32), ("out_stride", C.c_int32),
+                ("res0_stride", C.c_int32), ("res1_stride", C.c_int32), ("mask_stride", C.c_int32),
+                ("dtype", C.c_int32), ("flags", C.c_int32),
+                ("s0", C.c_float), ("t0", C.c_float), ("s1", C.c_float), ("t1", C.c_float), ("slope", C.c_float)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("cin", C.c_int32), ("cin0", C.c_int32), ("in0_stride", C.c_int32), ("in1_stride", C.c_int32),
+                ("cin_real", C.c_int32), ("cout", C.c_int32), ("cout_pad", C.c_int32), ("g_stride", C.c_int32),
+                ("dtype", C.c_int32), ("flags", C.c_int32), ("splits", C.c_int32), ("scale", C.c_float)]
+
+
+class PackChunk(C.Structure):
+    _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("src_cout", C.c_int32), ("src_cin", C.c_int32),
+                ("m_off", C.c_int32), ("m_count", C.c_int32), ("k_off", C.c_int32), ("k_count", C.c_int32),
+                ("mt", C.c_int32), ("transposed", C.c_int32), ("scale", C.c_float), ("pad_", C.c_int32)]
+
+
+class GeneratorDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("upscale", C.c_int32),
+                ("n_blocks", C.c_int32), ("dtype", C.c_int32), ("training", C.c_int32), ("wgrad_splits", C.c_int32)]
+
+
+_P = C.c_void_p
+_PROTOS = {
+    "resr_version": (C.c_int, []),
+    "resr_last_error": (C.c_char_p, []),
+    "resr_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "resr_wgrad_partial_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
+    "resr_conv3x3_wgrad": (C.c_int, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "resr_pack_weights": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P]),
+    "resr_nchw_to_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, _P, _P]),
+    "resr_nhwc_to_nchw": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, _P]),
+    "resr_sumpool2x2": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P]),
+    "resr_generator_param_count": (C.c_size_t, [C.POINTER(GeneratorDesc)]),
+    "resr_generator_packed_bytes": (C.c_size_t, [C.POINTER(GeneratorDesc), C.c_int32]),
+    "resr_generator_workspace_bytes": (C.c_size_t, [C.POINTER(GeneratorDesc)]),
+    "resr_generator_pack_table": (C.c_int64, [C.POINTER(GeneratorDesc), C.c_int32, _P, C.c_int64]),
+    "resr_generator_forward": (C.c_int, [C.POINTER(GeneratorDesc), _P, _P, _P, _P, C.c_size_t, _P, _P]),
+    "resr_generator_backward": (C.c_int, [C.POINTER(GeneratorDesc), _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
+    "resr_ema_update": (C.c_int, [_P, _P, C.c_int64, C.c_double, _P]),
+    "resr_debug_tr_probe": (C.c_int, [_P, _P]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libresr_hip.so (built by csrc/build.py).  Raises if it is missing -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python real_esrgan-pytorch_amd/csrc/build.py` "
+                "(or __graft_entry__.build()); the MI355X path has no CPU/PyTorch fallback")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def check(rc: int, what: str = "resr") -> None:
+    if rc != 0:
+        msg = lib().resr_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: expected a tensor on the MI355X device, got {t.device}; "
+                           "this package has no CPU path (the CPU oracle lives under oracle/ for tests only)")

@@ -1,0 +1,124 @@
+// api.hip -- the extern "C" boundary of libresr_hip.so (declared in include/resr.h).
+// Plain pointers and sizes only; no torch / ATen types; errors become negative status codes plus a
+// thread-local message.  Every entry point enqueues on the caller's stream and returns.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace resr {
+
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*, const float*, const void*,
+                     const void*, const void*, void*, void*, hipStream_t);
+int wgrad_dispatch(const ResrWgradDesc*, const void*, const void*, const void*, float*, float*, float*, hipStream_t);
+size_t wgrad_partial_bytes(const ResrWgradDesc*);
+int pack_dispatch(const ResrPackChunk*, int, const float*, void*, int, hipStream_t);
+int ema_dispatch(float*, const float*, long, double, hipStream_t);
+int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t);
+int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t);
+int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int, float, hipStream_t);
+size_t generator_param_count(const ResrGeneratorDesc*);
+size_t generator_packed_bytes(const ResrGeneratorDesc*, int);
+size_t generator_workspace_bytes(const ResrGeneratorDesc*);
+int64_t generator_pack_table(const ResrGeneratorDesc*, int, ResrPackChunk*, int64_t);
+int generator_forward(const ResrGeneratorDesc*, const float*, const float*, const void*, void*, size_t, float*, hipStream_t);
+int generator_backward(const ResrGeneratorDesc*, const float*, const float*, const void*, void*, size_t, float*, float*,
+                       hipStream_t, hipStream_t);
+
+// probe used by tests: what does ds_read_b64_tr_b16 hand to (lane, element)?  LDS holds the element
+// index at every position; lane l supplies byte address l*8.
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_t;
+__global__ void tr_probe_kernel(float* out) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[256];
+    const int l = threadIdx.x;
+    for (int i = l; i < 256; i += 64) lds[i] = (_Float16)i;
+    __syncthreads();
+    auto p = reinterpret_cast<__attribute__((address_space(3))) fp16x4_t*>(
+        (__attribute__((address_space(3))) _Float16*)(lds + l * 4));
+    const fp16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4f16(p);
+    for (int j = 0; j < 4; ++j) out[l * 4 + j] = (float)r[j];
+}
+
+}  // namespace resr
+
+using namespace resr;
+
+extern "C" {
+
+int resr_version(void) { return RESR_VERSION; }
+const char* resr_last_error(void) { return err_buf(); }
+
+int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const void* w_packed, const float* bias,
+                 const void* res0, const void* res1, const void* mask, void* out, void* aux_out, void* stream) {
+    return conv3x3_dispatch(d, in0, in1, w_packed, bias, res0, res1, mask, out, aux_out, (hipStream_t)stream);
+}
+
+size_t resr_wgrad_partial_bytes(const ResrWgradDesc* d) { return d ? wgrad_partial_bytes(d) : 0; }
+
+int resr_conv3x3_wgrad(const ResrWgradDesc* d, const void* x0, const void* x1, const void* g, float* partial,
+                       float* dw, float* db, void* stream) {
+    return wgrad_dispatch(d, x0, x1, g, partial, dw, db, (hipStream_t)stream);
+}
+
+int resr_pack_weights(const ResrPackChunk* chunks_dev, int32_t n_chunks, const float* arena, void* packed,
+                      int32_t dtype, void* stream) {
+    return pack_dispatch(chunks_dev, n_chunks, arena, packed, dtype, (hipStream_t)stream);
+}
+
+int resr_nchw_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t unshuffle,
+                      int32_t c_pad, int32_t dtype, const uint8_t* mask, void* stream) {
+    return nchw_to_nhwc_dispatch(src, dst, n, c, h, w, unshuffle, c_pad, dtype, mask, (hipStream_t)stream);
+}
+
+int resr_nhwc_to_nchw(const void* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t shuffle,
+                      int32_t src_stride, int32_t dtype, void* stream) {
+    return nhwc_to_nchw_dispatch(src, dst, n, c, h, w, shuffle, src_stride, dtype, (hipStream_t)stream);
+}
+
+int resr_sumpool2x2(const void* src, void* dst, const void* mask, int32_t n, int32_t h_out, int32_t w_out, int32_t c,
+                    int32_t dtype, float slope, void* stream) {
+    return sumpool2x2_dispatch(src, dst, mask, n, h_out, w_out, c, dtype, slope, (hipStream_t)stream);
+}
+
+size_t resr_generator_param_count(const ResrGeneratorDesc* d) { return generator_param_count(d); }
+size_t resr_generator_packed_bytes(const ResrGeneratorDesc* d, int32_t backward) { return generator_packed_bytes(d, backward); }
+size_t resr_generator_workspace_bytes(const ResrGeneratorDesc* d) { return generator_workspace_bytes(d); }
+int64_t resr_generator_pack_table(const ResrGeneratorDesc* d, int32_t backward, ResrPackChunk* chunks, int64_t capacity) {
+    return generator_pack_table(d, backward, chunks, capacity);
+}
+
+int resr_generator_forward(const ResrGeneratorDesc* d, const float* x_nchw, const float* params, const void* packed,
+                           void* workspace, size_t workspace_bytes, float* y_nchw, void* stream) {
+    return generator_forward(d, x_nchw, params, packed, workspace, workspace_bytes, y_nchw, (hipStream_t)stream);
+}
+
+int resr_generator_backward(const ResrGeneratorDesc* d, const float* gy_nchw, const float* params, const void* packed,
+                            void* workspace, size_t workspace_bytes, float* grad_params, float* gx_nchw, void* stream,
+                            void* side_stream) {
+    return generator_backward(d, gy_nchw, params, packed, workspace, workspace_bytes, grad_params, gx_nchw,
+                              (hipStream_t)stream, (hipStream_t)side_stream);
+}
+
+int resr_ema_update(float* shadow, const float* params, int64_t count, double decay, void* stream) {
+    return ema_dispatch(shadow, params, (long)count, decay, (hipStream_t)stream);
+}
+
+int resr_debug_tr_probe(float* out256, void* stream) {
+    hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out256);
+    RESR_CHECK_LAUNCH("tr_probe_kernel");
+    return RESR_OK;
+}
+
+}  // extern "C"

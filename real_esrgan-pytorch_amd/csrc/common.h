@@ -1,0 +1,41 @@
+// Shared host/device helpers for libresr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "resr.h"
+
+namespace resr {
+
+typedef _Float16 half_t;
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+// thread-local error text for resr_last_error()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+#define RESR_CHECK_LAUNCH(name)                                                        \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) return fail(RESR_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+inline size_t elem_size(int dtype) { return dtype == RESR_F16 ? 2 : 4; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// MI355X: blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8).  Give every XCD a
+// contiguous range of tiles so neighbouring tiles (shared halo rows, same weights) meet in one L2.
+// Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace resr

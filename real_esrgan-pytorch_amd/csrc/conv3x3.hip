@@ -1,0 +1,365 @@
+// conv3x3.hip -- 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on the gfx950 matrix cores.
+//
+// Replaces the F.conv2d + LeakyReLU + torch.cat + mul/add call sites of the reference generator
+// (model.py:87-98 dense block, :123-132 RRDB tail, :255-272 head/tail) and, with transposed
+// weights, their autograd backward-data passes.
+//
+// GEMM view:  C[cout][pixel] = sum_{tap, cin} W[cout][cin][tap] * X[pixel + tap][cin]
+//   A operand = packed weights (M = cout, 32 rows per MFMA tile), streamed from L2 in fragment order
+//   B operand = input pixels   (N = 32 pixels of one image row), read from an LDS halo tile
+//   K         = 9 taps x cin, walked as 32-channel chunks; "im2col" is only an LDS address offset.
+// A workgroup (4 waves) owns a (4*NT) x 32 pixel tile and all output channels; wave w owns rows
+// [w*NT, w*NT+NT).  The (4*NT+2) x 34 x 32ch halo tile of the next chunk is fetched while the
+// current one is multiplied (double-buffered LDS, one barrier per chunk).
+//
+// f16 (fast) : v_mfma_f32_32x32x16_f16, fp32 accumulate.   f32 (strict): v_mfma_f32_32x32x2_f32.
+// Both read 16 bytes per lane per operand per k-step, so one template serves both.
+//
+// LDS layout: pixel-major, PB = 32*sizeof(T) bytes per pixel, i.e. SPP = PB/16 sixteen-byte slots.
+// ds_read_b128 is served in 16-lane groups whose pixel x-coordinates cover all residues mod 16;
+// XOR-ing the slot index with a function of x makes the 16 lanes hit 16 distinct slots of the
+// 256-byte bank row (conflict-free) -- see swz().
+#include "common.h"
+
+namespace resr {
+
+struct ConvArgs {
+    const char* in0;
+    const char* in1;
+    const char* w;
+    const float* bias;
+    const char* res0;
+    const char* res1;
+    const char* mask;
+    char* out;
+    uint8_t* aux;
+    int n, h, w_, hs, ws;
+    int cin, cin0;
+    int in0_stride_b, in1_stride_b;  // bytes per pixel
+    int cout;
+    int out_stride, res0_stride, res1_stride, mask_stride;  // elements
+    int flags;
+    float s0, t0, s1, t1, slope;
+    int tiles_x, tiles_y;
+};
+
+template <int SPP>
+__device__ __forceinline__ int swz(int hx) {
+    // SPP slots per pixel; 16/SPP consecutive pixels fill one 256-byte bank row.
+    if constexpr (SPP == 4) return (hx >> 2) & 3;
+    else return (hx >> 1) & 7;
+}
+
+template <typename T>
+struct Frag;
+template <>
+struct Frag<half_t> {
+    static __device__ __forceinline__ float16v mma(const uint4& a, const uint4& b, float16v c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a),
+                                                      __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float ld(const char* p, int idx) {
+        return (float)reinterpret_cast<const half_t*>(p)[idx];
+    }
+};
+template <>
+struct Frag<float> {
+    static __device__ __forceinline__ float16v mma(const uint4& a, const uint4& b, float16v c) {
+        const float4v fa = __builtin_bit_cast(float4v, a), fb = __builtin_bit_cast(float4v, b);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], c, 0, 0, 0);
+        return c;
+    }
+    static __device__ __forceinline__ float ld(const char* p, int idx) {
+        return reinterpret_cast<const float*>(p)[idx];
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void load4(const char* base, size_t idx, float v[4]) {
+    if constexpr (sizeof(T) == 2) {
+        const half4 h = *reinterpret_cast<const half4*>(base + idx * 2);
+        v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
+    } else {
+        const float4v f = *reinterpret_cast<const float4v*>(base + idx * 4);
+        v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(char* base, size_t idx, const float v[4]) {
+    if constexpr (sizeof(T) == 2) {
+        half4 h;
+        h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
+        *reinterpret_cast<half4*>(base + idx * 2) = h;
+    } else {
+        float4v f;
+        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+        *reinterpret_cast<float4v*>(base + idx * 4) = f;
+    }
+}
+
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
+    constexpr int E = 16 / (int)sizeof(T);  // elements per 16-byte slot
+    constexpr int SPP = 32 / E;             // slots per pixel per chunk (4 f16, 8 f32)
+    constexpr int KS = SPP / 2;             // k-steps per chunk
+    constexpr int PB = 32 * (int)sizeof(T); // bytes per pixel per chunk
+    constexpr int TH = 4 * NT, TW = 32, HH = TH + 2, HW = TW + 2;
+    constexpr int NSLOT = HH * HW * SPP;
+    constexpr int NS = (NSLOT + 255) / 256;
+    constexpr int BUF = HH * HW * PB;
+    constexpr int WTAP = KS * MT * 1024;    // packed weight bytes per (chunk, tap)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = bid % a.tiles_x;
+    const int t2 = bid / a.tiles_x;
+    const int ty = t2 % a.tiles_y;
+    const int n = t2 / a.tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const bool up = (a.flags & RESR_CONV_UPSAMPLE_IN) != 0;
+
+    // ---- staging map: slot s = tid + i*256  ->  halo pixel (hy,hx), 16-byte piece c16 ----------
+    const int c16 = tid % SPP;  // 256 % SPP == 0: identical for every i
+    int pix[NS];                // source pixel index inside the image, -1 = zero (padding / unused)
+    int loff[NS];               // swizzled LDS byte offset inside one buffer, -1 = no slot
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int s = tid + i * 256;
+        const int hp = s / SPP;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const bool slot_ok = s < NSLOT;
+        const bool in_img = slot_ok && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w_;
+        const int sy = up ? (iy >> 1) : iy, sx = up ? (ix >> 1) : ix;
+        pix[i] = in_img ? sy * a.ws + sx : -1;
+        loff[i] = slot_ok ? hp * PB + ((c16 ^ swz<SPP>(hx)) << 4) : -1;
+    }
+    const size_t img_px = (size_t)a.hs * a.ws;
+    const char* in0 = a.in0 + (size_t)n * img_px * a.in0_stride_b;
+    const char* in1 = a.in1 ? a.in1 + (size_t)n * img_px * a.in1_stride_b : nullptr;
+
+    uint4 stg[NS];
+    auto stage_load = [&](int ck) {
+        const int c0 = ck * 32;
+        const bool seg1 = c0 >= a.cin0;
+        const char* base = seg1 ? in1 : in0;
+        const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
+        const unsigned ch_b = (unsigned)(seg1 ? c0 - a.cin0 : c0) * (unsigned)sizeof(T) + (c16 << 4);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (pix[i] >= 0) v = *reinterpret_cast<const uint4*>(base + (size_t)pix[i] * stride_b + ch_b);
+            stg[i] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+        char* dst = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+            if (loff[i] >= 0) *reinterpret_cast<uint4*>(dst + loff[i]) = stg[i];
+    };
+
+    // ---- per-lane operand addressing -----------------------------------------------------------
+    const int lx = lane & 31, kh = lane >> 5;
+    int colb[3], colsw[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int hx = lx + dx;
+        colb[dx] = hx * PB;
+        colsw[dx] = swz<SPP>(hx);
+    }
+    const int row0 = wave * NT;
+    const char* wp = a.w + (lane << 4);
+
+    float16v acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+    const int nchunks = a.cin >> 5;
+
+    uint4 wcur[KS * MT], wnext[KS * MT];
+#pragma unroll
+    for (int j = 0; j < KS * MT; ++j) wcur[j] = *reinterpret_cast<const uint4*>(wp + j * 1024);
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+
+    for (int ck = 0; ck < nchunks; ++ck) {
+        const bool more = ck + 1 < nchunks;
+        if (more) stage_load(ck + 1);
+        const char* lbuf = smem + (ck & 1) * BUF;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            // prefetch the next (chunk, tap) weight fragments; the tail over-read stays inside the
+            // packed buffer because the packer appends one dummy tap (see pack.hip)
+            const char* wn = wp + (size_t)(ck * 9 + tap + 1) * WTAP;
+#pragma unroll
+            for (int j = 0; j < KS * MT; ++j) wnext[j] = *reinterpret_cast<const uint4*>(wn + j * 1024);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                uint4 b[NT];
+                const int so = ((ks * 2 + kh) ^ colsw[dx]) << 4;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    b[t] = *reinterpret_cast<const uint4*>(lbuf + (row0 + t + dy) * (HW * PB) + colb[dx] + so);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[m][t] = Frag<T>::mma(wcur[ks * MT + m], b[t], acc[m][t]);
+            }
+#pragma unroll
+            for (int j = 0; j < KS * MT; ++j) wcur[j] = wnext[j];
+        }
+        if (more) stage_store((ck + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns pixel (row0+t, lx) and 4 consecutive couts per accumulator quad ----
+    const bool f_lrelu = a.flags & RESR_CONV_LRELU, f_clamp = a.flags & RESR_CONV_CLAMP01;
+    const bool f_nchw = a.flags & RESR_CONV_OUT_NCHW_F32, f_mask = a.flags & RESR_CONV_MASK;
+    const bool f_bias = !(a.flags & RESR_CONV_NO_BIAS) && a.bias != nullptr;
+    const int x = x0 + lx;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int y = y0 + row0 + t;
+        if (y >= a.h || x >= a.w_) continue;
+        const size_t p = ((size_t)n * a.h + y) * a.w_ + x;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = m * 32 + g * 8 + kh * 4;
+                if (co >= a.cout) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[m][t][g * 4 + r];
+                if (f_bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < a.cout) v[r] += a.bias[co + r];
+                }
+                if (f_mask) {
+                    float mk[4];
+                    load4<T>(a.mask, p * a.mask_stride + co, mk);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= (mk[r] > 0.f ? 1.f : a.slope);
+                }
+                if (f_lrelu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
+                }
+                if (a.res0) {
+                    float rr[4];
+                    load4<T>(a.res0, p * a.res0_stride + co, rr);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * a.s0 + a.t0 * rr[r];
+                }
+                if (a.res1) {
+                    float rr[4];
+                    load4<T>(a.res1, p * a.res1_stride + co, rr);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * a.s1 + a.t1 * rr[r];
+                }
+                if (f_nchw) {
+                    float* o = reinterpret_cast<float*>(a.out);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (co + r >= a.cout) continue;
+                        const size_t q = (((size_t)n * a.cout + co + r) * a.h + y) * a.w_ + x;
+                        float u = v[r];
+                        if (f_clamp) {
+                            if (a.aux) a.aux[q] = (u >= 0.f && u <= 1.f) ? 1 : 0;
+                            u = fminf(fmaxf(u, 0.f), 1.f);
+                        }
+                        o[q] = u;
+                    }
+                } else {
+                    if (f_clamp) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], 0.f), 1.f);
+                    }
+                    store4<T>(a.out, p * a.out_stride + co, v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int MT, int NT>
+static int launch_conv(const ConvArgs& a, hipStream_t stream) {
+    constexpr int PB = 32 * (int)sizeof(T);
+    constexpr int TH = 4 * NT;
+    constexpr int BUF = (TH + 2) * 34 * PB;
+    ConvArgs args = a;
+    args.tiles_x = (a.w_ + 31) / 32;
+    args.tiles_y = (a.h + TH - 1) / TH;
+    const size_t lds = 2 * BUF;
+    static bool attr_done = false;  // benign race: idempotent
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT, NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)(args.tiles_x * args.tiles_y * a.n);
+    hipLaunchKernelGGL((conv3x3_kernel<T, MT, NT>), dim3(grid), dim3(256), lds, stream, args);
+    RESR_CHECK_LAUNCH("conv3x3_kernel");
+    return RESR_OK;
+}
+
+int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, const void* w,
+                     const float* bias, const void* res0, const void* res1, const void* mask,
+                     void* out, void* aux, hipStream_t stream) {
+    if (!d || !in0 || !w || !out) return fail(RESR_ERR_ARG, "conv3x3: null argument");
+    if (d->cin <= 0 || (d->cin & 31) || (d->cin0 & 31) || d->cin0 <= 0 || d->cin0 > d->cin)
+        return fail(RESR_ERR_ARG, "conv3x3: cin=%d cin0=%d must be positive multiples of 32", d->cin, d->cin0);
+    if (d->cin0 < d->cin && !in1) return fail(RESR_ERR_ARG, "conv3x3: in1 missing for cin0 < cin");
+    if (d->cout_pad != 32 && d->cout_pad != 64) return fail(RESR_ERR_ARG, "conv3x3: cout_pad=%d", d->cout_pad);
+    if (d->cout <= 0 || d->cout > d->cout_pad) return fail(RESR_ERR_ARG, "conv3x3: cout=%d", d->cout);
+    if (!(d->flags & RESR_CONV_OUT_NCHW_F32) && (d->cout & 3))
+        return fail(RESR_ERR_ARG, "conv3x3: NHWC output needs cout %% 4 == 0");
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0) return fail(RESR_ERR_ARG, "conv3x3: empty shape");
+    if ((d->flags & RESR_CONV_UPSAMPLE_IN) && ((d->h | d->w) & 1))
+        return fail(RESR_ERR_ARG, "conv3x3: upsampled input needs even h,w");
+    if ((d->flags & RESR_CONV_MASK) && !mask) return fail(RESR_ERR_ARG, "conv3x3: mask missing");
+    const size_t es = elem_size(d->dtype);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in0 = (const char*)in0; a.in1 = (const char*)in1; a.w = (const char*)w; a.bias = bias;
+    a.res0 = (const char*)res0; a.res1 = (const char*)res1; a.mask = (const char*)mask;
+    a.out = (char*)out; a.aux = (uint8_t*)aux;
+    a.n = d->n; a.h = d->h; a.w_ = d->w;
+    const bool up = d->flags & RESR_CONV_UPSAMPLE_IN;
+    a.hs = up ? d->h / 2 : d->h; a.ws = up ? d->w / 2 : d->w;
+    a.cin = d->cin; a.cin0 = d->cin0;
+    a.in0_stride_b = (int)(d->in0_stride * es); a.in1_stride_b = (int)(d->in1_stride * es);
+    a.cout = d->cout; a.out_stride = d->out_stride;
+    a.res0_stride = d->res0_stride; a.res1_stride = d->res1_stride; a.mask_stride = d->mask_stride;
+    a.flags = d->flags; a.s0 = d->s0; a.t0 = d->t0; a.s1 = d->s1; a.t1 = d->t1; a.slope = d->slope;
+    const int mt = d->cout_pad / 32;
+    // rows per wave: 4 when that still yields enough workgroups to fill 256 CUs twice over
+    const long tiles4 = (long)((d->w + 31) / 32) * ((d->h + 15) / 16) * d->n;
+    const bool big = tiles4 >= 512;
+    if (d->dtype == RESR_F16) {
+        if (mt == 1) return big ? launch_conv<half_t, 1, 4>(a, stream) : launch_conv<half_t, 1, 2>(a, stream);
+        // <f16,2,4> needs 128 accumulator + 170 other registers -> 1 wave/SIMD; keep 2 waves/SIMD instead
+        return launch_conv<half_t, 2, 2>(a, stream);
+    } else if (d->dtype == RESR_F32) {
+        if (mt == 1) return launch_conv<float, 1, 2>(a, stream);
+        return launch_conv<float, 2, 2>(a, stream);
+    }
+    return fail(RESR_ERR_ARG, "conv3x3: dtype=%d", d->dtype);
+}
+
+}  // namespace resr

@@ -1,0 +1,501 @@
+// generator.hip -- whole-RRDBNet passes enqueued natively (reference model.py:206-275 and its
+// autograd backward).  No kernels here: this file owns the HBM plan and the launch order.
+//
+// HBM plan (T = f16 fast / f32 strict, all tensors pixel-major / NHWC):
+//   x_in              [N,h,w,CI]      input image, pixel-unshuffled, channels padded to 32/64
+//   ws[r], r=0..3B-1  [N,h,w,192]     one dense-block workspace per RDB: [x | o1 | o2 | o3 | o4];
+//                                     conv_k reads the channel prefix [0, 64+32(k-1)) and writes
+//                                     its 32-channel slice, conv5 writes x of ws[r+1]  -> the four
+//                                     torch.cat copies of model.py:91-94 never exist.
+//                                     Inference keeps 3 rotating workspaces, training keeps all
+//                                     (they are the saved activations: 192 ch/px/RDB, not 640).
+//   trunk_out, feat   [N,h,w,64]      model.py:260-262
+//   u1 [N,2h,2w,64], u2, c3 [N,4h,4w,64]   model.py:264-267 (nearest x2 folded into the conv's gather)
+//   y                 [N,3,4h,4w] fp32 planar (module surface) + 1 byte/elem clamp pass-mask
+// Backward-data runs the *mirrored* dense block: gradients are laid out [g_y | g_o4 | g_o3 | g_o2 | g_o1]
+// so that every pass is again "3x3 conv over a channel prefix -> 32/64-channel slice" with the
+// transposed/flipped weights (pack.hip) -- no read-modify-write accumulation of partial input grads.
+#include <vector>
+
+#include "common.h"
+
+namespace resr {
+
+int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*, const float*, const void*,
+                     const void*, const void*, void*, void*, hipStream_t);
+int wgrad_dispatch(const ResrWgradDesc*, const void*, const void*, const void*, float*, float*, float*, hipStream_t);
+size_t wgrad_partial_bytes(const ResrWgradDesc*);
+int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t);
+int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t);
+int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int, float, hipStream_t);
+int add_inplace_dispatch(void*, const void*, long, int, hipStream_t);
+
+namespace {
+
+struct ConvSpec {
+    int cout, cin, cin_pad, cout_pad;
+    size_t w_off, b_off;      // element offsets in the fp32 parameter arena
+    size_t pk_fwd, pk_bwd;    // element offsets in the packed buffer (bwd: first pass of this conv)
+};
+
+struct Plan {
+    ResrGeneratorDesc d;
+    int r;        // pixel-unshuffle factor
+    int h, w;     // trunk resolution
+    int ci_real, ci_pad;
+    int nrdb;
+    std::vector<ConvSpec> convs;  // conv1, trunk..., conv2, up1, up2, conv3, conv4
+    size_t n_params;
+    size_t pk_fwd_elems, pk_total_elems;
+    // indices
+    int i_conv1, i_trunk0, i_conv2, i_up1, i_up2, i_conv3, i_conv4;
+    // backward packed offsets of trunk passes: [rdb][pass 0..4] (pass 0 -> g_o4 ... pass 4 -> g_x)
+    std::vector<size_t> pk_bwd_trunk;
+    size_t pk_bwd_conv4, pk_bwd_conv3, pk_bwd_up2, pk_bwd_up1, pk_bwd_conv2, pk_bwd_conv1;
+};
+
+int round32(int v) { return (v + 31) / 32 * 32; }
+
+bool build_plan(const ResrGeneratorDesc* d, Plan& p) {
+    if (!d) return false;
+    if (d->upscale != 4 && d->upscale != 2 && d->upscale != 1) return false;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->n_blocks <= 0 || d->in_channels <= 0 || d->out_channels <= 0) return false;
+    p.d = *d;
+    p.r = d->upscale == 4 ? 1 : (d->upscale == 2 ? 2 : 4);
+    if ((d->h % p.r) || (d->w % p.r)) return false;
+    p.h = d->h / p.r;
+    p.w = d->w / p.r;
+    p.ci_real = d->in_channels * p.r * p.r;
+    p.ci_pad = round32(p.ci_real);
+    if (p.ci_pad > 64 || d->out_channels > 32) return false;
+    p.nrdb = d->n_blocks * 3;
+    size_t off = 0;
+    auto add = [&](int cout, int cin) {
+        ConvSpec c;
+        c.cout = cout; c.cin = cin; c.cin_pad = round32(cin); c.cout_pad = round32(cout);
+        c.w_off = off; off += (size_t)cout * cin * 9;
+        c.b_off = off; off += cout;
+        c.pk_fwd = c.pk_bwd = 0;
+        p.convs.push_back(c);
+        return (int)p.convs.size() - 1;
+    };
+    p.i_conv1 = add(64, p.ci_real);
+    p.i_trunk0 = (int)p.convs.size();
+    for (int r = 0; r < p.nrdb; ++r)
+        for (int k = 1; k <= 5; ++k) add(k < 5 ? 32 : 64, 64 + 32 * (k - 1));
+    p.i_conv2 = add(64, 64);
+    p.i_up1 = add(64, 64);
+    p.i_up2 = add(64, 64);
+    p.i_conv3 = add(64, 64);
+    p.i_conv4 = add(d->out_channels, 64);
+    p.n_params = off;
+    // packed layout: forward chunks of every conv, then backward-data passes
+    size_t pk = 0;
+    for (auto& c : p.convs) {
+        c.pk_fwd = pk;
+        pk += (size_t)(c.cin_pad / 32) * 9 * (c.cout_pad / 32) * 1024;
+    }
+    p.pk_fwd_elems = pk;
+    auto bwd_simple = [&](int idx) {  // transposed conv: M = cin_pad (as cout_pad), K = cout_pad
+        const ConvSpec& c = p.convs[idx];
+        const size_t o = pk;
+        pk += (size_t)(c.cout_pad / 32) * 9 * (c.cin_pad / 32) * 1024;
+        return o;
+    };
+    p.pk_bwd_conv4 = bwd_simple(p.i_conv4);
+    p.pk_bwd_conv3 = bwd_simple(p.i_conv3);
+    p.pk_bwd_up2 = bwd_simple(p.i_up2);
+    p.pk_bwd_up1 = bwd_simple(p.i_up1);
+    p.pk_bwd_conv2 = bwd_simple(p.i_conv2);
+    p.pk_bwd_conv1 = bwd_simple(p.i_conv1);
+    p.pk_bwd_trunk.resize((size_t)p.nrdb * 5);
+    for (int r = 0; r < p.nrdb; ++r)
+        for (int ps = 0; ps < 5; ++ps) {
+            // pass ps: K chunks = 2 (g_y through conv5) + ps (conv4 .. conv(5-ps)); M tiles = 1 (ps<4) or 2
+            p.pk_bwd_trunk[(size_t)r * 5 + ps] = pk;
+            pk += (size_t)(2 + ps) * 9 * (ps < 4 ? 1 : 2) * 1024;
+        }
+    p.pk_total_elems = pk;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace carving
+// ---------------------------------------------------------------------------------------------
+struct Bufs {
+    char* x_in;
+    std::vector<char*> ws;
+    char* out1;       // conv1 output kept for the skip of model.py:262 (aliases ws[0] when training)
+    int out1_stride;
+    char *trunk_out, *feat, *u1, *u2, *c3;
+    uint8_t* ymask;
+    // backward
+    char *g4, *gA, *gB, *gM1, *gF, *gT[4], *gS, *gxin;
+    float* partial;
+    size_t partial_bytes;
+    size_t total;
+};
+
+int default_splits(const Plan& p, long npix_tiles) {
+    (void)p;
+    // aim for >= 8 pixel tiles per workgroup and <= 64 splits
+    long s = npix_tiles / 8;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+int splits_for(const Plan& p, int h, int w) {
+    if (p.d.wgrad_splits > 0) return p.d.wgrad_splits;
+    const int th = p.d.dtype == RESR_F16 ? 8 : 4;
+    const long tiles = (long)((w + 31) / 32) * ((h + th - 1) / th) * p.d.n;
+    return default_splits(p, tiles);
+}
+
+void carve(const Plan& p, char* base, Bufs& b) {
+    const size_t es = elem_size(p.d.dtype);
+    const size_t px = (size_t)p.d.n * p.h * p.w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* ptr = base ? base + off : nullptr;
+        off += align_up(bytes, 256);
+        return ptr;
+    };
+    b.x_in = take(px * p.ci_pad * es);
+    const int nws = p.d.training ? p.nrdb : 3;
+    b.ws.resize(nws);
+    for (int i = 0; i < nws; ++i) b.ws[i] = take(px * 192 * es);
+    if (p.d.training) { b.out1 = b.ws[0]; b.out1_stride = 192; }
+    else { b.out1 = take(px * 64 * es); b.out1_stride = 64; }  // rotating workspaces overwrite ws[0]
+    b.trunk_out = take(px * 64 * es);
+    b.feat = take(px * 64 * es);
+    b.u1 = take(px * 4 * 64 * es);
+    b.u2 = take(px * 16 * 64 * es);
+    b.c3 = take(px * 16 * 64 * es);
+    b.ymask = (uint8_t*)take(px * 16 * p.d.out_channels);
+    if (p.d.training) {
+        b.g4 = take(px * 16 * 32 * es);
+        b.gA = take(px * 16 * 64 * es);
+        b.gB = take(px * 16 * 64 * es);
+        b.gM1 = take(px * 4 * 64 * es);
+        b.gF = take(px * 64 * es);
+        for (int i = 0; i < 4; ++i) b.gT[i] = take(px * 64 * es);
+        b.gS = take(px * 128 * es);
+        b.gxin = take(px * p.ci_pad * es);
+        // wgrad slabs: largest of (trunk conv5 at LR, 64x64 convs at HR)
+        ResrWgradDesc wd;
+        memset(&wd, 0, sizeof(wd));
+        wd.cin = 192; wd.cout_pad = 64; wd.splits = splits_for(p, p.h, p.w);
+        size_t pb = wgrad_partial_bytes(&wd);
+        wd.cin = 64; wd.splits = splits_for(p, p.h * 4, p.w * 4);
+        size_t pb2 = wgrad_partial_bytes(&wd);
+        wd.splits = splits_for(p, p.h * 2, p.w * 2);
+        size_t pb3 = wgrad_partial_bytes(&wd);
+        b.partial_bytes = pb > pb2 ? pb : pb2;
+        if (pb3 > b.partial_bytes) b.partial_bytes = pb3;
+        b.partial = (float*)take(b.partial_bytes);
+    } else {
+        b.g4 = b.gA = b.gB = b.gM1 = b.gF = b.gS = b.gxin = nullptr;
+        for (int i = 0; i < 4; ++i) b.gT[i] = nullptr;
+        b.partial = nullptr;
+        b.partial_bytes = 0;
+    }
+    b.total = off;
+}
+
+ResrConvDesc conv_desc(const Plan& p, int n, int h, int w, int cin, int cin0, int s0, int s1, int cout, int cout_pad,
+                       int out_stride, int flags) {
+    ResrConvDesc c;
+    memset(&c, 0, sizeof(c));
+    c.n = n; c.h = h; c.w = w; c.cin = cin; c.cin0 = cin0; c.in0_stride = s0; c.in1_stride = s1;
+    c.cout = cout; c.cout_pad = cout_pad; c.out_stride = out_stride; c.dtype = p.d.dtype; c.flags = flags;
+    c.s0 = c.s1 = 1.f; c.t0 = c.t1 = 1.f; c.slope = 0.2f;
+    return c;
+}
+
+}  // namespace
+
+size_t generator_param_count(const ResrGeneratorDesc* d) {
+    Plan p;
+    return build_plan(d, p) ? p.n_params : 0;
+}
+
+size_t generator_packed_bytes(const ResrGeneratorDesc* d, int backward) {
+    Plan p;
+    if (!build_plan(d, p)) return 0;
+    // + one dummy (chunk,tap) of slack: conv3x3_kernel prefetches one tap past the end
+    return (backward ? p.pk_total_elems : p.pk_fwd_elems) * elem_size(d->dtype) + 8192;
+}
+
+size_t generator_workspace_bytes(const ResrGeneratorDesc* d) {
+    Plan p;
+    if (!build_plan(d, p)) return 0;
+    Bufs b;
+    carve(p, nullptr, b);
+    return b.total;
+}
+
+int64_t generator_pack_table(const ResrGeneratorDesc* d, int backward, ResrPackChunk* out, int64_t cap) {
+    Plan p;
+    if (!build_plan(d, p)) return fail(RESR_ERR_ARG, "generator: bad descriptor");
+    std::vector<ResrPackChunk> t;
+    auto push = [&](const ConvSpec& c, size_t dst, int m_off, int m_count, int k_off, int k_count, int mt, int tr,
+                    float scale) {
+        ResrPackChunk ch;
+        memset(&ch, 0, sizeof(ch));
+        ch.src_off = (int64_t)c.w_off; ch.dst_off = (int64_t)dst;
+        ch.src_cout = c.cout; ch.src_cin = c.cin;
+        ch.m_off = m_off; ch.m_count = m_count; ch.k_off = k_off; ch.k_count = k_count;
+        ch.mt = mt; ch.transposed = tr; ch.scale = scale;
+        t.push_back(ch);
+    };
+    for (const auto& c : p.convs) {
+        const int mt = c.cout_pad / 32;
+        for (int ck = 0; ck < c.cin_pad / 32; ++ck) {
+            const int kc = c.cin - ck * 32;
+            push(c, c.pk_fwd + (size_t)ck * 9 * mt * 1024, 0, c.cout, ck * 32, kc > 32 ? 32 : kc, mt, 0, 1.f);
+        }
+    }
+    if (backward) {
+        auto simple = [&](int idx, size_t base) {
+            const ConvSpec& c = p.convs[idx];
+            const int mt = c.cin_pad / 32;
+            for (int ck = 0; ck < c.cout_pad / 32; ++ck) {
+                const int kc = c.cout - ck * 32;
+                push(c, base + (size_t)ck * 9 * mt * 1024, 0, c.cin, ck * 32, kc > 32 ? 32 : kc, mt, 1, 1.f);
+            }
+        };
+        simple(p.i_conv4, p.pk_bwd_conv4);
+        simple(p.i_conv3, p.pk_bwd_conv3);
+        simple(p.i_up2, p.pk_bwd_up2);
+        simple(p.i_up1, p.pk_bwd_up1);
+        simple(p.i_conv2, p.pk_bwd_conv2);
+        simple(p.i_conv1, p.pk_bwd_conv1);
+        for (int r = 0; r < p.nrdb; ++r) {
+            // the 0.2 of model.py:95 (and, for the third RDB of a block, the 0.2 of model.py:129) folded in
+            const float fold = (r % 3 == 2) ? 0.2f * 0.2f : 0.2f;
+            for (int ps = 0; ps < 5; ++ps) {
+                const int mt = ps < 4 ? 1 : 2;
+                const int m_off = ps < 4 ? 64 + 32 * (3 - ps) : 0;  // slice of o_(4-ps), or x
+                const int m_cnt = ps < 4 ? 32 : 64;
+                size_t dst = p.pk_bwd_trunk[(size_t)r * 5 + ps];
+                const ConvSpec& c5 = p.convs[p.i_trunk0 + r * 5 + 4];
+                push(c5, dst, m_off, m_cnt, 0, 32, mt, 1, fold); dst += (size_t)9 * mt * 1024;
+                push(c5, dst, m_off, m_cnt, 32, 32, mt, 1, fold); dst += (size_t)9 * mt * 1024;
+                for (int j = 0; j < ps; ++j) {  // g_o4, g_o3, ... in gS channel order
+                    const ConvSpec& ck = p.convs[p.i_trunk0 + r * 5 + (3 - j)];
+                    push(ck, dst, m_off, m_cnt, 0, 32, mt, 1, 1.f);
+                    dst += (size_t)9 * mt * 1024;
+                }
+            }
+        }
+    }
+    if (out) {
+        if ((int64_t)t.size() > cap) return fail(RESR_ERR_ARG, "generator_pack_table: capacity %lld < %zu", (long long)cap, t.size());
+        memcpy(out, t.data(), t.size() * sizeof(ResrPackChunk));
+    }
+    return (int64_t)t.size();
+}
+
+#define RUN(expr)                 \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != RESR_OK) return rc_; \
+    } while (0)
+
+int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* params, const void* packed,
+                      void* workspace, size_t workspace_bytes, float* y, hipStream_t st) {
+    Plan p;
+    if (!build_plan(d, p)) return fail(RESR_ERR_ARG, "generator_forward: bad descriptor");
+    if (!x || !params || !packed || !workspace || !y) return fail(RESR_ERR_ARG, "generator_forward: null argument");
+    Bufs b;
+    carve(p, (char*)workspace, b);
+    if (b.total > workspace_bytes) return fail(RESR_ERR_WORKSPACE, "generator_forward: workspace %zu < %zu", workspace_bytes, b.total);
+    const size_t es = elem_size(d->dtype);
+    const char* pk = (const char*)packed;
+    const int N = d->n, h = p.h, w = p.w;
+    const int nws = (int)b.ws.size();
+    auto W = [&](const ConvSpec& c) { return pk + c.pk_fwd * es; };
+    auto Bias = [&](const ConvSpec& c) { return params + c.b_off; };
+
+    RUN(nchw_to_nhwc_dispatch(x, b.x_in, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, nullptr, st));
+    {   // conv1 -> ws[0][0:64]                                           model.py:259
+        const ConvSpec& c = p.convs[p.i_conv1];
+        ResrConvDesc cd = conv_desc(p, N, h, w, p.ci_pad, p.ci_pad, p.ci_pad, 0, 64, 64, 192, 0);
+        RUN(conv3x3_dispatch(&cd, b.x_in, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.ws[0], nullptr, st));
+        if (b.out1 != b.ws[0]) {  // inference: second copy of out1 (0.01 % of the FLOPs) instead of a pinned workspace
+            cd.out_stride = b.out1_stride;
+            RUN(conv3x3_dispatch(&cd, b.x_in, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.out1, nullptr, st));
+        }
+    }
+    for (int r = 0; r < p.nrdb; ++r) {
+        char* cur = b.ws[r % nws];
+        for (int k = 1; k <= 4; ++k) {  // model.py:90-93
+            const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
+            ResrConvDesc cd = conv_desc(p, N, h, w, c.cin, c.cin, 192, 0, 32, 32, 192, RESR_CONV_LRELU);
+            RUN(conv3x3_dispatch(&cd, cur, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr,
+                                 cur + (size_t)(64 + 32 * (k - 1)) * es, nullptr, st));
+        }
+        const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + 4];
+        const bool last = r == p.nrdb - 1;
+        char* dst = last ? b.trunk_out : b.ws[(r + 1) % nws];
+        ResrConvDesc cd = conv_desc(p, N, h, w, 192, 192, 192, 0, 64, 64, last ? 64 : 192, 0);
+        cd.s0 = 0.2f; cd.t0 = 1.f; cd.res0_stride = 192;  // model.py:95-96
+        const char* res1 = nullptr;
+        if (r % 3 == 2) {  // model.py:129-130
+            res1 = b.ws[(r - 2) % nws];
+            cd.s1 = 0.2f; cd.t1 = 1.f; cd.res1_stride = 192;
+        }
+        RUN(conv3x3_dispatch(&cd, cur, nullptr, W(c), Bias(c), cur, res1, nullptr, dst, nullptr, st));
+    }
+    {   // conv2 + skip                                                   model.py:261-262
+        const ConvSpec& c = p.convs[p.i_conv2];
+        ResrConvDesc cd = conv_desc(p, N, h, w, 64, 64, 64, 0, 64, 64, 64, 0);
+        cd.res0_stride = b.out1_stride;
+        RUN(conv3x3_dispatch(&cd, b.trunk_out, nullptr, W(c), Bias(c), b.out1, nullptr, nullptr, b.feat, nullptr, st));
+    }
+    {   // model.py:264
+        const ConvSpec& c = p.convs[p.i_up1];
+        ResrConvDesc cd = conv_desc(p, N, 2 * h, 2 * w, 64, 64, 64, 0, 64, 64, 64, RESR_CONV_LRELU | RESR_CONV_UPSAMPLE_IN);
+        RUN(conv3x3_dispatch(&cd, b.feat, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.u1, nullptr, st));
+    }
+    {   // model.py:265
+        const ConvSpec& c = p.convs[p.i_up2];
+        ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 64, 0, 64, 64, 64, RESR_CONV_LRELU | RESR_CONV_UPSAMPLE_IN);
+        RUN(conv3x3_dispatch(&cd, b.u1, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.u2, nullptr, st));
+    }
+    {   // model.py:267
+        const ConvSpec& c = p.convs[p.i_conv3];
+        ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 64, 0, 64, 64, 64, RESR_CONV_LRELU);
+        RUN(conv3x3_dispatch(&cd, b.u2, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.c3, nullptr, st));
+    }
+    {   // model.py:268-270
+        const ConvSpec& c = p.convs[p.i_conv4];
+        ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 64, 0, c.cout, c.cout_pad, 0,
+                                    RESR_CONV_CLAMP01 | RESR_CONV_OUT_NCHW_F32);
+        RUN(conv3x3_dispatch(&cd, b.c3, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, y, b.ymask, st));
+    }
+    return RESR_OK;
+}
+
+int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float* params, const void* packed,
+                       void* workspace, size_t workspace_bytes, float* grad, float* gx, hipStream_t st,
+                       hipStream_t side) {
+    (void)side; (void)params;
+    Plan p;
+    if (!build_plan(d, p)) return fail(RESR_ERR_ARG, "generator_backward: bad descriptor");
+    if (!d->training) return fail(RESR_ERR_ARG, "generator_backward: forward was not run with training=1");
+    if (!gy || !packed || !workspace || !grad) return fail(RESR_ERR_ARG, "generator_backward: null argument");
+    Bufs b;
+    carve(p, (char*)workspace, b);
+    if (b.total > workspace_bytes) return fail(RESR_ERR_WORKSPACE, "generator_backward: workspace %zu < %zu", workspace_bytes, b.total);
+    const size_t es = elem_size(d->dtype);
+    const char* pk = (const char*)packed;
+    const int N = d->n, h = p.h, w = p.w;
+    const int H4 = 4 * h, W4 = 4 * w, H2 = 2 * h, W2 = 2 * w;
+
+    auto wgrad = [&](const ConvSpec& c, int hh, int ww, const void* x0, int cin, int s0, const void* g, int gstride,
+                     int flags, float scale) -> int {
+        ResrWgradDesc wd;
+        memset(&wd, 0, sizeof(wd));
+        wd.n = N; wd.h = hh; wd.w = ww; wd.cin = cin; wd.cin0 = cin; wd.in0_stride = s0; wd.cin_real = c.cin;
+        wd.cout = c.cout; wd.cout_pad = c.cout_pad; wd.g_stride = gstride; wd.dtype = d->dtype; wd.flags = flags;
+        wd.splits = splits_for(p, hh, ww); wd.scale = scale;
+        if (wgrad_partial_bytes(&wd) > b.partial_bytes) return fail(RESR_ERR_WORKSPACE, "wgrad slab buffer too small");
+        return wgrad_dispatch(&wd, x0, nullptr, g, b.partial, grad + c.w_off, grad + c.b_off, st);
+    };
+    auto dgrad = [&](int hh, int ww, const void*, int cin0, int s0, const void*, int cin, int s1, size_t, int cout,
+                     int cout_pad, void*, int out_stride, int flags) {
+        return conv_desc(p, N, hh, ww, cin, cin0, s0, s1, cout, cout_pad, out_stride, flags | RESR_CONV_NO_BIAS);
+    };
+
+    // clamp_ backward + layout                                              model.py:270
+    RUN(nchw_to_nhwc_dispatch(gy, b.g4, N, d->out_channels, H4, W4, 1, 32, d->dtype, b.ymask, st));
+    {   // conv4                                                            model.py:268
+        const ConvSpec& c = p.convs[p.i_conv4];
+        RUN(wgrad(c, H4, W4, b.c3, 64, 64, b.g4, 32, 0, 1.f));
+        ResrConvDesc cd = dgrad(H4, W4, b.g4, 32, 32, nullptr, 32, 0, 0, 64, 64, b.gA, 64, RESR_CONV_MASK);
+        cd.mask_stride = 64;
+        RUN(conv3x3_dispatch(&cd, b.g4, nullptr, pk + p.pk_bwd_conv4 * es, nullptr, nullptr, nullptr, b.c3, b.gA, nullptr, st));
+    }
+    {   // conv3                                                            model.py:267
+        const ConvSpec& c = p.convs[p.i_conv3];
+        RUN(wgrad(c, H4, W4, b.u2, 64, 64, b.gA, 64, 0, 1.f));
+        ResrConvDesc cd = dgrad(H4, W4, b.gA, 64, 64, nullptr, 64, 0, 0, 64, 64, b.gB, 64, RESR_CONV_MASK);
+        cd.mask_stride = 64;
+        RUN(conv3x3_dispatch(&cd, b.gA, nullptr, pk + p.pk_bwd_conv3 * es, nullptr, nullptr, nullptr, b.u2, b.gB, nullptr, st));
+    }
+    {   // upsampling2                                                      model.py:265
+        const ConvSpec& c = p.convs[p.i_up2];
+        RUN(wgrad(c, H4, W4, b.u1, 64, 64, b.gB, 64, RESR_CONV_UPSAMPLE_IN, 1.f));
+        ResrConvDesc cd = dgrad(H4, W4, b.gB, 64, 64, nullptr, 64, 0, 0, 64, 64, b.gA, 64, 0);
+        RUN(conv3x3_dispatch(&cd, b.gB, nullptr, pk + p.pk_bwd_up2 * es, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
+        RUN(sumpool2x2_dispatch(b.gA, b.gM1, b.u1, N, H2, W2, 64, d->dtype, 0.2f, st));
+    }
+    {   // upsampling1                                                      model.py:264
+        const ConvSpec& c = p.convs[p.i_up1];
+        RUN(wgrad(c, H2, W2, b.feat, 64, 64, b.gM1, 64, RESR_CONV_UPSAMPLE_IN, 1.f));
+        ResrConvDesc cd = dgrad(H2, W2, b.gM1, 64, 64, nullptr, 64, 0, 0, 64, 64, b.gA, 64, 0);
+        RUN(conv3x3_dispatch(&cd, b.gM1, nullptr, pk + p.pk_bwd_up1 * es, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
+        RUN(sumpool2x2_dispatch(b.gA, b.gF, nullptr, N, h, w, 64, d->dtype, 0.2f, st));
+    }
+    int cur = 0;  // index into gT ring of the gradient wrt the current RDB's output chain
+    {   // conv2                                                            model.py:261
+        const ConvSpec& c = p.convs[p.i_conv2];
+        RUN(wgrad(c, h, w, b.trunk_out, 64, 64, b.gF, 64, 0, 1.f));
+        ResrConvDesc cd = dgrad(h, w, b.gF, 64, 64, nullptr, 64, 0, 0, 64, 64, b.gT[0], 64, 0);
+        RUN(conv3x3_dispatch(&cd, b.gF, nullptr, pk + p.pk_bwd_conv2 * es, nullptr, nullptr, nullptr, nullptr, b.gT[0], nullptr, st));
+    }
+    // trunk, mirrored dense blocks.  gT ring: e (grad wrt RRDB output) must survive its three RDBs.
+    int e_idx = 0;
+    for (int r = p.nrdb - 1; r >= 0; --r) {
+        const int pos = r % 3;  // 2: rdb3 (first in backward), 0: rdb1 (last)
+        if (pos == 2) e_idx = cur;
+        const char* gin = b.gT[cur];
+        const char* act = b.ws[r];
+        const float fold = pos == 2 ? 0.04f : 0.2f;
+        {   // conv5: G = fold * gin
+            const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + 4];
+            RUN(wgrad(c, h, w, act, 192, 192, gin, 64, 0, fold));
+        }
+        for (int ps = 0; ps < 4; ++ps) {   // g_o4, g_o3, g_o2, g_o1
+            const int k = 4 - ps;           // conv index whose pre-activation gradient this pass yields
+            const int cin = 64 + 32 * ps;
+            ResrConvDesc cd = dgrad(h, w, gin, 64, 64, b.gS, cin, 128, 0, 32, 32, nullptr, 128, RESR_CONV_MASK);
+            cd.mask_stride = 192;
+            char* out = b.gS + (size_t)(32 * ps) * es;
+            const char* mask = act + (size_t)(64 + 32 * (k - 1)) * es;
+            RUN(conv3x3_dispatch(&cd, gin, b.gS, pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * es, nullptr, nullptr, nullptr,
+                                 mask, out, nullptr, st));
+            const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
+            RUN(wgrad(c, h, w, act, c.cin, 192, out, 128, 0, 1.f));
+        }
+        {   // g_x = convT(all) + (skip terms)
+            int nxt = (cur + 1) & 3;
+            if (nxt == e_idx && pos != 2) nxt = (nxt + 1) & 3;
+            ResrConvDesc cd = dgrad(h, w, gin, 64, 64, b.gS, 192, 128, 0, 64, 64, nullptr, 64, 0);
+            const char* res0 = gin;
+            const char* res1 = nullptr;
+            cd.res0_stride = 64; cd.s0 = 1.f;
+            cd.t0 = pos == 2 ? 0.2f : 1.f;       // d(rdb3_out*0.2 + x)/d(rdb3_out) reaches x3 scaled
+            if (pos == 0) { res1 = b.gT[e_idx]; cd.res1_stride = 64; cd.s1 = 1.f; cd.t1 = 1.f; }
+            RUN(conv3x3_dispatch(&cd, gin, b.gS, pk + p.pk_bwd_trunk[(size_t)r * 5 + 4] * es, nullptr, res0, res1, nullptr,
+                                 b.gT[nxt], nullptr, st));
+            cur = nxt;
+        }
+    }
+    // gradient wrt out1 = trunk path + skip (model.py:262)
+    RUN(add_inplace_dispatch(b.gT[cur], b.gF, (long)N * h * w * 64, d->dtype, st));
+    {   // conv1                                                            model.py:259
+        const ConvSpec& c = p.convs[p.i_conv1];
+        RUN(wgrad(c, h, w, b.x_in, p.ci_pad, p.ci_pad, b.gT[cur], 64, 0, 1.f));
+        if (gx) {
+            ResrConvDesc cd = dgrad(h, w, b.gT[cur], 64, 64, nullptr, 64, 0, 0, p.ci_pad, p.ci_pad, b.gxin, p.ci_pad, 0);
+            RUN(conv3x3_dispatch(&cd, b.gT[cur], nullptr, pk + p.pk_bwd_conv1 * es, nullptr, nullptr, nullptr, nullptr, b.gxin, nullptr, st));
+            RUN(nhwc_to_nchw_dispatch(b.gxin, gx, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, st));
+        }
+    }
+    return RESR_OK;
+}
+
+}  // namespace resr

@@ -1,0 +1,166 @@
+// layout.hip -- HBM-bound layout / elementwise kernels around the generator.
+//   nchw_to_nhwc : module surface [N,C,H,W] fp32  ->  pixel-major, channel-padded T, with the
+//                  PixelUnshuffle of model.py:220,257 folded in (x2 / x1 generators) and an optional
+//                  pass-mask (backward of clamp_, model.py:270)
+//   nhwc_to_nchw : the inverse (gradient wrt the input image), PixelShuffle folded in
+//   sumpool2x2   : backward of F.interpolate(scale_factor=2, mode="nearest") (model.py:264-265)
+//                  fused with the LeakyReLU backward of the producer
+//   add_inplace  : skip-connection gradient merge (model.py:262)
+// All are one-pass, 16-byte vectorised where the layout allows; each thread owns one pixel.
+#include "common.h"
+
+namespace resr {
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                           int n, int c, int h, int w, int r, int c_pad,
+                                                           const uint8_t* __restrict__ mask) {
+    // output pixel grid is (h/r) x (w/r); output channel = ch*r*r + i*r + j  (torch pixel_unshuffle)
+    const int ho = h / r, wo = w / r;
+    const long total = (long)n * ho * wo;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const int xo = (int)(p % wo);
+    const int yo = (int)((p / wo) % ho);
+    const int b = (int)(p / ((long)wo * ho));
+    T* o = dst + p * c_pad;
+    const int creal = c * r * r;
+    for (int co = 0; co < c_pad; ++co) {
+        float v = 0.f;
+        if (co < creal) {
+            const int ch = co / (r * r), ij = co % (r * r), i = ij / r, j = ij % r;
+            const size_t q = (((size_t)b * c + ch) * h + (yo * r + i)) * w + (xo * r + j);
+            v = src[q];
+            if (mask) v = mask[q] ? v : 0.f;
+        }
+        o[co] = (T)v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst,
+                                                           int n, int c, int h, int w, int r, int src_stride) {
+    // src pixel grid (h/r) x (w/r) with c*r*r channels; dst [n,c,h,w]
+    const long total = (long)n * c * h * w;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const int x = (int)(q % w);
+    const int y = (int)((q / w) % h);
+    const int ch = (int)((q / ((long)w * h)) % c);
+    const int b = (int)(q / ((long)w * h * c));
+    const int ho = h / r, wo = w / r;
+    const int co = ch * r * r + (y % r) * r + (x % r);
+    const size_t p = ((size_t)b * ho + y / r) * wo + x / r;
+    dst[q] = (float)src[p * src_stride + co];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                         const T* __restrict__ mask, int n, int ho, int wo, int c,
+                                                         float slope) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const int groups = c / E;
+    const long total = (long)n * ho * wo * groups;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int g = (int)(t % groups);
+    const long p = t / groups;
+    const int x = (int)(p % wo);
+    const int y = (int)((p / wo) % ho);
+    const int b = (int)(p / ((long)wo * ho));
+    const int wi = wo * 2;
+    const T* s = src + (((size_t)b * ho * 2 + y * 2) * wi + x * 2) * c + g * E;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(s + ((size_t)dy * wi + dx) * c);
+            const T* v = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] += (float)v[e];
+        }
+    if (mask) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(mask + p * c + g * E);
+        const T* v = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] *= ((float)v[e] > 0.f ? 1.f : slope);
+    }
+    uint4 outv;
+    T* o = reinterpret_cast<T*>(&outv);
+#pragma unroll
+    for (int e = 0; e < E; ++e) o[e] = (T)acc[e];
+    *reinterpret_cast<uint4*>(dst + p * c + g * E) = outv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ src, long count) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * E;
+    if (i >= count) return;
+    uint4 a = *reinterpret_cast<const uint4*>(dst + i);
+    const uint4 b = *reinterpret_cast<const uint4*>(src + i);
+    T* pa = reinterpret_cast<T*>(&a);
+    const T* pb = reinterpret_cast<const T*>(&b);
+#pragma unroll
+    for (int e = 0; e < E; ++e) pa[e] = (T)((float)pa[e] + (float)pb[e]);
+    *reinterpret_cast<uint4*>(dst + i) = a;
+}
+
+static unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
+
+int nchw_to_nhwc_dispatch(const float* src, void* dst, int n, int c, int h, int w, int r, int c_pad, int dtype,
+                          const uint8_t* mask, hipStream_t stream) {
+    if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || r <= 0 || (h % r) || (w % r) || c * r * r > c_pad)
+        return fail(RESR_ERR_ARG, "nchw_to_nhwc: bad argument (c=%d r=%d c_pad=%d h=%d w=%d)", c, r, c_pad, h, w);
+    const long total = (long)n * (h / r) * (w / r);
+    if (dtype == RESR_F16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, src, (half_t*)dst, n, c, h, w, r, c_pad, mask);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, src, (float*)dst, n, c, h, w, r, c_pad, mask);
+    RESR_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+    return RESR_OK;
+}
+
+int nhwc_to_nchw_dispatch(const void* src, float* dst, int n, int c, int h, int w, int r, int src_stride, int dtype,
+                          hipStream_t stream) {
+    if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || r <= 0 || (h % r) || (w % r))
+        return fail(RESR_ERR_ARG, "nhwc_to_nchw: bad argument");
+    const long total = (long)n * c * h * w;
+    if (dtype == RESR_F16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, (const half_t*)src, dst, n, c, h, w, r, src_stride);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, (const float*)src, dst, n, c, h, w, r, src_stride);
+    RESR_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+    return RESR_OK;
+}
+
+int sumpool2x2_dispatch(const void* src, void* dst, const void* mask, int n, int ho, int wo, int c, int dtype,
+                        float slope, hipStream_t stream) {
+    const int E = dtype == RESR_F16 ? 8 : 4;
+    if (!src || !dst || n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || (c % E))
+        return fail(RESR_ERR_ARG, "sumpool2x2: bad argument");
+    const long total = (long)n * ho * wo * (c / E);
+    if (dtype == RESR_F16)
+        hipLaunchKernelGGL(sumpool2x2_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, (const half_t*)src, (half_t*)dst, (const half_t*)mask, n, ho, wo, c, slope);
+    else
+        hipLaunchKernelGGL(sumpool2x2_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, (const float*)src, (float*)dst, (const float*)mask, n, ho, wo, c, slope);
+    RESR_CHECK_LAUNCH("sumpool2x2_kernel");
+    return RESR_OK;
+}
+
+int add_inplace_dispatch(void* dst, const void* src, long count, int dtype, hipStream_t stream) {
+    const int E = dtype == RESR_F16 ? 8 : 4;
+    if (!dst || !src || count <= 0 || (count % E)) return fail(RESR_ERR_ARG, "add_inplace: bad argument");
+    const long total = count / E;
+    if (dtype == RESR_F16)
+        hipLaunchKernelGGL(add_inplace_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, (half_t*)dst, (const half_t*)src, count);
+    else
+        hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, (float*)dst, (const float*)src, count);
+    RESR_CHECK_LAUNCH("add_inplace_kernel");
+    return RESR_OK;
+}
+
+}  // namespace resr

@@ -1,0 +1,103 @@
+// pack.hip -- parameter-side kernels: weight packing into MFMA A-fragment order, EMA update.
+//
+// resr_pack_weights: the module keeps the reference's OIHW fp32 parameters (state_dict surface,
+// SURVEY.md §8b).  Every optimiser step they are re-packed (one launch for all 351 convs, both the
+// forward and the backward-data forms) into the order conv3x3.hip streams them:
+//     chunk (32 K-channels) -> tap (9) -> k-step -> M-tile -> lane (kh*32 + m) -> 16 bytes
+// so that a wave's A-fragment is one contiguous, coalesced 1 KiB load.
+// Backward-data chunks are gathered transposed (M = cin, K = cout) with flipped taps and an optional
+// scale (the 0.2 residual scalings of model.py:95,129 folded into the weights).
+#include "common.h"
+
+namespace resr {
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const ResrPackChunk* __restrict__ chunks,
+                                                   const float* __restrict__ arena, T* __restrict__ packed) {
+    constexpr int E = 16 / (int)sizeof(T);
+    constexpr int KS = 32 / E / 2;
+    const ResrPackChunk c = chunks[blockIdx.x];
+    const int total = 9 * c.mt * 1024;
+    T* dst = packed + c.dst_off;
+    const float* src = arena + c.src_off;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        int r = idx;
+        const int e = r % E; r /= E;
+        const int m = r % 32; r /= 32;
+        const int kh = r % 2; r /= 2;
+        const int mt = r % c.mt; r /= c.mt;
+        const int ks = r % KS; r /= KS;
+        const int tap = r;
+        const int k = (ks * 2 + kh) * E + e;
+        const int mm = mt * 32 + m;
+        float v = 0.f;
+        if (mm < c.m_count && k < c.k_count) {
+            if (!c.transposed) {
+                const int co = c.m_off + mm, ci = c.k_off + k;
+                v = src[((size_t)co * c.src_cin + ci) * 9 + tap];
+            } else {
+                const int ci = c.m_off + mm, co = c.k_off + k;
+                v = src[((size_t)co * c.src_cin + ci) * 9 + (8 - tap)];
+            }
+            v *= c.scale;
+        }
+        dst[idx] = (T)v;
+    }
+}
+
+int pack_dispatch(const ResrPackChunk* chunks_dev, int n_chunks, const float* arena, void* packed,
+                  int dtype, hipStream_t stream) {
+    if (!chunks_dev || !arena || !packed || n_chunks <= 0) return fail(RESR_ERR_ARG, "pack_weights: bad argument");
+    if (dtype == RESR_F16)
+        hipLaunchKernelGGL(pack_kernel<half_t>, dim3(n_chunks), dim3(256), 0, stream, chunks_dev, arena, (half_t*)packed);
+    else if (dtype == RESR_F32)
+        hipLaunchKernelGGL(pack_kernel<float>, dim3(n_chunks), dim3(256), 0, stream, chunks_dev, arena, (float*)packed);
+    else
+        return fail(RESR_ERR_ARG, "pack_weights: dtype=%d", dtype);
+    RESR_CHECK_LAUNCH("pack_kernel");
+    return RESR_OK;
+}
+
+// EMA.update (reference model.py:43-48): shadow = (1 - decay) * p + decay * shadow, evaluated as two
+// rounded products and one rounded sum (no FMA contraction) so it is bit-identical to the reference.
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ shadow, const float* __restrict__ p,
+                                                  long count, float one_minus, float decay) {
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < count; i += stride) {
+        if (i + 4 <= count) {
+            const float4v a = *reinterpret_cast<const float4v*>(p + i);
+            float4v s = *reinterpret_cast<const float4v*>(shadow + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] = __fadd_rn(__fmul_rn(one_minus, a[j]), __fmul_rn(decay, s[j]));
+            *reinterpret_cast<float4v*>(shadow + i) = s;
+        } else {
+            for (long j = i; j < count; ++j) shadow[j] = __fadd_rn(__fmul_rn(one_minus, p[j]), __fmul_rn(decay, shadow[j]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ema_scalar_kernel(float* __restrict__ shadow, const float* __restrict__ p,
+                                                         long count, float one_minus, float decay) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) shadow[i] = __fadd_rn(__fmul_rn(one_minus, p[i]), __fmul_rn(decay, shadow[i]));
+}
+
+int ema_dispatch(float* shadow, const float* params, long count, double decay, hipStream_t stream) {
+    if (!shadow || !params || count <= 0) return fail(RESR_ERR_ARG, "ema_update: bad argument");
+    if ((reinterpret_cast<uintptr_t>(shadow) | reinterpret_cast<uintptr_t>(params)) & 15) {
+        // unaligned per-tensor call: peel to the scalar tail path by treating every element as tail
+        hipLaunchKernelGGL(ema_scalar_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, shadow,
+                           params, count, (float)(1.0 - decay), (float)decay);
+        RESR_CHECK_LAUNCH("ema_scalar_kernel");
+        return RESR_OK;
+    }
+    long blocks = (count / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, shadow, params, count,
+                       (float)(1.0 - decay), (float)decay);
+    RESR_CHECK_LAUNCH("ema_kernel");
+    return RESR_OK;
+}
+
+}  // namespace resr

@@ -1,0 +1,345 @@
+"""MI355X-native networks behind the reference's `model.py` surface.
+
+Same class names, constructor arguments, forward semantics and state_dict keys as the reference
+(`Generator`, `ResidualDenseBlock`, `ResidualResidualDenseBlock`, `EMA`; reference model.py:22-27),
+but `forward`/`backward` are one C-ABI call each into libresr_hip.so (include/resr.h), which
+enqueues the hand-written gfx950 kernels.  There is no PyTorch/CPU fallback: CPU tensors raise.
+
+Parameters stay OIHW fp32 `nn.Parameter`s (optimiser / checkpoint surface) but are *views into
+one flat arena* in reference `named_parameters()` order, so weight packing, EMA and the
+data-parallel all-reduce are single passes over contiguous HBM.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+__all__ = ["EMA", "ResidualDenseBlock", "ResidualResidualDenseBlock", "Generator"]
+
+
+def _precision_to_dtype(precision: str) -> int:
+    if precision == "fast":
+        return _lib.RESR_F16
+    if precision == "strict":
+        return _lib.RESR_F32
+    raise ValueError(f"precision must be 'fast' (f16 MFMA, fp32 accumulate) or 'strict' (f32 MFMA), got {precision!r}")
+
+
+class ResidualDenseBlock(nn.Module):
+    """Parameter container for one dense block (reference model.py:64-106).
+
+    The convs are `nn.Conv2d` objects so that construction consumes the RNG exactly like the
+    reference (same weights under the same seed) and the state_dict keys match; the arithmetic
+    runs inside `Generator.forward`."""
+
+    def __init__(self, channels: int, growth_channels: int) -> None:
+        super().__init__()
+        self.conv1 = nn.Conv2d(channels + growth_channels * 0, growth_channels, (3, 3), (1, 1), (1, 1))
+        self.conv2 = nn.Conv2d(channels + growth_channels * 1, growth_channels, (3, 3), (1, 1), (1, 1))
+        self.conv3 = nn.Conv2d(channels + growth_channels * 2, growth_channels, (3, 3), (1, 1), (1, 1))
+        self.conv4 = nn.Conv2d(channels + growth_channels * 3, growth_channels, (3, 3), (1, 1), (1, 1))
+        self.conv5 = nn.Conv2d(channels + growth_channels * 4, channels, (3, 3), (1, 1), (1, 1))
+        self.leaky_relu = nn.LeakyReLU(0.2, True)
+        self.identity = nn.Identity()
+        for m in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):  # model.py:100-106
+            nn.init.kaiming_normal_(m.weight)
+            m.weight.data *= 0.1
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):  # pragma: no cover
+        raise RuntimeError("ResidualDenseBlock is fused into Generator.forward on MI355X; call the Generator")
+
+
+class ResidualResidualDenseBlock(nn.Module):
+    """Parameter container for one RRDB (reference model.py:109-132)."""
+
+    def __init__(self, channels: int, growth_channels: int) -> None:
+        super().__init__()
+        self.rdb1 = ResidualDenseBlock(channels, growth_channels)
+        self.rdb2 = ResidualDenseBlock(channels, growth_channels)
+        self.rdb3 = ResidualDenseBlock(channels, growth_channels)
+
+    def forward(self, x):  # pragma: no cover
+        raise RuntimeError("ResidualResidualDenseBlock is fused into Generator.forward on MI355X; call the Generator")
+
+
+class _Workspace:
+    """One activation workspace; `busy` while an autograd graph that saved into it is alive."""
+
+    def __init__(self, nbytes: int, device) -> None:
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.busy = False
+
+
+class _GeneratorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module: "Generator", x: torch.Tensor, *params: torch.Tensor):
+        training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        y, desc, ws = module._run_forward(x, training)
+        ctx.module, ctx.desc, ctx.ws = module, desc, ws
+        ctx.x_needs_grad = x.requires_grad
+        if training:
+            ws.busy = True
+            ctx._token = _WsToken(ws)   # frees the workspace when the graph is dropped without backward
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: torch.Tensor):
+        module: Generator = ctx.module
+        grads, gx = module._run_backward(ctx.desc, ctx.ws, gy.contiguous().float(), ctx.x_needs_grad)
+        ctx.ws.busy = False
+        return (None, gx) + tuple(grads)
+
+
+class _WsToken:
+    def __init__(self, ws: _Workspace) -> None:
+        self.ws = ws
+
+    def __del__(self) -> None:
+        self.ws.busy = False
+
+
+class Generator(nn.Module):
+    """RRDBNet generator (reference model.py:206-275) on hand-written gfx950 kernels.
+
+    Args mirror the reference: Generator(in_channels, out_channels, upscale_factor) with
+    upscale_factor in {1, 2, 4}.  Extra keyword `precision`: "fast" = f16 operands on
+    v_mfma_f32_32x32x16_f16 with fp32 accumulation (the reference's CUDA-autocast numerics class),
+    "strict" = f32 operands on v_mfma_f32_32x32x2_f32 (parity gate vs the fp32 CPU oracle).
+    Default from $RESR_PRECISION, else "fast".
+    forward(x[N,C,H,W] float in [0,1]) -> [N,out,H*s,W*s] clamped to [0,1]; differentiable.
+    """
+
+    N_BLOCKS = 23
+
+    def __init__(self, in_channels: int, out_channels: int, upscale_factor: int,
+                 precision: Optional[str] = None, n_blocks: Optional[int] = None) -> None:
+        super().__init__()
+        if upscale_factor not in (1, 2, 4):
+            raise ValueError("upscale_factor must be 1, 2 or 4")
+        self.in_channels, self.out_channels, self.upscale_factor = in_channels, out_channels, upscale_factor
+        self.precision = precision or os.environ.get("RESR_PRECISION", "fast")
+        self._dtype = _precision_to_dtype(self.precision)
+        self.n_blocks = n_blocks or self.N_BLOCKS
+        if upscale_factor == 2:
+            conv_in, downscale_factor = in_channels * 4, 2
+        elif upscale_factor == 1:
+            conv_in, downscale_factor = in_channels * 16, 4
+        else:
+            conv_in, downscale_factor = in_channels, 1
+        # same construction order as the reference so the RNG stream (hence the init) is identical
+        self.downsampling = nn.PixelUnshuffle(downscale_factor)
+        self.conv1 = nn.Conv2d(conv_in, 64, (3, 3), (1, 1), (1, 1))
+        self.trunk = nn.Sequential(*[ResidualResidualDenseBlock(64, 32) for _ in range(self.n_blocks)])
+        self.conv2 = nn.Conv2d(64, 64, (3, 3), (1, 1), (1, 1))
+        self.upsampling1 = nn.Sequential(nn.Conv2d(64, 64, (3, 3), (1, 1), (1, 1)), nn.LeakyReLU(0.2, True))
+        self.upsampling2 = nn.Sequential(nn.Conv2d(64, 64, (3, 3), (1, 1), (1, 1)), nn.LeakyReLU(0.2, True))
+        self.conv3 = nn.Sequential(nn.Conv2d(64, 64, (3, 3), (1, 1), (1, 1)), nn.LeakyReLU(0.2, True))
+        self.conv4 = nn.Conv2d(64, out_channels, (3, 3), (1, 1), (1, 1))
+
+        self._flat: Optional[torch.Tensor] = None        # fp32 parameter arena
+        self._flat_grad: Optional[torch.Tensor] = None   # fp32 gradient arena (written by backward)
+        self._packed: Optional[torch.Tensor] = None
+        self._table_dev: Dict[int, tuple] = {}
+        self._workspaces: Dict[tuple, List[_Workspace]] = {}
+        self.grad_hook = None   # callable(flat_grad) run after backward wrote the arena (data-parallel all-reduce)
+
+    # ---- flat arena ---------------------------------------------------------------------------
+    def _ordered_params(self) -> List[nn.Parameter]:
+        return [p for _, p in self.named_parameters()]
+
+    def _flatten(self) -> None:
+        params = self._ordered_params()
+        dev = params[0].device
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1).float())
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        self._flat = flat
+        self._flat_grad = None
+        self._packed = None
+        self._table_dev.clear()
+        self._workspaces.clear()
+
+    def _arena_ok(self) -> bool:
+        if self._flat is None:
+            return False
+        params = self._ordered_params()
+        base = self._flat.data_ptr()
+        off = 0
+        for p in params:
+            if p.data_ptr() != base + off * 4 or p.dtype != torch.float32:
+                return False
+            off += p.numel()
+        return off == self._flat.numel()
+
+    def flat_parameters(self) -> torch.Tensor:
+        """The fp32 arena all parameters are views of (reference named_parameters order)."""
+        if not self._arena_ok():
+            self._flatten()
+        return self._flat
+
+    def flat_grad(self) -> Optional[torch.Tensor]:
+        return self._flat_grad
+
+    # ---- C-ABI plumbing -------------------------------------------------------------------------
+    def _desc(self, x: torch.Tensor, training: bool) -> _lib.GeneratorDesc:
+        n, c, h, w = x.shape
+        if c != self.in_channels:
+            raise RuntimeError(f"Generator: expected {self.in_channels} input channels, got {c}")
+        return _lib.GeneratorDesc(n, h, w, self.in_channels, self.out_channels, self.upscale_factor,
+                                  self.n_blocks, self._dtype, 1 if training else 0,
+                                  int(os.environ.get("RESR_WGRAD_SPLITS", "0")))
+
+    def _pack(self, desc: _lib.GeneratorDesc, backward: bool) -> None:
+        L = _lib.lib()
+        flat = self.flat_parameters()
+        key = 1 if backward else 0
+        if key not in self._table_dev:
+            n = L.resr_generator_pack_table(C.byref(desc), key, None, 0)
+            if n <= 0:
+                _lib.check(int(n) if n < 0 else -1, "resr_generator_pack_table")
+            host = (_lib.PackChunk * n)()
+            n2 = L.resr_generator_pack_table(C.byref(desc), key, C.cast(host, C.c_void_p), n)
+            assert n2 == n
+            raw = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(flat.device)
+            self._table_dev[key] = (raw, int(n))
+        nbytes = L.resr_generator_packed_bytes(C.byref(desc), 1)
+        if self._packed is None or self._packed.numel() < nbytes or self._packed.device != flat.device:
+            self._packed = torch.zeros(nbytes, dtype=torch.uint8, device=flat.device)
+        raw, n = self._table_dev[key]
+        _lib.check(L.resr_pack_weights(_lib.ptr(raw), n, _lib.ptr(flat), _lib.ptr(self._packed), self._dtype,
+                                       _lib.stream_ptr()), "resr_pack_weights")
+
+    def _workspace(self, desc: _lib.GeneratorDesc, device) -> _Workspace:
+        L = _lib.lib()
+        key = (desc.n, desc.h, desc.w, desc.training, desc.dtype, desc.wgrad_splits)
+        pool = self._workspaces.setdefault(key, [])
+        for ws in pool:
+            if not ws.busy:
+                return ws
+        nbytes = L.resr_generator_workspace_bytes(C.byref(desc))
+        if nbytes == 0:
+            raise RuntimeError("resr_generator_workspace_bytes: unsupported shape")
+        ws = _Workspace(nbytes, device)
+        pool.append(ws)
+        return ws
+
+    def _run_forward(self, x: torch.Tensor, training: bool):
+        _lib.require_cuda(x, "Generator.forward")
+        L = _lib.lib()
+        flat = self.flat_parameters()
+        _lib.require_cuda(flat, "Generator parameters")
+        xc = x.detach().float().contiguous()  # also normalises channels_last strides (inference.py:28,49)
+        desc = self._desc(xc, training)
+        self._pack(desc, backward=training)
+        ws = self._workspace(desc, xc.device)
+        s = self.upscale_factor
+        y = torch.empty((desc.n, self.out_channels, desc.h * s, desc.w * s), dtype=torch.float32, device=xc.device)
+        _lib.check(L.resr_generator_forward(C.byref(desc), _lib.ptr(xc), _lib.ptr(flat), _lib.ptr(self._packed),
+                                            _lib.ptr(ws.buf), ws.buf.numel(), _lib.ptr(y), _lib.stream_ptr()),
+                   "resr_generator_forward")
+        return y, desc, ws
+
+    def _run_backward(self, desc, ws: _Workspace, gy: torch.Tensor, need_gx: bool):
+        L = _lib.lib()
+        flat = self.flat_parameters()
+        if self._flat_grad is None or self._flat_grad.device != flat.device:
+            self._flat_grad = torch.zeros_like(flat)
+        gx = None
+        if need_gx:
+            gx = torch.empty((desc.n, self.in_channels, desc.h, desc.w), dtype=torch.float32, device=gy.device)
+        _lib.check(L.resr_generator_backward(C.byref(desc), _lib.ptr(gy), _lib.ptr(flat), _lib.ptr(self._packed),
+                                             _lib.ptr(ws.buf), ws.buf.numel(), _lib.ptr(self._flat_grad),
+                                             _lib.ptr(gx), _lib.stream_ptr(), None),
+                   "resr_generator_backward")
+        if self.grad_hook is not None:
+            self.grad_hook(self._flat_grad)
+        grads, off = [], 0
+        for p in self._ordered_params():
+            n = p.numel()
+            grads.append(self._flat_grad[off:off + n].view(p.shape) if p.requires_grad else None)
+            off += n
+        return grads, gx
+
+    # ---- module surface ---------------------------------------------------------------------------
+    def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
+        self.flat_parameters()
+        return _GeneratorFn.apply(self, x, *self._ordered_params())
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._forward_impl(x)
+
+
+class EMA(nn.Module):
+    """Exponential moving average of a model's trainable parameters (reference model.py:30-61).
+
+    Same surface (`register/update/apply_shadow/restore`, `.shadow`, `.backup` dicts).  When the
+    wrapped model exposes `flat_parameters()` the update is one fused launch over the flat arena
+    (resr_ema_update) that reproduces the reference's rounding: (1-d)*p and d*shadow rounded
+    separately, then added."""
+
+    def __init__(self, model: nn.Module, weight_decay: float) -> None:
+        super().__init__()
+        self.model = model
+        self.weight_decay = weight_decay
+        self.shadow: Dict[str, torch.Tensor] = {}
+        self.backup: Dict[str, torch.Tensor] = {}
+        self._flat_shadow: Optional[torch.Tensor] = None
+
+    def _flat_ok(self) -> bool:
+        return (hasattr(self.model, "flat_parameters")
+                and all(p.requires_grad for p in self.model.parameters()))
+
+    def register(self) -> None:
+        if self._flat_ok():
+            flat = self.model.flat_parameters()
+            _lib.require_cuda(flat, "EMA.register")
+            self._flat_shadow = flat.detach().clone()
+            off = 0
+            self.shadow = {}
+            for name, p in self.model.named_parameters():
+                n = p.numel()
+                self.shadow[name] = self._flat_shadow[off:off + n].view(p.shape)
+                off += n
+            return
+        for name, param in self.model.named_parameters():
+            if param.requires_grad:
+                _lib.require_cuda(param, "EMA.register")
+                self.shadow[name] = param.data.clone()
+
+    def update(self) -> None:
+        if self._flat_shadow is not None and self._flat_ok():
+            flat = self.model.flat_parameters()
+            _lib.check(_lib.lib().resr_ema_update(_lib.ptr(self._flat_shadow), _lib.ptr(flat), flat.numel(),
+                                                  float(self.weight_decay), _lib.stream_ptr()), "resr_ema_update")
+            return
+        for name, param in self.model.named_parameters():
+            if param.requires_grad:
+                assert name in self.shadow
+                s = self.shadow[name]
+                _lib.check(_lib.lib().resr_ema_update(_lib.ptr(s), _lib.ptr(param.data.contiguous()), s.numel(),
+                                                      float(self.weight_decay), _lib.stream_ptr()), "resr_ema_update")
+
+    def apply_shadow(self) -> None:
+        for name, param in self.model.named_parameters():
+            if param.requires_grad:
+                assert name in self.shadow
+                self.backup[name] = param.data
+                param.data = self.shadow[name]
+
+    def restore(self) -> None:
+        for name, param in self.model.named_parameters():
+            if param.requires_grad:
+                assert name in self.backup
+                param.data = self.backup[name]

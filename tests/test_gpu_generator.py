@@ -1,0 +1,90 @@
+"""-m gpu parity of the whole generator (forward + backward) against the CPU oracle."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(upscale, n_blocks, seed, precision):
+    import real_esrgan_pytorch_amd as R
+    from oracle import model_ref as M
+    sd = M.init_generator_state(seed, 3, 3, upscale, bias_noise=0.02)
+    sd = {k: v for k, v in sd.items() if not k.startswith("trunk.") or int(k.split(".")[1]) < n_blocks}
+    sd["conv4.bias"] = sd["conv4.bias"] + 0.5     # centre the output inside the clamp range
+    g = R.Generator(3, 3, upscale, precision=precision, n_blocks=n_blocks)
+    g.load_state_dict(sd)
+    return g.cuda(), sd, M
+
+
+CASES = [(4, 23, 1, 24, 24), (4, 2, 1, 20, 24), (4, 1, 2, 33, 17), (2, 1, 1, 24, 40), (1, 1, 1, 16, 32)]
+
+
+@pytest.mark.parametrize("precision", ["strict", "fast"])
+@pytest.mark.parametrize("upscale,n_blocks,n,h,w", CASES)
+def test_generator_forward_backward(upscale, n_blocks, n, h, w, precision, diag_dir):
+    g, sd, M = _setup(upscale, n_blocks, 11, precision)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(n, 3, h, w, generator=gen)
+    gw = torch.randn(n, 3, h * upscale, w * upscale, generator=gen)
+
+    # oracle (CPU fp32 autograd)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = M.generator_forward(xo, sdo, upscale, n_blocks)
+    (yo * gw).sum().backward()
+
+    xd = x.cuda().requires_grad_(True)
+    y = g(xd)
+    (y * gw.cuda()).sum().backward()
+    torch.cuda.synchronize()
+
+    tol_y = 1e-3 if precision == "strict" else 2e-2      # north_star: 1e-3 max-abs vs the CPU path
+    err_y = (y.detach().cpu() - yo.detach()).abs().max().item()
+    rep = {"err_y": err_y, "frac_unclamped": ((yo > 0) & (yo < 1)).float().mean().item()}
+    worst = 0.0
+    for name, p in g.named_parameters():
+        ref = sdo[name].grad
+        e = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+        rep["g_" + name] = e
+        worst = max(worst, e)
+    egx = (xd.grad.cpu() - xo.grad).abs().max().item() / max(xo.grad.abs().max().item(), 1e-6)
+    rep["gx"] = egx
+    with open(os.path.join(diag_dir, f"gen_{precision}_{upscale}_{n_blocks}_{n}.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    rep_std = yo.std().item()
+    assert err_y < tol_y, f"forward max abs err {err_y}"
+    if precision == "strict":
+        assert err_y < 5e-5, f"strict forward err {err_y} (output std {rep_std})"
+    tol_g = 2e-3 if precision == "strict" else 8e-2      # relative to each gradient tensor's max
+    assert worst < tol_g and egx < tol_g, f"worst rel grad err {worst}, gx {egx}"
+
+
+def test_generator_inference_matches_training_forward():
+    g, sd, M = _setup(4, 3, 3, "strict")
+    x = torch.rand(1, 3, 40, 36).cuda()
+    with torch.no_grad():
+        y0 = g(x)                      # rotating-workspace inference plan
+    y1 = g(x.clone().requires_grad_(True))   # saved-activation training plan
+    assert torch.equal(y0, y1.detach())
+    yo = M.generator_forward(x.cpu(), sd, 4, 3)
+    assert (y0.cpu() - yo).abs().max().item() < 1e-3
+
+
+def test_state_dict_surface_and_channels_last():
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(0)
+    g = R.Generator(3, 3, 4, precision="strict", n_blocks=1)
+    keys = list(g.state_dict().keys())
+    assert keys[:2] == ["conv1.weight", "conv1.bias"] and "trunk.0.rdb3.conv5.bias" in keys
+    assert "upsampling1.0.weight" in keys and "conv3.0.bias" in keys and keys[-1] == "conv4.bias"
+    g = g.to(memory_format=torch.channels_last, device="cuda")     # reference inference.py:28
+    x = torch.rand(1, 3, 16, 16).cuda()
+    with torch.no_grad():
+        a = g(x)
+        b = g(x.to(memory_format=torch.channels_last))              # reference inference.py:49
+    assert torch.equal(a, b) and a.shape == (1, 3, 64, 64)
+    with pytest.raises(RuntimeError):
+        g(x.cpu())

@@ -1,0 +1,207 @@
+"""-m gpu parity tests of the individual kernels, through the C-ABI, against plain fp32 torch on
+the CPU (the same ops the oracle is made of) on seeded inputs."""
+import ctypes as C
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def U():
+    import tests.gpu_util as U
+    return U
+
+
+def _tol(dtype, U):
+    return 2e-2 if dtype == U.L.RESR_F16 else 2e-4
+
+
+def test_tr_probe(U, diag_dir):
+    out = torch.zeros(256, device="cuda")
+    U.L.check(U.L.lib().resr_debug_tr_probe(U.L.ptr(out), U.L.stream_ptr()))
+    got = out.cpu().view(64, 4).long()
+    with open(os.path.join(diag_dir, "tr_probe.json"), "w") as f:
+        json.dump(got.tolist(), f)
+    # assumed semantics (wgrad.hip): within a 16-lane group whose lanes point at consecutive
+    # 8-byte pieces of a row-major [4][16] block, lane n receives column n: elements n + 16*j
+    exp = torch.tensor([[(l & 15) + 16 * j + (l >> 4) * 64 for j in range(4)] for l in range(64)])
+    assert torch.equal(got, exp), got[:20].tolist()
+
+
+CONV_CASES = [
+    # name, cin, cin0, cout, flags(str), n, h, w
+    ("rdb_conv1", 64, 64, 32, "lrelu", 2, 19, 45),
+    ("rdb_conv3_2seg", 128, 64, 32, "lrelu", 1, 33, 32),
+    ("rdb_conv5_res", 192, 192, 64, "res0,res1", 2, 16, 70),
+    ("up_conv", 64, 64, 64, "lrelu,up", 1, 36, 40),
+    ("conv4_nchw", 64, 64, 3, "nchw,clamp", 2, 21, 37),
+    ("dgrad_mask", 96, 64, 32, "mask,nobias,res0", 1, 17, 64),
+    ("big_tiles", 64, 64, 32, "lrelu", 1, 256, 64),
+]
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "f16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3x3(U, case, dtype_name, diag_dir):
+    L = U.L
+    dtype = L.RESR_F16 if dtype_name == "f16" else L.RESR_F32
+    name, cin, cin0, cout, fl, n, h, w = case
+    fl = set(fl.split(","))
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    hs, ws = (h // 2, w // 2) if "up" in fl else (h, w)
+    x = U.quant(torch.randn(n, cin, hs, ws, generator=g), dtype)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    cout_pad = (cout + 31) // 32 * 32
+    # two-segment input: channels [0,cin0) in tensor A (stride cin0+32, offset 0), rest in tensor B
+    a = U.to_nhwc(x[:, :cin0], dtype, stride=cin0 + 32)
+    b = U.to_nhwc(x[:, cin0:], dtype, stride=cin - cin0 + 64, offset=32) if cin0 < cin else None
+    packed = U.pack_conv(wt, dtype)
+    flags = 0
+    d = L.ConvDesc(n, h, w, cin, cin0, cin0 + 32, (cin - cin0 + 64) if b is not None else 0, cout, cout_pad,
+                   cout_pad + 32, 0, 0, 0, dtype, 0, 1.0, 1.0, 1.0, 1.0, 0.2)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if "up" in fl else x
+    ref = F.conv2d(xin, U.quant(wt, dtype), None if "nobias" in fl else bias, padding=1)
+    res0 = res1 = mask = None
+    if "up" in fl:
+        flags |= L.CONV_UPSAMPLE_IN
+    if "nobias" in fl:
+        flags |= L.CONV_NO_BIAS
+    if "mask" in fl:
+        mk = U.quant(torch.randn(n, cout, h, w, generator=g), dtype)
+        mask = U.to_nhwc(mk, dtype, stride=cout + 32)
+        d.mask_stride = cout + 32
+        flags |= L.CONV_MASK
+        ref = ref * torch.where(mk > 0, 1.0, 0.2)
+    if "lrelu" in fl:
+        flags |= L.CONV_LRELU
+        ref = F.leaky_relu(ref, 0.2)
+    if "res0" in fl:
+        r0 = U.quant(torch.randn(n, cout, h, w, generator=g), dtype)
+        res0 = U.to_nhwc(r0, dtype, stride=cout + 64)
+        d.res0_stride, d.s0, d.t0 = cout + 64, 0.2, 1.0
+        ref = ref * 0.2 + r0
+    if "res1" in fl:
+        r1 = U.quant(torch.randn(n, cout, h, w, generator=g), dtype)
+        res1 = U.to_nhwc(r1, dtype, stride=cout)
+        d.res1_stride, d.s1, d.t1 = cout, 0.2, 0.5
+        ref = ref * 0.2 + 0.5 * r1
+    aux = None
+    if "nchw" in fl:
+        flags |= L.CONV_OUT_NCHW_F32
+        out = torch.full((n, cout, h, w), -7.0, device="cuda")
+        if "clamp" in fl:
+            flags |= L.CONV_CLAMP01
+            aux = torch.full((n, cout, h, w), 9, dtype=torch.uint8, device="cuda")
+            ref_mask = ((ref >= 0) & (ref <= 1))
+            ref = ref.clamp(0, 1)
+    else:
+        out = torch.full((n, h, w, cout_pad + 32), -7.0, dtype=U.tdtype(dtype), device="cuda")
+    d.flags = flags
+    L.check(L.lib().resr_conv3x3(C.byref(d), L.ptr(a), L.ptr(b) if b is None else U.sptr(b, 32), L.ptr(packed),
+                                 L.ptr(bias.cuda()), L.ptr(res0), L.ptr(res1), L.ptr(mask), L.ptr(out), L.ptr(aux),
+                                 L.stream_ptr()), "resr_conv3x3")
+    torch.cuda.synchronize()
+    if "nchw" in fl:
+        got = out.cpu()
+    else:
+        got = U.from_nhwc(out, cout)
+        assert (out[..., cout_pad:].float() == -7.0).all(), "wrote outside its channel slice"
+    err = (got - ref).abs().max().item()
+    with open(os.path.join(diag_dir, f"conv_{name}_{dtype_name}.json"), "w") as f:
+        json.dump({"max_abs_err": err, "ref_absmax": ref.abs().max().item()}, f)
+    assert err < _tol(dtype, U) * max(1.0, ref.abs().max().item()), f"{name}/{dtype_name}: max abs err {err}"
+    if aux is not None:
+        am = aux.cpu().bool()
+        # pass-mask may differ only where the pre-clamp value is within rounding of 0 or 1
+        assert (am != ref_mask).float().mean().item() < 1e-3
+
+
+WGRAD_CASES = [
+    ("w_64_32", 64, 32, 0, 2, 19, 45),
+    ("w_192_64", 192, 64, 0, 1, 24, 40),
+    ("w_up", 64, 64, 1, 1, 16, 64),
+    ("w_cout3", 64, 3, 0, 1, 17, 33),
+    ("w_cin3", 3, 64, 0, 2, 12, 36),
+]
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "f16"])
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_wgrad(U, case, dtype_name, diag_dir):
+    L = U.L
+    dtype = L.RESR_F16 if dtype_name == "f16" else L.RESR_F32
+    name, cin, cout, up, n, h, w = case
+    g = torch.Generator().manual_seed(7)
+    hs, ws = (h // 2, w // 2) if up else (h, w)
+    x = U.quant(torch.randn(n, cin, hs, ws, generator=g), dtype)
+    gy = U.quant(torch.randn(n, cout, h, w, generator=g), dtype)
+    cin_pad, cout_pad = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+    xb = U.to_nhwc(x, dtype, c_pad=cin_pad, stride=cin_pad + 32)
+    gb = U.to_nhwc(gy, dtype, c_pad=cout_pad, stride=cout_pad + 32)
+    splits = 3
+    d = L.WgradDesc(n, h, w, cin_pad, cin_pad, cin_pad + 32, 0, cin, cout, cout_pad, cout_pad + 32, dtype,
+                    L.CONV_UPSAMPLE_IN if up else 0, splits, 0.5)
+    nbytes = L.lib().resr_wgrad_partial_bytes(C.byref(d))
+    partial = torch.empty(nbytes // 4, device="cuda")
+    dw = torch.full((cout, cin, 3, 3), -7.0, device="cuda")
+    db = torch.full((cout,), -7.0, device="cuda")
+    L.check(L.lib().resr_conv3x3_wgrad(C.byref(d), L.ptr(xb), None, L.ptr(gb), L.ptr(partial), L.ptr(dw), L.ptr(db),
+                                       L.stream_ptr()), "resr_conv3x3_wgrad")
+    torch.cuda.synchronize()
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    bs = torch.zeros(cout, requires_grad=True)
+    (F.conv2d(xin, wt, bs, padding=1) * gy).sum().backward()
+    ref_w, ref_b = wt.grad * 0.5, bs.grad * 0.5
+    err_w = (dw.cpu() - ref_w).abs().max().item()
+    err_b = (db.cpu() - ref_b).abs().max().item()
+    scale = max(1.0, ref_w.abs().max().item())
+    with open(os.path.join(diag_dir, f"wgrad_{name}_{dtype_name}.json"), "w") as f:
+        json.dump({"err_w": err_w, "err_b": err_b, "ref_absmax": scale}, f)
+    tol = 2e-3 if dtype == L.RESR_F16 else 2e-4
+    assert err_w < tol * scale, f"dW max abs err {err_w} (ref max {scale})"
+    assert err_b < tol * max(1.0, ref_b.abs().max().item()), f"db max abs err {err_b}"
+
+
+def test_layout_and_pool(U):
+    L = U.L
+    g = torch.Generator().manual_seed(3)
+    for dtype in (L.RESR_F32, L.RESR_F16):
+        x = torch.rand(2, 3, 8, 12, generator=g)
+        for r, cpad in ((1, 32), (2, 32), (4, 64)):
+            dst = torch.full((2, 8 // r, 12 // r, cpad), -1.0, dtype=U.tdtype(dtype), device="cuda")
+            L.check(L.lib().resr_nchw_to_nhwc(L.ptr(x.cuda()), L.ptr(dst), 2, 3, 8, 12, r, cpad, dtype, None,
+                                              L.stream_ptr()))
+            ref = F.pixel_unshuffle(x, r) if r > 1 else x
+            got = U.from_nhwc(dst, 3 * r * r)
+            assert torch.allclose(got, U.quant(ref, dtype), atol=0), (r, dtype)
+            assert (dst[..., 3 * r * r:] == 0).all()
+            back = torch.empty(2, 3, 8, 12, device="cuda")
+            L.check(L.lib().resr_nhwc_to_nchw(L.ptr(dst), L.ptr(back), 2, 3, 8, 12, r, cpad, dtype, L.stream_ptr()))
+            assert torch.allclose(back.cpu(), U.quant(x, dtype), atol=0)
+        src = U.quant(torch.randn(2, 64, 12, 20, generator=g), dtype)
+        mk = U.quant(torch.randn(2, 64, 6, 10, generator=g), dtype)
+        out = torch.empty(2, 6, 10, 64, dtype=U.tdtype(dtype), device="cuda")
+        L.check(L.lib().resr_sumpool2x2(L.ptr(U.to_nhwc(src, dtype)), L.ptr(out), L.ptr(U.to_nhwc(mk, dtype)), 2, 6, 10,
+                                        64, dtype, 0.2, L.stream_ptr()))
+        ref = F.avg_pool2d(src, 2) * 4 * torch.where(mk > 0, 1.0, 0.2)
+        assert (U.from_nhwc(out, 64) - ref).abs().max().item() < (2e-2 if dtype == L.RESR_F16 else 1e-5)
+
+
+def test_ema_bit_exact(U):
+    L = U.L
+    g = torch.Generator().manual_seed(5)
+    p = torch.randn(100003, generator=g)
+    s = torch.randn(100003, generator=g)
+    sd, pd = s.cuda(), p.cuda()
+    ref = s.clone()
+    for _ in range(3):
+        L.check(L.lib().resr_ema_update(L.ptr(sd), L.ptr(pd), sd.numel(), 0.999, L.stream_ptr()))
+        ref = (1.0 - 0.999) * p + 0.999 * ref     # reference model.py:47
+    assert torch.equal(sd.cpu(), ref)
