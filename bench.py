@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""bench.py -- x4 SR train images/sec (256x256 -> 1024x1024) on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one RealESRNet optimisation step (reference train_realesrnet.py:258-413 loop body) on a
+batch of synthetic HR tiles already resident in HBM: second-order degradation -> RRDBNet forward ->
+L1 -> backward (data + weight gradients) -> RCCL all-reduce of the flat gradient arena (N > 1) ->
+fused Adam -> EMA.  Rank 0 prints ONE JSON line (contract in the task statement) carrying
+`roofline` (dominant MFMA kernel, timed live with events on the launch stream) and `cpu_baseline`
+(the CPU oracle timed on the host cores, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MAC_PER_LR_PX = 17_926_848          # generator x4 forward MACs per LR pixel
+PEAK_F16_TFLOPS = 2500.0            # dense f16/bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--lr-size", type=int, default=256, help="LR tile edge; HR = 4x (headline: 256 -> 1024)")
+    ap.add_argument("--precision", default="fast", choices=["fast", "strict"])
+    ap.add_argument("--no-degradation", action="store_true", help="debug only: feed pre-degraded LR tiles")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true")
+    return ap.parse_args()
+
+
+def ensure_built():
+    lib = os.path.join(ROOT, "real_esrgan-pytorch_amd", "csrc", "libresr_hip.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+def conv_launch_table(batch, lr, n_blocks=23):
+    """(cin, cout, cout_pad, res_mult, flags) -> launches per train step, by kernel instance.
+    Mirrors generator.hip: forward convs + mirrored backward-data passes (weight-gradient kernels are
+    a different instance and are listed in DESIGN.md)."""
+    nrdb = 3 * n_blocks
+    t = {}
+
+    def add(cin, cout, cout_pad, mult, count):
+        t[(cin, cout, cout_pad, mult)] = t.get((cin, cout, cout_pad, mult), 0) + count
+
+    for cin in (64, 96, 128, 160):
+        add(cin, 32, 32, 1, 2 * nrdb)       # conv1..4 forward + backward passes g_o4..g_o1
+    add(192, 64, 64, 1, 2 * nrdb)           # conv5 forward + backward pass g_x
+    add(32, 64, 64, 1, 1)                   # conv1 forward (3 real input channels, padded to 32)
+    add(64, 64, 64, 1, 2)                   # conv2 fwd + bwd
+    add(64, 64, 64, 2, 2)                   # upsampling1 fwd + bwd
+    add(64, 64, 64, 4, 4)                   # upsampling2 + conv3, fwd + bwd
+    add(64, 3, 32, 4, 1)                    # conv4 forward
+    add(32, 64, 64, 4, 1)                   # conv4 backward-data
+    return t
+
+
+def probe_conv_kernels(batch, lr, dtype_name, reps=8):
+    """Time every conv3x3 launch shape of the step on the launch stream with events; returns rows."""
+    import real_esrgan_pytorch_amd as R
+    L = R._lib
+    lib = L.lib()
+    dtype = L.RESR_F16 if dtype_name == "fast" else L.RESR_F32
+    tdt = torch.float16 if dtype == L.RESR_F16 else torch.float32
+    rows = []
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for (cin, cout, cout_pad, mult), count in conv_launch_table(batch, lr).items():
+        h = w = lr * mult
+        x = (torch.rand(batch, h, w, cin, device="cuda", generator=gen) - 0.5).to(tdt)
+        y = torch.empty(batch, h, w, cout_pad, device="cuda", dtype=tdt)
+        yn = torch.empty(batch, max(cout, 1), h, w, device="cuda", dtype=torch.float32) if cout < 4 else None
+        mt = cout_pad // 32
+        # timing only: any finite weights in packed order will do (+ one tap of prefetch slack)
+        packed = ((torch.rand(((cin // 32) * 9 * mt * 1024 + 4096,), device="cuda", generator=gen) - 0.5) * 0.1).to(tdt)
+        flags = L.CONV_LRELU | (L.CONV_OUT_NCHW_F32 | L.CONV_CLAMP01 if yn is not None else 0)
+        d = L.ConvDesc(batch, h, w, cin, cin, cin, 0, cout, cout_pad, cout_pad, 0, 0, 0, dtype, flags,
+                       1.0, 1.0, 1.0, 1.0, 0.2)
+        out = yn if yn is not None else y
+        st = L.stream_ptr()
+
+        def launch():
+            L.check(lib.resr_conv3x3(C.byref(d), L.ptr(x), None, L.ptr(packed), None, None, None, None, L.ptr(out),
+                                     None, st), "resr_conv3x3")
+        for _ in range(2):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            launch()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        flop = 2.0 * 9 * cin * cout * batch * h * w
+        big = ((w + 31) // 32) * ((h + 15) // 16) * batch >= 512
+        inst = f"conv3x3_kernel<{'f16' if dtype == L.RESR_F16 else 'f32'},{mt},{4 if (mt == 1 and big and dtype == L.RESR_F16) else 2}>"
+        rows.append({"kernel": inst, "cin": cin, "cout": cout, "res": h, "launches_per_step": count,
+                     "ms": ms, "tflops": flop / ms / 1e9, "flop": flop})
+        del x, y, yn, packed
+    return rows
+
+
+def roofline_from_probe(rows, precision):
+    by = {}
+    for r in rows:
+        b = by.setdefault(r["kernel"], {"t": 0.0, "f": 0.0, "n": 0})
+        b["t"] += r["ms"] * r["launches_per_step"]
+        b["f"] += r["flop"] * r["launches_per_step"]
+        b["n"] += r["launches_per_step"]
+    name, b = max(by.items(), key=lambda kv: kv[1]["t"])
+    achieved = b["f"] / b["t"] / 1e9
+    peak = PEAK_F16_TFLOPS if precision == "fast" else PEAK_F32_TFLOPS
+    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "avg_launch_ms": round(b["t"] / b["n"], 4), "launches_per_step": b["n"],
+            "per_instance": {k: {"tflops": round(v["f"] / v["t"] / 1e9, 2), "ms_per_step": round(v["t"], 3),
+                                 "launches": v["n"]} for k, v in by.items()}}
+
+
+_CPU_BASELINE_SRC = r"""
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+import torch
+from oracle import model_ref as M
+threads = int(sys.argv[2]); lr_edge = int(sys.argv[3])
+torch.set_num_threads(threads)
+sd = M.init_generator_state(0)
+params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+opt = torch.optim.Adam(list(params.values()), 2e-4, (0.9, 0.99))
+gen = torch.Generator().manual_seed(1234)
+x = torch.rand(1, 3, lr_edge, lr_edge, generator=gen)
+hr = torch.rand(1, 3, lr_edge * 4, lr_edge * 4, generator=gen)
+times = []
+t_all = time.time()
+while len(times) < 4 and time.time() - t_all < 20.0:
+    t0 = time.time()
+    opt.zero_grad(set_to_none=True)
+    loss = (M.generator_forward(x, params, 4) - hr).abs().mean()
+    loss.backward()
+    opt.step()
+    times.append(time.time() - t0)
+print(json.dumps({"times": times}))
+"""
+
+
+def cpu_baseline(timeout_s=150.0):
+    """The CPU oracle (fp32 torch restatement of the reference, oracle/) on the host cores: generator
+    forward + backward + Adam on one image.  Runs in a child process with a hard timeout and a bounded
+    thread count (an unbounded torch thread pool on a 256-thread host was ~700x slower than 8 threads)."""
+    import subprocess
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 32))
+    lr_edge = 64
+    try:
+        r = subprocess.run([sys.executable, "-c", _CPU_BASELINE_SRC, ROOT, str(threads), str(lr_edge)],
+                           capture_output=True, text=True, timeout=timeout_s)
+        times = json.loads(r.stdout.strip().splitlines()[-1])["times"]
+    except Exception as e:
+        return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port",
+                "sample": f"CPU oracle step did not finish within {timeout_s:.0f} s ({type(e).__name__})"}
+    dt = min(times)
+    scale = (256 * 256) / float(lr_edge * lr_edge)      # work is linear in pixels
+    return {"value": round(1.0 / (dt * scale), 5), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"best of {len(times)} step(s) of generator fwd+bwd+Adam (fp32 torch CPU oracle, {threads} threads of "
+                      f"{avail} available) on 1 image {lr_edge}^2->{lr_edge * 4}^2: {dt:.2f} s/step, scaled x{scale:.0f} "
+                      "(work is linear in pixels) to the 256^2->1024^2 unit; degradation excluded (<2% of CPU step)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if rank == 0:
+        ensure_built()
+    if world > 1:
+        dist.barrier()
+
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd.train import DataParallel, RealESRNetStep
+
+    torch.manual_seed(0)                                  # reference config.py:64-66: same init on every rank
+    model = R.Generator(3, 3, 4, precision=args.precision).cuda()
+    model.train()
+    dp = DataParallel()
+    dp.attach(model)
+    ema = R.EMA(model, 0.999)                             # config.py:102
+    ema.register()
+    opt = torch.optim.Adam(model.parameters(), 2e-4, (0.9, 0.99), fused=True)   # config.py:100-101
+    scaler = torch.amp.GradScaler("cuda") if args.precision == "fast" else None  # train_realesrnet.py:97
+
+    B, lr_edge = args.batch, args.lr_size
+    hr_edge = lr_edge * 4
+    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    hr = torch.round(torch.rand(B, 3, hr_edge, hr_edge, device="cuda", generator=g) * 255.0) / 255.0
+
+    degrade = None
+    degradation = "none"
+    if not args.no_degradation:
+        try:
+            from real_esrgan_pytorch_amd.degrade import Degrader
+            degrade = Degrader(batch=B, hr_size=hr_edge, upscale=4, crop=hr_edge, seed=rank)
+            degradation = "hip"
+        except ImportError:
+            degradation = "missing"
+    lr_fixed = None
+    if degrade is None:
+        lr_fixed = torch.nn.functional.interpolate(hr, scale_factor=0.25, mode="area")
+    step = RealESRNetStep(model, ema, opt, scaler, degrade)
+
+    def one():
+        return step(hr, lr_fixed)
+
+    for _ in range(args.warmup):
+        one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    loss_v = float(loss)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        images = B * world * args.steps
+        value = images / dt
+        flop_per_image = 3 * 2 * MAC_PER_LR_PX * lr_edge * lr_edge
+        out = {
+            "metric": "x4 SR train images/sec (256->1024)", "value": round(value, 3), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if args.precision == "fast" else "f32", "data": "synthetic",
+            "config": {"workload": f"RealESRNet x4 L1 train step, RRDBNet 23 blocks, LR {lr_edge}^2 -> HR {hr_edge}^2, "
+                                   f"batch {B}/GPU, degradation={degradation}, Adam+EMA, GradScaler",
+                       "global_batch": B * world, "parallelism": f"dp{world}"},
+            "generator_tflops_per_gpu": round(value / world * flop_per_image / 1e12, 2),
+            "loss": loss_v,
+        }
+        if not args.no_probe:
+            try:
+                rows = probe_conv_kernels(B, lr_edge, args.precision)
+                out["roofline"] = roofline_from_probe(rows, args.precision)
+                out["conv_probe"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "flop"}
+                                     for r in rows]
+            except Exception as e:  # pragma: no cover
+                out["roofline"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # pragma: no cover
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

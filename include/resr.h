@@ -134,6 +134,9 @@ size_t resr_generator_workspace_bytes(const ResrGeneratorDesc* d);
  * then (if backward) the backward-data table; dst offsets are relative to one packed buffer */
 int64_t resr_generator_pack_table(const ResrGeneratorDesc* d, int32_t backward,
                                   ResrPackChunk* chunks, int64_t capacity);
+/* test aid: byte offsets inside the workspace of {x_in, ws[0], out1, trunk_out, feat, u1, u2, c3,
+ * ymask, g4, gA, gB, gM1, gF, gT0, gT1, gT2, gT3, gS, gxin, partial}; -1 = not allocated */
+int64_t resr_generator_buffer_offsets(const ResrGeneratorDesc* d, int64_t* out, int64_t capacity);
 int resr_generator_forward(const ResrGeneratorDesc* d, const float* x_nchw, const float* params,
                            const void* packed, void* workspace, size_t workspace_bytes,
                            float* y_nchw, void* stream);

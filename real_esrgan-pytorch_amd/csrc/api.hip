@@ -33,6 +33,7 @@ size_t generator_param_count(const ResrGeneratorDesc*);
 size_t generator_packed_bytes(const ResrGeneratorDesc*, int);
 size_t generator_workspace_bytes(const ResrGeneratorDesc*);
 int64_t generator_pack_table(const ResrGeneratorDesc*, int, ResrPackChunk*, int64_t);
+int64_t generator_buffer_offsets(const ResrGeneratorDesc*, int64_t*, int64_t);
 int generator_forward(const ResrGeneratorDesc*, const float*, const float*, const void*, void*, size_t, float*, hipStream_t);
 int generator_backward(const ResrGeneratorDesc*, const float*, const float*, const void*, void*, size_t, float*, float*,
                        hipStream_t, hipStream_t);
@@ -97,6 +98,10 @@ size_t resr_generator_packed_bytes(const ResrGeneratorDesc* d, int32_t backward)
 size_t resr_generator_workspace_bytes(const ResrGeneratorDesc* d) { return generator_workspace_bytes(d); }
 int64_t resr_generator_pack_table(const ResrGeneratorDesc* d, int32_t backward, ResrPackChunk* chunks, int64_t capacity) {
     return generator_pack_table(d, backward, chunks, capacity);
+}
+
+int64_t resr_generator_buffer_offsets(const ResrGeneratorDesc* d, int64_t* out, int64_t capacity) {
+    return generator_buffer_offsets(d, out, capacity);
 }
 
 int resr_generator_forward(const ResrGeneratorDesc* d, const float* x_nchw, const float* params, const void* packed,

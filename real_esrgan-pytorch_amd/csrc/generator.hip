@@ -15,6 +15,7 @@
 // Backward-data runs the *mirrored* dense block: gradients are laid out [g_y | g_o4 | g_o3 | g_o2 | g_o1]
 // so that every pass is again "3x3 conv over a channel prefix -> 32/64-channel slice" with the
 // transposed/flipped weights (pack.hip) -- no read-modify-write accumulation of partial input grads.
+#include <stdlib.h>
 #include <vector>
 
 #include "common.h"
@@ -235,6 +236,23 @@ size_t generator_workspace_bytes(const ResrGeneratorDesc* d) {
     return b.total;
 }
 
+// debug/test aid: byte offsets of the named workspace buffers (order documented in include/resr.h)
+int64_t generator_buffer_offsets(const ResrGeneratorDesc* d, int64_t* out, int64_t cap) {
+    Plan p;
+    if (!build_plan(d, p)) return fail(RESR_ERR_ARG, "generator: bad descriptor");
+    Bufs b;
+    char* base = reinterpret_cast<char*>(4096);  // fake non-null base, only differences are used
+    carve(p, base, b);
+    const char* ptrs[] = {b.x_in, b.ws[0], b.out1, b.trunk_out, b.feat, b.u1, b.u2, b.c3, (char*)b.ymask, b.g4, b.gA,
+                          b.gB, b.gM1, b.gF, b.gT[0], b.gT[1], b.gT[2], b.gT[3], b.gS, b.gxin, (char*)b.partial};
+    const int64_t n = sizeof(ptrs) / sizeof(ptrs[0]);
+    if (out) {
+        if (cap < n) return fail(RESR_ERR_ARG, "generator_buffer_offsets: capacity");
+        for (int64_t i = 0; i < n; ++i) out[i] = ptrs[i] ? (int64_t)(ptrs[i] - base) : -1;
+    }
+    return n;
+}
+
 int64_t generator_pack_table(const ResrGeneratorDesc* d, int backward, ResrPackChunk* out, int64_t cap) {
     Plan p;
     if (!build_plan(d, p)) return fail(RESR_ERR_ARG, "generator: bad descriptor");
@@ -297,10 +315,25 @@ int64_t generator_pack_table(const ResrGeneratorDesc* d, int backward, ResrPackC
     return (int64_t)t.size();
 }
 
+static int debug_stop() {
+    const char* e = getenv("RESR_DEBUG_STOP");
+    return e ? atoi(e) : 0;
+}
+
+static bool debug_sync() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("RESR_DEBUG_SYNC"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 #define RUN(expr)                 \
     do {                          \
         int rc_ = (expr);         \
         if (rc_ != RESR_OK) return rc_; \
+        if (debug_sync()) {       \
+            hipError_t e_ = hipStreamSynchronize(st); \
+            if (e_ != hipSuccess) return fail(RESR_ERR_LAUNCH, "%s: %s", #expr, hipGetErrorString(e_)); \
+        }                         \
     } while (0)
 
 int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* params, const void* packed,
@@ -425,6 +458,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         cd.mask_stride = 64;
         RUN(conv3x3_dispatch(&cd, b.gA, nullptr, pk + p.pk_bwd_conv3 * es, nullptr, nullptr, nullptr, b.u2, b.gB, nullptr, st));
     }
+    if (debug_stop() == 1) return RESR_OK;
     {   // upsampling2                                                      model.py:265
         const ConvSpec& c = p.convs[p.i_up2];
         RUN(wgrad(c, H4, W4, b.u1, 64, 64, b.gB, 64, RESR_CONV_UPSAMPLE_IN, 1.f));
@@ -432,6 +466,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         RUN(conv3x3_dispatch(&cd, b.gB, nullptr, pk + p.pk_bwd_up2 * es, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
         RUN(sumpool2x2_dispatch(b.gA, b.gM1, b.u1, N, H2, W2, 64, d->dtype, 0.2f, st));
     }
+    if (debug_stop() == 2) return RESR_OK;
     {   // upsampling1                                                      model.py:264
         const ConvSpec& c = p.convs[p.i_up1];
         RUN(wgrad(c, H2, W2, b.feat, 64, 64, b.gM1, 64, RESR_CONV_UPSAMPLE_IN, 1.f));
@@ -439,6 +474,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         RUN(conv3x3_dispatch(&cd, b.gM1, nullptr, pk + p.pk_bwd_up1 * es, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
         RUN(sumpool2x2_dispatch(b.gA, b.gF, nullptr, N, h, w, 64, d->dtype, 0.2f, st));
     }
+    if (debug_stop() == 3) return RESR_OK;
     int cur = 0;  // index into gT ring of the gradient wrt the current RDB's output chain
     {   // conv2                                                            model.py:261
         const ConvSpec& c = p.convs[p.i_conv2];
@@ -484,6 +520,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             cur = nxt;
         }
     }
+    if (debug_stop() == 4) return RESR_OK;
     // gradient wrt out1 = trunk path + skip (model.py:262)
     RUN(add_inplace_dispatch(b.gT[cur], b.gF, (long)N * h * w * 64, d->dtype, st));
     {   // conv1                                                            model.py:259

@@ -58,6 +58,14 @@ int pack_dispatch(const ResrPackChunk* chunks_dev, int n_chunks, const float* ar
     return RESR_OK;
 }
 
+// two rounded products, one rounded sum: the empty asm makes the products opaque so the compiler
+// cannot contract them into an FMA (HIP's default -ffp-contract=fast would)
+__device__ __forceinline__ float ema_step(float one_minus, float p, float decay, float s) {
+    float a = one_minus * p, b = decay * s;
+    asm volatile("" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 // EMA.update (reference model.py:43-48): shadow = (1 - decay) * p + decay * shadow, evaluated as two
 // rounded products and one rounded sum (no FMA contraction) so it is bit-identical to the reference.
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ shadow, const float* __restrict__ p,
@@ -68,10 +76,10 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ shadow, co
             const float4v a = *reinterpret_cast<const float4v*>(p + i);
             float4v s = *reinterpret_cast<const float4v*>(shadow + i);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[j] = __fadd_rn(__fmul_rn(one_minus, a[j]), __fmul_rn(decay, s[j]));
+            for (int j = 0; j < 4; ++j) s[j] = ema_step(one_minus, a[j], decay, s[j]);
             *reinterpret_cast<float4v*>(shadow + i) = s;
         } else {
-            for (long j = i; j < count; ++j) shadow[j] = __fadd_rn(__fmul_rn(one_minus, p[j]), __fmul_rn(decay, shadow[j]));
+            for (long j = i; j < count; ++j) shadow[j] = ema_step(one_minus, p[j], decay, shadow[j]);
         }
     }
 }
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ shadow, co
 __global__ __launch_bounds__(256) void ema_scalar_kernel(float* __restrict__ shadow, const float* __restrict__ p,
                                                          long count, float one_minus, float decay) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < count) shadow[i] = __fadd_rn(__fmul_rn(one_minus, p[i]), __fmul_rn(decay, shadow[i]));
+    if (i < count) shadow[i] = ema_step(one_minus, p[i], decay, shadow[i]);
 }
 
 int ema_dispatch(float* shadow, const float* params, long count, double decay, hipStream_t stream) {

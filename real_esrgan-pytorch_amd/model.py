@@ -79,8 +79,7 @@ class _Workspace:
 
 class _GeneratorFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module: "Generator", x: torch.Tensor, *params: torch.Tensor):
-        training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    def forward(ctx, module: "Generator", training: bool, x: torch.Tensor, *params: torch.Tensor):
         y, desc, ws = module._run_forward(x, training)
         ctx.module, ctx.desc, ctx.ws = module, desc, ws
         ctx.x_needs_grad = x.requires_grad
@@ -94,7 +93,7 @@ class _GeneratorFn(torch.autograd.Function):
         module: Generator = ctx.module
         grads, gx = module._run_backward(ctx.desc, ctx.ws, gy.contiguous().float(), ctx.x_needs_grad)
         ctx.ws.busy = False
-        return (None, gx) + tuple(grads)
+        return (None, None, gx) + tuple(grads)
 
 
 class _WsToken:
@@ -275,7 +274,10 @@ class Generator(nn.Module):
     # ---- module surface ---------------------------------------------------------------------------
     def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
         self.flat_parameters()
-        return _GeneratorFn.apply(self, x, *self._ordered_params())
+        params = self._ordered_params()
+        # grad mode is off inside autograd.Function.forward, so decide here whether to keep activations
+        training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return _GeneratorFn.apply(self, training, x, *params)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._forward_impl(x)

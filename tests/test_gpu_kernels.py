@@ -103,8 +103,9 @@ def test_conv3x3(U, case, dtype_name, diag_dir):
     else:
         out = torch.full((n, h, w, cout_pad + 32), -7.0, dtype=U.tdtype(dtype), device="cuda")
     d.flags = flags
+    bias_d = bias.cuda()
     L.check(L.lib().resr_conv3x3(C.byref(d), L.ptr(a), L.ptr(b) if b is None else U.sptr(b, 32), L.ptr(packed),
-                                 L.ptr(bias.cuda()), L.ptr(res0), L.ptr(res1), L.ptr(mask), L.ptr(out), L.ptr(aux),
+                                 L.ptr(bias_d), L.ptr(res0), L.ptr(res1), L.ptr(mask), L.ptr(out), L.ptr(aux),
                                  L.stream_ptr()), "resr_conv3x3")
     torch.cuda.synchronize()
     if "nchw" in fl:
@@ -176,8 +177,10 @@ def test_layout_and_pool(U):
         x = torch.rand(2, 3, 8, 12, generator=g)
         for r, cpad in ((1, 32), (2, 32), (4, 64)):
             dst = torch.full((2, 8 // r, 12 // r, cpad), -1.0, dtype=U.tdtype(dtype), device="cuda")
-            L.check(L.lib().resr_nchw_to_nhwc(L.ptr(x.cuda()), L.ptr(dst), 2, 3, 8, 12, r, cpad, dtype, None,
+            xd = x.cuda()
+            L.check(L.lib().resr_nchw_to_nhwc(L.ptr(xd), L.ptr(dst), 2, 3, 8, 12, r, cpad, dtype, None,
                                               L.stream_ptr()))
+            torch.cuda.synchronize()
             ref = F.pixel_unshuffle(x, r) if r > 1 else x
             got = U.from_nhwc(dst, 3 * r * r)
             assert torch.allclose(got, U.quant(ref, dtype), atol=0), (r, dtype)
@@ -188,8 +191,10 @@ def test_layout_and_pool(U):
         src = U.quant(torch.randn(2, 64, 12, 20, generator=g), dtype)
         mk = U.quant(torch.randn(2, 64, 6, 10, generator=g), dtype)
         out = torch.empty(2, 6, 10, 64, dtype=U.tdtype(dtype), device="cuda")
-        L.check(L.lib().resr_sumpool2x2(L.ptr(U.to_nhwc(src, dtype)), L.ptr(out), L.ptr(U.to_nhwc(mk, dtype)), 2, 6, 10,
-                                        64, dtype, 0.2, L.stream_ptr()))
+        src_d, mk_d = U.to_nhwc(src, dtype), U.to_nhwc(mk, dtype)   # keep alive while the kernel runs
+        L.check(L.lib().resr_sumpool2x2(L.ptr(src_d), L.ptr(out), L.ptr(mk_d), 2, 6, 10, 64, dtype, 0.2,
+                                        L.stream_ptr()))
+        torch.cuda.synchronize()
         ref = F.avg_pool2d(src, 2) * 4 * torch.where(mk > 0, 1.0, 0.2)
         assert (U.from_nhwc(out, 64) - ref).abs().max().item() < (2e-2 if dtype == L.RESR_F16 else 1e-5)
 
