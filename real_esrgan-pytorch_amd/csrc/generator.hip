@@ -24,8 +24,14 @@ namespace resr {
 
 int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*, const float*, const void*,
                      const void*, const void*, void*, void*, hipStream_t);
-int wgrad_dispatch(const ResrWgradDesc*, const void*, const void*, const void*, float*, float*, float*, hipStream_t);
-size_t wgrad_partial_bytes(const ResrWgradDesc*);
+struct WgradConv {
+    const void* x0; int cin, in0_stride, cin_real;
+    const void* g; int cout, cout_pad, g_stride;
+    float* dw; float* db; float scale;
+};
+size_t wgrad_batch_partial_bytes(const WgradConv*, int, int);
+int wgrad_batch(const WgradConv*, int, int, int, int, int, int, int, float*, hipStream_t);
+int wgrad_tile_rows(int dtype);
 int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t);
 int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t);
 int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int, float, hipStream_t);
@@ -137,20 +143,17 @@ struct Bufs {
     size_t total;
 };
 
-int default_splits(const Plan& p, long npix_tiles) {
-    (void)p;
-    // aim for >= 8 pixel tiles per workgroup and <= 64 splits
-    long s = npix_tiles / 8;
-    if (s < 1) s = 1;
-    if (s > 64) s = 64;
-    return (int)s;
-}
-
-int splits_for(const Plan& p, int h, int w) {
+// pixel splits of a batched weight-gradient launch: enough workgroups (jobs x splits) to fill 256 CUs
+// about three times over, but never fewer than two pixel tiles per workgroup
+int splits_for(const Plan& p, int njobs, int h, int w) {
     if (p.d.wgrad_splits > 0) return p.d.wgrad_splits;
-    const int th = p.d.dtype == RESR_F16 ? 8 : 4;
+    const int th = wgrad_tile_rows(p.d.dtype);
     const long tiles = (long)((w + 31) / 32) * ((h + th - 1) / th) * p.d.n;
-    return default_splits(p, tiles);
+    long s = 768 / njobs;
+    if (s > tiles / 2) s = tiles / 2;
+    if (s > 128) s = 128;
+    if (s < 1) s = 1;
+    return (int)s;
 }
 
 void carve(const Plan& p, char* base, Bufs& b) {
@@ -183,17 +186,16 @@ void carve(const Plan& p, char* base, Bufs& b) {
         for (int i = 0; i < 4; ++i) b.gT[i] = take(px * 64 * es);
         b.gS = take(px * 128 * es);
         b.gxin = take(px * p.ci_pad * es);
-        // wgrad slabs: largest of (trunk conv5 at LR, 64x64 convs at HR)
-        ResrWgradDesc wd;
-        memset(&wd, 0, sizeof(wd));
-        wd.cin = 192; wd.cout_pad = 64; wd.splits = splits_for(p, p.h, p.w);
-        size_t pb = wgrad_partial_bytes(&wd);
-        wd.cin = 64; wd.splits = splits_for(p, p.h * 4, p.w * 4);
-        size_t pb2 = wgrad_partial_bytes(&wd);
-        wd.splits = splits_for(p, p.h * 2, p.w * 2);
-        size_t pb3 = wgrad_partial_bytes(&wd);
-        b.partial_bytes = pb > pb2 ? pb : pb2;
-        if (pb3 > b.partial_bytes) b.partial_bytes = pb3;
+        // wgrad slabs: largest batch (a dense block = 26 jobs at LR; single 64->64 convs = 4 jobs at 1x/2x/4x)
+        const size_t slab = (9 * 1024 + 32) * sizeof(float);
+        size_t pb = (size_t)26 * splits_for(p, 26, p.h, p.w) * slab;
+        for (int m = 1; m <= 4; m *= 2) {
+            const size_t q = (size_t)4 * splits_for(p, 4, p.h * m, p.w * m) * slab;
+            if (q > pb) pb = q;
+            const size_t q2 = (size_t)2 * splits_for(p, 2, p.h * m, p.w * m) * slab;
+            if (q2 > pb) pb = q2;
+        }
+        b.partial_bytes = pb;
         b.partial = (float*)take(b.partial_bytes);
     } else {
         b.g4 = b.gA = b.gB = b.gM1 = b.gF = b.gS = b.gxin = nullptr;
@@ -427,15 +429,25 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     const int N = d->n, h = p.h, w = p.w;
     const int H4 = 4 * h, W4 = 4 * w, H2 = 2 * h, W2 = 2 * w;
 
+    auto wconv = [&](const ConvSpec& c, const void* x0, int cin, int s0, const void* g, int gstride, float scale) {
+        WgradConv wc;
+        wc.x0 = x0; wc.cin = cin; wc.in0_stride = s0; wc.cin_real = c.cin;
+        wc.g = g; wc.cout = c.cout; wc.cout_pad = c.cout_pad; wc.g_stride = gstride;
+        wc.dw = grad + c.w_off; wc.db = grad + c.b_off; wc.scale = scale;
+        return wc;
+    };
+    auto wgrad_run = [&](const WgradConv* wc, int nconv, int hh, int ww, int flags) -> int {
+        int njobs = 0;
+        for (int i = 0; i < nconv; ++i) njobs += (wc[i].cin / 32) * (wc[i].cout_pad / 32);
+        const int splits = splits_for(p, njobs, hh, ww);
+        if (wgrad_batch_partial_bytes(wc, nconv, splits) > b.partial_bytes)
+            return fail(RESR_ERR_WORKSPACE, "wgrad slab buffer too small");
+        return wgrad_batch(wc, nconv, N, hh, ww, d->dtype, flags, splits, b.partial, st);
+    };
     auto wgrad = [&](const ConvSpec& c, int hh, int ww, const void* x0, int cin, int s0, const void* g, int gstride,
                      int flags, float scale) -> int {
-        ResrWgradDesc wd;
-        memset(&wd, 0, sizeof(wd));
-        wd.n = N; wd.h = hh; wd.w = ww; wd.cin = cin; wd.cin0 = cin; wd.in0_stride = s0; wd.cin_real = c.cin;
-        wd.cout = c.cout; wd.cout_pad = c.cout_pad; wd.g_stride = gstride; wd.dtype = d->dtype; wd.flags = flags;
-        wd.splits = splits_for(p, hh, ww); wd.scale = scale;
-        if (wgrad_partial_bytes(&wd) > b.partial_bytes) return fail(RESR_ERR_WORKSPACE, "wgrad slab buffer too small");
-        return wgrad_dispatch(&wd, x0, nullptr, g, b.partial, grad + c.w_off, grad + c.b_off, st);
+        const WgradConv wc = wconv(c, x0, cin, s0, g, gstride, scale);
+        return wgrad_run(&wc, 1, hh, ww, flags);
     };
     auto dgrad = [&](int hh, int ww, const void*, int cin0, int s0, const void*, int cin, int s1, size_t, int cout,
                      int cout_pad, void*, int out_stride, int flags) {
@@ -490,10 +502,8 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         const char* gin = b.gT[cur];
         const char* act = b.ws[r];
         const float fold = pos == 2 ? 0.04f : 0.2f;
-        {   // conv5: G = fold * gin
-            const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + 4];
-            RUN(wgrad(c, h, w, act, 192, 192, gin, 64, 0, fold));
-        }
+        WgradConv wc[5];
+        wc[4] = wconv(p.convs[p.i_trunk0 + r * 5 + 4], act, 192, 192, gin, 64, fold);   // conv5: G = fold * gin
         for (int ps = 0; ps < 4; ++ps) {   // g_o4, g_o3, g_o2, g_o1
             const int k = 4 - ps;           // conv index whose pre-activation gradient this pass yields
             const int cin = 64 + 32 * ps;
@@ -504,8 +514,9 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             RUN(conv3x3_dispatch(&cd, gin, b.gS, pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * es, nullptr, nullptr, nullptr,
                                  mask, out, nullptr, st));
             const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
-            RUN(wgrad(c, h, w, act, c.cin, 192, out, 128, 0, 1.f));
+            wc[k - 1] = wconv(c, act, c.cin, 192, out, 128, 1.f);
         }
+        RUN(wgrad_run(wc, 5, h, w, 0));   // all five weight gradients of the block in one launch pair
         {   // g_x = convT(all) + (skip terms)
             int nxt = (cur + 1) & 3;
             if (nxt == e_idx && pos != 2) nxt = (nxt + 1) & 3;

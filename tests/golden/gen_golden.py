@@ -1,0 +1,161 @@
+"""Generate the golden vectors under tests/golden/*.npz from the REFERENCE itself.
+
+Run only in the build container (needs /root/reference; see ref_shim.py for the three stand-in
+formulas).  Weights are not stored: they are regenerated from a seed by oracle.model_ref.init_*_state
+(pure torch CPU generator, deterministic), loaded into the reference modules with load_state_dict, and
+the reference's own forward / autograd produce the stored outputs.  The CPU tests then run the oracle
+on the same seeds and compare -- that pins the oracle's arithmetic to the reference's.
+
+    python tests/golden/gen_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import ref_shim  # noqa: E402
+from oracle import model_ref as M  # noqa: E402
+
+PROBE_KEYS = ["conv1.weight", "conv1.bias", "trunk.0.rdb1.conv3.weight", "trunk.11.rdb2.conv1.weight",
+              "trunk.22.rdb3.conv5.weight", "trunk.22.rdb3.conv5.bias", "conv2.weight", "upsampling1.0.weight",
+              "upsampling2.0.bias", "conv3.0.weight", "conv4.weight", "conv4.bias"]
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: tuple(v.shape) for k, v in out.items()})
+
+
+def gen_generator(ref):
+    for tag, up, seed, shape in (("x4_a", 4, 101, (1, 3, 24, 24)), ("x4_b", 4, 102, (2, 3, 16, 20)),
+                                 ("x2", 2, 103, (1, 3, 32, 32)), ("x1", 1, 104, (1, 3, 32, 32))):
+        sd = M.init_generator_state(seed, 3, 3, up, bias_noise=0.02)
+        sd["conv4.bias"] = sd["conv4.bias"] + 0.5
+        g = ref.Generator(3, 3, up)
+        g.load_state_dict(sd)
+        g.train()
+        gen = torch.Generator().manual_seed(seed)
+        x = torch.rand(*shape, generator=gen).requires_grad_(True)
+        gw = torch.randn(shape[0], 3, shape[2] * up, shape[3] * up, generator=gen)
+        y = g(x)
+        (y * gw).sum().backward()
+        grads = dict(g.named_parameters())
+        arrs = {"x": x.detach(), "gw": gw, "y": y.detach(), "gx": x.grad, "seed": seed, "upscale": up,
+                "grad_norms": torch.stack([p.grad.norm() for p in g.parameters()])}
+        for k in PROBE_KEYS:
+            arrs["g_" + k] = grads[k].grad
+        save("generator_" + tag, **arrs)
+
+
+def gen_blocks(ref):
+    torch.manual_seed(7)
+    rdb = ref.ResidualDenseBlock(64, 32)
+    for p in rdb.parameters():          # exercise the bias path too
+        if p.dim() == 1:
+            p.data.normal_(0, 0.05)
+    x = torch.randn(1, 64, 16, 16).requires_grad_(True)
+    gw = torch.randn(1, 64, 16, 16)
+    y = rdb(x)
+    (y * gw).sum().backward()
+    arrs = {"x": x.detach(), "gw": gw, "y": y.detach(), "gx": x.grad}
+    for k, v in rdb.state_dict().items():
+        arrs["w_" + k] = v
+    for k, p in rdb.named_parameters():
+        arrs["g_" + k] = p.grad
+    save("rdb", **arrs)
+    torch.manual_seed(8)
+    rrdb = ref.ResidualResidualDenseBlock(64, 32)
+    x = torch.randn(1, 64, 12, 12)
+    with torch.no_grad():
+        y = rrdb(x)
+    arrs = {"x": x, "y": y}
+    for k, v in rrdb.state_dict().items():
+        arrs["w_" + k] = v.half()       # stored as f16 to keep the fixture small; the test casts back
+    rrdb.load_state_dict({k: v.half().float() for k, v in rrdb.state_dict().items()})
+    with torch.no_grad():
+        arrs["y"] = rrdb(x)
+    save("rrdb", **arrs)
+
+
+def gen_init(ref):
+    """Reference initialisation under torch.manual_seed(0) (config.py:65): per-tensor std and head values."""
+    torch.manual_seed(0)
+    g = ref.Generator(3, 3, 4)
+    sd = g.state_dict()
+    keys = list(sd.keys())
+    save("generator_init_seed0", keys=np.array(keys), numel=np.array([v.numel() for v in sd.values()]),
+         std=torch.stack([v.float().std() if v.numel() > 1 else v.float().abs().sum() for v in sd.values()]),
+         head=torch.stack([v.reshape(-1)[:4] if v.numel() >= 4 else torch.cat([v.reshape(-1), torch.zeros(4 - v.numel())])
+                           for v in sd.values()]),
+         total_sum=torch.stack([v.double().sum() for v in sd.values()]))
+    torch.manual_seed(0)
+    d = ref.Discriminator()
+    sdd = d.state_dict()
+    save("discriminator_init_seed0", keys=np.array(list(sdd.keys())),
+         shapes=np.array([str(tuple(v.shape)) for v in sdd.values()]),
+         total_sum=torch.stack([v.double().sum() for v in sdd.values()]))
+
+
+def gen_discriminator(ref):
+    sd = M.init_discriminator_state(201)
+    d = ref.Discriminator()
+    d.load_state_dict(sd)
+    d.train()
+    gen = torch.Generator().manual_seed(201)
+    x = torch.rand(2, 3, 64, 64, generator=gen).requires_grad_(True)
+    gw = torch.randn(2, 1, 64, 64, generator=gen)
+    arrs = {"x": x.detach(), "gw": gw, "seed": 201}
+    for call in range(3):                     # three training-mode calls per GAN step (train_realesrgan.py:479,500,508)
+        d.zero_grad()
+        if x.grad is not None:
+            x.grad = None
+        y = d(x)
+        (y * gw).sum().backward()
+        arrs[f"y{call}"] = y.detach()
+        arrs[f"gx{call}"] = x.grad.clone()
+        arrs[f"u{call}_up_block1"] = d.state_dict()["up_block1.0.weight_u"].clone()
+        arrs[f"v{call}_down_block3"] = d.state_dict()["down_block3.0.weight_v"].clone()
+        arrs[f"g{call}_conv1.weight"] = d.conv1.weight.grad.clone()
+        # slices keep the fixture small
+        arrs[f"g{call}_down_block2.weight_orig"] = dict(d.named_parameters())["down_block2.0.weight_orig"].grad[:4].clone()
+        arrs[f"g{call}_conv3.weight_orig"] = dict(d.named_parameters())["conv3.0.weight_orig"].grad[:8].clone()
+        arrs[f"g{call}_conv4.bias"] = d.conv4.bias.grad.clone()
+    d.eval()
+    with torch.no_grad():
+        arrs["y_eval"] = d(x.detach())
+    save("discriminator", **arrs)
+
+
+def gen_ema(ref):
+    torch.manual_seed(9)
+    lin = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.Conv2d(8, 4, 3))
+    ema = ref.EMA(lin, 0.999)
+    ema.register()
+    arrs = {}
+    for i, (k, p) in enumerate(lin.named_parameters()):
+        arrs[f"p0_{i}"] = p.detach().clone()
+    for step in range(3):
+        with torch.no_grad():
+            for p in lin.parameters():
+                p.add_(torch.randn_like(p) * 0.01)
+        ema.update()
+        for i, (k, p) in enumerate(lin.named_parameters()):
+            arrs[f"p{step + 1}_{i}"] = p.detach().clone()
+            arrs[f"s{step + 1}_{i}"] = ema.shadow[k].clone()
+    save("ema", **arrs)
+
+
+if __name__ == "__main__":
+    ref = ref_shim.load("model")
+    gen_init(ref)
+    gen_blocks(ref)
+    gen_generator(ref)
+    gen_discriminator(ref)
+    gen_ema(ref)

@@ -1,0 +1,101 @@
+"""CPU: the drop-in boundary.  The C-ABI library loads and exports every symbol include/resr.h
+declares; the nn.Module surface (names, state_dict keys, init RNG stream) matches the reference;
+the product refuses CPU tensors instead of falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__
+    __graft_entry__.build()
+    import real_esrgan_pytorch_amd as R
+    return R
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "resr.h")).read()
+    declared = sorted(set(re.findall(r"\b(resr_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(built._lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/resr.h but not exported"
+    assert set(built._lib.exported_symbols()) <= set(declared)
+    assert lib.resr_version() == 1
+
+
+def test_struct_layouts_match_header(built):
+    L = built._lib
+    assert ctypes.sizeof(L.ConvDesc) == 20 * 4
+    assert ctypes.sizeof(L.WgradDesc) == 15 * 4
+    assert ctypes.sizeof(L.PackChunk) == 56
+    assert ctypes.sizeof(L.GeneratorDesc) == 10 * 4
+
+
+def test_host_planning_calls_need_no_gpu(built):
+    L = built._lib
+    d = L.GeneratorDesc(16, 256, 256, 3, 3, 4, 23, L.RESR_F16, 1, 0)
+    lib = L.lib()
+    assert lib.resr_generator_param_count(ctypes.byref(d)) == 16_697_987
+    n = lib.resr_generator_pack_table(ctypes.byref(d), 1, None, 0)
+    # forward: conv1 1 + 69 dense blocks x (2+3+4+5+6) + 5 tail convs x 2; backward-data: same count
+    # (conv4^T 1 + four 64->64 convs x 2 + conv1^T 2 + 69 x 20)
+    assert n == 2 * (1 + 69 * 20 + 5 * 2)
+    assert lib.resr_generator_workspace_bytes(ctypes.byref(d)) > 30e9
+    bad = L.GeneratorDesc(1, 7, 8, 3, 3, 2, 23, L.RESR_F16, 0, 0)                # 7 not divisible by 2
+    assert lib.resr_generator_workspace_bytes(ctypes.byref(bad)) == 0
+
+
+def test_generator_surface_matches_reference_init(built):
+    z = np.load(os.path.join(G, "generator_init_seed0.npz"))
+    torch.manual_seed(0)
+    g = built.Generator(3, 3, 4)
+    sd = g.state_dict()
+    assert list(sd.keys()) == [str(k) for k in z["keys"]]
+    assert [v.numel() for v in sd.values()] == z["numel"].tolist()
+    sums = torch.stack([v.double().sum() for v in sd.values()])
+    assert torch.allclose(sums, torch.from_numpy(z["total_sum"]), rtol=0, atol=1e-9), "init RNG stream differs"
+    heads = torch.stack([v.reshape(-1)[:4] if v.numel() >= 4 else torch.cat([v.reshape(-1), torch.zeros(4 - v.numel())])
+                         for v in sd.values()])
+    assert torch.equal(heads, torch.from_numpy(z["head"]))
+
+
+def test_flat_arena_views_and_roundtrip(built):
+    torch.manual_seed(1)
+    g = built.Generator(3, 3, 2, n_blocks=1)
+    before = {k: v.clone() for k, v in g.state_dict().items()}
+    flat = g.flat_parameters()
+    assert flat.numel() == sum(p.numel() for p in g.parameters())
+    off = 0
+    for p in g.parameters():
+        assert p.data_ptr() == flat.data_ptr() + 4 * off
+        off += p.numel()
+    for k, v in g.state_dict().items():
+        assert torch.equal(v, before[k])
+    g.load_state_dict({k: v + 1 for k, v in before.items()})
+    assert torch.equal(g.flat_parameters()[:5], before["conv1.weight"].reshape(-1)[:5] + 1)
+
+
+def test_no_cpu_fallback(built):
+    g = built.Generator(3, 3, 4, n_blocks=1)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        g(torch.rand(1, 3, 8, 8))
+    with pytest.raises(ValueError):
+        built.Generator(3, 3, 3)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "real_esrgan-pytorch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
