@@ -152,10 +152,103 @@ def gen_ema(ref):
     save("ema", **arrs)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "imgproc"):
     ref = ref_shim.load("model")
     gen_init(ref)
     gen_blocks(ref)
     gen_generator(ref)
     gen_discriminator(ref)
     gen_ema(ref)
+
+
+# ---------------------------------------------------------------------------------------------------
+# degradation ops (reference imgproc.py) -- run with `python tests/golden/gen_golden.py imgproc`
+# ---------------------------------------------------------------------------------------------------
+def _img(gen, *shape):
+    return torch.round(torch.rand(*shape, generator=gen) * 255) / 255
+
+
+def gen_imgproc():
+    import random as pyrandom
+    import torch.nn.functional as F
+    ip = ref_shim.load("imgproc")
+    gen = torch.Generator().manual_seed(301)
+    # USM + filter2d
+    x = _img(gen, 2, 3, 72, 64)
+    usm = ip.USMSharp(50, 0)
+    k7 = torch.rand(1, 7, 7, generator=gen); k7 /= k7.sum()
+    k21 = torch.rand(2, 21, 21, generator=gen); k21 /= k21.sum(dim=(1, 2), keepdim=True)
+    save("imgproc_filter", x=x, usm=usm(x, 0.5, 10), usm_kernel=usm.kernel, k7=k7, f7=ip.filter2d_torch(x, k7),
+         k21=k21, f21=ip.filter2d_torch(x, k21))
+    # resize call sites (train_realesrnet.py:288 scale_factor=, :326-329 / :349-351 size=)
+    x = _img(gen, 2, 3, 48, 40)
+    arrs = {"x": x}
+    for mode in ("area", "bilinear", "bicubic"):
+        for s in (0.3731, 1.3177):
+            arrs[f"{mode}_sf_{s}"] = F.interpolate(x, scale_factor=s, mode=mode)
+        arrs[f"{mode}_size_30x27"] = F.interpolate(x, size=(30, 27), mode=mode)
+        arrs[f"{mode}_size_12x10"] = F.interpolate(x, size=(12, 10), mode=mode)
+    save("imgproc_resize", **arrs)
+    # noise with the global torch generator seeded (device RNG of the reference == CPU generator here)
+    x = _img(gen, 4, 3, 24, 20)
+    arrs = {"x": x}
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        arrs[f"gauss_{seed}"] = ip.random_add_gaussian_noise_torch(x, sigma_range=[1, 30], gray_prob=0.4, clip=True, rounds=False)
+        torch.manual_seed(seed)
+        arrs[f"poisson_{seed}"] = ip.random_add_poisson_noise_torch(x, scale_range=[0.05, 3], gray_prob=0.4, clip=True, rounds=False)
+    torch.manual_seed(4)
+    arrs["gauss_nogray"] = ip.random_add_gaussian_noise_torch(x, sigma_range=[1, 25], gray_prob=0.0, clip=True, rounds=False)
+    torch.manual_seed(4)
+    arrs["poisson_allgray"] = ip.random_add_poisson_noise_torch(x, scale_range=[0.05, 2.5], gray_prob=1.0, clip=True, rounds=False)
+    save("imgproc_noise", **arrs)
+    # DiffJPEG(False): sizes incl. non-multiples of 16, qualities on both sides of 50
+    jpeg = ip.DiffJPEG(False)
+    arrs = {}
+    for tag, (h, w) in (("48x40", (48, 40)), ("77x77", (77, 77)), ("100x100", (100, 100))):
+        x = _img(gen, 4, 3, h, w)
+        q = torch.tensor([30.0, 49.9, 50.0, 95.0])
+        arrs[f"x_{tag}"], arrs[f"q_{tag}"] = x, q.clone()
+        arrs[f"y_{tag}"] = jpeg(x, q.clone())                      # forward mutates its quality argument
+        factor = torch.tensor([ip._calculate_quality_factor(float(v)) for v in q])
+        hp, wp = (16 - h % 16) % 16, (16 - w % 16) % 16
+        yq, cbq, crq = jpeg.compress(F.pad(x, (0, wp, 0, hp)), factor)
+        arrs[f"cy_{tag}"], arrs[f"ccb_{tag}"], arrs[f"ccr_{tag}"] = yq, cbq, crq
+        arrs[f"factor_{tag}"] = factor
+    q = torch.tensor([30.0, 49.9, 50.0, 95.0])
+    jpeg(arrs["x_48x40"], q)
+    arrs["q_mutated"] = q                                           # quirk: caller's tensor now holds the factors
+    arrs["y_scalar_q70"] = jpeg(arrs["x_48x40"], 70)
+    save("imgproc_jpeg", **arrs)
+    # quantise + crop
+    lr = torch.rand(2, 3, 25, 25, generator=gen)
+    hr = _img(gen, 2, 3, 100, 100)
+    pyrandom.seed(5)
+    st = pyrandom.getstate()
+    top, left = pyrandom.randint(0, 100 - 64), pyrandom.randint(0, 100 - 64)
+    pyrandom.setstate(st)
+    plr, phr = ip.random_crop(lr, hr, 64, 4)
+    save("imgproc_crop", lr=lr, hr=hr, top=top, left=left, plr=plr, phr=phr)
+    # host kernel synthesis: fixed-parameter kernels of every type + seeded random draws
+    arrs = {}
+    for iso in (True, False):
+        t = "iso" if iso else "aniso"
+        arrs[f"gauss_{t}"] = ip._generate_bivariate_gaussian_kernel(21, 2.1, 0.9, 0.7, isotropic=iso)
+        arrs[f"general_{t}"] = ip._generate_bivariate_generalized_gaussian_kernel(15, 1.7, 0.6, -1.1, 2.3, isotropic=iso)
+        arrs[f"plateau_{t}"] = ip._generate_bivariate_plateau_gaussian_kernel(9, 2.6, 1.2, 2.0, 1.4, isotropic=iso)
+    arrs["sinc_7"] = ip.generate_sinc_kernel(2.5, 7, 0)
+    arrs["sinc_13_pad21"] = ip.generate_sinc_kernel(1.1, 13, 21)
+    cfg = ref_shim.load("config")
+    P = cfg.degradation_model_parameters_dict
+    for seed in range(8):
+        pyrandom.seed(seed)
+        np.random.seed(seed)
+        arrs[f"mixed_{seed}"] = ip.random_mixed_kernels(P["gaussian_kernel_type"], P["gaussian_kernel_probability1"], 7 + 2 * seed,
+                                                        P["gaussian_sigma_range1"], P["gaussian_sigma_range1"], [-np.pi, np.pi],
+                                                        P["generalized_kernel_beta_range1"], P["plateau_kernel_beta_range1"],
+                                                        noise_range=None)
+    save("imgproc_kernels", **arrs)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "imgproc":
+    gen_imgproc()
