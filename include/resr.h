@@ -144,6 +144,41 @@ int resr_generator_backward(const ResrGeneratorDesc* d, const float* gy_nchw, co
                             const void* packed, void* workspace, size_t workspace_bytes,
                             float* grad_params, float* gx_nchw, void* stream, void* side_stream);
 
+/* ---- second-order degradation (imgproc.py device ops; call sites train_realesrnet.py:268-377) ----------
+ * Images are planar fp32 [n,c,h,w] in [0,1].  No entry point synchronises or reads back. */
+
+/* filter2d_torch (imgproc.py:1089-1121): reflect pad, correlation with a kh x kw kernel (odd sizes);
+ * per_sample = 1: kernel is [n,kh,kw], else [kh,kw] shared. */
+int resr_filter2d(const float* src, float* dst, const float* kernel, int32_t n, int32_t c, int32_t h, int32_t w,
+                  int32_t kh, int32_t kw, int32_t per_sample, void* stream);
+/* USMSharp.forward (imgproc.py:1526-1537) with the Gaussian given as its 1-D factor k1d[ksize];
+ * tmp3 = 3*n*c*h*w floats of scratch. */
+int resr_usm_sharp(const float* src, float* dst, float* tmp3, const float* k1d, int32_t ksize, float weight,
+                   float threshold, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+/* F.interpolate (train_realesrnet.py:288,326-329,349-351,366-368): mode 0 area, 1 bilinear, 2 bicubic;
+ * scale_h/scale_w > 0: the caller used scale_factor= (coordinates use 1/scale), else size= semantics. */
+int resr_resize(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t oh, int32_t ow,
+                int32_t mode, double scale_h, double scale_w, void* stream);
+/* standard-normal field, Philox4x32-10 (the device RNG draws of imgproc.py:854,858) */
+int resr_randn_fill(float* dst, int64_t count, uint64_t seed, uint64_t stream_id, void* stream);
+/* random_add_gaussian_noise_torch (imgproc.py:1029-1057) with the draws given: sigma[n], gray[n] (0/1),
+ * field_gray[h*w] (ONE field for the batch, may be NULL when no sample is gray), field_color[n*c*h*w]. */
+int resr_noise_gaussian(const float* src, float* dst, const float* sigma, const float* gray, const float* field_gray,
+                        const float* field_color, int32_t n, int32_t c, int32_t h, int32_t w, int32_t clip, void* stream);
+/* random_add_poisson_noise_torch (imgproc.py:1060-1086): per-sample unique-value counts on the device,
+ * Poisson draws from Philox; scale[n], gray[n]. */
+size_t resr_noise_poisson_workspace_bytes(int32_t n);
+int resr_noise_poisson(const float* src, float* dst, const float* scale, const float* gray, uint64_t seed, void* workspace,
+                       int32_t n, int32_t c, int32_t h, int32_t w, int32_t clip, void* stream);
+/* DiffJPEG(differentiable=False).forward (imgproc.py:1462-1494); quality[n] (not mutated);
+ * coeffs (optional) receives the rounded coefficients [n][Y blocks | Cb blocks | Cr blocks][64]. */
+int resr_jpeg(const float* src, float* dst, const float* quality, float* coeffs, int32_t n, int32_t h, int32_t w,
+              int32_t flags /* bit0: clamp the input to [0,1] first (train_realesrnet.py:308) */, void* stream);
+/* clamp(round(x*255))/255 on lr + random_crop of both (train_realesrnet.py:374-377, imgproc.py:1894-1934) */
+int resr_quantize_crop(const float* lr, const float* hr, float* lr_out, float* hr_out, int32_t n, int32_t c, int32_t lr_h,
+                       int32_t lr_w, int32_t hr_h, int32_t hr_w, int32_t hr_size, int32_t upscale, int32_t hr_top,
+                       int32_t hr_left, void* stream);
+
 /* EMA.update (model.py:43-48) over the flat parameter arena, one launch. */
 int resr_ema_update(float* shadow, const float* params, int64_t count, double decay, void* stream);
 

@@ -65,6 +65,15 @@ _PROTOS = {
     "resr_generator_backward": (C.c_int, [C.POINTER(GeneratorDesc), _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     "resr_ema_update": (C.c_int, [_P, _P, C.c_int64, C.c_double, _P]),
     "resr_debug_tr_probe": (C.c_int, [_P, _P]),
+    "resr_filter2d": (C.c_int, [_P, _P, _P] + [C.c_int32] * 7 + [_P]),
+    "resr_usm_sharp": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_float, C.c_float] + [C.c_int32] * 4 + [_P]),
+    "resr_resize": (C.c_int, [_P, _P] + [C.c_int32] * 7 + [C.c_double, C.c_double, _P]),
+    "resr_randn_fill": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
+    "resr_noise_gaussian": (C.c_int, [_P] * 6 + [C.c_int32] * 5 + [_P]),
+    "resr_noise_poisson_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "resr_noise_poisson": (C.c_int, [_P] * 4 + [C.c_uint64, _P] + [C.c_int32] * 5 + [_P]),
+    "resr_jpeg": (C.c_int, [_P] * 4 + [C.c_int32] * 4 + [_P]),
+    "resr_quantize_crop": (C.c_int, [_P] * 4 + [C.c_int32] * 10 + [_P]),
 }
 
 _lib = None

@@ -1,0 +1,111 @@
+"""Configuration with the reference's names and values (reference config.py:20-158).
+
+Differences, all additive: `device` follows the visible GPU instead of hard-coding cuda:0 when
+LOCAL_RANK is set (one process per GPU), `precision` selects the kernel arithmetic, and the
+cudnn.benchmark switch is dropped (no cuDNN / MIOpen on this path).  `mode` gates the same
+name groups as the reference.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+
+degradation_model_parameters_dict = {
+    "sinc_kernel_size": 21,
+    "gaussian_kernel_range": [7, 9, 11, 13, 15, 17, 19, 21],
+    "gaussian_kernel_type": ["isotropic", "anisotropic",
+                             "generalized_isotropic", "generalized_anisotropic",
+                             "plateau_isotropic", "plateau_anisotropic"],
+    "gaussian_kernel_probability1": [0.45, 0.25, 0.12, 0.03, 0.12, 0.03],
+    "sinc_kernel_probability1": 0.1,
+    "gaussian_sigma_range1": [0.2, 3],
+    "generalized_kernel_beta_range1": [0.5, 4],
+    "plateau_kernel_beta_range1": [1, 2],
+    "gaussian_kernel_probability2": [0.45, 0.25, 0.12, 0.03, 0.12, 0.03],
+    "sinc_kernel_probability2": 0.1,
+    "gaussian_sigma_range2": [0.2, 1.5],
+    "generalized_kernel_beta_range2": [0.5, 4],
+    "plateau_kernel_beta_range2": [1, 2],
+    "sinc_kernel_probability3": 0.8,
+}
+
+degradation_process_parameters_dict = {
+    "first_blur_probability": 1.0,
+    "resize_probability1": [0.2, 0.7, 0.1],
+    "resize_range1": [0.15, 1.5],
+    "gray_noise_probability1": 0.4,
+    "gaussian_noise_probability1": 0.5,
+    "noise_range1": [1, 30],
+    "poisson_scale_range1": [0.05, 3],
+    "jpeg_range1": [30, 95],
+    "second_blur_probability": 0.8,
+    "resize_probability2": [0.3, 0.4, 0.3],
+    "resize_range2": [0.3, 1.2],
+    "gray_noise_probability2": 0.4,
+    "gaussian_noise_probability2": 0.5,
+    "noise_range2": [1, 25],
+    "poisson_scale_range2": [0.05, 2.5],
+    "jpeg_range2": [30, 95],
+}
+
+# Random seed to maintain reproducible results (reference config.py:64-66)
+random.seed(0)
+torch.manual_seed(0)
+np.random.seed(0)
+device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+precision = os.environ.get("RESR_PRECISION", "fast")     # "fast": f16 MFMA / "strict": f32 MFMA
+niqe_model_path = "./results/pretrained_models/niqe_model.mat"
+in_channels = 3
+out_channels = 3
+upscale_factor = 4
+mode = os.environ.get("RESR_MODE", "train_realesrnet")
+exp_name = "RealESRNet_baseline"
+
+if mode == "train_realesrnet":
+    train_image_dir = "./data/DIV2K/Real_ESRGAN/train"
+    valid_image_dir = "./data/DIV2K/Real_ESRGAN/valid"
+    test_lr_image_dir = f"./data/Set5/LRbicx{upscale_factor}"
+    test_hr_image_dir = "./data/Set5/GTmod12"
+    image_size = 256
+    batch_size = 48
+    num_workers = 4
+    resume = ""
+    epochs = 1298
+    model_lr = 2e-4
+    model_betas = (0.9, 0.99)
+    ema_model_weight_decay = 0.999
+    lr_scheduler_step_size = epochs // 5
+    lr_scheduler_gamma = 0.5
+    print_frequency = 200
+
+if mode == "train_realesrgan":
+    train_image_dir = "./data/DIV2K/Real_ESRGAN/train"
+    valid_image_dir = "./data/DIV2K/Real_ESRGAN/valid"
+    test_lr_image_dir = f"./data/Set5/LRbicx{upscale_factor}"
+    test_hr_image_dir = "./data/Set5/GTmod12"
+    image_size = 256
+    batch_size = 48
+    num_workers = 4
+    resume = "./results/RealESRNet_baseline/g_last.pth.tar"
+    resume_d = ""
+    resume_g = ""
+    epochs = 519
+    feature_model_extractor_nodes = ["features.2", "features.7", "features.16", "features.25", "features.34"]
+    feature_model_normalize_mean = [0.485, 0.456, 0.406]
+    feature_model_normalize_std = [0.229, 0.224, 0.225]
+    pixel_weight = 1.0
+    content_weight = [0.1, 0.1, 1.0, 1.0, 1.0]
+    adversarial_weight = 0.1
+    model_lr = 1e-4
+    model_betas = (0.9, 0.99)
+    ema_model_weight_decay = 0.999
+    lr_scheduler_milestones = [int(epochs * 0.125), int(epochs * 0.250), int(epochs * 0.500), int(epochs * 0.750)]
+    lr_scheduler_gamma = 0.5
+    print_frequency = 200
+
+if mode == "test":
+    lr_dir = f"./data/Set5/LRbicx{upscale_factor}"
+    sr_dir = f"./results/test/{exp_name}"
+    hr_dir = "./data/Set5/GTmod12"
+    model_path = "./results/pretrained_models/RealESRGAN_x4-DFO2K-678bf481.pth.tar"

@@ -38,6 +38,16 @@ int generator_forward(const ResrGeneratorDesc*, const float*, const float*, cons
 int generator_backward(const ResrGeneratorDesc*, const float*, const float*, const void*, void*, size_t, float*, float*,
                        hipStream_t, hipStream_t);
 
+int filter2d_dispatch(const float*, float*, const float*, int, int, int, int, int, int, int, hipStream_t);
+int usm_dispatch(const float*, float*, float*, const float*, int, float, float, int, int, int, int, hipStream_t);
+int resize_dispatch(const float*, float*, int, int, int, int, int, int, int, double, double, hipStream_t);
+int randn_dispatch(float*, long, uint64_t, uint64_t, hipStream_t);
+int gauss_noise_dispatch(const float*, float*, const float*, const float*, const float*, const float*, int, int, int, int, int,
+                         hipStream_t);
+int poisson_noise_dispatch(const float*, float*, const float*, const float*, uint64_t, void*, int, int, int, int, int, hipStream_t);
+int jpeg_dispatch(const float*, float*, const float*, float*, int, int, int, int, hipStream_t);
+int quantize_crop_dispatch(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+
 // probe used by tests: what does ds_read_b64_tr_b16 hand to (lane, element)?  LDS holds the element
 // index at every position; lane l supplies byte address l*8.
 typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_t;
@@ -118,6 +128,49 @@ int resr_generator_backward(const ResrGeneratorDesc* d, const float* gy_nchw, co
 
 int resr_ema_update(float* shadow, const float* params, int64_t count, double decay, void* stream) {
     return ema_dispatch(shadow, params, (long)count, decay, (hipStream_t)stream);
+}
+
+int resr_filter2d(const float* src, float* dst, const float* kernel, int32_t n, int32_t c, int32_t h, int32_t w, int32_t kh,
+                  int32_t kw, int32_t per_sample, void* stream) {
+    return filter2d_dispatch(src, dst, kernel, n, c, h, w, kh, kw, per_sample, (hipStream_t)stream);
+}
+
+int resr_usm_sharp(const float* src, float* dst, float* tmp3, const float* k1d, int32_t ksize, float weight, float threshold,
+                   int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+    return usm_dispatch(src, dst, tmp3, k1d, ksize, weight, threshold, n, c, h, w, (hipStream_t)stream);
+}
+
+int resr_resize(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t oh, int32_t ow, int32_t mode,
+                double scale_h, double scale_w, void* stream) {
+    return resize_dispatch(src, dst, n, c, h, w, oh, ow, mode, scale_h, scale_w, (hipStream_t)stream);
+}
+
+int resr_randn_fill(float* dst, int64_t count, uint64_t seed, uint64_t stream_id, void* stream) {
+    return randn_dispatch(dst, (long)count, seed, stream_id, (hipStream_t)stream);
+}
+
+int resr_noise_gaussian(const float* src, float* dst, const float* sigma, const float* gray, const float* field_gray,
+                        const float* field_color, int32_t n, int32_t c, int32_t h, int32_t w, int32_t clip, void* stream) {
+    return gauss_noise_dispatch(src, dst, sigma, gray, field_gray, field_color, n, c, h, w, clip, (hipStream_t)stream);
+}
+
+size_t resr_noise_poisson_workspace_bytes(int32_t n) { return (size_t)n * (512 * sizeof(unsigned) + 2 * sizeof(float)); }
+
+int resr_noise_poisson(const float* src, float* dst, const float* scale, const float* gray, uint64_t seed, void* workspace,
+                       int32_t n, int32_t c, int32_t h, int32_t w, int32_t clip, void* stream) {
+    return poisson_noise_dispatch(src, dst, scale, gray, seed, workspace, n, c, h, w, clip, (hipStream_t)stream);
+}
+
+int resr_jpeg(const float* src, float* dst, const float* quality, float* coeffs, int32_t n, int32_t h, int32_t w, int32_t flags,
+              void* stream) {
+    return jpeg_dispatch(src, dst, quality, coeffs, n, h, w, flags, (hipStream_t)stream);
+}
+
+int resr_quantize_crop(const float* lr, const float* hr, float* lr_out, float* hr_out, int32_t n, int32_t c, int32_t lr_h,
+                       int32_t lr_w, int32_t hr_h, int32_t hr_w, int32_t hr_size, int32_t upscale, int32_t hr_top,
+                       int32_t hr_left, void* stream) {
+    return quantize_crop_dispatch(lr, hr, lr_out, hr_out, n, c, lr_h, lr_w, hr_h, hr_w, hr_size, upscale, hr_top, hr_left,
+                                  (hipStream_t)stream);
 }
 
 int resr_debug_tr_probe(float* out256, void* stream) {

@@ -1,0 +1,549 @@
+// degrade.hip -- the second-order degradation pipeline as HIP kernels (reference imgproc.py device ops
+// and their call sites train_realesrnet.py:268-377).  Images are planar fp32 [N,3,H,W] in [0,1] (the
+// module surface); every op is one pass (or a short chain of passes) bounded by HBM bandwidth:
+//   filter2d      reflect-padded kh x kw correlation, shared or per-sample kernel (imgproc.py:1089-1121)
+//   usm combine   USMSharp.forward epilogues (imgproc.py:1526-1537); the 51x51 Gaussian is applied as its
+//                 two separable 51-tap passes (the kernel is an outer product, imgproc.py:1522-1523)
+//   resize        F.interpolate area / bilinear / bicubic, align_corners=False, scale_factor= or size=
+//   noise         Gaussian (one gray field shared by the batch, imgproc.py:854) and Poisson (per-sample
+//                 unique-value count without host sync, imgproc.py:892-905) with Philox4x32-10 sampling
+//   jpeg          DiffJPEG(differentiable=False) (imgproc.py:1195-1494), one workgroup per 16x16 macroblock
+//   quantize+crop train_realesrnet.py:374-377, imgproc.py:1894-1934
+// No host synchronisation anywhere: per-sample scalars live in small device arrays.
+#include <math.h>
+
+#include <mutex>
+
+#include "common.h"
+
+namespace resr {
+
+// ---------------------------------------------------------------------------------------------------------
+// filter2d
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+// block = 32 x 8 threads, tile = 32 x 32 outputs (4 rows per thread); LDS: tile + halo, then the taps
+__global__ __launch_bounds__(256) void filter2d_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       const float* __restrict__ kern, int c, int h, int w, int kh,
+                                                       int kw, int per_sample) {
+    extern __shared__ float sm[];
+    const int ry = kh / 2, rx = kw / 2;
+    const int tw = 32 + 2 * rx, th = 32 + 2 * ry;
+    float* tile = sm;
+    float* taps = sm + tw * th;
+    const int plane = blockIdx.z;                       // n * c + ch
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const float* sp = src + (size_t)plane * h * w;
+    const float* kp = kern + (per_sample ? (size_t)(plane / c) * kh * kw : 0);
+    for (int i = threadIdx.x; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const int iy = reflect(y0 + ty - ry, h), ix = reflect(x0 + tx - rx, w);
+        tile[i] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? sp[(size_t)iy * w + ix] : 0.f;
+    }
+    for (int i = threadIdx.x; i < kh * kw; i += 256) taps[i] = kp[i];
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int dy = 0; dy < kh; ++dy) {
+        for (int dx = 0; dx < kw; ++dx) {
+            const float wv = taps[dy * kw + dx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += wv * tile[(ly * 4 + j + dy) * tw + lx + dx];
+        }
+    }
+    float* dp = dst + (size_t)plane * h * w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int y = y0 + ly * 4 + j, x = x0 + lx;
+        if (y < h && x < w) dp[(size_t)y * w + x] = acc[j];
+    }
+}
+
+int filter2d_dispatch(const float* src, float* dst, const float* kern, int n, int c, int h, int w, int kh, int kw,
+                      int per_sample, hipStream_t st) {
+    if (!src || !dst || !kern || n <= 0 || c <= 0 || h <= 0 || w <= 0) return fail(RESR_ERR_ARG, "filter2d: bad argument");
+    if (!(kh & 1) || !(kw & 1) || kh > 63 || kw > 63) return fail(RESR_ERR_ARG, "Wrong kernel size.");   // imgproc.py:1106
+    if (kh / 2 >= h || kw / 2 >= w) return fail(RESR_ERR_ARG, "filter2d: reflect padding needs pad < image size");
+    const size_t lds = ((size_t)(32 + 2 * (kw / 2)) * (32 + 2 * (kh / 2)) + (size_t)kh * kw) * sizeof(float);
+    hipLaunchKernelGGL(filter2d_kernel, dim3((w + 31) / 32, (h + 31) / 32, n * c), dim3(256), lds, st, src, dst, kern, c,
+                       h, w, kh, kw, per_sample);
+    RESR_CHECK_LAUNCH("filter2d_kernel");
+    return RESR_OK;
+}
+
+// USMSharp epilogues
+__global__ __launch_bounds__(256) void usm_mask_kernel(const float* __restrict__ x, const float* __restrict__ blur,
+                                                       float* __restrict__ mask, long count, float threshold) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float res = x[i] - blur[i];
+    mask[i] = (fabsf(res) * 255.f > threshold) ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void usm_combine_kernel(const float* __restrict__ x, const float* __restrict__ blur,
+                                                          const float* __restrict__ soft, float* __restrict__ out,
+                                                          long count, float weight) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float xv = x[i], res = xv - blur[i], s = soft[i];
+    const float sharp = fminf(fmaxf(xv + weight * res, 0.f), 1.f);
+    out[i] = s * sharp + (1.f - s) * xv;
+}
+
+int usm_dispatch(const float* src, float* dst, float* tmp, const float* k1d, int ksize, float weight, float threshold,
+                 int n, int c, int h, int w, hipStream_t st) {
+    if (!src || !dst || !tmp || !k1d) return fail(RESR_ERR_ARG, "usm_sharp: null argument");
+    const long count = (long)n * c * h * w;
+    float* t0 = tmp;               // row pass
+    float* blur = tmp + count;     // blurred x, later soft mask input
+    float* t2 = tmp + 2 * count;   // mask / soft
+    int rc;
+    if ((rc = filter2d_dispatch(src, t0, k1d, n, c, h, w, 1, ksize, 0, st))) return rc;
+    if ((rc = filter2d_dispatch(t0, blur, k1d, n, c, h, w, ksize, 1, 0, st))) return rc;
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    hipLaunchKernelGGL(usm_mask_kernel, dim3(blocks), dim3(256), 0, st, src, blur, t2, count, threshold);
+    RESR_CHECK_LAUNCH("usm_mask_kernel");
+    if ((rc = filter2d_dispatch(t2, t0, k1d, n, c, h, w, 1, ksize, 0, st))) return rc;
+    if ((rc = filter2d_dispatch(t0, t2, k1d, n, c, h, w, ksize, 1, 0, st))) return rc;
+    hipLaunchKernelGGL(usm_combine_kernel, dim3(blocks), dim3(256), 0, st, src, blur, t2, dst, count, weight);
+    RESR_CHECK_LAUNCH("usm_combine_kernel");
+    return RESR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// resize (torch.nn.functional.interpolate, align_corners=False, antialias=False)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes,
+                                                     int h, int w, int oh, int ow, int mode, float sh, float sw) {
+    const long total = (long)planes * oh * ow;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % ow);
+    const int oy = (int)((i / ow) % oh);
+    const int p = (int)(i / ((long)ow * oh));
+    const float* sp = src + (size_t)p * h * w;
+    float v;
+    if (mode == 0) {            // area == adaptive_avg_pool2d
+        const int y0 = (int)floorf((float)(oy * h) / oh), y1 = (int)ceilf((float)((oy + 1) * h) / oh);
+        const int x0 = (int)floorf((float)(ox * w) / ow), x1 = (int)ceilf((float)((ox + 1) * w) / ow);
+        float s = 0.f;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) s += sp[(size_t)y * w + x];
+        v = s / (float)((y1 - y0) * (x1 - x0));
+    } else if (mode == 1) {     // bilinear
+        float fy = sh * (oy + 0.5f) - 0.5f, fx = sw * (ox + 0.5f) - 0.5f;
+        if (fy < 0.f) fy = 0.f;
+        if (fx < 0.f) fx = 0.f;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int yp = y0 < h - 1 ? 1 : 0, xp = x0 < w - 1 ? 1 : 0;
+        const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float* r0 = sp + (size_t)y0 * w + x0;
+        const float* r1 = r0 + (size_t)yp * w;
+        v = hy * (hx * r0[0] + lx * r0[xp]) + ly * (hx * r1[0] + lx * r1[xp]);
+    } else {                    // bicubic, A = -0.75
+        const float A = -0.75f;
+        const float fy = sh * (oy + 0.5f) - 0.5f, fx = sw * (ox + 0.5f) - 0.5f;
+        const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+        const float ty = fy - iy, tx = fx - ix;
+        float cy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+        float cx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+        v = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int yy = min(max(iy - 1 + a, 0), h - 1);
+            float row = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int xx = min(max(ix - 1 + b, 0), w - 1);
+                row += cx[b] * sp[(size_t)yy * w + xx];
+            }
+            v += cy[a] * row;
+        }
+    }
+    dst[i] = v;
+}
+
+int resize_dispatch(const float* src, float* dst, int n, int c, int h, int w, int oh, int ow, int mode, double scale_h,
+                    double scale_w, hipStream_t st) {
+    if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || mode < 0 || mode > 2)
+        return fail(RESR_ERR_ARG, "resize: bad argument");
+    // coordinate scale: 1/scale_factor when the caller gave scale_factor= (torch area_pixel_compute_scale),
+    // in/out otherwise
+    const float sh = scale_h > 0. ? (float)(1.0 / scale_h) : (float)h / (float)oh;
+    const float sw = scale_w > 0. ? (float)(1.0 / scale_w) : (float)w / (float)ow;
+    const long total = (long)n * c * oh * ow;
+    hipLaunchKernelGGL(resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, n * c, h, w, oh,
+                       ow, mode, sh, sw);
+    RESR_CHECK_LAUNCH("resize_kernel");
+    return RESR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// RNG: Philox4x32-10, counter = (element index, stream), key = seed
+// ---------------------------------------------------------------------------------------------------------
+struct Philox {
+    uint32_t c[4], k[2];
+    __device__ Philox(uint64_t seed, uint64_t idx, uint64_t stream) {
+        k[0] = (uint32_t)seed; k[1] = (uint32_t)(seed >> 32);
+        c[0] = (uint32_t)idx; c[1] = (uint32_t)(idx >> 32); c[2] = (uint32_t)stream; c[3] = (uint32_t)(stream >> 32);
+    }
+    __device__ void next(uint32_t out[4]) {
+        uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], k0 = k[0], k1 = k[1];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+            c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+        if (++c[3] == 0) ++c[2];   // advance the stream word: independent draws for the same element
+    }
+};
+
+__device__ __forceinline__ float u01(uint32_t x) { return (x >> 8) * (1.0f / 16777216.0f) + (0.5f / 16777216.0f); }  // (0,1)
+
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ dst, long count, uint64_t seed, uint64_t stream) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;     // 4 normals per thread
+    if (q * 4 >= count) return;
+    Philox ph(seed, (uint64_t)q, stream);
+    uint32_t r[4];
+    ph.next(r);
+    float z[4];
+    const float a = sqrtf(-2.f * logf(u01(r[0]))), b = 6.283185307179586f * u01(r[1]);
+    const float c = sqrtf(-2.f * logf(u01(r[2]))), d = 6.283185307179586f * u01(r[3]);
+    z[0] = a * cosf(b); z[1] = a * sinf(b); z[2] = c * cosf(d); z[3] = c * sinf(d);
+    for (int j = 0; j < 4 && q * 4 + j < count; ++j) dst[q * 4 + j] = z[j];
+}
+
+int randn_dispatch(float* dst, long count, uint64_t seed, uint64_t stream, hipStream_t st) {
+    if (!dst || count <= 0) return fail(RESR_ERR_ARG, "randn_fill: bad argument");
+    hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((count / 4 + 256) / 256)), dim3(256), 0, st, dst, count, seed, stream);
+    RESR_CHECK_LAUNCH("randn_kernel");
+    return RESR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// noise
+// ---------------------------------------------------------------------------------------------------------
+// clip/rounds combinations of imgproc.py:1050-1055: bit0 = clip, bit1 = rounds
+__device__ __forceinline__ float finish_noise(float v, int mode) {
+    if (mode == 3) return fminf(fmaxf(rintf(v * 255.f), 0.f), 255.f) / 255.f;
+    if (mode == 1) return fminf(fmaxf(v, 0.f), 1.f);
+    if (mode == 2) return rintf(v * 255.f) / 255.f;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void gauss_noise_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          const float* __restrict__ sigma, const float* __restrict__ gray,
+                                                          const float* __restrict__ fg, const float* __restrict__ fc,
+                                                          int c, int hw, long count, int clip) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const int b = (int)(i / ((long)c * hw));
+    const int px = (int)(i % hw);
+    const float s = sigma[b], g = gray[b];
+    float noise = fc[i] * s / 255.f;
+    if (fg) noise = noise * (1.f - g) + (fg[px] * s / 255.f) * g;     // imgproc.py:861, one gray field for the batch
+    dst[i] = finish_noise(src[i] + noise, clip);
+}
+
+int gauss_noise_dispatch(const float* src, float* dst, const float* sigma, const float* gray, const float* fg,
+                         const float* fc, int n, int c, int h, int w, int clip, hipStream_t st) {
+    if (!src || !dst || !sigma || !gray || !fc) return fail(RESR_ERR_ARG, "noise_gaussian: null argument");
+    const long count = (long)n * c * h * w;
+    hipLaunchKernelGGL(gauss_noise_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, src, dst, sigma, gray,
+                       fg, fc, c, h * w, count, clip);
+    RESR_CHECK_LAUNCH("gauss_noise_kernel");
+    return RESR_OK;
+}
+
+__device__ __forceinline__ float q255(float v) { return fminf(fmaxf(rintf(v * 255.f), 0.f), 255.f); }
+__device__ __forceinline__ float gray_of(float r, float g, float b) { return 0.2989f * r + 0.587f * g + 0.114f * b; }
+
+// presence bitmaps of the quantised values per sample: flags[b][0][256] colour, flags[b][1][256] gray
+__global__ __launch_bounds__(256) void unique_flags_kernel(const float* __restrict__ src, unsigned* __restrict__ flags,
+                                                           int hw) {
+    __shared__ unsigned present[512];
+    const int b = blockIdx.y;
+    present[threadIdx.x] = 0;
+    present[256 + threadIdx.x] = 0;
+    __syncthreads();
+    const float* sp = src + (size_t)b * 3 * hw;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += gridDim.x * 256) {
+        const float r = sp[p], g = sp[hw + p], bl = sp[2 * hw + p];
+        present[(int)q255(r)] = 1; present[(int)q255(g)] = 1; present[(int)q255(bl)] = 1;
+        present[256 + (int)q255(gray_of(r, g, bl))] = 1;
+    }
+    __syncthreads();
+    if (present[threadIdx.x]) flags[(size_t)b * 512 + threadIdx.x] = 1;
+    if (present[256 + threadIdx.x]) flags[(size_t)b * 512 + 256 + threadIdx.x] = 1;
+}
+
+// vals[b][0] colour, vals[b][1] gray: 2^ceil(log2(#unique))
+__global__ void unique_vals_kernel(const unsigned* __restrict__ flags, float* __restrict__ vals) {
+    __shared__ int cnt[2];
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int b = blockIdx.x;
+    if (flags[(size_t)b * 512 + threadIdx.x]) atomicAdd(&cnt[0], 1);
+    if (flags[(size_t)b * 512 + 256 + threadIdx.x]) atomicAdd(&cnt[1], 1);
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        int v = 1;
+        while (v < cnt[threadIdx.x]) v <<= 1;
+        vals[b * 2 + threadIdx.x] = (float)v;
+    }
+}
+
+// Poisson sampler: inversion for small means, Hormann's PTRS (transformed rejection) otherwise -- the same
+// two regimes torch.poisson uses.
+__device__ float poisson_draw(float lam, Philox& ph) {
+    uint32_t r[4];
+    if (lam <= 0.f) return 0.f;
+    if (lam < 10.f) {
+        const float el = expf(-lam);
+        float prod = 1.f;
+        int k = 0;
+        for (;;) {
+            ph.next(r);
+            for (int j = 0; j < 4; ++j) {
+                prod *= u01(r[j]);
+                if (prod <= el) return (float)k;
+                ++k;
+            }
+        }
+    }
+    const float slam = sqrtf(lam), loglam = logf(lam);
+    const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
+    const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.f);
+    for (;;) {
+        ph.next(r);
+        for (int j = 0; j < 4; j += 2) {
+            const float U = u01(r[j]) - 0.5f, V = u01(r[j + 1]);
+            const float us = 0.5f - fabsf(U);
+            const float k = floorf((2.f * a / us + b) * U + lam + 0.43f);
+            if (us >= 0.07f && V <= vr) return k;
+            if (k < 0.f || (us < 0.013f && V > us)) continue;
+            if (logf(V) + logf(invalpha) - logf(a / (us * us) + b) <= -lam + k * loglam - lgammaf(k + 1.f)) return k;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void poisson_noise_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            const float* __restrict__ scale, const float* __restrict__ gray,
+                                                            const float* __restrict__ vals, int hw, long npix,
+                                                            uint64_t seed, int clip) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;      // one pixel (3 channels) per thread
+    if (i >= npix) return;
+    const int b = (int)(i / hw);
+    const int p = (int)(i % hw);
+    const float* sp = src + (size_t)b * 3 * hw + p;
+    float* dp = dst + (size_t)b * 3 * hw + p;
+    const float ch[3] = {sp[0], sp[hw], sp[2 * hw]};
+    const float sc = scale[b], g = gray[b];
+    Philox ph(seed, (uint64_t)i, 0);
+    float ng = 0.f;
+    if (g > 0.f) {                                               // imgproc.py:887-897
+        const float vg = vals[b * 2 + 1];
+        const float gq = q255(gray_of(ch[0], ch[1], ch[2])) / 255.f;
+        ng = poisson_draw(gq * vg, ph) / vg - gq;
+    }
+    const float v = vals[b * 2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                                // imgproc.py:899-914
+        const float q = q255(ch[k]) / 255.f;
+        float noise = poisson_draw(q * v, ph) / v - q;
+        noise = noise * (1.f - g) + ng * g;
+        dp[k * hw] = finish_noise(ch[k] + noise * sc, clip);
+    }
+}
+
+int poisson_noise_dispatch(const float* src, float* dst, const float* scale, const float* gray, uint64_t seed,
+                           void* workspace, int n, int c, int h, int w, int clip, hipStream_t st) {
+    if (!src || !dst || !scale || !gray || !workspace) return fail(RESR_ERR_ARG, "noise_poisson: null argument");
+    if (c != 3) return fail(RESR_ERR_ARG, "noise_poisson: needs 3 channels");
+    unsigned* flags = (unsigned*)workspace;                       // n*512 uint32, then n*2 float
+    float* vals = (float*)(flags + (size_t)n * 512);
+    if (hipMemsetAsync(flags, 0, (size_t)n * 512 * sizeof(unsigned), st) != hipSuccess)
+        return fail(RESR_ERR_LAUNCH, "noise_poisson: memset failed");
+    const int hw = h * w;
+    int bx = (hw + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(unique_flags_kernel, dim3(bx, n), dim3(256), 0, st, src, flags, hw);
+    RESR_CHECK_LAUNCH("unique_flags_kernel");
+    hipLaunchKernelGGL(unique_vals_kernel, dim3(n), dim3(256), 0, st, flags, vals);
+    RESR_CHECK_LAUNCH("unique_vals_kernel");
+    const long npix = (long)n * hw;
+    hipLaunchKernelGGL(poisson_noise_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, src, dst, scale, gray,
+                       vals, hw, npix, seed, clip);
+    RESR_CHECK_LAUNCH("poisson_noise_kernel");
+    return RESR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DiffJPEG(differentiable=False)
+// ---------------------------------------------------------------------------------------------------------
+struct JpegTables {
+    float basis[4096];    // [x][y][u][v] = cos((2x+1)u pi/16) cos((2y+1)v pi/16), float32 of the float64 product
+    float scale[64];      // 0.25 * alpha(u) alpha(v)
+    float alpha[64];      // alpha(u) alpha(v)
+    float ytab[64], ctab[64];   // the reference's (transposed) tables, imgproc.py:40-49
+};
+__device__ JpegTables g_jpeg;
+
+static void jpeg_tables_host(JpegTables& t) {
+    static const float ystd[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
+                                   14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+                                   49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+    static const float cstd[16] = {17, 18, 24, 47, 18, 21, 26, 66, 24, 26, 56, 99, 47, 66, 99, 99};
+    for (int x = 0; x < 8; ++x)
+        for (int y = 0; y < 8; ++y)
+            for (int u = 0; u < 8; ++u)
+                for (int v = 0; v < 8; ++v)
+                    t.basis[((x * 8 + y) * 8 + u) * 8 + v] = (float)(cos((2 * x + 1) * u * M_PI / 16) * cos((2 * y + 1) * v * M_PI / 16));
+    for (int u = 0; u < 8; ++u)
+        for (int v = 0; v < 8; ++v) {
+            const double au = u == 0 ? 1.0 / sqrt(2.0) : 1.0, av = v == 0 ? 1.0 / sqrt(2.0) : 1.0;
+            t.scale[u * 8 + v] = (float)(au * av * 0.25);
+            t.alpha[u * 8 + v] = (float)(au * av);
+            t.ytab[u * 8 + v] = ystd[v * 8 + u];                                   // transposed
+            t.ctab[u * 8 + v] = (u < 4 && v < 4) ? cstd[v * 4 + u] : 99.f;          // transposed 4x4 corner
+        }
+}
+
+// one workgroup per 16x16 macroblock: 6 blocks of 8x8 (4 Y, Cb, Cr) -> 384 coefficients
+__global__ __launch_bounds__(256) void jpeg_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                   const float* __restrict__ quality, float* __restrict__ coeffs, int h,
+                                                   int w, int mbx, int mby, int clamp_in) {
+    __shared__ float ycc[3][256];      // Y, Cb, Cr at full resolution
+    __shared__ float blk[6][64];       // level-shifted blocks
+    __shared__ float coef[6][64];      // dequantised coefficients * alpha
+    __shared__ float rec[6][64];
+    const int b = blockIdx.z, my = blockIdx.y, mx = blockIdx.x;
+    const int t = threadIdx.x, ly = t >> 4, lx = t & 15;
+    const int y = my * 16 + ly, x = mx * 16 + lx;
+    const size_t hw = (size_t)h * w;
+    const float* sp = src + (size_t)b * 3 * hw;
+    float r = 0.f, g = 0.f, bl = 0.f;                 // zero padding up to a multiple of 16 (imgproc.py:1488)
+    if (y < h && x < w) {
+        r = sp[(size_t)y * w + x]; g = sp[hw + (size_t)y * w + x]; bl = sp[2 * hw + (size_t)y * w + x];
+        if (clamp_in) {            // torch.clamp(out, 0, 1) of train_realesrnet.py:308,357,362 folded in
+            r = fminf(fmaxf(r, 0.f), 1.f); g = fminf(fmaxf(g, 0.f), 1.f); bl = fminf(fmaxf(bl, 0.f), 1.f);
+        }
+        r *= 255.f; g *= 255.f; bl *= 255.f;
+    }
+    ycc[0][t] = 0.299f * r + 0.587f * g + 0.114f * bl + 0.f;
+    ycc[1][t] = -0.168736f * r + -0.331264f * g + 0.5f * bl + 128.f;
+    ycc[2][t] = 0.5f * r + -0.418688f * g + -0.081312f * bl + 128.f;
+    __syncthreads();
+    // block split: Y block (ly>>3, lx>>3); chroma = 2x2 average
+    blk[(ly >> 3) * 2 + (lx >> 3)][(ly & 7) * 8 + (lx & 7)] = ycc[0][t] - 128.f;
+    if (t < 128) {
+        const int cidx = t >> 6, e = t & 63, cy = e >> 3, cx = e & 7;
+        const float* pc = ycc[1 + cidx];
+        const float s = (pc[(2 * cy) * 16 + 2 * cx] + pc[(2 * cy) * 16 + 2 * cx + 1] + pc[(2 * cy + 1) * 16 + 2 * cx] +
+                         pc[(2 * cy + 1) * 16 + 2 * cx + 1]) * 0.25f;
+        blk[4 + cidx][e] = s - 128.f;
+    }
+    __syncthreads();
+    const float qv = quality[b];
+    const float factor = qv < 50.f ? (5000.f / qv) / 100.f : (200.f - qv * 2.f) / 100.f;   // imgproc.py:1134-1139
+    for (int i = t; i < 384; i += 256) {
+        const int bi = i >> 6, uv = i & 63;
+        float s = 0.f;
+#pragma unroll 8
+        for (int xy = 0; xy < 64; ++xy) s += blk[bi][xy] * g_jpeg.basis[xy * 64 + uv];
+        const float table = (bi < 4 ? g_jpeg.ytab[uv] : g_jpeg.ctab[uv]) * factor;
+        const float q = rintf((g_jpeg.scale[uv] * s) / table);                                 // torch.round: half to even
+        if (coeffs) {
+            // layout: per image [Y blocks (H/8 * W/8) | Cb blocks | Cr blocks] x 64, block order row-major
+            const int nyb = mbx * 2 * mby * 2, ncb = mbx * mby;
+            size_t off;
+            if (bi < 4) off = (size_t)((my * 2 + (bi >> 1)) * (mbx * 2) + mx * 2 + (bi & 1));
+            else off = (size_t)nyb + (size_t)(bi - 4) * ncb + (size_t)my * mbx + mx;
+            coeffs[((size_t)b * (nyb + 2 * ncb) + off) * 64 + uv] = q;
+        }
+        coef[bi][uv] = (q * table) * g_jpeg.alpha[uv];
+    }
+    __syncthreads();
+    for (int i = t; i < 384; i += 256) {
+        const int bi = i >> 6, uv = i & 63;      // here (u,v) index the spatial position of the output
+        float s = 0.f;
+#pragma unroll 8
+        for (int xy = 0; xy < 64; ++xy) s += coef[bi][xy] * g_jpeg.basis[uv * 64 + xy];   // basis^T: [u][v][x][y]
+        rec[bi][uv] = 0.25f * s + 128.f;
+    }
+    __syncthreads();
+    if (y < h && x < w) {
+        const float Y = rec[(ly >> 3) * 2 + (lx >> 3)][(ly & 7) * 8 + (lx & 7)];
+        const float cb = rec[4][(ly >> 1) * 8 + (lx >> 1)] - 128.f, cr = rec[5][(ly >> 1) * 8 + (lx >> 1)] - 128.f;
+        float* dp = dst + (size_t)b * 3 * hw + (size_t)y * w + x;
+        const float R = Y + 1.402f * cr;
+        const float G = Y + -0.344136f * cb + -0.714136f * cr;
+        const float B = Y + 1.772f * cb;
+        dp[0] = fminf(fmaxf(R, 0.f), 255.f) / 255.f;
+        dp[hw] = fminf(fmaxf(G, 0.f), 255.f) / 255.f;
+        dp[2 * hw] = fminf(fmaxf(B, 0.f), 255.f) / 255.f;
+    }
+}
+
+int jpeg_dispatch(const float* src, float* dst, const float* quality, float* coeffs, int n, int h, int w, int flags,
+                  hipStream_t st) {
+    if (!src || !dst || !quality || n <= 0 || h <= 0 || w <= 0) return fail(RESR_ERR_ARG, "jpeg: bad argument");
+    static std::once_flag once[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipError_t err = hipSuccess;
+    std::call_once(once[dev & 15], [&]() {
+        static JpegTables host;
+        jpeg_tables_host(host);
+        err = hipMemcpyToSymbol(HIP_SYMBOL(g_jpeg), &host, sizeof(JpegTables));
+    });
+    if (err != hipSuccess) return fail(RESR_ERR_LAUNCH, "jpeg: table upload failed: %s", hipGetErrorString(err));
+    const int mbx = (w + 15) / 16, mby = (h + 15) / 16;
+    hipLaunchKernelGGL(jpeg_kernel, dim3(mbx, mby, n), dim3(256), 0, st, src, dst, quality, coeffs, h, w, mbx, mby, flags & 1);
+    RESR_CHECK_LAUNCH("jpeg_kernel");
+    return RESR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// final quantise + crop
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crop_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes, int h,
+                                                   int w, int size, int top, int left, int quant) {
+    const long total = (long)planes * size * size;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % size), y = (int)((i / size) % size), p = (int)(i / ((long)size * size));
+    float v = src[((size_t)p * h + top + y) * w + left + x];
+    if (quant) v = fminf(fmaxf(rintf(v * 255.f), 0.f), 255.f) / 255.f;     // train_realesrnet.py:374
+    dst[i] = v;
+}
+
+int quantize_crop_dispatch(const float* lr, const float* hr, float* lr_out, float* hr_out, int n, int c, int lr_h, int lr_w,
+                           int hr_h, int hr_w, int hr_size, int upscale, int hr_top, int hr_left, hipStream_t st) {
+    if (!lr || !hr || !lr_out || !hr_out || upscale <= 0) return fail(RESR_ERR_ARG, "quantize_crop: bad argument");
+    const int lr_size = hr_size / upscale, lr_top = hr_top / upscale, lr_left = hr_left / upscale;     // imgproc.py:1917-1919
+    if (hr_top < 0 || hr_left < 0 || hr_top + hr_size > hr_h || hr_left + hr_size > hr_w || lr_top + lr_size > lr_h ||
+        lr_left + lr_size > lr_w)
+        return fail(RESR_ERR_ARG, "quantize_crop: window outside the image");
+    const long tl = (long)n * c * lr_size * lr_size, th = (long)n * c * hr_size * hr_size;
+    hipLaunchKernelGGL(crop_kernel, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, st, lr, lr_out, n * c, lr_h, lr_w, lr_size,
+                       lr_top, lr_left, 1);
+    RESR_CHECK_LAUNCH("crop_kernel");
+    hipLaunchKernelGGL(crop_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, hr, hr_out, n * c, hr_h, hr_w, hr_size,
+                       hr_top, hr_left, 0);
+    RESR_CHECK_LAUNCH("crop_kernel");
+    return RESR_OK;
+}
+
+}  // namespace resr

@@ -1,0 +1,302 @@
+"""Degradation ops behind the reference's `imgproc.py` surface (same names, argument order, return
+shapes; reference imgproc.py:29-38), executed by the HIP kernels of csrc/degrade.hip through the C-ABI.
+Inputs must live on the MI355X; there is no CPU path.
+
+Host-side blur / sinc kernel synthesis (reference imgproc.py:170-603, dataset.py:82-143) is float64
+numpy, as in the reference's DataLoader workers: 3 kernels of 21x21 per sample.
+"""
+from __future__ import annotations
+
+import math
+import random
+from typing import Any, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+
+__all__ = ["random_add_gaussian_noise_torch", "random_add_poisson_noise_torch", "random_mixed_kernels",
+           "generate_sinc_kernel", "image_to_tensor", "tensor_to_image", "random_crop", "filter2d_torch",
+           "interpolate", "DiffJPEG", "USMSharp"]
+
+_MODES = {"area": 0, "bilinear": 1, "bicubic": 2}
+_seed_counter = [0x5EED]
+
+
+def _next_seed() -> int:
+    _seed_counter[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0]) & 0xFFFFFFFFFFFFFFFF
+
+
+def _img(x: torch.Tensor, what: str) -> torch.Tensor:
+    _lib.require_cuda(x, what)
+    if x.dim() != 4:
+        raise ValueError(f"{what}: expected [N,C,H,W]")
+    return x.float().contiguous()
+
+
+# ---- filters -------------------------------------------------------------------------------------------
+def filter2d_torch(image: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
+    """cv2.filter2D equivalent (reference imgproc.py:1089-1121): reflect padding, correlation;
+    kernel [1,k,k] shared by the batch or [B,k,k] per sample."""
+    x = _img(image, "filter2d_torch")
+    k = kernel.size(-1)
+    if k % 2 != 1:
+        raise ValueError("Wrong kernel size.")
+    b, c, h, w = x.shape
+    kk = kernel.to(device=x.device, dtype=torch.float32).contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().resr_filter2d(_lib.ptr(x), _lib.ptr(out), _lib.ptr(kk), b, c, h, w, k, k,
+                                        0 if kernel.size(0) == 1 else 1, _lib.stream_ptr()), "resr_filter2d")
+    return out
+
+
+def _gaussian_1d(ksize: int, sigma: float) -> np.ndarray:
+    # cv2.getGaussianKernel, general branch (reference imgproc.py:1522)
+    if sigma <= 0:
+        sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    g = np.exp(-(x * x) / (2.0 * sigma * sigma))
+    return g / g.sum()
+
+
+class USMSharp(nn.Module):
+    """Unsharp masking (reference imgproc.py:1514-1537).  The [1,k,k] `kernel` buffer is kept for
+    state_dict compatibility; the blur itself runs as the two separable k-tap passes of its factor."""
+
+    def __init__(self, radius: int, sigma: int) -> None:
+        super().__init__()
+        if radius % 2 == 0:
+            radius += 1
+        self.radius = radius
+        g = _gaussian_1d(radius, sigma)
+        self.register_buffer("kernel", torch.from_numpy(np.outer(g, g).astype(np.float32)).unsqueeze_(0))
+        self.register_buffer("k1d", torch.from_numpy(g.astype(np.float32)), persistent=False)
+
+    def forward(self, x, weight: float, threshold: int) -> torch.Tensor:
+        xi = _img(x, "USMSharp")
+        b, c, h, w = xi.shape
+        out = torch.empty_like(xi)
+        tmp = torch.empty(3 * xi.numel(), dtype=torch.float32, device=xi.device)
+        _lib.check(_lib.lib().resr_usm_sharp(_lib.ptr(xi), _lib.ptr(out), _lib.ptr(tmp), _lib.ptr(self.k1d), self.radius,
+                                             float(weight), float(threshold), b, c, h, w, _lib.stream_ptr()), "resr_usm_sharp")
+        return out
+
+
+def interpolate(image: torch.Tensor, size=None, scale_factor=None, mode: str = "bilinear") -> torch.Tensor:
+    """F.interpolate(mode in area|bilinear|bicubic, align_corners=False) as used at reference
+    train_realesrnet.py:288 (scale_factor=) and :326-329, :349-351, :366-368 (size=)."""
+    x = _img(image, "interpolate")
+    b, c, h, w = x.shape
+    if (size is None) == (scale_factor is None):
+        raise ValueError("give exactly one of size / scale_factor")
+    if size is not None:
+        oh, ow = (size, size) if isinstance(size, int) else size
+        sh = sw = 0.0
+    else:
+        sh = sw = float(scale_factor)
+        oh, ow = int(math.floor(float(h) * sh)), int(math.floor(float(w) * sw))
+    out = torch.empty((b, c, oh, ow), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().resr_resize(_lib.ptr(x), _lib.ptr(out), b, c, h, w, oh, ow, _MODES[mode], sh, sw,
+                                      _lib.stream_ptr()), "resr_resize")
+    return out
+
+
+# ---- noise ---------------------------------------------------------------------------------------------
+def _finish_mode(clip: bool, rounds: bool) -> int:
+    return (1 if clip else 0) | (2 if rounds else 0)
+
+
+def add_gaussian_noise_fields(image, sigma, gray, field_gray, field_color, clip=True, rounds=False):
+    """Gaussian noise with every random draw given (parity tests inject the reference's draws)."""
+    x = _img(image, "gaussian noise")
+    b, c, h, w = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().resr_noise_gaussian(_lib.ptr(x), _lib.ptr(out), _lib.ptr(sigma.float().contiguous()),
+                                              _lib.ptr(gray.float().contiguous()),
+                                              _lib.ptr(field_gray.contiguous()) if field_gray is not None else None,
+                                              _lib.ptr(field_color.contiguous()), b, c, h, w, _finish_mode(clip, rounds),
+                                              _lib.stream_ptr()), "resr_noise_gaussian")
+    return out
+
+
+def random_add_gaussian_noise_torch(image: torch.Tensor, sigma_range: tuple = (0, 1.0), gray_prob: int = 0,
+                                    clip: bool = True, rounds: bool = False) -> torch.Tensor:
+    """Reference imgproc.py:1029-1057.  Per-sample sigma ~ U(range), gray flag ~ Bernoulli(gray_prob); the
+    gray noise is ONE h x w field shared by the whole batch (reference quirk, imgproc.py:854-855).  All draws
+    stay on the device (Philox); nothing is read back."""
+    x = _img(image, "random_add_gaussian_noise_torch")
+    b, c, h, w = x.shape
+    sigma = torch.rand(b, device=x.device) * (sigma_range[1] - sigma_range[0]) + sigma_range[0]
+    gray = (torch.rand(b, device=x.device) < gray_prob).float()
+    fields = torch.empty(h * w + x.numel(), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().resr_randn_fill(_lib.ptr(fields), fields.numel(), _next_seed(), 0, _lib.stream_ptr()), "resr_randn_fill")
+    return add_gaussian_noise_fields(x, sigma, gray, fields[:h * w], fields[h * w:], clip, rounds)
+
+
+def add_poisson_noise(image, scale, gray, seed: int, clip=True, rounds=False, return_vals=False):
+    x = _img(image, "poisson noise")
+    b, c, h, w = x.shape
+    out = torch.empty_like(x)
+    ws = torch.empty(_lib.lib().resr_noise_poisson_workspace_bytes(b), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().resr_noise_poisson(_lib.ptr(x), _lib.ptr(out), _lib.ptr(scale.float().contiguous()),
+                                             _lib.ptr(gray.float().contiguous()), seed, _lib.ptr(ws), b, c, h, w,
+                                             _finish_mode(clip, rounds), _lib.stream_ptr()), "resr_noise_poisson")
+    if return_vals:
+        return out, ws[b * 2048:].view(torch.float32).view(b, 2)
+    return out
+
+
+def random_add_poisson_noise_torch(image: torch.Tensor, scale_range: tuple = (0, 1.0), gray_prob: int = 0,
+                                   clip: bool = True, rounds: bool = False) -> torch.Tensor:
+    """Reference imgproc.py:1060-1086; the per-sample `len(torch.unique(...))` host loop (imgproc.py:892,903)
+    is a 256-bin presence bitmap on the device -- no synchronisation."""
+    x = _img(image, "random_add_poisson_noise_torch")
+    b = x.shape[0]
+    scale = torch.rand(b, device=x.device) * (scale_range[1] - scale_range[0]) + scale_range[0]
+    gray = (torch.rand(b, device=x.device) < gray_prob).float()
+    return add_poisson_noise(x, scale, gray, _next_seed(), clip, rounds)
+
+
+# ---- JPEG ----------------------------------------------------------------------------------------------
+class DiffJPEG(nn.Module):
+    """DiffJPEG (reference imgproc.py:1462-1494), non-differentiable rounding only (the reference's train
+    loops construct DiffJPEG(False), train_realesrnet.py:231).  `quality` may be a number or a [B] tensor;
+    like the reference, a tensor argument is overwritten in place with the quantisation factors."""
+
+    def __init__(self, differentiable: bool) -> None:
+        super().__init__()
+        if differentiable:
+            raise NotImplementedError("the MI355X path implements DiffJPEG(differentiable=False), the only form the "
+                                      "reference's training loops use (train_realesrnet.py:231, train_realesrgan.py)")
+
+    def forward(self, x: torch.Tensor, quality, return_coeffs: bool = False, clamp_input: bool = False):
+        xi = _img(x, "DiffJPEG")
+        b, c, h, w = xi.shape
+        if c != 3:
+            raise ValueError("DiffJPEG expects RGB input")
+        if isinstance(quality, (int, float)):
+            q = torch.full((b,), float(quality), dtype=torch.float32, device=xi.device)
+        else:
+            q = quality.to(device=xi.device, dtype=torch.float32).contiguous().clone()
+        out = torch.empty_like(xi)
+        coeffs = None
+        if return_coeffs:
+            mb = ((h + 15) // 16) * ((w + 15) // 16)
+            coeffs = torch.empty((b, mb * 6, 64), dtype=torch.float32, device=xi.device)
+        _lib.check(_lib.lib().resr_jpeg(_lib.ptr(xi), _lib.ptr(out), _lib.ptr(q), _lib.ptr(coeffs), b, h, w,
+                                        1 if clamp_input else 0, _lib.stream_ptr()), "resr_jpeg")
+        if isinstance(quality, torch.Tensor):       # reference quirk: factor[i] = f(quality[i]) written into the caller's tensor
+            quality.copy_(torch.where(q < 50, (5000.0 / q) / 100.0, (200.0 - q * 2) / 100.0))
+        return (out, coeffs) if return_coeffs else out
+
+
+# ---- crop / conversions --------------------------------------------------------------------------------
+def quantize_crop(lr_images, hr_images, hr_image_size, upscale_factor, hr_top, hr_left):
+    """clamp(round(lr*255))/255 fused with the crop of both tensors (train_realesrnet.py:374-377)."""
+    lr, hr = _img(lr_images, "quantize_crop"), _img(hr_images, "quantize_crop")
+    b, c = lr.shape[:2]
+    ls = hr_image_size // upscale_factor
+    plr = torch.empty((b, c, ls, ls), dtype=torch.float32, device=lr.device)
+    phr = torch.empty((b, c, hr_image_size, hr_image_size), dtype=torch.float32, device=lr.device)
+    _lib.check(_lib.lib().resr_quantize_crop(_lib.ptr(lr), _lib.ptr(hr), _lib.ptr(plr), _lib.ptr(phr), b, c, lr.shape[2],
+                                             lr.shape[3], hr.shape[2], hr.shape[3], hr_image_size, upscale_factor,
+                                             hr_top, hr_left, _lib.stream_ptr()), "resr_quantize_crop")
+    return plr, phr
+
+
+def random_crop(lr_images: torch.Tensor, hr_images: torch.Tensor, hr_image_size: int,
+                upscale_factor: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Reference imgproc.py:1894-1934: ONE (top,left) for the whole batch from python `random`; the LR window
+    starts at hr offset // upscale (up to upscale-1 HR pixels of misalignment, as in the reference).
+    NOTE: the reference crops an already-quantised lr; this helper does not re-quantise."""
+    hr_h, hr_w = hr_images.shape[2:]
+    hr_top = random.randint(0, hr_h - hr_image_size)
+    hr_left = random.randint(0, hr_w - hr_image_size)
+    lt, ll, ls = hr_top // upscale_factor, hr_left // upscale_factor, hr_image_size // upscale_factor
+    _lib.require_cuda(lr_images, "random_crop")
+    return (lr_images[:, :, lt:lt + ls, ll:ll + ls].contiguous(),
+            hr_images[:, :, hr_top:hr_top + hr_image_size, hr_left:hr_left + hr_image_size].contiguous())
+
+
+def image_to_tensor(image: np.ndarray, range_norm: bool, half: bool) -> torch.Tensor:
+    """HWC float ndarray -> CHW tensor (reference imgproc.py:1540-1567)."""
+    t = torch.from_numpy(np.ascontiguousarray(image.transpose(2, 0, 1)))
+    if range_norm:
+        t = t.mul(2.0).sub(1.0)
+    return t.half() if half else t
+
+
+def tensor_to_image(tensor: torch.Tensor, range_norm: bool, half: bool) -> Any:
+    """[1,C,H,W] in [0,1] -> HWC uint8, truncating like the reference (imgproc.py:1594)."""
+    if range_norm:
+        tensor = tensor.add(1.0).div(2.0)
+    if half:
+        tensor = tensor.half()
+    return tensor.squeeze(0).permute(1, 2, 0).mul(255).clamp(0, 255).cpu().numpy().astype("uint8")
+
+
+# ---- host kernel synthesis (float64 numpy) ---------------------------------------------------------------
+def _quad_form(kernel_size: int, sigma_x: float, sigma_y: float, theta: float, isotropic: bool) -> np.ndarray:
+    ax = np.arange(-kernel_size // 2 + 1.0, kernel_size // 2 + 1.0)
+    xx, yy = np.meshgrid(ax, ax)
+    grid = np.stack([xx, yy], axis=2)
+    if isotropic:
+        cov = np.array([[sigma_x ** 2, 0], [0, sigma_x ** 2]])
+    else:
+        rot = np.array([[np.cos(theta), -np.sin(theta)], [np.sin(theta), np.cos(theta)]])
+        cov = rot @ np.array([[sigma_x ** 2, 0], [0, sigma_y ** 2]]) @ rot.T
+    return np.sum(np.dot(grid, np.linalg.inv(cov)) * grid, 2)
+
+
+def _kernel_of(family: str, kernel_size, sigma_x, sigma_y, theta, beta, isotropic) -> np.ndarray:
+    q = _quad_form(kernel_size, sigma_x, sigma_y, theta, isotropic)
+    if family == "gaussian":
+        k = np.exp(-0.5 * q)
+    elif family == "generalized":
+        k = np.exp(-0.5 * np.power(q, beta))
+    else:
+        k = np.reciprocal(np.power(q, beta) + 1)
+    return k / np.sum(k)
+
+
+def random_mixed_kernels(kernel_type: list, kernel_prob: Sequence[float], kernel_size: int, sigma_x_range: list,
+                         sigma_y_range: list, rotation_range: list, generalized_kernel_beta_range: list,
+                         plateau_kernel_beta_range: list, noise_range: tuple = None) -> np.ndarray:
+    """Reference imgproc.py:492-573 (same draw order from `random` / `np.random`)."""
+    kind = random.choices(kernel_type, kernel_prob)[0]
+    family = "generalized" if kind.startswith("generalized") else ("plateau" if kind.startswith("plateau") else "gaussian")
+    isotropic = not kind.endswith("anisotropic")
+    sigma_x = np.random.uniform(sigma_x_range[0], sigma_x_range[1])
+    if isotropic:
+        sigma_y, theta = sigma_x, 0
+    else:
+        sigma_y = np.random.uniform(sigma_y_range[0], sigma_y_range[1])
+        theta = np.random.uniform(rotation_range[0], rotation_range[1])
+    beta = 1.0
+    if family != "gaussian":
+        rng = generalized_kernel_beta_range if family == "generalized" else plateau_kernel_beta_range
+        beta = np.random.uniform(rng[0], 1) if np.random.uniform() < 0.5 else np.random.uniform(1, rng[1])
+    k = _kernel_of(family, kernel_size, sigma_x, sigma_y, theta, beta, isotropic)
+    if noise_range is not None and family != "plateau":
+        k = k * np.random.uniform(noise_range[0], noise_range[1], size=k.shape)
+    return k / np.sum(k)
+
+
+def generate_sinc_kernel(cutoff: float, kernel_size: int, padding: int = 0) -> np.ndarray:
+    """2-D sinc (jinc) low-pass kernel, reference imgproc.py:576-603."""
+    from scipy import special
+    assert kernel_size % 2 == 1, "Kernel size must be an odd number."
+    c = (kernel_size - 1) / 2
+    ii, jj = np.meshgrid(np.arange(kernel_size), np.arange(kernel_size), indexing="ij")
+    r = np.sqrt((ii - c) ** 2 + (jj - c) ** 2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        k = cutoff * special.j1(cutoff * r) / (2 * np.pi * r)
+    k[(kernel_size - 1) // 2, (kernel_size - 1) // 2] = cutoff ** 2 / (4 * np.pi)
+    k = k / np.sum(k)
+    if padding > kernel_size:
+        p = (padding - kernel_size) // 2
+        k = np.pad(k, ((p, p), (p, p)))
+    return k
