@@ -90,7 +90,7 @@ def probe_conv_kernels(batch, lr, dtype_name, reps=8):
         yn = torch.empty(batch, max(cout, 1), h, w, device="cuda", dtype=torch.float32) if cout < 4 else None
         mt = cout_pad // 32
         # timing only: any finite weights in packed order will do (+ one tap of prefetch slack)
-        packed = ((torch.rand(((cin // 32) * 9 * mt * 1024 + 4096,), device="cuda", generator=gen) - 0.5) * 0.1).to(tdt)
+        packed = ((torch.rand(((cin // 32) * 9 * mt * 1024 + 8192,), device="cuda", generator=gen) - 0.5) * 0.1).to(tdt)
         flags = L.CONV_LRELU | (L.CONV_OUT_NCHW_F32 | L.CONV_CLAMP01 if yn is not None else 0)
         d = L.ConvDesc(batch, h, w, cin, cin, cin, 0, cout, cout_pad, cout_pad, 0, 0, 0, dtype, flags,
                        1.0, 1.0, 1.0, 1.0, 0.2)

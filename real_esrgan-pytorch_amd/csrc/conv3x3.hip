@@ -19,6 +19,8 @@
 // ds_read_b128 is served in 16-lane groups whose pixel x-coordinates cover all residues mod 16;
 // XOR-ing the slot index with a function of x makes the 16 lanes hit 16 distinct slots of the
 // 256-byte bank row (conflict-free) -- see swz().
+#include <type_traits>
+
 #include "common.h"
 
 namespace resr {
@@ -145,6 +147,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     const char* in1 = a.in1 ? a.in1 + (size_t)n * img_px * a.in1_stride_b : nullptr;
 
     uint4 stg[NS];
+    // branch-free: out-of-image / unused slots read pixel 0 of the image (always mapped) and are zeroed by a
+    // select -- a branch per load would make the compiler wait for each load separately
     auto stage_load = [&](int ck) {
         const int c0 = ck * 32;
         const bool seg1 = c0 >= a.cin0;
@@ -153,16 +157,15 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
         const unsigned ch_b = (unsigned)(seg1 ? c0 - a.cin0 : c0) * (unsigned)sizeof(T) + (c16 << 4);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (pix[i] >= 0) v = *reinterpret_cast<const uint4*>(base + (size_t)pix[i] * stride_b + ch_b);
-            stg[i] = v;
+            const unsigned pi = pix[i] >= 0 ? (unsigned)pix[i] : 0u;
+            stg[i] = *reinterpret_cast<const uint4*>(base + (size_t)pi * stride_b + ch_b);
         }
     };
     auto stage_store = [&](int buf) {
         char* dst = smem + buf * BUF;
 #pragma unroll
         for (int i = 0; i < NS; ++i)
-            if (loff[i] >= 0) *reinterpret_cast<uint4*>(dst + loff[i]) = stg[i];
+            if (loff[i] >= 0) *reinterpret_cast<uint4*>(dst + loff[i]) = pix[i] >= 0 ? stg[i] : make_uint4(0, 0, 0, 0);
     };
 
     // ---- per-lane operand addressing -----------------------------------------------------------
@@ -187,44 +190,59 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
 
     const int nchunks = a.cin >> 5;
 
-    uint4 wcur[KS * MT], wnext[KS * MT];
+    // Weight fragments: 3-slot register ring, fetched two taps ahead of use (L2 latency ~ 2 taps of MFMA
+    // work per wave).  9 taps per chunk and 3 slots => the slot index stays static across the chunk loop.
+    // sched_barrier pins the loads where they are written; otherwise the scheduler sinks them to their use.
+    uint4 wr[3][KS * MT];
+    auto wload = [&](int slot, int q) {
+        const char* wq = wp + (size_t)q * WTAP;
 #pragma unroll
-    for (int j = 0; j < KS * MT; ++j) wcur[j] = *reinterpret_cast<const uint4*>(wp + j * 1024);
+        for (int j = 0; j < KS * MT; ++j) wr[slot][j] = *reinterpret_cast<const uint4*>(wq + j * 1024);
+    };
+    wload(0, 0);
+    wload(1, 1);
 
     stage_load(0);
     stage_store(0);
     __syncthreads();
 
-    for (int ck = 0; ck < nchunks; ++ck) {
-        const bool more = ck + 1 < nchunks;
+    // The last chunk is peeled (compile-time `more`): with a run-time flag the compiler's wait-count merge of
+    // the two paths makes every chunk wait for its own staging loads before the first MFMA.
+    auto chunk_body = [&](int ck, auto more_tag) {
+        constexpr bool more = decltype(more_tag)::value;
         if (more) stage_load(ck + 1);
         const char* lbuf = smem + (ck & 1) * BUF;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        // k-steps of the chunk, software-pipelined: the B fragments of step s+1 are read from LDS while the
+        // MFMAs of step s run (ping-pong registers; 9*KS is even, so the parity is static across chunks)
+        uint4 bb[2][NT];
+        auto bload = [&](int slot, int sidx) {
+            const int tap = sidx / KS, ks = sidx % KS;
             const int dy = tap / 3, dx = tap % 3;
-            // prefetch the next (chunk, tap) weight fragments; the tail over-read stays inside the
-            // packed buffer because the packer appends one dummy tap (see pack.hip)
-            const char* wn = wp + (size_t)(ck * 9 + tap + 1) * WTAP;
+            const int so = ((ks * 2 + kh) ^ colsw[dx]) << 4;
 #pragma unroll
-            for (int j = 0; j < KS * MT; ++j) wnext[j] = *reinterpret_cast<const uint4*>(wn + j * 1024);
+            for (int t = 0; t < NT; ++t)
+                bb[slot][t] = *reinterpret_cast<const uint4*>(lbuf + (row0 + t + dy) * (HW * PB) + colb[dx] + so);
+        };
+        bload(0, 0);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                uint4 b[NT];
-                const int so = ((ks * 2 + kh) ^ colsw[dx]) << 4;
+        for (int sidx = 0; sidx < 9 * KS; ++sidx) {
+            const int tap = sidx / KS, ks = sidx % KS;
+            // weights two taps ahead; the tail over-reads stay inside the packed buffer's slack
+            if (ks == 0) wload((tap + 2) % 3, ck * 9 + tap + 2);
+            if (sidx + 1 < 9 * KS) bload((sidx + 1) & 1, sidx + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    b[t] = *reinterpret_cast<const uint4*>(lbuf + (row0 + t + dy) * (HW * PB) + colb[dx] + so);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[m][t] = Frag<T>::mma(wcur[ks * MT + m], b[t], acc[m][t]);
-            }
-#pragma unroll
-            for (int j = 0; j < KS * MT; ++j) wcur[j] = wnext[j];
+                    acc[m][t] = Frag<T>::mma(wr[tap % 3][ks * MT + m], bb[sidx & 1][t], acc[m][t]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) stage_store((ck + 1) & 1);
         __syncthreads();
-    }
+    };
+    for (int ck = 0; ck + 1 < nchunks; ++ck) chunk_body(ck, std::true_type{});
+    chunk_body(nchunks - 1, std::false_type{});
 
     // ---- epilogue: lane owns pixel (row0+t, lx) and 4 consecutive couts per accumulator quad ----
     const bool f_lrelu = a.flags & RESR_CONV_LRELU, f_clamp = a.flags & RESR_CONV_CLAMP01;

@@ -226,8 +226,8 @@ size_t generator_param_count(const ResrGeneratorDesc* d) {
 size_t generator_packed_bytes(const ResrGeneratorDesc* d, int backward) {
     Plan p;
     if (!build_plan(d, p)) return 0;
-    // + one dummy (chunk,tap) of slack: conv3x3_kernel prefetches one tap past the end
-    return (backward ? p.pk_total_elems : p.pk_fwd_elems) * elem_size(d->dtype) + 8192;
+    // + two dummy (chunk,tap) of slack: conv3x3_kernel prefetches two taps past the end
+    return (backward ? p.pk_total_elems : p.pk_fwd_elems) * elem_size(d->dtype) + 16384;
 }
 
 size_t generator_workspace_bytes(const ResrGeneratorDesc* d) {

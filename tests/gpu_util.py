@@ -46,7 +46,7 @@ def pack_conv(weight, dtype, transposed=False, scale=1.0):
     table = torch.frombuffer(bytearray(bytes(chunks)), dtype=torch.uint8).cuda()
     arena = weight.reshape(-1).float().cuda()
     es = 2 if dtype == L.RESR_F16 else 4
-    packed = torch.zeros(nck * 9 * mt * 1024 * es + 8192, dtype=torch.uint8, device="cuda")
+    packed = torch.zeros(nck * 9 * mt * 1024 * es + 16384, dtype=torch.uint8, device="cuda")
     L.check(L.lib().resr_pack_weights(L.ptr(table), nck, L.ptr(arena), L.ptr(packed), dtype, L.stream_ptr()),
             "resr_pack_weights")
     return packed

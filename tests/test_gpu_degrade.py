@@ -66,10 +66,11 @@ def test_gaussian_noise_injected_draws_and_rng(ip):
     # gray samples share ONE field across the batch (reference quirk): noise of sample 0 and 2 is proportional
     n0, n2 = (got[0].cpu() - x[0]), (got[2].cpu() - x[2])
     g0, g2 = got[0].cpu(), got[2].cpu()
-    inner = (g0 > 0) & (g0 < 1) & (g2 > 0) & (g2 < 1)          # not clipped
-    assert inner.float().mean() > 0.5
-    assert torch.allclose(n0[inner] / sigma[0], n2[inner] / sigma[2], atol=1e-5)
-    assert torch.allclose(n0[0][inner[0]], n0[1][inner[0]], atol=1e-6)   # gray: same noise in every channel
+    inner = ((g0 > 0) & (g0 < 1) & (g2 > 0) & (g2 < 1)).all(dim=0)          # pixels not clipped in any channel
+    assert inner.float().mean() > 0.3
+    for ch in range(3):
+        assert torch.allclose(n0[ch][inner] / sigma[0], n2[ch][inner] / sigma[2], atol=1e-5)
+    assert torch.allclose(n0[0][inner], n0[1][inner], atol=1e-6)             # gray: same noise in every channel
     # the device RNG itself: moments of the Philox/Box-Muller field
     out = ip.random_add_gaussian_noise_torch(torch.full((8, 3, 128, 128), 0.5).cuda(), (10, 10), 0.0, False, False)
     z = (out.cpu() - 0.5) * 255 / 10
