@@ -179,6 +179,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     }
     const int row0 = wave * NT;
     const char* wp = a.w + (lane << 4);
+    // per-lane LDS byte offsets of the B fragment for (dx, k-step); rows / taps add compile-time immediates
+    int boff[3][KS];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) boff[dx][ks] = row0 * (HW * PB) + colb[dx] + (((ks * 2 + kh) ^ colsw[dx]) << 4);
 
     float16v acc[MT][NT];
 #pragma unroll
@@ -218,10 +224,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
         auto bload = [&](int slot, int sidx) {
             const int tap = sidx / KS, ks = sidx % KS;
             const int dy = tap / 3, dx = tap % 3;
-            const int so = ((ks * 2 + kh) ^ colsw[dx]) << 4;
+            const char* bp = lbuf + boff[dx][ks];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                bb[slot][t] = *reinterpret_cast<const uint4*>(lbuf + (row0 + t + dy) * (HW * PB) + colb[dx] + so);
+            for (int t = 0; t < NT; ++t) bb[slot][t] = *reinterpret_cast<const uint4*>(bp + (t + dy) * (HW * PB));
         };
         bload(0, 0);
 #pragma unroll

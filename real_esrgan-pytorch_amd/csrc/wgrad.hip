@@ -37,8 +37,9 @@ struct WgradJob {
 struct WgradArgs {
     WgradJob jobs[kMaxJobs];
     float* partial;
+    const char* zero;     // 16 zero bytes in global memory
     int n, h, w_, hs, ws;
-    int up, splits;
+    int up, splits, njobs;
     int tiles_x, tiles_y, ntiles;
 };
 
@@ -66,76 +67,89 @@ __device__ __forceinline__ uint2 tr_read(const char* lds_addr) {
     return __builtin_bit_cast(uint2, r);
 }
 
+// 16-byte LDS-DMA: the LDS destination is wave-uniform base + lane*16, the global source is per lane
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ uint4 g_zero16 = {0, 0, 0, 0};
+
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+// sum of the 8 f16 of a fragment in fp32: 4 x v_dot2_f32_f16 against (1,1)
 __device__ __forceinline__ float sum8_f16(const uint4& v) {
-    const half8 h = __builtin_bit_cast(half8, v);
-    return ((float)h[0] + (float)h[1]) + ((float)h[2] + (float)h[3]) + ((float)h[4] + (float)h[5]) +
-           ((float)h[6] + (float)h[7]);
+    const half2v one = {(_Float16)1.0f, (_Float16)1.0f};
+    float s = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, v.x), one, 0.f, false);
+    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, v.y), one, s, false);
+    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, v.z), one, s, false);
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, v.w), one, s, false);
 }
 
 template <typename T, int RPW>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     constexpr int E = 16 / (int)sizeof(T);
     constexpr int SPP = 32 / E;
     constexpr int PB = 32 * (int)sizeof(T);
     constexpr int TH = 4 * RPW, HH = TH + 2, HW = 34;
     constexpr int XSLOT = HH * HW * SPP, GSLOT = TH * 32 * SPP;
     constexpr int NSX = (XSLOT + 255) / 256, NSG = GSLOT / 256;
-    constexpr int XBUF = HH * HW * PB, GBUF = TH * 32 * PB, BUF = XBUF + GBUF;
+    constexpr int XSLOT_PAD = (XSLOT + 63) / 64 * 64;       // whole waves of LDS-DMA lanes
+    constexpr int XBUF = XSLOT_PAD * 16, GBUF = TH * 32 * PB, BUF = XBUF + GBUF;
     static_assert(GSLOT % 256 == 0, "G tile must split evenly");
     static_assert(2 * BUF >= 4 * 16 * 64 * 4, "LDS must hold one tap of 4 waves for the final reduce");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const WgradJob job = a.jobs[blockIdx.x];
-    const int split = blockIdx.y;
+    // XCD-aware work map.  Blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with its own
+    // L2).  All jobs of one pixel split read the same X / G tiles, so they are placed on ONE XCD, adjacent in
+    // dispatch order: the k-th block of XCD x takes job k % njobs of split x + 8 * (k / njobs).
+    const int bx = blockIdx.x & 7, bk = blockIdx.x >> 3;
+    const int split = bx + 8 * (bk / a.njobs);
+    const WgradJob job = a.jobs[bk % a.njobs];
+    if (split >= a.splits) return;
     const size_t src_px = (size_t)a.hs * a.ws;
 
-    uint4 sx[NSX], sg[NSG];
-    auto stage_load = [&](int tile) {
+    // Staging is LDS-DMA (global_load_lds, 16 B per lane): no staging VGPRs, no ds_write pass.  The LDS image is
+    // lane-linear (slot s at byte 16*s), which is exactly the pixel-major tile the transpose reads want; lanes
+    // whose pixel lies outside the image fetch from a 16-byte zero page instead.
+    auto stage = [&](int tile, int buf) {
         const int tx = tile % a.tiles_x;
         const int t2 = tile / a.tiles_x;
         const int ty = t2 % a.tiles_y;
         const int n = t2 / a.tiles_y;
         const int x0 = tx * 32, y0 = ty * TH;
-        const char* xb = job.x + (size_t)n * src_px * job.xstride_b;
+        const char* xg = job.x + (size_t)n * src_px * job.xstride_b;
+        const char* gg = job.g + (size_t)n * a.h * a.w_ * job.gstride_b;
+        char* xl = smem + buf * BUF;
+        char* gl = xl + XBUF;
 #pragma unroll
         for (int i = 0; i < NSX; ++i) {
-            const int s = tid + i * 256;
-            const int c16 = s % SPP, hp = s / SPP;
-            const int hy = hp / HW, hx = hp - hy * HW;
-            const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (s < XSLOT && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w_) {
+            const int sbase = i * 256 + wave * 64;            // wave-uniform
+            if (sbase < XSLOT_PAD) {
+                const int s = sbase + lane;
+                const int c16 = s % SPP, hp = s / SPP;
+                const int hy = hp / HW, hx = hp - hy * HW;
+                const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+                const bool ok = s < XSLOT && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w_;
                 const int sy = a.up ? (iy >> 1) : iy, sxx = a.up ? (ix >> 1) : ix;
-                v = *reinterpret_cast<const uint4*>(xb + (size_t)(sy * a.ws + sxx) * job.xstride_b + (c16 << 4));
+                const char* src = ok ? xg + (size_t)(sy * a.ws + sxx) * job.xstride_b + (c16 << 4) : a.zero;
+                glds16(src, xl + (sbase << 4));
             }
-            sx[i] = v;
         }
-        const char* gb = job.g + (size_t)n * a.h * a.w_ * job.gstride_b;
 #pragma unroll
         for (int i = 0; i < NSG; ++i) {
-            const int s = tid + i * 256;
+            const int sbase = i * 256 + wave * 64;
+            const int s = sbase + lane;
             const int c16 = s % SPP;
             const int r = s / SPP;
             const int px = r % 32, row = r / 32;
             const int iy = y0 + row, ix = x0 + px;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy < a.h && ix < a.w_)
-                v = *reinterpret_cast<const uint4*>(gb + (size_t)(iy * a.w_ + ix) * job.gstride_b + (c16 << 4));
-            sg[i] = v;
+            const bool ok = iy < a.h && ix < a.w_;
+            const char* src = ok ? gg + (size_t)(iy * a.w_ + ix) * job.gstride_b + (c16 << 4) : a.zero;
+            glds16(src, gl + (sbase << 4));
         }
-    };
-    auto stage_store = [&](int buf) {
-        char* xb = smem + buf * BUF;
-        char* gb = xb + XBUF;
-#pragma unroll
-        for (int i = 0; i < NSX; ++i) {
-            const int s = tid + i * 256;
-            if (s < XSLOT) *reinterpret_cast<uint4*>(xb + (s << 4)) = sx[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NSG; ++i) *reinterpret_cast<uint4*>(gb + ((tid + i * 256) << 4)) = sg[i];
     };
 
     float16v acc[9];
@@ -147,43 +161,48 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void wgrad_kernel(co
 
     const int kh = lane >> 5;
     int tile = split;
-    if (tile < a.ntiles) {
-        stage_load(tile);
-        stage_store(0);
-    }
-    __syncthreads();
+    if (tile < a.ntiles) stage(tile, 0);
+    __syncthreads();                 // drains the LDS-DMA (vmcnt) before the barrier
     int it = 0;
     for (; tile < a.ntiles; tile += a.splits, ++it) {
         const int next = tile + a.splits;
-        const bool more = next < a.ntiles;
-        if (more) stage_load(next);
+        if (next < a.ntiles) stage(next, (it + 1) & 1);
         const char* xb = smem + (it & 1) * BUF;
         const char* gb = xb + XBUF;
         if constexpr (sizeof(T) == 2) {
             // lane -> (pixel sub-row a16>>2, 4-channel group a16&3) inside its 16-lane group; the two groups
-            // of a half-wave take channels 0-15 / 16-31, the half-waves pixels +0..7 / +8..15 of the k-step
+            // of a half-wave take channels 0-15 / 16-31, the half-waves pixels +0..7 / +8..15 of the k-step.
+            // Two waves per SIMD (144 accumulator + ~100 other registers each): the partner wave's MFMAs cover
+            // this wave's 20 transpose reads, so no register ping-pong is needed.
             const int a16 = lane & 15;
             const int chb = ((((lane >> 4) & 1) << 4) + ((a16 & 3) << 2)) * 2;
             const int pxl = (kh << 3) + (a16 >> 2);
+            constexpr int NSTEP = RPW * 2;
+            uint4 fa[1], fb[1][9];
+            // one per-lane base address per operand; every (row, k-step, tap) is a compile-time immediate offset
+            const char* gbase = gb + ((wave * RPW * 32 + pxl) * PB) + chb;
+            const char* xbase = xb + ((wave * RPW * HW + pxl) * PB) + chb;
+            auto fload = [&](int slot, int step) {
+                const int r = step / 2, kb = (step & 1) * 16;
+                const char* ga = gbase + (r * 32 + kb) * PB;
+                const uint2 alo = tr_read(ga), ahi = tr_read(ga + 4 * PB);
+                fa[slot] = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
 #pragma unroll
-            for (int rr = 0; rr < RPW; ++rr) {
-                const int row = wave * RPW + rr;
-#pragma unroll
-                for (int kb = 0; kb < 32; kb += 16) {
-                    const char* ga = gb + ((row * 32 + kb + pxl) * PB) + chb;
-                    const uint2 alo = tr_read(ga), ahi = tr_read(ga + 4 * PB);
-                    const uint4 af = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
-                    bsum += sum8_f16(af);
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        const int dy = tap / 3, dx = tap % 3;
-                        const char* xa = xb + (((row + dy) * HW + kb + pxl + dx) * PB) + chb;
-                        const uint2 lo = tr_read(xa), hi = tr_read(xa + 4 * PB);
-                        const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af),
-                                                                          __builtin_bit_cast(half8, bf), acc[tap], 0, 0, 0);
-                    }
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dy = tap / 3, dx = tap % 3;
+                    const char* xa = xbase + ((r + dy) * HW + kb + dx) * PB;
+                    const uint2 lo = tr_read(xa), hi = tr_read(xa + 4 * PB);
+                    fb[slot][tap] = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 }
+            };
+#pragma unroll
+            for (int step = 0; step < NSTEP; ++step) {
+                fload(0, step);
+                if (job.want_bias) bsum += sum8_f16(fa[0]);      // wave-uniform: one job per cout tile
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[0]),
+                                                                      __builtin_bit_cast(half8, fb[0][tap]), acc[tap], 0, 0, 0);
             }
         } else {
             const int ch = (lane & 31) * 4;
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void wgrad_kernel(co
 #pragma unroll 4
                 for (int kb = 0; kb < 32; kb += 2) {
                     const float av = *reinterpret_cast<const float*>(gb + ((row * 32 + kb + kh) * PB) + ch);
-                    bsum += av;
+                    if (job.want_bias) bsum += av;
 #pragma unroll
                     for (int tap = 0; tap < 9; ++tap) {
                         const int dy = tap / 3, dx = tap % 3;
@@ -203,7 +222,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 2 : 1)) void wgrad_kernel(co
                 }
             }
         }
-        if (more) stage_store((it + 1) & 1);
         __syncthreads();
     }
 
@@ -264,7 +282,8 @@ template <typename T, int RPW>
 static int launch_wgrad(WgradArgs& a, int njobs, hipStream_t stream) {
     constexpr int PB = 32 * (int)sizeof(T);
     constexpr int TH = 4 * RPW;
-    constexpr int BUF = (TH + 2) * 34 * PB + TH * 32 * PB;
+    constexpr int SPP_ = PB / 16;
+    constexpr int BUF = (((TH + 2) * 34 * SPP_ + 63) / 64 * 64) * 16 + TH * 32 * PB;
     a.tiles_x = (a.w_ + 31) / 32;
     a.tiles_y = (a.h + TH - 1) / TH;
     a.ntiles = a.tiles_x * a.tiles_y * a.n;
@@ -275,7 +294,14 @@ static int launch_wgrad(WgradArgs& a, int njobs, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, RPW>), dim3(njobs, a.splits), dim3(256), lds, stream, a);
+    a.njobs = njobs;
+    {
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess || !zp) return fail(RESR_ERR_LAUNCH, "wgrad: zero page");
+        a.zero = (const char*)zp;
+    }
+    const int splits8 = (a.splits + 7) / 8 * 8;
+    hipLaunchKernelGGL((wgrad_kernel<T, RPW>), dim3(njobs * splits8), dim3(256), lds, stream, a);
     RESR_CHECK_LAUNCH("wgrad_kernel");
     return RESR_OK;
 }
