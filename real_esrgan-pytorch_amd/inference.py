@@ -1,0 +1,45 @@
+"""Single-image super-resolution entry point with the reference's CLI (reference inference.py:25-70):
+
+    python -m real_esrgan_pytorch_amd.inference --inputs_path lr.png --output_path sr.png --weights_path g.pth.tar
+
+Same flow as the reference: build `Generator`, load `checkpoint["state_dict"]` with the "model." prefix
+stripped, read the image as RGB float in [0,1], run the model under no_grad on the whole image, write
+`tensor_to_image` (truncating uint8 conversion, imgproc.py:1594).  Image I/O uses PIL (cv2 is not part of
+this environment); the BGR<->RGB swaps of the reference cancel out and are therefore absent.
+"""
+import argparse
+
+import numpy as np
+import torch
+
+from . import config, imgproc
+from .model import Generator
+
+
+def main(args) -> None:
+    from PIL import Image
+    model = Generator(config.in_channels, config.out_channels, config.upscale_factor,
+                      precision=getattr(args, "precision", None))
+    model = model.to(memory_format=torch.channels_last, device=config.device)        # inference.py:28
+    print("Build Real_ESRGAN model successfully.")
+    checkpoint = torch.load(args.weights_path, map_location=lambda storage, loc: storage)
+    model.load_state_dict({k.replace("model.", ""): v for k, v in checkpoint["state_dict"].items()})   # inference.py:33
+    print(f"Load Real_ESRGAN model weights `{args.weights_path}` successfully.")
+    model.eval()
+    lr_image = np.asarray(Image.open(args.inputs_path).convert("RGB")).astype(np.float32) / 255.0
+    lr_tensor = imgproc.image_to_tensor(lr_image, False, False).unsqueeze_(0)
+    lr_tensor = lr_tensor.to(device=config.device, memory_format=torch.channels_last, non_blocking=True)
+    with torch.no_grad():
+        sr_tensor = model(lr_tensor)                                                   # inference.py:53
+    sr_image = imgproc.tensor_to_image(sr_tensor, False, False)
+    Image.fromarray(sr_image).save(args.output_path)
+    print(f"SR image save to `{args.output_path}`")
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser(description="Using the Real_ESRGAN model generator super-resolution images.")
+    parser.add_argument("--inputs_path", type=str, help="Low-resolution image path.")
+    parser.add_argument("--output_path", type=str, help="Super-resolution image path.")
+    parser.add_argument("--weights_path", type=str, help="Model weights file path.")
+    parser.add_argument("--precision", type=str, default=None, choices=["fast", "strict"])
+    main(parser.parse_args())

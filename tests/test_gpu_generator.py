@@ -99,3 +99,27 @@ def test_state_dict_surface_and_channels_last():
     assert torch.equal(a, b) and a.shape == (1, 3, 64, 64)
     with pytest.raises(RuntimeError):
         g(x.cpu())
+
+
+def test_inference_entry_point(tmp_path):
+    """reference inference.py flow: checkpoint with 'model.'-prefixed keys -> PNG in -> PNG out, vs the oracle."""
+    import numpy as np
+    from PIL import Image
+    from oracle import model_ref as M
+    from real_esrgan_pytorch_amd import inference
+    sd = M.init_generator_state(21, bias_noise=0.02)
+    sd["conv4.bias"] = sd["conv4.bias"] + 0.5
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}}, tmp_path / "g.pth.tar")
+    rng = np.random.RandomState(0)
+    lr = rng.randint(0, 256, size=(24, 28, 3), dtype=np.uint8)
+    Image.fromarray(lr).save(tmp_path / "lr.png")
+
+    class A:
+        inputs_path, output_path, weights_path, precision = str(tmp_path / "lr.png"), str(tmp_path / "sr.png"), str(tmp_path / "g.pth.tar"), "strict"
+    inference.main(A)
+    got = np.asarray(Image.open(tmp_path / "sr.png")).astype(np.int32)
+    x = torch.from_numpy(lr.astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+    ref = M.generator_forward(x, sd, 4).squeeze(0).permute(1, 2, 0).mul(255).clamp(0, 255).numpy().astype("uint8").astype(np.int32)
+    assert got.shape == (96, 112, 3)
+    d = np.abs(got - ref)
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3      # truncating uint8 conversion: ties within 2e-6 may flip a level
