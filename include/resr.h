@@ -43,7 +43,9 @@ enum {
     RESR_CONV_CLAMP01 = 1 << 2,      /* v = min(max(v,0),1)                   (model.py:270)                */
     RESR_CONV_OUT_NCHW_F32 = 1 << 3, /* write planar fp32 [N,cout,H,W] (+ pass-mask bytes to aux)           */
     RESR_CONV_MASK = 1 << 4,         /* v *= (mask[p,c] > 0 ? 1 : slope): LeakyReLU backward                */
-    RESR_CONV_NO_BIAS = 1 << 5
+    RESR_CONV_NO_BIAS = 1 << 5,
+    RESR_CONV_AUX_BEFORE_MASK = 1 << 6, /* aux_out (NHWC, out_stride) also receives v after bias, before the mask     */
+    RESR_CONV_AUX_BEFORE_RES = 1 << 7   /* aux_out (NHWC, out_stride) also receives v after LeakyReLU, before residuals */
 };
 
 /* One 3x3, stride 1, pad 1 convolution pass (forward conv or backward-data conv):
@@ -100,7 +102,9 @@ typedef struct {
     int32_t mt;          /* M tiles (1 or 2)                                                      */
     int32_t transposed;  /* 0: M = cout, K = cin;  1: M = cin, K = cout, taps flipped             */
     float scale;
-    int32_t pad_;
+    int32_t virtual4x4;  /* 1: source is a [cout][C=src_cin][4][4] stride-2 kernel seen as a 3x3 kernel
+                            over the 2x2 space-to-depth image (4C virtual channels, (i*2+j)*C + c)       */
+    const float* scale_ptr; /* optional device scalar multiplied in (1/sigma of spectral norm)           */
 } ResrPackChunk;
 
 int resr_pack_weights(const ResrPackChunk* chunks_dev, int32_t n_chunks, const float* arena,
@@ -155,6 +159,10 @@ int resr_filter2d(const float* src, float* dst, const float* kernel, int32_t n, 
  * tmp3 = 3*n*c*h*w floats of scratch. */
 int resr_usm_sharp(const float* src, float* dst, float* tmp3, const float* k1d, int32_t ksize, float weight,
                    float threshold, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+/* backward of resr_usm_sharp wrt its input (the GAN step differentiates through usm_sharpener(sr),
+ * train_realesrgan.py:476): saved_tmp3 = the forward's tmp3 (kept), tmp2 = 2*n*c*h*w floats of scratch. */
+int resr_usm_sharp_bwd(const float* x, const float* saved_tmp3, const float* g, float* gx, float* tmp2, const float* k1d,
+                       int32_t ksize, float weight, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 /* F.interpolate (train_realesrnet.py:288,326-329,349-351,366-368): mode 0 area, 1 bilinear, 2 bicubic;
  * scale_h/scale_w > 0: the caller used scale_factor= (coordinates use 1/scale), else size= semantics. */
 int resr_resize(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t oh, int32_t ow,
@@ -178,6 +186,27 @@ int resr_jpeg(const float* src, float* dst, const float* quality, float* coeffs,
 int resr_quantize_crop(const float* lr, const float* hr, float* lr_out, float* hr_out, int32_t n, int32_t c, int32_t lr_h,
                        int32_t lr_w, int32_t hr_h, int32_t hr_w, int32_t hr_size, int32_t upscale, int32_t hr_top,
                        int32_t hr_left, void* stream);
+
+/* ---- discriminator helpers (model.py:135-203) -------------------------------------------------------- */
+/* 2x2 space-to-depth of an NHWC tensor [n,h,w,c] -> [n,h/2,w/2,4c] (inverse != 0: depth-to-space) */
+int resr_space_to_depth(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t dtype,
+                        int32_t inverse, void* stream);
+/* F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) on NHWC [n,h,w,c] (model.py:186,190,194);
+ * backward != 0: src is the gradient [n,2h,2w,c], dst the input gradient [n,h,w,c] */
+int resr_bilinear_up2x(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t dtype,
+                       int32_t backward, void* stream);
+/* out = (a + b) * (mask > 0 ? 1 : slope); b and mask optional */
+int resr_add_mask(const void* a, const void* b, const void* mask, void* out, int64_t count, int32_t dtype, float slope,
+                  void* stream);
+/* torch.nn.utils.spectral_norm forward (model.py:140-168): W [rows][cols] fp32; training: one power iteration
+ * updating u[rows], v[cols] in place; sigma2[0] = sigma, sigma2[1] = 1/sigma; tmp = rows+cols floats */
+int resr_spectral_norm(const float* w, float* u, float* v, int32_t rows, int32_t cols, int32_t training, float eps,
+                       float* sigma2, float* tmp, void* stream);
+/* gradient wrt W_orig from the gradient wrt W = W_orig/sigma; tmp1 = 1 float */
+int resr_spectral_norm_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma2, float* dst,
+                           int32_t rows, int32_t cols, int32_t accumulate, float* tmp1, void* stream);
+/* virtual [cout][4C][3][3] weight gradient of a space-to-depth conv -> real [cout][C][4][4] */
+int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* stream);
 
 /* EMA.update (model.py:43-48) over the flat parameter arena, one launch. */
 int resr_ema_update(float* shadow, const float* params, int64_t count, double decay, void* stream);

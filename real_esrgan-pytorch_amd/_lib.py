@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libresr_hip.so")
 
 RESR_F16, RESR_F32 = 0, 1
 CONV_LRELU, CONV_UPSAMPLE_IN, CONV_CLAMP01, CONV_OUT_NCHW_F32, CONV_MASK, CONV_NO_BIAS = 1, 2, 4, 8, 16, 32
+CONV_AUX_BEFORE_MASK, CONV_AUX_BEFORE_RES = 64, 128
 
 
 class ConvDesc(C.Structure):
@@ -34,7 +35,8 @@ class WgradDesc(C.Structure):
 class PackChunk(C.Structure):
     _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("src_cout", C.c_int32), ("src_cin", C.c_int32),
                 ("m_off", C.c_int32), ("m_count", C.c_int32), ("k_off", C.c_int32), ("k_count", C.c_int32),
-                ("mt", C.c_int32), ("transposed", C.c_int32), ("scale", C.c_float), ("pad_", C.c_int32)]
+                ("mt", C.c_int32), ("transposed", C.c_int32), ("scale", C.c_float), ("virtual4x4", C.c_int32),
+                ("scale_ptr", C.c_void_p)]
 
 
 class GeneratorDesc(C.Structure):
@@ -65,8 +67,15 @@ _PROTOS = {
     "resr_generator_backward": (C.c_int, [C.POINTER(GeneratorDesc), _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     "resr_ema_update": (C.c_int, [_P, _P, C.c_int64, C.c_double, _P]),
     "resr_debug_tr_probe": (C.c_int, [_P, _P]),
+    "resr_space_to_depth": (C.c_int, [_P, _P] + [C.c_int32] * 6 + [_P]),
+    "resr_bilinear_up2x": (C.c_int, [_P, _P] + [C.c_int32] * 6 + [_P]),
+    "resr_add_mask": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "resr_spectral_norm": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
+    "resr_spectral_norm_bwd": (C.c_int, [_P] * 6 + [C.c_int32] * 3 + [_P, _P]),
+    "resr_fold4x4": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "resr_filter2d": (C.c_int, [_P, _P, _P] + [C.c_int32] * 7 + [_P]),
     "resr_usm_sharp": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_float, C.c_float] + [C.c_int32] * 4 + [_P]),
+    "resr_usm_sharp_bwd": (C.c_int, [_P] * 6 + [C.c_int32, C.c_float] + [C.c_int32] * 4 + [_P]),
     "resr_resize": (C.c_int, [_P, _P] + [C.c_int32] * 7 + [C.c_double, C.c_double, _P]),
     "resr_randn_fill": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
     "resr_noise_gaussian": (C.c_int, [_P] * 6 + [C.c_int32] * 5 + [_P]),

@@ -41,12 +41,21 @@ int generator_backward(const ResrGeneratorDesc*, const float*, const float*, con
 int filter2d_dispatch(const float*, float*, const float*, int, int, int, int, int, int, int, hipStream_t);
 int usm_dispatch(const float*, float*, float*, const float*, int, float, float, int, int, int, int, hipStream_t);
 int resize_dispatch(const float*, float*, int, int, int, int, int, int, int, double, double, hipStream_t);
+int usm_bwd_dispatch(const float*, const float*, const float*, float*, float*, const float*, int, float, int, int, int, int, hipStream_t);
 int randn_dispatch(float*, long, uint64_t, uint64_t, hipStream_t);
 int gauss_noise_dispatch(const float*, float*, const float*, const float*, const float*, const float*, int, int, int, int, int,
                          hipStream_t);
 int poisson_noise_dispatch(const float*, float*, const float*, const float*, uint64_t, void*, int, int, int, int, int, hipStream_t);
 int jpeg_dispatch(const float*, float*, const float*, float*, int, int, int, int, hipStream_t);
 int quantize_crop_dispatch(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+
+int s2d_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
+int bilinear_up_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
+int add_mask_dispatch(const void*, const void*, const void*, void*, long, int, float, hipStream_t);
+int spectral_norm_dispatch(const float*, float*, float*, int, int, int, float, float*, float*, hipStream_t);
+int spectral_norm_bwd_dispatch(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, float*,
+                               hipStream_t);
+int fold4x4_dispatch(const float*, float*, int, int, hipStream_t);
 
 // probe used by tests: what does ds_read_b64_tr_b16 hand to (lane, element)?  LDS holds the element
 // index at every position; lane l supplies byte address l*8.
@@ -140,6 +149,11 @@ int resr_usm_sharp(const float* src, float* dst, float* tmp3, const float* k1d, 
     return usm_dispatch(src, dst, tmp3, k1d, ksize, weight, threshold, n, c, h, w, (hipStream_t)stream);
 }
 
+int resr_usm_sharp_bwd(const float* x, const float* saved_tmp3, const float* g, float* gx, float* tmp2, const float* k1d,
+                       int32_t ksize, float weight, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+    return usm_bwd_dispatch(x, saved_tmp3, g, gx, tmp2, k1d, ksize, weight, n, c, h, w, (hipStream_t)stream);
+}
+
 int resr_resize(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t oh, int32_t ow, int32_t mode,
                 double scale_h, double scale_w, void* stream) {
     return resize_dispatch(src, dst, n, c, h, w, oh, ow, mode, scale_h, scale_w, (hipStream_t)stream);
@@ -171,6 +185,35 @@ int resr_quantize_crop(const float* lr, const float* hr, float* lr_out, float* h
                        int32_t hr_left, void* stream) {
     return quantize_crop_dispatch(lr, hr, lr_out, hr_out, n, c, lr_h, lr_w, hr_h, hr_w, hr_size, upscale, hr_top, hr_left,
                                   (hipStream_t)stream);
+}
+
+int resr_space_to_depth(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t dtype, int32_t inverse,
+                        void* stream) {
+    return s2d_dispatch(src, dst, n, h, w, c, dtype, inverse, (hipStream_t)stream);
+}
+
+int resr_bilinear_up2x(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t dtype, int32_t backward,
+                       void* stream) {
+    return bilinear_up_dispatch(src, dst, n, h, w, c, dtype, backward, (hipStream_t)stream);
+}
+
+int resr_add_mask(const void* a, const void* b, const void* mask, void* out, int64_t count, int32_t dtype, float slope,
+                  void* stream) {
+    return add_mask_dispatch(a, b, mask, out, (long)count, dtype, slope, (hipStream_t)stream);
+}
+
+int resr_spectral_norm(const float* w, float* u, float* v, int32_t rows, int32_t cols, int32_t training, float eps, float* sigma2,
+                       float* tmp, void* stream) {
+    return spectral_norm_dispatch(w, u, v, rows, cols, training, eps, sigma2, tmp, (hipStream_t)stream);
+}
+
+int resr_spectral_norm_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma2, float* dst,
+                           int32_t rows, int32_t cols, int32_t accumulate, float* tmp1, void* stream) {
+    return spectral_norm_bwd_dispatch(g, w, u, v, sigma2, dst, rows, cols, accumulate, tmp1, (hipStream_t)stream);
+}
+
+int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* stream) {
+    return fold4x4_dispatch(dw3, dw4, cout, c, (hipStream_t)stream);
 }
 
 int resr_debug_tr_probe(float* out256, void* stream) {

@@ -253,6 +253,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     const bool f_lrelu = a.flags & RESR_CONV_LRELU, f_clamp = a.flags & RESR_CONV_CLAMP01;
     const bool f_nchw = a.flags & RESR_CONV_OUT_NCHW_F32, f_mask = a.flags & RESR_CONV_MASK;
     const bool f_bias = !(a.flags & RESR_CONV_NO_BIAS) && a.bias != nullptr;
+    const bool f_aux_mask = (a.flags & RESR_CONV_AUX_BEFORE_MASK) && a.aux && !f_nchw;
+    const bool f_aux_res = (a.flags & RESR_CONV_AUX_BEFORE_RES) && a.aux && !f_nchw;
     const int x = x0 + lx;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
                     for (int r = 0; r < 4; ++r)
                         if (co + r < a.cout) v[r] += a.bias[co + r];
                 }
+                if (f_aux_mask) store4<T>(reinterpret_cast<char*>(a.aux), p * a.out_stride + co, v);
                 if (f_mask) {
                     float mk[4];
                     load4<T>(a.mask, p * a.mask_stride + co, mk);
@@ -283,6 +286,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
                 }
+                if (f_aux_res) store4<T>(reinterpret_cast<char*>(a.aux), p * a.out_stride + co, v);
                 if (a.res0) {
                     float rr[4];
                     load4<T>(a.res0, p * a.res0_stride + co, rr);

@@ -115,6 +115,68 @@ int usm_dispatch(const float* src, float* dst, float* tmp, const float* k1d, int
     return RESR_OK;
 }
 
+// ---- USMSharp backward (the reference's GAN step differentiates through usm_sharpener(sr), train_realesrgan.py:476) --
+// forward: out = soft*clip(x + w*(x - Bx), 0, 1) + (1-soft)*x with soft piecewise constant in x.
+//   a  = soft * 1[0 <= x + w*(x-Bx) <= 1] * g
+//   gx = (1-soft)*g + (1+w)*a - w * B^T a          B^T = adjoint of (reflect pad + separable Gaussian)
+__global__ __launch_bounds__(256) void usm_bwd_prep_kernel(const float* __restrict__ x, const float* __restrict__ blur,
+                                                           const float* __restrict__ soft, const float* __restrict__ g,
+                                                           float* __restrict__ a, float* __restrict__ b, long count, float weight) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float xv = x[i], s = soft[i], gv = g[i];
+    const float pre = xv + weight * (xv - blur[i]);
+    const float av = (pre >= 0.f && pre <= 1.f) ? s * gv : 0.f;
+    a[i] = av;
+    b[i] = (1.f - s) * gv + (1.f + weight) * av;
+}
+
+// adjoint of a reflect-padded 1-D correlation along x (axis 0) or y (axis 1):
+//   z[j] = sum_t k[t] * g0[j - t + r] (g0 = g, zero outside), gx[p] = z[p] + z[-p] (1<=p<=r) + z[2(n-1)-p] (n-1-r<=p<=n-2)
+__global__ __launch_bounds__(256) void filter1d_adjoint_kernel(const float* __restrict__ g, float* __restrict__ out,
+                                                               const float* __restrict__ k, int planes, int h, int w, int ksize,
+                                                               int axis, const float* __restrict__ sub_from, float sub_scale) {
+    const long total = (long)planes * h * w;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % w), y = (int)((i / w) % h);
+    const long pbase = (i / ((long)w * h)) * (long)h * w;
+    const int r = ksize / 2, n = axis == 0 ? w : h, p = axis == 0 ? x : y;
+    const long stride = axis == 0 ? 1 : w;
+    const float* line = g + pbase + (axis == 0 ? (long)y * w : x);
+    auto z = [&](int j) {
+        float s = 0.f;
+        for (int t = 0; t < ksize; ++t) {
+            const int q = j - t + r;
+            if (q >= 0 && q < n) s += k[t] * line[(long)q * stride];
+        }
+        return s;
+    };
+    float v = z(p);
+    if (p >= 1 && p <= r) v += z(-p);
+    if (p <= n - 2 && p >= n - 1 - r) v += z(2 * (n - 1) - p);
+    out[i] = sub_from ? sub_from[i] - sub_scale * v : v;
+}
+
+int usm_bwd_dispatch(const float* x, const float* saved, const float* g, float* gx, float* tmp2, const float* k1d, int ksize,
+                     float weight, int n, int c, int h, int w, hipStream_t st) {
+    if (!x || !saved || !g || !gx || !tmp2 || !k1d) return fail(RESR_ERR_ARG, "usm_sharp_bwd: null argument");
+    const long count = (long)n * c * h * w;
+    const float* blur = saved + count;       // layout of resr_usm_sharp's tmp3: [row pass | blur | soft]
+    const float* soft = saved + 2 * count;
+    float* a = tmp2;
+    float* b = tmp2 + count;
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    hipLaunchKernelGGL(usm_bwd_prep_kernel, dim3(blocks), dim3(256), 0, st, x, blur, soft, g, a, b, count, weight);
+    // B^T a: vertical adjoint then horizontal adjoint (forward applied horizontal then vertical)
+    hipLaunchKernelGGL(filter1d_adjoint_kernel, dim3(blocks), dim3(256), 0, st, a, gx, k1d, n * c, h, w, ksize, 1, (const float*)nullptr, 0.f);
+    hipLaunchKernelGGL(filter1d_adjoint_kernel, dim3(blocks), dim3(256), 0, st, gx, a, k1d, n * c, h, w, ksize, 0, (const float*)b, weight);
+    if (hipMemcpyAsync(gx, a, count * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(RESR_ERR_LAUNCH, "usm_sharp_bwd: copy failed");
+    RESR_CHECK_LAUNCH("usm_bwd kernels");
+    return RESR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // resize (torch.nn.functional.interpolate, align_corners=False, antialias=False)
 // ---------------------------------------------------------------------------------------------------------

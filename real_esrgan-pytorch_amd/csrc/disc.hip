@@ -1,0 +1,310 @@
+// disc.hip -- kernels specific to the U-Net spectral-norm discriminator (reference model.py:135-203):
+//   space_to_depth / depth_to_space   a 4x4 stride-2 pad-1 conv (model.py:140,144,148) is evaluated as a 3x3
+//                                     pad-1 conv over the 2x2 space-to-depth image with a sparse virtual kernel
+//                                     (pack.hip mode "virtual 4x4"), so it runs on the same MFMA conv kernel
+//   bilinear_up2x (+ backward)        F.interpolate(scale_factor=2, mode="bilinear", align_corners=False)
+//                                     (model.py:186,190,194)
+//   spectral norm                     torch.nn.utils.spectral_norm's power iteration, sigma = u.(W v), and the
+//                                     backward of W = W_orig / sigma
+//   add_mask                          skip-connection gradient merge fused with the LeakyReLU backward
+//   fold4x4                           virtual 3x3x4C weight gradient -> real 4x4xC layout
+// All HBM-bound helpers; pixel-major (NHWC) activations of type T.
+#include "common.h"
+
+namespace resr {
+
+// dst[Y][X][(i*2+j)*C + c] = src[2Y+i][2X+j][c]   (inverse: the other way round)
+template <typename T>
+__global__ __launch_bounds__(256) void s2d_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w, int c,
+                                                  int inverse) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const int groups = c / E;
+    const long total = (long)n * h * w * groups;      // h, w = full-resolution dims
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int g = (int)(t % groups);
+    const long p = t / groups;
+    const int x = (int)(p % w), y = (int)((p / w) % h), b = (int)(p / ((long)w * h));
+    const size_t full = (((size_t)b * h + y) * w + x) * c + g * E;
+    const size_t packed = ((((size_t)b * (h / 2) + y / 2) * (w / 2) + x / 2) * 4 + (y & 1) * 2 + (x & 1)) * c + g * E;
+    if (!inverse) *reinterpret_cast<uint4*>(dst + packed) = *reinterpret_cast<const uint4*>(src + full);
+    else *reinterpret_cast<uint4*>(dst + full) = *reinterpret_cast<const uint4*>(src + packed);
+}
+
+int s2d_dispatch(const void* src, void* dst, int n, int h, int w, int c, int dtype, int inverse, hipStream_t st) {
+    const int E = dtype == RESR_F16 ? 8 : 4;
+    if (!src || !dst || n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || c <= 0 || (c % E))
+        return fail(RESR_ERR_ARG, "space_to_depth: bad argument");
+    const long total = (long)n * h * w * (c / E);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == RESR_F16) hipLaunchKernelGGL(s2d_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, inverse);
+    else hipLaunchKernelGGL(s2d_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, inverse);
+    RESR_CHECK_LAUNCH("s2d_kernel");
+    return RESR_OK;
+}
+
+// torch upsample_bilinear2d, scale 2, align_corners=False: src = (o + 0.5) * 0.5 - 0.5, clamped at 0
+__device__ __forceinline__ void bil_coord(int o, int n, int& i0, int& i1, float& l) {
+    float f = (o + 0.5f) * 0.5f - 0.5f;
+    if (f < 0.f) f = 0.f;
+    i0 = (int)f;
+    i1 = i0 + (i0 < n - 1 ? 1 : 0);
+    l = f - i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w,
+                                                          int c) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const int groups = c / E, oh = 2 * h, ow = 2 * w;
+    const long total = (long)n * oh * ow * groups;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int g = (int)(t % groups);
+    const long p = t / groups;
+    const int ox = (int)(p % ow), oy = (int)((p / ow) % oh), b = (int)(p / ((long)ow * oh));
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bil_coord(oy, h, y0, y1, ly);
+    bil_coord(ox, w, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const T* base = src + (size_t)b * h * w * c + g * E;
+    uint4 r00 = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * w + x0) * c);
+    uint4 r01 = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * w + x1) * c);
+    uint4 r10 = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * w + x0) * c);
+    uint4 r11 = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * w + x1) * c);
+    const T *a = reinterpret_cast<const T*>(&r00), *bq = reinterpret_cast<const T*>(&r01), *cq = reinterpret_cast<const T*>(&r10),
+            *d = reinterpret_cast<const T*>(&r11);
+    uint4 o;
+    T* ov = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        ov[e] = (T)(hy * (hx * (float)a[e] + lx * (float)bq[e]) + ly * (hx * (float)cq[e] + lx * (float)d[e]));
+    *reinterpret_cast<uint4*>(dst + p * c + g * E) = o;
+}
+
+// backward as a gather: input pixel (y,x) collects from the <= 4x4 outputs whose stencil touches it
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const T* __restrict__ g, T* __restrict__ gin, int n, int h, int w,
+                                                              int c) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const int groups = c / E, oh = 2 * h, ow = 2 * w;
+    const long total = (long)n * h * w * groups;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int gi = (int)(t % groups);
+    const long p = t / groups;
+    const int x = (int)(p % w), y = (int)((p / w) % h), b = (int)(p / ((long)w * h));
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    const T* base = g + (size_t)b * oh * ow * c + gi * E;
+    for (int oy = max(2 * y - 2, 0); oy <= min(2 * y + 2, oh - 1); ++oy) {
+        int y0, y1;
+        float ly;
+        bil_coord(oy, h, y0, y1, ly);
+        const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = max(2 * x - 2, 0); ox <= min(2 * x + 2, ow - 1); ++ox) {
+            int x0, x1;
+            float lx;
+            bil_coord(ox, w, x0, x1, lx);
+            const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+            if (wx == 0.f) continue;
+            const uint4 raw = *reinterpret_cast<const uint4*>(base + ((size_t)oy * ow + ox) * c);
+            const T* v = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] += wy * wx * (float)v[e];
+        }
+    }
+    uint4 o;
+    T* ov = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < E; ++e) ov[e] = (T)acc[e];
+    *reinterpret_cast<uint4*>(gin + p * c + gi * E) = o;
+}
+
+int bilinear_up_dispatch(const void* src, void* dst, int n, int h, int w, int c, int dtype, int backward, hipStream_t st) {
+    const int E = dtype == RESR_F16 ? 8 : 4;
+    if (!src || !dst || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c % E)) return fail(RESR_ERR_ARG, "bilinear_up2x: bad argument");
+    const long total = (long)n * h * w * (c / E) * (backward ? 1 : 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == RESR_F16) {
+        if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c);
+        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c);
+    } else {
+        if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c);
+        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c);
+    }
+    RESR_CHECK_LAUNCH("bilinear_up_kernel");
+    return RESR_OK;
+}
+
+// out = (a + b) * (mask > 0 ? 1 : slope)      (b, mask optional)
+template <typename T>
+__global__ __launch_bounds__(256) void add_mask_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ mask,
+                                                       T* __restrict__ out, long count, float slope) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * E;
+    if (i >= count) return;
+    const uint4 ra = *reinterpret_cast<const uint4*>(a + i);
+    uint4 rb = make_uint4(0, 0, 0, 0), rm = make_uint4(0, 0, 0, 0);
+    if (b) rb = *reinterpret_cast<const uint4*>(b + i);
+    if (mask) rm = *reinterpret_cast<const uint4*>(mask + i);
+    const T *pa = reinterpret_cast<const T*>(&ra), *pb = reinterpret_cast<const T*>(&rb), *pm = reinterpret_cast<const T*>(&rm);
+    uint4 o;
+    T* po = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        float v = (float)pa[e] + (b ? (float)pb[e] : 0.f);
+        if (mask) v *= ((float)pm[e] > 0.f ? 1.f : slope);
+        po[e] = (T)v;
+    }
+    *reinterpret_cast<uint4*>(out + i) = o;
+}
+
+int add_mask_dispatch(const void* a, const void* b, const void* mask, void* out, long count, int dtype, float slope, hipStream_t st) {
+    const int E = dtype == RESR_F16 ? 8 : 4;
+    if (!a || !out || count <= 0 || (count % E)) return fail(RESR_ERR_ARG, "add_mask: bad argument");
+    const unsigned blocks = (unsigned)((count / E + 255) / 256);
+    if (dtype == RESR_F16) hipLaunchKernelGGL(add_mask_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)a, (const half_t*)b, (const half_t*)mask, (half_t*)out, count, slope);
+    else hipLaunchKernelGGL(add_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)mask, (float*)out, count, slope);
+    RESR_CHECK_LAUNCH("add_mask_kernel");
+    return RESR_OK;
+}
+
+// ---- spectral norm -----------------------------------------------------------------------------------------------
+// W is [rows = cout][cols = cin*k*k] row-major fp32 (the OIHW parameter viewed as a matrix).
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ vraw,
+                                                      int rows, int cols) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += W[(size_t)r * cols + k] * u[r];
+    vraw[k] = s;
+}
+
+__device__ float block_sum(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+
+// dst = src / max(||src||, eps); optionally out2[0] = dot(dst, src), out2[1] = 1 / out2[0]
+__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, float eps,
+                                                           float* __restrict__ sigma2) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += src[i] * src[i];
+    const float nrm = sqrtf(block_sum(s, red));
+    const float inv = 1.f / fmaxf(nrm, eps);
+    float d = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = src[i] * inv;
+        if (dst) dst[i] = v;
+        d += v * src[i];
+    }
+    if (sigma2) {
+        const float dot = block_sum(d, red);
+        if (threadIdx.x == 0) { sigma2[0] = dot; sigma2[1] = 1.f / dot; }
+    }
+}
+
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v, float* __restrict__ wv,
+                                                     int cols) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < cols; k += 256) s += W[(size_t)r * cols + k] * v[k];
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) wv[r] = t;
+}
+
+// sigma = u . wv (eval mode: u, v are not updated)
+__global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ u, const float* __restrict__ wv, int n,
+                                                     float* __restrict__ sigma2) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += u[i] * wv[i];
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) { sigma2[0] = t; sigma2[1] = 1.f / t; }
+}
+
+int spectral_norm_dispatch(const float* W, float* u, float* v, int rows, int cols, int training, float eps, float* sigma2,
+                           float* tmp, hipStream_t st) {
+    if (!W || !u || !v || !sigma2 || !tmp || rows <= 0 || cols <= 0) return fail(RESR_ERR_ARG, "spectral_norm: bad argument");
+    float* vraw = tmp;            // [cols]
+    float* wv = tmp + cols;       // [rows]
+    if (training) {               // one power iteration, u and v updated in place (torch spectral_norm, training forward)
+        hipLaunchKernelGGL(sn_wt_u_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, W, u, vraw, rows, cols);
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, vraw, v, cols, eps, (float*)nullptr);
+        hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, st, W, v, wv, cols);
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, wv, u, rows, eps, sigma2);   // sigma = u_new . (W v_new)
+    } else {
+        hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, st, W, v, wv, cols);
+        hipLaunchKernelGGL(sn_dot_kernel, dim3(1), dim3(256), 0, st, u, wv, rows, sigma2);
+    }
+    RESR_CHECK_LAUNCH("spectral_norm kernels");
+    return RESR_OK;
+}
+
+// backward of W = W_orig / sigma, sigma = u^T W_orig v (u, v constants):
+//   dW_orig = G / sigma - (<G, W_orig> / sigma^2) * u v^T          (accumulated into dst when accumulate != 0)
+__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ G, const float* __restrict__ W, long count,
+                                                         float* __restrict__ dot) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) s += G[i] * W[i];
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(dot, t);
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ u,
+                                                           const float* __restrict__ v, const float* __restrict__ sigma2,
+                                                           const float* __restrict__ dot, float* __restrict__ dst, int cols, long count,
+                                                           int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const int r = (int)(i / cols), k = (int)(i % cols);
+    const float inv = sigma2[1];
+    const float val = G[i] * inv - dot[0] * inv * inv * u[r] * v[k];
+    dst[i] = accumulate ? dst[i] + val : val;
+}
+
+int spectral_norm_bwd_dispatch(const float* G, const float* W, const float* u, const float* v, const float* sigma2, float* dst,
+                               int rows, int cols, int accumulate, float* tmp1, hipStream_t st) {
+    if (!G || !W || !u || !v || !sigma2 || !dst || !tmp1) return fail(RESR_ERR_ARG, "spectral_norm_bwd: bad argument");
+    const long count = (long)rows * cols;
+    if (hipMemsetAsync(tmp1, 0, sizeof(float), st) != hipSuccess) return fail(RESR_ERR_LAUNCH, "spectral_norm_bwd: memset");
+    long blocks = (count + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, W, count, tmp1);
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, G, u, v, sigma2, tmp1, dst, cols,
+                       count, accumulate);
+    RESR_CHECK_LAUNCH("spectral_norm_bwd kernels");
+    return RESR_OK;
+}
+
+// virtual [cout][4C][3][3] gradient -> real [cout][C][4][4]:  ky = 2*ty + i - 1, kx = 2*tx + j - 1, virtual ci = (i*2+j)*C + c
+__global__ __launch_bounds__(256) void fold4x4_kernel(const float* __restrict__ dw3, float* __restrict__ dw4, int cout, int C) {
+    const long total = (long)cout * C * 16;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int kx = (int)(t % 4), ky = (int)((t / 4) % 4), c = (int)((t / 16) % C), co = (int)(t / (16L * C));
+    const int ty = (ky + 1) >> 1, i = (ky + 1) & 1, tx = (kx + 1) >> 1, j = (kx + 1) & 1;
+    dw4[t] = dw3[(((size_t)co * 4 * C + (i * 2 + j) * C + c) * 3 + ty) * 3 + tx];
+}
+
+int fold4x4_dispatch(const float* dw3, float* dw4, int cout, int C, hipStream_t st) {
+    if (!dw3 || !dw4 || cout <= 0 || C <= 0) return fail(RESR_ERR_ARG, "fold4x4: bad argument");
+    const long total = (long)cout * C * 16;
+    hipLaunchKernelGGL(fold4x4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dw3, dw4, cout, C);
+    RESR_CHECK_LAUNCH("fold4x4_kernel");
+    return RESR_OK;
+}
+
+}  // namespace resr

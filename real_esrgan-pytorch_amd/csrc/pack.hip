@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const ResrPackChunk* __restri
     const int total = 9 * c.mt * 1024;
     T* dst = packed + c.dst_off;
     const float* src = arena + c.src_off;
+    const float sc = c.scale * (c.scale_ptr ? *c.scale_ptr : 1.f);
     for (int idx = threadIdx.x; idx < total; idx += 256) {
         int r = idx;
         const int e = r % E; r /= E;
@@ -32,14 +33,17 @@ __global__ __launch_bounds__(256) void pack_kernel(const ResrPackChunk* __restri
         const int mm = mt * 32 + m;
         float v = 0.f;
         if (mm < c.m_count && k < c.k_count) {
-            if (!c.transposed) {
-                const int co = c.m_off + mm, ci = c.k_off + k;
-                v = src[((size_t)co * c.src_cin + ci) * 9 + tap];
-            } else {
-                const int ci = c.m_off + mm, co = c.k_off + k;
-                v = src[((size_t)co * c.src_cin + ci) * 9 + (8 - tap)];
+            const int co = c.transposed ? c.k_off + k : c.m_off + mm;
+            const int ci = c.transposed ? c.m_off + mm : c.k_off + k;
+            const int t = c.transposed ? 8 - tap : tap;
+            if (!c.virtual4x4) {
+                v = src[((size_t)co * c.src_cin + ci) * 9 + t];
+            } else {                                    // 4x4 stride-2 kernel as a 3x3 kernel over space-to-depth
+                const int C = c.src_cin, sub = ci / C, ch = ci % C;
+                const int ky = 2 * (t / 3) + (sub >> 1) - 1, kx = 2 * (t % 3) + (sub & 1) - 1;
+                if (ky >= 0 && ky < 4 && kx >= 0 && kx < 4) v = src[((size_t)co * C + ch) * 16 + ky * 4 + kx];
             }
-            v *= c.scale;
+            v *= sc;
         }
         dst[idx] = (T)v;
     }

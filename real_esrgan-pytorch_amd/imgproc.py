@@ -76,13 +76,35 @@ class USMSharp(nn.Module):
         self.register_buffer("k1d", torch.from_numpy(g.astype(np.float32)), persistent=False)
 
     def forward(self, x, weight: float, threshold: int) -> torch.Tensor:
+        # differentiable wrt x (the soft mask is piecewise constant), as the reference's GAN step requires
+        return _USMFn.apply(x, self.k1d, self.radius, float(weight), float(threshold))
+
+
+class _USMFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k1d, radius, weight, threshold):
         xi = _img(x, "USMSharp")
         b, c, h, w = xi.shape
         out = torch.empty_like(xi)
         tmp = torch.empty(3 * xi.numel(), dtype=torch.float32, device=xi.device)
-        _lib.check(_lib.lib().resr_usm_sharp(_lib.ptr(xi), _lib.ptr(out), _lib.ptr(tmp), _lib.ptr(self.k1d), self.radius,
-                                             float(weight), float(threshold), b, c, h, w, _lib.stream_ptr()), "resr_usm_sharp")
+        _lib.check(_lib.lib().resr_usm_sharp(_lib.ptr(xi), _lib.ptr(out), _lib.ptr(tmp), _lib.ptr(k1d), radius, weight,
+                                             threshold, b, c, h, w, _lib.stream_ptr()), "resr_usm_sharp")
+        if x.requires_grad:
+            ctx.save_for_backward(xi, tmp, k1d)
+            ctx.radius, ctx.weight = radius, weight
         return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xi, tmp, k1d = ctx.saved_tensors
+        b, c, h, w = xi.shape
+        gi = g.contiguous().float()
+        gx = torch.empty_like(xi)
+        tmp2 = torch.empty(2 * xi.numel(), dtype=torch.float32, device=xi.device)
+        _lib.check(_lib.lib().resr_usm_sharp_bwd(_lib.ptr(xi), _lib.ptr(tmp), _lib.ptr(gi), _lib.ptr(gx), _lib.ptr(tmp2),
+                                                 _lib.ptr(k1d), ctx.radius, ctx.weight, b, c, h, w, _lib.stream_ptr()),
+                   "resr_usm_sharp_bwd")
+        return gx, None, None, None, None
 
 
 def interpolate(image: torch.Tensor, size=None, scale_factor=None, mode: str = "bilinear") -> torch.Tensor:

@@ -72,3 +72,67 @@ class RealESRNetStep:
         if self.ema is not None:
             self.ema.update()                              # :394
         return loss.detach()
+
+
+class RealESRGANStep:
+    """One RealESRGAN optimisation step (reference train_realesrgan.py:459-521): generator update with the
+    discriminator frozen (pixel L1 on the USM-sharpened sr + adversarial BCE), then two discriminator
+    backwards (real, fake) accumulated into one update, one shared GradScaler updated twice, EMA.
+
+    The VGG19 perceptual term is omitted: the reference wraps it in `torch.Tensor(...)` (:477-478), which
+    detaches it -- it contributes to the logged loss only, never to a gradient -- and the pretrained
+    torchvision weights it needs are not available in this environment."""
+
+    def __init__(self, generator, discriminator, ema, g_optimizer, d_optimizer, scaler=None, degrade=None,
+                 pixel_weight: float = 1.0, adversarial_weight: float = 0.1) -> None:
+        from . import imgproc
+        self.g, self.d, self.ema = generator, discriminator, ema
+        self.g_opt, self.d_opt, self.scaler, self.degrade = g_optimizer, d_optimizer, scaler, degrade
+        self.pixel_weight, self.adversarial_weight = pixel_weight, adversarial_weight
+        self.pixel = nn.L1Loss()
+        self.adv = nn.BCEWithLogitsLoss()
+        dev = next(generator.parameters()).device
+        self.usm = imgproc.USMSharp(50, 0).to(dev)
+
+    def _backward(self, loss):
+        if self.scaler is not None:
+            self.scaler.scale(loss).backward()
+        else:
+            loss.backward()
+
+    def _step(self, opt):
+        if self.scaler is not None:
+            self.scaler.step(opt)
+            self.scaler.update()
+        else:
+            opt.step()
+
+    def __call__(self, hr: torch.Tensor, lr: Optional[torch.Tensor] = None) -> dict:
+        if lr is None:
+            lr, hr = self.degrade(hr)
+        b, _, h, w = hr.shape
+        real = torch.full([b, 1, h, w], 1.0, dtype=torch.float, device=hr.device)          # :460
+        fake = torch.full([b, 1, h, w], 0.0, dtype=torch.float, device=hr.device)          # :461
+        for p in self.d.parameters():                                                      # :465-466
+            p.requires_grad = False
+        self.g.zero_grad(set_to_none=True)                                                 # :469
+        sr = self.g(lr)                                                                    # :474
+        pixel_loss = self.pixel_weight * self.pixel(self.usm(sr, 0.5, 10), hr)             # :475
+        adversarial_loss = self.adversarial_weight * self.adv(self.d(sr), real)            # :478
+        g_loss = pixel_loss + adversarial_loss                                             # :480 (content term detached, see class doc)
+        self._backward(g_loss)                                                             # :483
+        self._step(self.g_opt)                                                             # :485-486
+        for p in self.d.parameters():                                                      # :491-492
+            p.requires_grad = True
+        self.d.zero_grad(set_to_none=True)                                                 # :495
+        hr_out = self.d(hr)                                                                # :499
+        d_loss_hr = self.adv(hr_out, real)
+        self._backward(d_loss_hr)                                                          # :503
+        sr_out = self.d(sr.detach().clone())                                               # :507
+        d_loss_sr = self.adv(sr_out, fake)
+        self._backward(d_loss_sr)                                                          # :513
+        self._step(self.d_opt)                                                             # :515-516
+        if self.ema is not None:
+            self.ema.update()                                                              # :520
+        return {"pixel_loss": pixel_loss.detach(), "adversarial_loss": adversarial_loss.detach(),
+                "d_loss_hr": d_loss_hr.detach(), "d_loss_sr": d_loss_sr.detach()}

@@ -42,7 +42,7 @@ def pack_conv(weight, dtype, transposed=False, scale=1.0):
     for ck in range(nck):
         kc = min(32, k_real - ck * 32)
         chunks[ck] = L.PackChunk(0, ck * 9 * mt * 1024, cout, cin, 0, m_real, ck * 32, kc, mt,
-                                 1 if transposed else 0, scale, 0)
+                                 1 if transposed else 0, scale, 0, None)
     table = torch.frombuffer(bytearray(bytes(chunks)), dtype=torch.uint8).cuda()
     arena = weight.reshape(-1).float().cuda()
     es = 2 if dtype == L.RESR_F16 else 4

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header(built):
     L = built._lib
     assert ctypes.sizeof(L.ConvDesc) == 20 * 4
     assert ctypes.sizeof(L.WgradDesc) == 15 * 4
-    assert ctypes.sizeof(L.PackChunk) == 56
+    assert ctypes.sizeof(L.PackChunk) == 64
     assert ctypes.sizeof(L.GeneratorDesc) == 10 * 4
 
 
@@ -99,3 +99,16 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_discriminator_surface_matches_reference_init(built):
+    z = np.load(os.path.join(G, "discriminator_init_seed0.npz"))
+    torch.manual_seed(0)
+    d = built.Discriminator()
+    sd = d.state_dict()
+    assert list(sd.keys()) == [str(k) for k in z["keys"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in z["shapes"]]
+    sums = torch.stack([v.double().sum() for v in sd.values()])
+    assert torch.allclose(sums, torch.from_numpy(z["total_sum"]), rtol=0, atol=1e-9), "init RNG stream differs"
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        d(torch.rand(1, 3, 16, 16))
