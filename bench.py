@@ -111,7 +111,7 @@ def probe_conv_kernels(batch, lr, dtype_name, reps=8):
         ms = e0.elapsed_time(e1) / reps
         flop = 2.0 * 9 * cin * cout * batch * h * w
         big = ((w + 31) // 32) * ((h + 15) // 16) * batch >= 512
-        inst = f"conv3x3_kernel<{'f16' if dtype == L.RESR_F16 else 'f32'},{mt},{4 if (mt == 1 and big and dtype == L.RESR_F16) else 2}>"
+        inst = f"conv3x3_kernel<{'f16' if dtype == L.RESR_F16 else 'f32'},{mt},2,{8 if (mt == 1 and big and dtype == L.RESR_F16) else 4}>"
         rows.append({"kernel": inst, "cin": cin, "cout": cout, "res": h, "launches_per_step": count,
                      "ms": ms, "tflops": flop / ms / 1e9, "flop": flop})
         del x, y, yn, packed

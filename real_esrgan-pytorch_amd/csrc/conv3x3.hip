@@ -19,6 +19,8 @@
 // ds_read_b128 is served in 16-lane groups whose pixel x-coordinates cover all residues mod 16;
 // XOR-ing the slot index with a function of x makes the 16 lanes hit 16 distinct slots of the
 // 256-byte bank row (conflict-free) -- see swz().
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -103,15 +105,16 @@ __device__ __forceinline__ void store4(char* base, size_t idx, const float v[4])
     }
 }
 
-template <typename T, int MT, int NT>
-__global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
+template <typename T, int MT, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
+    constexpr int NTHR = 64 * NW;            // NW waves per workgroup, each owning NT rows of the tile
     constexpr int E = 16 / (int)sizeof(T);  // elements per 16-byte slot
     constexpr int SPP = 32 / E;             // slots per pixel per chunk (4 f16, 8 f32)
     constexpr int KS = SPP / 2;             // k-steps per chunk
     constexpr int PB = 32 * (int)sizeof(T); // bytes per pixel per chunk
-    constexpr int TH = 4 * NT, TW = 32, HH = TH + 2, HW = TW + 2;
+    constexpr int TH = NW * NT, TW = 32, HH = TH + 2, HW = TW + 2;
     constexpr int NSLOT = HH * HW * SPP;
-    constexpr int NS = (NSLOT + 255) / 256;
+    constexpr int NS = (NSLOT + NTHR - 1) / NTHR;
     constexpr int BUF = HH * HW * PB;
     constexpr int WTAP = KS * MT * 1024;    // packed weight bytes per (chunk, tap)
 
@@ -126,13 +129,13 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     const int x0 = tx * TW, y0 = ty * TH;
     const bool up = (a.flags & RESR_CONV_UPSAMPLE_IN) != 0;
 
-    // ---- staging map: slot s = tid + i*256  ->  halo pixel (hy,hx), 16-byte piece c16 ----------
-    const int c16 = tid % SPP;  // 256 % SPP == 0: identical for every i
+    // ---- staging map: slot s = tid + i*NTHR  ->  halo pixel (hy,hx), 16-byte piece c16 ----------
+    const int c16 = tid % SPP;  // NTHR % SPP == 0: identical for every i
     int pix[NS];                // source pixel index inside the image, -1 = zero (padding / unused)
     int loff[NS];               // swizzled LDS byte offset inside one buffer, -1 = no slot
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        const int s = tid + i * 256;
+        const int s = tid + i * NTHR;
         const int hp = s / SPP;
         const int hy = hp / HW, hx = hp - hy * HW;
         const int iy = y0 + hy - 1, ix = x0 + hx - 1;
@@ -324,10 +327,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, int NW = 4>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int PB = 32 * (int)sizeof(T);
-    constexpr int TH = 4 * NT;
+    constexpr int TH = NW * NT;
     constexpr int BUF = (TH + 2) * 34 * PB;
     ConvArgs args = a;
     args.tiles_x = (a.w_ + 31) / 32;
@@ -335,12 +338,12 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     const size_t lds = 2 * BUF;
     static bool attr_done = false;  // benign race: idempotent
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT, NT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MT, NT, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     const unsigned grid = (unsigned)(args.tiles_x * args.tiles_y * a.n);
-    hipLaunchKernelGGL((conv3x3_kernel<T, MT, NT>), dim3(grid), dim3(256), lds, stream, args);
+    hipLaunchKernelGGL((conv3x3_kernel<T, MT, NT, NW>), dim3(grid), dim3(64 * NW), lds, stream, args);
     RESR_CHECK_LAUNCH("conv3x3_kernel");
     return RESR_OK;
 }
@@ -375,13 +378,30 @@ int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, co
     a.res0_stride = d->res0_stride; a.res1_stride = d->res1_stride; a.mask_stride = d->mask_stride;
     a.flags = d->flags; a.s0 = d->s0; a.t0 = d->t0; a.s1 = d->s1; a.t1 = d->t1; a.slope = d->slope;
     const int mt = d->cout_pad / 32;
-    // rows per wave: 4 when that still yields enough workgroups to fill 256 CUs twice over
+    // 16-row tiles only when that still yields enough workgroups to fill 256 CUs twice over
     const long tiles4 = (long)((d->w + 31) / 32) * ((d->h + 15) / 16) * d->n;
-    const bool big = tiles4 >= 512;
+    static const char* nt_env = getenv("RESR_CONV_NT");     // tuning knob: force rows-per-wave 2 or 4
+    const bool big = nt_env ? (nt_env[0] == '4') : tiles4 >= 512;
+    static const char* nw_env = getenv("RESR_CONV_NW");
     if (d->dtype == RESR_F16) {
-        if (mt == 1) return big ? launch_conv<half_t, 1, 4>(a, stream) : launch_conv<half_t, 1, 2>(a, stream);
-        // <f16,2,4> needs 128 accumulator + 170 other registers -> 1 wave/SIMD; keep 2 waves/SIMD instead
-        return launch_conv<half_t, 2, 2>(a, stream);
+        if (nw_env) {   // tuning knob "<mt1 cfg><mt2 cfg>", each one of: a=<2,4> b=<4,4> c=<2,8> d=<4,8> e=<1,8>
+            const char c = mt == 1 ? nw_env[0] : nw_env[1];
+            if (mt == 1) {
+                if (c == 'a') return launch_conv<half_t, 1, 2, 4>(a, stream);
+                if (c == 'b') return launch_conv<half_t, 1, 4, 4>(a, stream);
+                if (c == 'c') return launch_conv<half_t, 1, 2, 8>(a, stream);
+                if (c == 'd') return launch_conv<half_t, 1, 4, 8>(a, stream);
+            } else {
+                if (c == 'a') return launch_conv<half_t, 2, 2, 4>(a, stream);
+                if (c == 'b') return launch_conv<half_t, 2, 4, 4>(a, stream);
+                if (c == 'c') return launch_conv<half_t, 2, 2, 8>(a, stream);
+                if (c == 'e') return launch_conv<half_t, 2, 1, 8>(a, stream);
+            }
+        }
+        // measured on MI355X (B=8, 256^2): cout 32 -> 8 waves x 2 rows (4 waves/SIMD, 2 workgroups/CU) beats
+        // 4 waves x 4 rows by 5-16 %; cout 64 -> 4 waves x 2 rows (2 waves/SIMD) beats every 8-wave shape
+        if (mt == 1) return big ? launch_conv<half_t, 1, 2, 8>(a, stream) : launch_conv<half_t, 1, 2, 4>(a, stream);
+        return launch_conv<half_t, 2, 2, 4>(a, stream);
     } else if (d->dtype == RESR_F32) {
         if (mt == 1) return launch_conv<float, 1, 2>(a, stream);
         return launch_conv<float, 2, 2>(a, stream);

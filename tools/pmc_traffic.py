@@ -1,0 +1,42 @@
+"""Reduce rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, separate runs) of `bench.py` to per-launch HBM traffic
+per kernel.  gfx950 note (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports exactly half of the bytes of wide coalesced
+reads, so reads are doubled; both counters are in KiB.
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> > profiles/rNN_pmc_traffic.json
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r"conv3x3_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)E", name)
+    if m:
+        return f"conv3x3_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'},{m.group(2)},{m.group(3)},{m.group(4)}>"
+    m = re.search(r"wgrad_kernelI(DF16_|f)Li(\d)E", name)
+    if m:
+        return f"wgrad_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'},{m.group(2)}>"
+    return re.sub(r"\(.*", "", name)[:60]
+
+
+def load(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+fetch = load(sys.argv[1], "FETCH_SIZE")
+write = load(sys.argv[2], "WRITE_SIZE")
+out = {}
+for k in fetch:
+    if k not in write:
+        continue
+    f = sum(fetch[k]) / len(fetch[k]) * 1024 * 2      # KiB -> B, x2 gfx950 correction for wide reads
+    w = sum(write[k]) / len(write[k]) * 1024
+    out[k] = {"launches": len(fetch[k]), "read_bytes_per_launch": round(f), "write_bytes_per_launch": round(w),
+              "hbm_bytes_per_launch": round(f + w)}
+print(json.dumps(out, indent=1))
