@@ -1,0 +1,61 @@
+"""Spatial tiling of large inputs with a hipGraph-captured tile loop (BASELINE config 5: x2 model on a
+3840x2160 LR frame).  Net-new relative to the reference, which runs whole images (inference.py:53).
+
+Every tile is a fixed-size window (tile + 2*halo, shifted inwards at the image border so that all
+windows have the same shape); the generator pass over one window is captured once into a hipGraph and
+replayed per tile on static input/output buffers; only the tile's own pixels are stitched into the
+result.  Per pixel the arithmetic is that of `Generator` on the window, so with halo >= the network's
+receptive-field radius the stitched image equals whole-image inference bit for bit (tested with a short
+trunk); with the 23-block trunk (radius ~350 LR px) the halo is a quality/speed choice.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .model import Generator
+
+
+class TiledGenerator:
+    def __init__(self, model: Generator, tile: int = 512, halo: int = 32, use_graph: bool = True) -> None:
+        self.model, self.tile, self.halo, self.use_graph = model, tile, halo, use_graph
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._static_in: Optional[torch.Tensor] = None
+        self._static_out: Optional[torch.Tensor] = None
+        self._win = None
+
+    def _window_forward(self, xin: torch.Tensor) -> torch.Tensor:
+        if not self.use_graph:
+            with torch.no_grad():
+                return self.model(xin)
+        if self._graph is None or self._win != tuple(xin.shape):
+            self._win = tuple(xin.shape)
+            self._static_in = xin.clone()
+            with torch.no_grad():
+                for _ in range(2):                      # warm-up: one-time init + workspace allocation outside capture
+                    self.model(self._static_in)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), torch.no_grad():
+                self._static_out = self.model(self._static_in)
+            self._graph = g
+        self._static_in.copy_(xin)
+        self._graph.replay()
+        return self._static_out
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        n, c, H, W = x.shape
+        s = self.model.upscale_factor
+        win_h, win_w = min(H, self.tile + 2 * self.halo), min(W, self.tile + 2 * self.halo)
+        out = torch.empty((n, self.model.out_channels, H * s, W * s), dtype=torch.float32, device=x.device)
+        for y0 in range(0, H, self.tile):
+            y1 = min(H, y0 + self.tile)
+            wy = min(max(y0 - self.halo, 0), H - win_h)
+            for x0 in range(0, W, self.tile):
+                x1 = min(W, x0 + self.tile)
+                wx = min(max(x0 - self.halo, 0), W - win_w)
+                sr = self._window_forward(x[:, :, wy:wy + win_h, wx:wx + win_w].contiguous())
+                out[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = sr[:, :, (y0 - wy) * s:(y1 - wy) * s, (x0 - wx) * s:(x1 - wx) * s]
+        return out

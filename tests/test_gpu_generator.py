@@ -123,3 +123,16 @@ def test_inference_entry_point(tmp_path):
     assert got.shape == (96, 112, 3)
     d = np.abs(got - ref)
     assert d.max() <= 1 and (d > 0).mean() < 1e-3      # truncating uint8 conversion: ties within 2e-6 may flip a level
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_tiled_inference_equals_whole_image(use_graph):
+    """Halo >= receptive-field radius (1-block trunk: ~21 LR px)  =>  stitched tiles == whole-image pass, bit for bit."""
+    from real_esrgan_pytorch_amd.tiling import TiledGenerator
+    g, sd, M = _setup(2, 1, 5, "fast")
+    x = torch.rand(1, 3, 144, 176).cuda()
+    with torch.no_grad():
+        whole = g(x)
+    tiled = TiledGenerator(g, tile=64, halo=24, use_graph=use_graph)(x)
+    assert tiled.shape == whole.shape == (1, 3, 288, 352)
+    assert torch.equal(tiled, whole)
