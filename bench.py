@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--precision", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-degradation", action="store_true", help="debug only: feed pre-degraded LR tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="skip the in-situ roofline step")
+    ap.add_argument("--isolated-probe", action="store_true", help="also time every conv shape back-to-back in isolation")
     return ap.parse_args()
 
 
@@ -116,6 +117,65 @@ def probe_conv_kernels(batch, lr, dtype_name, reps=8):
                      "ms": ms, "tflops": flop / ms / 1e9, "flop": flop})
         del x, y, yn, packed
     return rows
+
+
+def pmc_traffic(kernel, batch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r*_pmc_traffic_b<batch>.json, made by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate
+    runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  PMC counters cannot be read from inside
+    the process, so this is the last measured value for this batch size, or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_b{batch}.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if kernel in d:
+                return d[kernel]["hbm_bytes_per_launch"], os.path.basename(path)
+        except Exception:
+            pass
+    return None, None
+
+
+def kernel_name(kid):
+    if kid >= 50000:
+        k = kid - 50000
+        return f"wgrad_kernel<{'f32' if k >= 100 else 'f16'},{k % 100}>"
+    t = "f32" if kid >= 10000 else "f16"
+    k = kid % 10000
+    return f"conv3x3_kernel<{t},{k // 100},{(k // 10) % 10},{k % 10}>"
+
+
+def roofline_in_situ(step_fn, precision, batch):
+    """One extra (untimed) train step with every conv3x3 / wgrad launch bracketed by HIP events on its launch stream
+    (resr_profile_begin/end).  The dominant kernel is the instance with the largest summed duration; achieved =
+    sum of its launches' algorithmic FLOP (2*9*cin*cout*pixels each) / sum of their durations."""
+    import real_esrgan_pytorch_amd as R
+    L = R._lib
+    lib = L.lib()
+    lib.resr_profile_begin()
+    step_fn()
+    torch.cuda.synchronize()
+    cap = 8192
+    buf = (L.ProfEntry * cap)()
+    n = int(lib.resr_profile_end(C.cast(buf, C.c_void_p), cap))
+    by = {}
+    for i in range(min(n, cap)):
+        b = by.setdefault(kernel_name(buf[i].kernel_id), {"t": 0.0, "f": 0.0, "n": 0})
+        b["t"] += buf[i].ms
+        b["f"] += buf[i].flop
+        b["n"] += 1
+    name, b = max(by.items(), key=lambda kv: kv[1]["t"])
+    achieved = b["f"] / b["t"] / 1e9
+    peak = PEAK_F16_TFLOPS if precision == "fast" else PEAK_F32_TFLOPS
+    traffic, src = pmc_traffic(name, batch)
+    r = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+         "frac": round(achieved / peak, 4), "traffic": traffic,
+         "avg_launch_ms": round(b["t"] / b["n"], 4), "launches_per_step": b["n"],
+         "method": "HIP events around each launch of one extra train step (in situ, launch stream)",
+         "per_instance": {k: {"tflops": round(v["f"] / v["t"] / 1e9, 2), "ms_per_step": round(v["t"], 3), "launches": v["n"],
+                              "avg_launch_ms": round(v["t"] / v["n"], 4)} for k, v in by.items()}}
+    if src:
+        r["traffic_source"] = "profiles/" + src
+    return r
 
 
 def roofline_from_probe(rows, precision):
@@ -276,12 +336,13 @@ def main():
         }
         if not args.no_probe:
             try:
-                rows = probe_conv_kernels(B, lr_edge, args.precision)
-                out["roofline"] = roofline_from_probe(rows, args.precision)
-                out["conv_probe"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "flop"}
-                                     for r in rows]
+                out["roofline"] = roofline_in_situ(one, args.precision, B)
             except Exception as e:  # pragma: no cover
                 out["roofline"] = {"error": repr(e)}
+        if args.isolated_probe:
+            rows = probe_conv_kernels(B, lr_edge, args.precision)
+            out["conv_probe_isolated"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "flop"}
+                                          for r in rows]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

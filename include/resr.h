@@ -214,6 +214,18 @@ int resr_ema_update(float* shadow, const float* params, int64_t count, double de
 /* test probe: lane/element map of ds_read_b64_tr_b16 (256 floats out) */
 int resr_debug_tr_probe(float* out256, void* stream);
 
+/* In-situ kernel timing for bench.py: between begin and end every conv3x3 / wgrad launch is bracketed by HIP events
+ * on its launch stream.  kernel_id = dtype*10000 + MT*100 + NT*10 + NW for conv3x3_kernel<T,MT,NT,NW>,
+ * 50000 + dtype*100 + RPW for wgrad_kernel<T,RPW>.  resr_profile_end synchronises the events (host-side, test/bench
+ * only), fills up to `capacity` entries and returns the number recorded. */
+typedef struct {
+    int32_t kernel_id;
+    float ms;
+    double flop; /* algorithmic FLOP of the launch: 2*9*cin*cout*pixels */
+} ResrProfEntry;
+int resr_profile_begin(void);
+int64_t resr_profile_end(ResrProfEntry* out, int64_t capacity);
+
 const char* resr_last_error(void);
 int resr_version(void);
 

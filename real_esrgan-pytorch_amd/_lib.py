@@ -39,6 +39,10 @@ class PackChunk(C.Structure):
                 ("scale_ptr", C.c_void_p)]
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [("kernel_id", C.c_int32), ("ms", C.c_float), ("flop", C.c_double)]
+
+
 class GeneratorDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
                 ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("upscale", C.c_int32),
@@ -67,6 +71,8 @@ _PROTOS = {
     "resr_generator_backward": (C.c_int, [C.POINTER(GeneratorDesc), _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     "resr_ema_update": (C.c_int, [_P, _P, C.c_int64, C.c_double, _P]),
     "resr_debug_tr_probe": (C.c_int, [_P, _P]),
+    "resr_profile_begin": (C.c_int, []),
+    "resr_profile_end": (C.c_int64, [_P, C.c_int64]),
     "resr_space_to_depth": (C.c_int, [_P, _P] + [C.c_int32] * 6 + [_P]),
     "resr_bilinear_up2x": (C.c_int, [_P, _P] + [C.c_int32] * 6 + [_P]),
     "resr_add_mask": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),

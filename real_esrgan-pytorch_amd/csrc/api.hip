@@ -3,6 +3,8 @@
 // thread-local message.  Every entry point enqueues on the caller's stream and returns.
 #include <stdarg.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace resr {
@@ -18,6 +20,29 @@ int fail(int code, const char* fmt, ...) {
     vsnprintf(err_buf(), 512, fmt, ap);
     va_end(ap);
     return code;
+}
+
+// ---- in-situ profiling -------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t e0, e1; int id; double flop; };
+std::vector<ProfRec> g_prof;
+bool g_prof_on = false;
+hipEvent_t g_prof_e0 = nullptr;
+}  // namespace
+bool prof_on() { return g_prof_on; }
+void prof_before(hipStream_t st) {
+    if (!g_prof_on) return;
+    (void)hipEventCreate(&g_prof_e0);
+    (void)hipEventRecord(g_prof_e0, st);
+}
+void prof_after(hipStream_t st, int kernel_id, double flop) {
+    if (!g_prof_on || !g_prof_e0) return;
+    ProfRec r;
+    r.e0 = g_prof_e0; r.id = kernel_id; r.flop = flop;
+    (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e1, st);
+    g_prof.push_back(r);
+    g_prof_e0 = nullptr;
 }
 
 int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*, const float*, const void*,
@@ -214,6 +239,29 @@ int resr_spectral_norm_bwd(const float* g, const float* w, const float* u, const
 
 int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* stream) {
     return fold4x4_dispatch(dw3, dw4, cout, c, (hipStream_t)stream);
+}
+
+int resr_profile_begin(void) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_on = true;
+    return RESR_OK;
+}
+
+int64_t resr_profile_end(ResrProfEntry* out, int64_t capacity) {
+    g_prof_on = false;
+    int64_t n = 0;
+    for (auto& r : g_prof) {
+        (void)hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (out && n < capacity) { out[n].kernel_id = r.id; out[n].ms = ms; out[n].flop = r.flop; }
+        ++n;
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    return n;
 }
 
 int resr_debug_tr_probe(float* out256, void* stream) {

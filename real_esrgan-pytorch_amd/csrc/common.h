@@ -25,6 +25,11 @@ int fail(int code, const char* fmt, ...);
         if (e_ != hipSuccess) return fail(RESR_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
+// optional in-situ kernel timing (resr_profile_begin/end): HIP events around individual launches on the launch stream
+bool prof_on();
+void prof_before(hipStream_t st);
+void prof_after(hipStream_t st, int kernel_id, double flop);
+
 inline size_t elem_size(int dtype) { return dtype == RESR_F16 ? 2 : 4; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -343,7 +343,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
         attr_done = true;
     }
     const unsigned grid = (unsigned)(args.tiles_x * args.tiles_y * a.n);
+    prof_before(stream);
     hipLaunchKernelGGL((conv3x3_kernel<T, MT, NT, NW>), dim3(grid), dim3(64 * NW), lds, stream, args);
+    prof_after(stream, (sizeof(T) == 2 ? 0 : 10000) + MT * 100 + NT * 10 + NW,
+               2.0 * 9 * a.cin * a.cout * (double)a.n * a.h * a.w_);
     RESR_CHECK_LAUNCH("conv3x3_kernel");
     return RESR_OK;
 }

@@ -301,7 +301,9 @@ static int launch_wgrad(WgradArgs& a, int njobs, hipStream_t stream) {
         a.zero = (const char*)zp;
     }
     const int splits8 = (a.splits + 7) / 8 * 8;
+    prof_before(stream);
     hipLaunchKernelGGL((wgrad_kernel<T, RPW>), dim3(njobs * splits8), dim3(256), lds, stream, a);
+    prof_after(stream, 50000 + (sizeof(T) == 2 ? 0 : 100) + RPW, 2.0 * 9 * 32 * 32 * njobs * (double)a.n * a.h * a.w_);
     RESR_CHECK_LAUNCH("wgrad_kernel");
     return RESR_OK;
 }
