@@ -1,0 +1,73 @@
+"""-m gpu: data-parallel step with the real kernels.  Two processes share the one GPU of the test box (gloo
+backend, since RCCL refuses two ranks on one device); each runs the generator on its half of the batch, the
+flat-gradient all-reduce(mean) must reproduce the single-process gradient of the whole batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(0)
+    return R.Generator(3, 3, 4, precision="strict", n_blocks=1).cuda()
+
+
+def _data():
+    g = torch.Generator().manual_seed(9)
+    return torch.rand(4, 3, 16, 16, generator=g), torch.rand(4, 3, 64, 64, generator=g)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from real_esrgan_pytorch_amd.train import DataParallel
+    torch.cuda.set_device(0)
+    model = _model()
+    if rank == 1:                                   # replicas must be made identical by the initial broadcast
+        with torch.no_grad():
+            model.flat_parameters().add_(1.0)
+    DataParallel(bucket_bytes=64 << 10).attach(model)
+    lr, hr = _data()
+    half = slice(rank * 2, rank * 2 + 2)
+    loss = (model(lr[half].cuda()) - hr[half].cuda()).abs().mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    q.put((rank, model.flat_grad().cpu().numpy(), model.flat_parameters().detach().cpu().numpy()))   # by value
+    dist.destroy_process_group()
+
+
+def test_two_rank_dp_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r, g, w = q.get(timeout=600)
+        res[r] = (torch.from_numpy(g), torch.from_numpy(w))
+    for p in procs:
+        p.join(timeout=120)
+    model = _model()
+    lr, hr = _data()
+    (model(lr.cuda()) - hr.cuda()).abs().mean().backward()
+    ref = model.flat_grad().cpu()
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][1], model.flat_parameters().detach().cpu())   # broadcast
+    assert torch.equal(res[0][0], res[1][0])                                                            # same reduced gradient
+    rel = ((res[0][0] - ref).norm() / ref.norm()).item()
+    assert rel < 1e-5, rel                    # fp32: mean of two half-batch gradients == whole-batch gradient

@@ -11,6 +11,7 @@ ap.add_argument("--res", type=int, default=256)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--shapes", default="64:32,160:32,192:64")
 ap.add_argument("--wgrad", action="store_true")
+ap.add_argument("--stride", type=int, default=0, help="input/output pixel stride in channels (0 = packed)")
 a = ap.parse_args()
 lib = L.lib()
 gen = torch.Generator(device="cuda").manual_seed(1)
@@ -18,10 +19,12 @@ for sh in a.shapes.split(","):
     cin, cout = map(int, sh.split(":"))
     cout_pad = (cout + 31) // 32 * 32
     mt = cout_pad // 32
-    x = (torch.rand(a.batch, a.res, a.res, cin, device="cuda", generator=gen) - 0.5).half()
-    y = torch.empty(a.batch, a.res, a.res, cout_pad, device="cuda", dtype=torch.float16)
+    xs = a.stride or cin
+    ys = a.stride or cout_pad
+    x = (torch.rand(a.batch, a.res, a.res, xs, device="cuda", generator=gen) - 0.5).half()
+    y = torch.empty(a.batch, a.res, a.res, ys, device="cuda", dtype=torch.float16)
     w = ((torch.rand((cin // 32) * 9 * mt * 1024 + 8192, device="cuda", generator=gen) - 0.5) * 0.1).half()
-    d = L.ConvDesc(a.batch, a.res, a.res, cin, cin, cin, 0, cout, cout_pad, cout_pad, 0, 0, 0, L.RESR_F16, L.CONV_LRELU, 1, 1, 1, 1, 0.2)
+    d = L.ConvDesc(a.batch, a.res, a.res, cin, cin, xs, 0, cout, cout_pad, ys, 0, 0, 0, L.RESR_F16, L.CONV_LRELU, 1, 1, 1, 1, 0.2)
     def launch():
         L.check(lib.resr_conv3x3(C.byref(d), L.ptr(x), None, L.ptr(w), None, None, None, None, L.ptr(y), None, L.stream_ptr()))
     launch(); torch.cuda.synchronize()
