@@ -205,6 +205,9 @@ int resr_spectral_norm(const float* w, float* u, float* v, int32_t rows, int32_t
 /* gradient wrt W_orig from the gradient wrt W = W_orig/sigma; tmp1 = 1 float */
 int resr_spectral_norm_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma2, float* dst,
                            int32_t rows, int32_t cols, int32_t accumulate, float* tmp1, void* stream);
+/* 2x2 stride-2 max pooling on NHWC [n,2*h_out,2*w_out,c] (VGG19 of ContentLoss, model.py:296-298) */
+int resr_maxpool2x2(const void* src, void* dst, int32_t n, int32_t h_out, int32_t w_out, int32_t c, int32_t dtype,
+                    void* stream);
 /* virtual [cout][4C][3][3] weight gradient of a space-to-depth conv -> real [cout][C][4][4] */
 int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* stream);
 

@@ -9,5 +9,6 @@ binding of csrc/libresr_hip.so, C-ABI in include/resr.h), `csrc/` (HIP kernels +
 from . import _lib  # noqa: F401
 from .model import EMA, Generator, ResidualDenseBlock, ResidualResidualDenseBlock  # noqa: F401
 from .discriminator import Discriminator  # noqa: F401
+from .content_loss import ContentLoss  # noqa: F401
 
-__all__ = ["EMA", "Generator", "Discriminator", "ResidualDenseBlock", "ResidualResidualDenseBlock"]
+__all__ = ["EMA", "Generator", "Discriminator", "ContentLoss", "ResidualDenseBlock", "ResidualResidualDenseBlock"]

@@ -81,6 +81,7 @@ int spectral_norm_dispatch(const float*, float*, float*, int, int, int, float, f
 int spectral_norm_bwd_dispatch(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, float*,
                                hipStream_t);
 int fold4x4_dispatch(const float*, float*, int, int, hipStream_t);
+int maxpool2x2_dispatch(const void*, void*, int, int, int, int, int, hipStream_t);
 
 // probe used by tests: what does ds_read_b64_tr_b16 hand to (lane, element)?  LDS holds the element
 // index at every position; lane l supplies byte address l*8.
@@ -235,6 +236,10 @@ int resr_spectral_norm(const float* w, float* u, float* v, int32_t rows, int32_t
 int resr_spectral_norm_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma2, float* dst,
                            int32_t rows, int32_t cols, int32_t accumulate, float* tmp1, void* stream) {
     return spectral_norm_bwd_dispatch(g, w, u, v, sigma2, dst, rows, cols, accumulate, tmp1, (hipStream_t)stream);
+}
+
+int resr_maxpool2x2(const void* src, void* dst, int32_t n, int32_t h_out, int32_t w_out, int32_t c, int32_t dtype, void* stream) {
+    return maxpool2x2_dispatch(src, dst, n, h_out, w_out, c, dtype, (hipStream_t)stream);
 }
 
 int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* stream) {

@@ -173,6 +173,49 @@ int add_mask_dispatch(const void* a, const void* b, const void* mask, void* out,
     return RESR_OK;
 }
 
+// 2x2 / stride-2 max pooling on NHWC (VGG19 perceptual branch, reference model.py:296-298)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int ho, int wo, int c) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const int groups = c / E;
+    const long total = (long)n * ho * wo * groups;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int g = (int)(t % groups);
+    const long p = t / groups;
+    const int x = (int)(p % wo), y = (int)((p / wo) % ho), b = (int)(p / ((long)wo * ho));
+    const int wi = wo * 2;
+    const T* s = src + (((size_t)b * ho * 2 + y * 2) * wi + x * 2) * c + g * E;
+    float m[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) m[e] = -3.4e38f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(s + ((size_t)dy * wi + dx) * c);
+            const T* v = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+            for (int e = 0; e < E; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+        }
+    uint4 o;
+    T* ov = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < E; ++e) ov[e] = (T)m[e];
+    *reinterpret_cast<uint4*>(dst + p * c + g * E) = o;
+}
+
+int maxpool2x2_dispatch(const void* src, void* dst, int n, int ho, int wo, int c, int dtype, hipStream_t st) {
+    const int E = dtype == RESR_F16 ? 8 : 4;
+    if (!src || !dst || n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || (c % E)) return fail(RESR_ERR_ARG, "maxpool2x2: bad argument");
+    const long total = (long)n * ho * wo * (c / E);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == RESR_F16) hipLaunchKernelGGL(maxpool2x2_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, ho, wo, c);
+    else hipLaunchKernelGGL(maxpool2x2_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, ho, wo, c);
+    RESR_CHECK_LAUNCH("maxpool2x2_kernel");
+    return RESR_OK;
+}
+
 // ---- spectral norm -----------------------------------------------------------------------------------------------
 // W is [rows = cout][cols = cin*k*k] row-major fp32 (the OIHW parameter viewed as a matrix).
 __global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ vraw,

@@ -79,16 +79,19 @@ class RealESRGANStep:
     discriminator frozen (pixel L1 on the USM-sharpened sr + adversarial BCE), then two discriminator
     backwards (real, fake) accumulated into one update, one shared GradScaler updated twice, EMA.
 
-    The VGG19 perceptual term is omitted: the reference wraps it in `torch.Tensor(...)` (:477-478), which
-    detaches it -- it contributes to the logged loss only, never to a gradient -- and the pretrained
-    torchvision weights it needs are not available in this environment."""
+    The VGG19 perceptual term (`content_criterion`, optional): the reference wraps it in `torch.Tensor(...)`
+    (:477-478), which detaches it -- it is added to the logged g_loss but never back-propagated.  The same
+    happens here: `ContentLoss.forward` returns detached scalars (and, unlike the reference, stays on the
+    device: no 5 D2H syncs)."""
 
     def __init__(self, generator, discriminator, ema, g_optimizer, d_optimizer, scaler=None, degrade=None,
-                 pixel_weight: float = 1.0, adversarial_weight: float = 0.1) -> None:
+                 pixel_weight: float = 1.0, adversarial_weight: float = 0.1, content_criterion=None,
+                 content_weight=(0.1, 0.1, 1.0, 1.0, 1.0)) -> None:
         from . import imgproc
         self.g, self.d, self.ema = generator, discriminator, ema
         self.g_opt, self.d_opt, self.scaler, self.degrade = g_optimizer, d_optimizer, scaler, degrade
         self.pixel_weight, self.adversarial_weight = pixel_weight, adversarial_weight
+        self.content, self.content_weight = content_criterion, content_weight
         self.pixel = nn.L1Loss()
         self.adv = nn.BCEWithLogitsLoss()
         dev = next(generator.parameters()).device
@@ -117,7 +120,12 @@ class RealESRGANStep:
             p.requires_grad = False
         self.g.zero_grad(set_to_none=True)                                                 # :469
         sr = self.g(lr)                                                                    # :474
-        pixel_loss = self.pixel_weight * self.pixel(self.usm(sr, 0.5, 10), hr)             # :475
+        sr_usm = self.usm(sr, 0.5, 10)
+        pixel_loss = self.pixel_weight * self.pixel(sr_usm, hr)                            # :475
+        content_loss = None
+        if self.content is not None:                                                       # :476-477 (detached)
+            cl = self.content(sr_usm, hr)
+            content_loss = sum(w * c for w, c in zip(self.content_weight, cl))
         adversarial_loss = self.adversarial_weight * self.adv(self.d(sr), real)            # :478
         g_loss = pixel_loss + adversarial_loss                                             # :480 (content term detached, see class doc)
         self._backward(g_loss)                                                             # :483
@@ -134,5 +142,8 @@ class RealESRGANStep:
         self._step(self.d_opt)                                                             # :515-516
         if self.ema is not None:
             self.ema.update()                                                              # :520
-        return {"pixel_loss": pixel_loss.detach(), "adversarial_loss": adversarial_loss.detach(),
-                "d_loss_hr": d_loss_hr.detach(), "d_loss_sr": d_loss_sr.detach()}
+        out = {"pixel_loss": pixel_loss.detach(), "adversarial_loss": adversarial_loss.detach(),
+               "d_loss_hr": d_loss_hr.detach(), "d_loss_sr": d_loss_sr.detach()}
+        if content_loss is not None:
+            out["content_loss"] = content_loss
+        return out

@@ -159,3 +159,23 @@ def test_gan_step_vs_oracle():
     for name, p in d.named_parameters():
         assert rel(p.grad.cpu(), dp[name].grad) < 2e-2, name
     assert torch.allclose(d.state_dict()["conv2.0.weight_u"].cpu(), dp["conv2.0.weight_u"], atol=1e-5)   # three power iterations
+
+
+@pytest.mark.parametrize("precision,tol", [("strict", 1e-4), ("fast", 2e-2)])
+def test_content_loss_forward_vs_oracle(precision, tol):
+    from oracle import model_ref as M
+    from real_esrgan_pytorch_amd.content_loss import ContentLoss
+    nodes = ["features.2", "features.7", "features.16", "features.25", "features.34"]      # config.py:131
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    torch.manual_seed(4)
+    for aliasing in (True, False):
+        cl = ContentLoss(nodes, mean, std, precision=precision, inplace_relu_aliasing=aliasing).cuda()
+        sd = {k: v.detach().cpu() for k, v in cl.state_dict().items() if k.startswith("features.")}
+        gen = torch.Generator().manual_seed(6)
+        sr, hr = torch.rand(2, 3, 64, 48, generator=gen), torch.rand(2, 3, 64, 48, generator=gen)
+        ref = M.content_loss(sr, hr, sd, nodes, mean, std, aliasing)
+        got = cl(sr.cuda(), hr.cuda())
+        assert len(got) == 5
+        for g, r in zip(got, ref):
+            assert not g.requires_grad                              # detached, like torch.Tensor(...) at train_realesrgan.py:477
+            assert abs(g.item() - r.item()) < tol * max(r.item(), 1e-6), (precision, aliasing, g.item(), r.item())
