@@ -139,6 +139,9 @@ def kernel_name(kid):
     if kid >= 50000:
         k = kid - 50000
         return f"wgrad_kernel<{'f32' if k >= 100 else 'f16'},{k % 100}>"
+    if kid >= 20000:  # fast-mode producer/consumer kernel: <f16, MT, NT, consumer waves>
+        k = kid - 20000
+        return f"conv3x3_ws_kernel<f16,{k // 100},{(k // 10) % 10},{k % 10}>"
     t = "f32" if kid >= 10000 else "f16"
     k = kid % 10000
     return f"conv3x3_kernel<{t},{k // 100},{(k // 10) % 10},{k % 10}>"

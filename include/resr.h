@@ -214,6 +214,8 @@ int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* st
 /* EMA.update (model.py:43-48) over the flat parameter arena, one launch. */
 int resr_ema_update(float* shadow, const float* params, int64_t count, double decay, void* stream);
 
+/* Debug: per-workgroup timeline of the fast-mode conv kernel (32 workgroups x 2 roles x 64 uint64 stamps, 100 MHz). */
+int resr_debug_conv_trace(void* dev_buf);
 /* test probe: lane/element map of ds_read_b64_tr_b16 (256 floats out) */
 int resr_debug_tr_probe(float* out256, void* stream);
 

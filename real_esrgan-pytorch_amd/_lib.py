@@ -71,6 +71,7 @@ _PROTOS = {
     "resr_generator_backward": (C.c_int, [C.POINTER(GeneratorDesc), _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     "resr_ema_update": (C.c_int, [_P, _P, C.c_int64, C.c_double, _P]),
     "resr_debug_tr_probe": (C.c_int, [_P, _P]),
+    "resr_debug_conv_trace": (C.c_int, [_P]),
     "resr_profile_begin": (C.c_int, []),
     "resr_profile_end": (C.c_int64, [_P, C.c_int64]),
     "resr_space_to_depth": (C.c_int, [_P, _P] + [C.c_int32] * 6 + [_P]),

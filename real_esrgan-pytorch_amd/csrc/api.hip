@@ -45,6 +45,7 @@ void prof_after(hipStream_t st, int kernel_id, double flop) {
     g_prof_e0 = nullptr;
 }
 
+void conv_trace_set(void*);
 int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*, const float*, const void*,
                      const void*, const void*, void*, void*, hipStream_t);
 int wgrad_dispatch(const ResrWgradDesc*, const void*, const void*, const void*, float*, float*, float*, hipStream_t);
@@ -267,6 +268,12 @@ int64_t resr_profile_end(ResrProfEntry* out, int64_t capacity) {
     }
     g_prof.clear();
     return n;
+}
+
+// debug: device buffer of 32*2*64 uint64 receiving s_memrealtime stamps of the next conv launches (null = off)
+int resr_debug_conv_trace(void* dev_buf) {
+    resr::conv_trace_set(dev_buf);
+    return RESR_OK;
 }
 
 int resr_debug_tr_probe(float* out256, void* stream) {

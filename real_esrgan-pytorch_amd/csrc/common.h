@@ -13,6 +13,7 @@ typedef _Float16 half_t;
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 // thread-local error text for resr_last_error()

@@ -1,0 +1,89 @@
+// Shared pieces of the 3x3 convolution kernels (conv3x3.hip: register-staged tiles; conv3x3_ws.hip: persistent,
+// producer/consumer wave-specialised tiles).
+#pragma once
+#include "common.h"
+
+namespace resr {
+
+struct ConvArgs {
+    const char* in0;
+    const char* in1;
+    const char* w;
+    const float* bias;
+    const char* res0;
+    const char* res1;
+    const char* mask;
+    char* out;
+    uint8_t* aux;
+    int n, h, w_, hs, ws;
+    int cin, cin0;
+    int in0_stride_b, in1_stride_b;  // bytes per pixel
+    int cout;
+    int out_stride, res0_stride, res1_stride, mask_stride;  // elements
+    int flags;
+    float s0, t0, s1, t1, slope;
+    int tiles_x, tiles_y;
+    const char* zero;  // 16 zero bytes in device memory (source of out-of-image LDS-DMA lanes)
+    unsigned long long* trace;  // debug: per-workgroup s_memrealtime stamps (resr_debug_conv_trace), else null
+};
+
+template <int SPP>
+__device__ __forceinline__ int swz(int hx) {
+    // SPP slots per pixel; 16/SPP consecutive pixels fill one 256-byte bank row.
+    if constexpr (SPP == 4) return (hx >> 2) & 3;
+    else return (hx >> 1) & 7;
+}
+
+template <typename T>
+struct Frag;
+template <>
+struct Frag<half_t> {
+    static __device__ __forceinline__ float16v mma(const uint4& a, const uint4& b, float16v c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a),
+                                                      __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float ld(const char* p, int idx) {
+        return (float)reinterpret_cast<const half_t*>(p)[idx];
+    }
+};
+template <>
+struct Frag<float> {
+    static __device__ __forceinline__ float16v mma(const uint4& a, const uint4& b, float16v c) {
+        const float4v fa = __builtin_bit_cast(float4v, a), fb = __builtin_bit_cast(float4v, b);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], c, 0, 0, 0);
+        return c;
+    }
+    static __device__ __forceinline__ float ld(const char* p, int idx) {
+        return reinterpret_cast<const float*>(p)[idx];
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void load4(const char* base, size_t idx, float v[4]) {
+    if constexpr (sizeof(T) == 2) {
+        const half4 h = *reinterpret_cast<const half4*>(base + idx * 2);
+        v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
+    } else {
+        const float4v f = *reinterpret_cast<const float4v*>(base + idx * 4);
+        v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(char* base, size_t idx, const float v[4]) {
+    if constexpr (sizeof(T) == 2) {
+        half4 h;
+        h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
+        *reinterpret_cast<half4*>(base + idx * 2) = h;
+    } else {
+        float4v f;
+        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+        *reinterpret_cast<float4v*>(base + idx * 4) = f;
+    }
+}
+
+
+}  // namespace resr

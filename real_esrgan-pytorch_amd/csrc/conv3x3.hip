@@ -23,87 +23,9 @@
 
 #include <type_traits>
 
-#include "common.h"
+#include "conv3x3.h"
 
 namespace resr {
-
-struct ConvArgs {
-    const char* in0;
-    const char* in1;
-    const char* w;
-    const float* bias;
-    const char* res0;
-    const char* res1;
-    const char* mask;
-    char* out;
-    uint8_t* aux;
-    int n, h, w_, hs, ws;
-    int cin, cin0;
-    int in0_stride_b, in1_stride_b;  // bytes per pixel
-    int cout;
-    int out_stride, res0_stride, res1_stride, mask_stride;  // elements
-    int flags;
-    float s0, t0, s1, t1, slope;
-    int tiles_x, tiles_y;
-};
-
-template <int SPP>
-__device__ __forceinline__ int swz(int hx) {
-    // SPP slots per pixel; 16/SPP consecutive pixels fill one 256-byte bank row.
-    if constexpr (SPP == 4) return (hx >> 2) & 3;
-    else return (hx >> 1) & 7;
-}
-
-template <typename T>
-struct Frag;
-template <>
-struct Frag<half_t> {
-    static __device__ __forceinline__ float16v mma(const uint4& a, const uint4& b, float16v c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a),
-                                                      __builtin_bit_cast(half8, b), c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ float ld(const char* p, int idx) {
-        return (float)reinterpret_cast<const half_t*>(p)[idx];
-    }
-};
-template <>
-struct Frag<float> {
-    static __device__ __forceinline__ float16v mma(const uint4& a, const uint4& b, float16v c) {
-        const float4v fa = __builtin_bit_cast(float4v, a), fb = __builtin_bit_cast(float4v, b);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], c, 0, 0, 0);
-        return c;
-    }
-    static __device__ __forceinline__ float ld(const char* p, int idx) {
-        return reinterpret_cast<const float*>(p)[idx];
-    }
-};
-
-template <typename T>
-__device__ __forceinline__ void load4(const char* base, size_t idx, float v[4]) {
-    if constexpr (sizeof(T) == 2) {
-        const half4 h = *reinterpret_cast<const half4*>(base + idx * 2);
-        v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
-    } else {
-        const float4v f = *reinterpret_cast<const float4v*>(base + idx * 4);
-        v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ void store4(char* base, size_t idx, const float v[4]) {
-    if constexpr (sizeof(T) == 2) {
-        half4 h;
-        h[0] = (half_t)v[0]; h[1] = (half_t)v[1]; h[2] = (half_t)v[2]; h[3] = (half_t)v[3];
-        *reinterpret_cast<half4*>(base + idx * 2) = h;
-    } else {
-        float4v f;
-        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
-        *reinterpret_cast<float4v*>(base + idx * 4) = f;
-    }
-}
 
 template <typename T, int MT, int NT, int NW>
 __global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
@@ -351,6 +273,9 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     return RESR_OK;
 }
 
+int conv3x3_ws_f16(const ConvArgs& a, int mt, hipStream_t stream);  // conv3x3_ws.hip
+bool conv3x3_ws_supported(const ConvArgs& a);
+
 int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, const void* w,
                      const float* bias, const void* res0, const void* res1, const void* mask,
                      void* out, void* aux, hipStream_t stream) {
@@ -387,6 +312,8 @@ int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, co
     const bool big = nt_env ? (nt_env[0] == '4') : tiles4 >= 512;
     static const char* nw_env = getenv("RESR_CONV_NW");
     if (d->dtype == RESR_F16) {
+        static const char* old_env = getenv("RESR_CONV_ONE_ROLE");  // tuning knob: the register-staged kernel below
+        if (!old_env && conv3x3_ws_supported(a)) return conv3x3_ws_f16(a, mt, stream);
         if (nw_env) {   // tuning knob "<mt1 cfg><mt2 cfg>", each one of: a=<2,4> b=<4,4> c=<2,8> d=<4,8> e=<1,8>
             const char c = mt == 1 ? nw_env[0] : nw_env[1];
             if (mt == 1) {
