@@ -75,8 +75,9 @@ __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
     asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 
-// EPI: epilogue features of the instantiation (bit 0 LeakyReLU-mask multiply, bit 1 residual adds, bit 2 the rest:
-// aux tensors, NCHW fp32 output, clamp).  The dispatcher picks the smallest set that covers the call.
+// EPI: epilogue features of the instantiation -- bit 0 LeakyReLU-mask multiply, bit 1 residual 0, bit 2 residual 1 (each
+// unconditional when set, absent when clear), bit 3 the rest (aux tensors, NCHW fp32 output, clamp; with bit 3 the
+// other features are run-time flags).  The dispatcher instantiates the combinations the networks use.
 template <typename T, int MT, int NT, int NWC, int EPI>
 __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void conv3x3_ws_kernel(const ConvArgs a) {
     using C = WsCfg<T, MT, NT, NWC>;
@@ -232,16 +233,19 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void con
             const int nck = ck + 1 < nchunks ? ck + 1 : 0;  // next stage's chunk (first chunk of the next tile)
             const char* lbuf = smem + par * BUF;
             // halo rows of group gi+1 are read from LDS while the MFMAs of group gi run (ping-pong registers; NG is even)
-            uint4 rowf[2][NT + 2];
+            // when the register budget allows (PP); otherwise each group reads its own rows first
+            constexpr int PP = (MT * NT * 16 + (NT + 2) * 8 <= 112) ? 1 : 0;
+            uint4 rowf[PP + 1][NT + 2];
             auto rload = [&](int slot, int gi) {
                 const char* bp = lbuf + boff[gi % 3][gi / 3];
 #pragma unroll
                 for (int r = 0; r < NT + 2; ++r) rowf[slot][r] = *reinterpret_cast<const uint4*>(bp + r * (HW * PB));
             };
-            rload(0, 0);
+            if (PP) rload(0, 0);
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
-                if (gi + 1 < NG) rload((gi + 1) & 1, gi + 1);
+                if (!PP) rload(0, gi);
+                else if (gi + 1 < NG) rload((gi + 1) & 1, gi + 1);
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const int u = gi * 3 + dy;
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void con
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
                         for (int m = 0; m < MT; ++m)
-                            acc[m][t] = Frag<T>::mma(wr[u % RING][m], rowf[gi & 1][t + dy], acc[m][t]);
+                            acc[m][t] = Frag<T>::mma(wr[u % RING][m], rowf[PP ? (gi & 1) : 0][t + dy], acc[m][t]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -283,12 +287,13 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void con
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int lx_e = lane_e & 31, kh_e = lane_e >> 5;
-        constexpr bool EM = (EPI & 1) != 0, ER = (EPI & 2) != 0, EX = (EPI & 4) != 0;
+        constexpr bool EX = (EPI & 8) != 0, EM = (EPI & 1) != 0, ER = (EPI & 6) != 0;
         const bool f_lrelu = e.flags & RESR_CONV_LRELU, f_clamp = EX && (e.flags & RESR_CONV_CLAMP01);
-        const bool f_nchw = EX && (e.flags & RESR_CONV_OUT_NCHW_F32), f_mask = EM && (e.flags & RESR_CONV_MASK);
+        const bool f_nchw = EX && (e.flags & RESR_CONV_OUT_NCHW_F32);
+        const bool f_mask = EX ? (e.flags & RESR_CONV_MASK) != 0 : EM;
         const bool f_aux_mask = EX && (e.flags & RESR_CONV_AUX_BEFORE_MASK) && e.aux && !f_nchw;
         const bool f_aux_res = EX && (e.flags & RESR_CONV_AUX_BEFORE_RES) && e.aux && !f_nchw;
-        const bool f_res0 = ER && e.res0 != nullptr, f_res1 = ER && e.res1 != nullptr;
+        const bool f_res0 = EX ? e.res0 != nullptr : (EPI & 2) != 0, f_res1 = EX ? e.res1 != nullptr : (EPI & 4) != 0;
         const int x = x0 + lx_e;
         // MFMA results -> first non-MFMA reader: the swaps below are asm, so the compiler cannot count this hazard
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");
@@ -306,27 +311,32 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void con
             const size_t p = ((size_t)n * e.h + (y < e.h ? y : e.h - 1)) * e.w_ + (x < e.w_ ? x : e.w_ - 1);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                half8 rmask[2], rres0[2], rres1[2];
+                // mask-only (the dense-block backward convs): both pieces' masks are requested before the first store;
+                // with residuals the batch is one piece (register budget)
+                constexpr int JB = (ER || EX) ? 1 : 2;
                 int co[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) co[j] = m * 32 + (2 * j + kh_e) * 8;
+#pragma unroll
+                for (int j0 = 0; j0 < 2; j0 += JB) {
+                half8 rmask[2], rres0[2], rres1[2];
                 if (f_mask) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = j0; j < j0 + JB; ++j)
                         rmask[j] = *reinterpret_cast<const half8*>(e.mask + (p * e.mask_stride + (co[j] < e.cout ? co[j] : 0)) * 2);
                 }
                 if (f_res0) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = j0; j < j0 + JB; ++j)
                         rres0[j] = *reinterpret_cast<const half8*>(e.res0 + (p * e.res0_stride + (co[j] < e.cout ? co[j] : 0)) * 2);
                 }
                 if (f_res1) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = j0; j < j0 + JB; ++j)
                         rres1[j] = *reinterpret_cast<const half8*>(e.res1 + (p * e.res1_stride + (co[j] < e.cout ? co[j] : 0)) * 2);
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = j0; j < j0 + JB; ++j) {
                     float v[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -380,6 +390,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void con
                         if (ok) store8(e.out, p * e.out_stride + co[j]);
                     }
                 }
+                }
             }
         }
         init_acc();
@@ -424,14 +435,18 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
 template <typename T, int MT, int NT, int NWC>
 static int launch_ws(const ConvArgs& a, hipStream_t stream) {
     const bool extras = a.aux || (a.flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_CLAMP01));
-    const bool mask = a.flags & RESR_CONV_MASK, res = a.res0 || a.res1;
-    if (extras) return launch_ws_epi<T, MT, NT, NWC, 7>(a, stream);
-    if (mask) return launch_ws_epi<T, MT, NT, NWC, 3>(a, stream);
-    if (res) return launch_ws_epi<T, MT, NT, NWC, 2>(a, stream);
-    return launch_ws_epi<T, MT, NT, NWC, 0>(a, stream);
+    const int combo = ((a.flags & RESR_CONV_MASK) ? 1 : 0) | (a.res0 ? 2 : 0) | (a.res1 ? 4 : 0);
+    if (!extras) switch (combo) {
+        case 0: return launch_ws_epi<T, MT, NT, NWC, 0>(a, stream);  // forward convs 1-4, upsampling, D forward
+        case 1: return launch_ws_epi<T, MT, NT, NWC, 1>(a, stream);  // backward-data through a LeakyReLU
+        case 2: return launch_ws_epi<T, MT, NT, NWC, 2>(a, stream);  // conv5 of a dense block
+        case 6: return launch_ws_epi<T, MT, NT, NWC, 6>(a, stream);  // conv5 closing an RRDB / its backward
+        case 3: return launch_ws_epi<T, MT, NT, NWC, 3>(a, stream);  // masked backward with gradient accumulation
+        default: break;
+    }
+    return launch_ws_epi<T, MT, NT, NWC, 15>(a, stream);
 }
 
-// f16 entry used by conv3x3_dispatch (conv3x3.hip); mt = cout_pad / 32
 // Preconditions of the producer's 24 x 24-bit offsets and of the 8-channel epilogue; otherwise the caller uses the
 // one-role kernel.
 bool conv3x3_ws_supported(const ConvArgs& a) {
@@ -444,6 +459,7 @@ bool conv3x3_ws_supported(const ConvArgs& a) {
 
 int conv3x3_ws_f16(const ConvArgs& a, int mt, hipStream_t stream) {
     if (mt == 1) return launch_ws<half_t, 1, 4, 8>(a, stream);
+    // cout 64: 3 rows per wave (24-row tiles) measured slower than 2 (123 vs 151 us for 192->64 at B=8, 256^2)
     return launch_ws<half_t, 2, 2, 8>(a, stream);
 }
 
