@@ -42,6 +42,13 @@ CONV_CASES = [
     ("conv4_nchw", 64, 64, 3, "nchw,clamp", 2, 21, 37),
     ("dgrad_mask", 96, 64, 32, "mask,nobias,res0", 1, 17, 64),
     ("big_tiles", 64, 64, 32, "lrelu", 1, 256, 64),
+    # fast-mode persistent kernel: more tiles than resident workgroups (several tiles per workgroup), and the
+    # epilogue kinds it instantiates (mask only / residual 0 only / two-segment input with 5 chunks)
+    ("persist_multi", 64, 64, 32, "lrelu", 4, 320, 256),
+    ("persist_multi64", 64, 64, 64, "lrelu", 2, 272, 256),
+    ("mask_only", 64, 64, 64, "mask,nobias", 1, 40, 72),
+    ("res0_only", 192, 192, 64, "res0", 1, 33, 40),
+    ("two_seg_5chunks", 160, 64, 32, "lrelu", 1, 50, 33),
 ]
 
 
@@ -121,6 +128,18 @@ def test_conv3x3(U, case, dtype_name, diag_dir):
         am = aux.cpu().bool()
         # pass-mask may differ only where the pre-clamp value is within rounding of 0 or 1
         assert (am != ref_mask).float().mean().item() < 1e-3
+
+
+def test_conv3x3_one_role_fallback():
+    """The register-staged f16 kernel (used when the producer/consumer kernel's preconditions fail) stays correct:
+    re-run the f16 conv cases in a subprocess with RESR_CONV_ONE_ROLE=1 (the knob is read once per process)."""
+    import subprocess, sys
+    env = dict(os.environ, RESR_CONV_ONE_ROLE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_conv3x3 and f16 and not fallback and not persist"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 WGRAD_CASES = [
