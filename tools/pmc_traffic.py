@@ -12,6 +12,9 @@ import sys
 
 
 def short(name):
+    m = re.search(r"conv3x3_ws_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)E", name)  # epilogue kinds are summed
+    if m:
+        return f"conv3x3_ws_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'},{m.group(2)},{m.group(3)},{m.group(4)}>"
     m = re.search(r"conv3x3_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)E", name)
     if m:
         return f"conv3x3_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'},{m.group(2)},{m.group(3)},{m.group(4)}>"
