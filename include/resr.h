@@ -66,6 +66,12 @@ typedef struct {
     int32_t dtype;           /* resr_dtype of activations and packed weights                          */
     int32_t flags;
     float s0, t0, s1, t1, slope;
+    /* Chunk strides, in elements: distance between consecutive 32-channel chunks of an operand.  0 means 32, i.e. the
+     * chunks of a pixel are interleaved (plain NHWC).  A chunk-planar tensor [C/32][N,H,W,32] has pixel stride 32 and
+     * chunk stride N*H*W*32: every 64-byte (f16) piece a pass touches is then contiguous with its x-neighbours, so
+     * HBM lines are consumed whole (the generator keeps its dense-block workspaces this way). */
+    int32_t in0_chunk_stride, in1_chunk_stride, out_chunk_stride;
+    int32_t res0_chunk_stride, res1_chunk_stride, mask_chunk_stride;
 } ResrConvDesc;
 
 int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const void* w_packed,

@@ -22,7 +22,9 @@ class ConvDesc(C.Structure):
                 ("cout", C.c_int32), ("cout_pad", C.c_int32), ("out_stride", C.c_int32),
                 ("res0_stride", C.c_int32), ("res1_stride", C.c_int32), ("mask_stride", C.c_int32),
                 ("dtype", C.c_int32), ("flags", C.c_int32),
-                ("s0", C.c_float), ("t0", C.c_float), ("s1", C.c_float), ("t1", C.c_float), ("slope", C.c_float)]
+                ("s0", C.c_float), ("t0", C.c_float), ("s1", C.c_float), ("t1", C.c_float), ("slope", C.c_float),
+                ("in0_chunk_stride", C.c_int32), ("in1_chunk_stride", C.c_int32), ("out_chunk_stride", C.c_int32),
+                ("res0_chunk_stride", C.c_int32), ("res1_chunk_stride", C.c_int32), ("mask_chunk_stride", C.c_int32)]
 
 
 class WgradDesc(C.Structure):

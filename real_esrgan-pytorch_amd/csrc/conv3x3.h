@@ -20,6 +20,8 @@ struct ConvArgs {
     int in0_stride_b, in1_stride_b;  // bytes per pixel
     int cout;
     int out_stride, res0_stride, res1_stride, mask_stride;  // elements
+    size_t in0_chunk_b, in1_chunk_b;                        // bytes between consecutive 32-channel chunks
+    int out_chunk, res0_chunk, res1_chunk, mask_chunk;      // elements between consecutive 32-channel chunks
     int flags;
     float s0, t0, s1, t1, slope;
     int tiles_x, tiles_y;

@@ -77,9 +77,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
     auto stage_load = [&](int ck) {
         const int c0 = ck * 32;
         const bool seg1 = c0 >= a.cin0;
-        const char* base = seg1 ? in1 : in0;
+        const char* base = seg1 ? in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
         const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
-        const unsigned ch_b = (unsigned)(seg1 ? c0 - a.cin0 : c0) * (unsigned)sizeof(T) + (c16 << 4);
+        const unsigned ch_b = c16 << 4;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const unsigned pi = pix[i] >= 0 ? (unsigned)pix[i] : 0u;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int co = m * 32 + g * 8 + kh * 4;
+                const int cq = g * 8 + kh * 4, co = m * 32 + cq;  // cq: channel inside the 32-channel chunk m
                 if (co >= a.cout) continue;
                 float v[4];
 #pragma unroll
@@ -200,10 +200,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
                     for (int r = 0; r < 4; ++r)
                         if (co + r < a.cout) v[r] += a.bias[co + r];
                 }
-                if (f_aux_mask) store4<T>(reinterpret_cast<char*>(a.aux), p * a.out_stride + co, v);
+                if (f_aux_mask) store4<T>(reinterpret_cast<char*>(a.aux), p * a.out_stride + (size_t)m * a.out_chunk + cq, v);
                 if (f_mask) {
                     float mk[4];
-                    load4<T>(a.mask, p * a.mask_stride + co, mk);
+                    load4<T>(a.mask, p * a.mask_stride + (size_t)m * a.mask_chunk + cq, mk);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= (mk[r] > 0.f ? 1.f : a.slope);
                 }
@@ -211,16 +211,16 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
                 }
-                if (f_aux_res) store4<T>(reinterpret_cast<char*>(a.aux), p * a.out_stride + co, v);
+                if (f_aux_res) store4<T>(reinterpret_cast<char*>(a.aux), p * a.out_stride + (size_t)m * a.out_chunk + cq, v);
                 if (a.res0) {
                     float rr[4];
-                    load4<T>(a.res0, p * a.res0_stride + co, rr);
+                    load4<T>(a.res0, p * a.res0_stride + (size_t)m * a.res0_chunk + cq, rr);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = v[r] * a.s0 + a.t0 * rr[r];
                 }
                 if (a.res1) {
                     float rr[4];
-                    load4<T>(a.res1, p * a.res1_stride + co, rr);
+                    load4<T>(a.res1, p * a.res1_stride + (size_t)m * a.res1_chunk + cq, rr);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = v[r] * a.s1 + a.t1 * rr[r];
                 }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], 0.f), 1.f);
                     }
-                    store4<T>(a.out, p * a.out_stride + co, v);
+                    store4<T>(a.out, p * a.out_stride + (size_t)m * a.out_chunk + cq, v);
                 }
             }
         }
@@ -304,6 +304,10 @@ int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, co
     a.in0_stride_b = (int)(d->in0_stride * es); a.in1_stride_b = (int)(d->in1_stride * es);
     a.cout = d->cout; a.out_stride = d->out_stride;
     a.res0_stride = d->res0_stride; a.res1_stride = d->res1_stride; a.mask_stride = d->mask_stride;
+    auto chunk = [](int32_t v) { return v > 0 ? v : 32; };
+    a.in0_chunk_b = (size_t)chunk(d->in0_chunk_stride) * es; a.in1_chunk_b = (size_t)chunk(d->in1_chunk_stride) * es;
+    a.out_chunk = chunk(d->out_chunk_stride); a.res0_chunk = chunk(d->res0_chunk_stride);
+    a.res1_chunk = chunk(d->res1_chunk_stride); a.mask_chunk = chunk(d->mask_chunk_stride);
     a.flags = d->flags; a.s0 = d->s0; a.t0 = d->t0; a.s1 = d->s1; a.t1 = d->t1; a.slope = d->slope;
     const int mt = d->cout_pad / 32;
     // 16-row tiles only when that still yields enough workgroups to fill 256 CUs twice over

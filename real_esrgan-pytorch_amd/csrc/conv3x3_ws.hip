@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void con
             for (int ck = 0; ck < nchunks; ++ck) {
                 const int c0 = ck * 32;
                 const bool seg1 = c0 >= a.cin0;
-                const char* base = (seg1 ? a.in1 : a.in0) + (size_t)(seg1 ? c0 - a.cin0 : c0) * sizeof(T);
+                const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
                 const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
                 const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + par * BUF);
 #pragma unroll
@@ -278,11 +278,13 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void con
             char* out;
             uint8_t* aux;
             int h, w_, cout, out_stride, res0_stride, res1_stride, mask_stride, flags;
+            int out_chunk, res0_chunk, res1_chunk, mask_chunk;
             float s0, t0, s1, t1, slope;
         } e;
         e.res0 = ep->res0; e.res1 = ep->res1; e.mask = ep->mask; e.out = ep->out; e.aux = ep->aux;
         e.h = ep->h; e.w_ = ep->w_; e.cout = ep->cout; e.out_stride = ep->out_stride;
         e.res0_stride = ep->res0_stride; e.res1_stride = ep->res1_stride; e.mask_stride = ep->mask_stride;
+        e.out_chunk = ep->out_chunk; e.res0_chunk = ep->res0_chunk; e.res1_chunk = ep->res1_chunk; e.mask_chunk = ep->mask_chunk;
         e.flags = ep->flags; e.s0 = ep->s0; e.t0 = ep->t0; e.s1 = ep->s1; e.t1 = ep->t1; e.slope = ep->slope;
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
@@ -317,23 +319,25 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void con
                 int co[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) co[j] = m * 32 + (2 * j + kh_e) * 8;
+                // element offset of piece j inside a pixel of an operand with chunk stride cs (clamped when beyond cout)
+                auto poff = [&](int j, int cs) { return co[j] < e.cout ? (size_t)m * cs + (2 * j + kh_e) * 8 : (size_t)0; };
 #pragma unroll
                 for (int j0 = 0; j0 < 2; j0 += JB) {
                 half8 rmask[2], rres0[2], rres1[2];
                 if (f_mask) {
 #pragma unroll
                     for (int j = j0; j < j0 + JB; ++j)
-                        rmask[j] = *reinterpret_cast<const half8*>(e.mask + (p * e.mask_stride + (co[j] < e.cout ? co[j] : 0)) * 2);
+                        rmask[j] = *reinterpret_cast<const half8*>(e.mask + (p * e.mask_stride + poff(j, e.mask_chunk)) * 2);
                 }
                 if (f_res0) {
 #pragma unroll
                     for (int j = j0; j < j0 + JB; ++j)
-                        rres0[j] = *reinterpret_cast<const half8*>(e.res0 + (p * e.res0_stride + (co[j] < e.cout ? co[j] : 0)) * 2);
+                        rres0[j] = *reinterpret_cast<const half8*>(e.res0 + (p * e.res0_stride + poff(j, e.res0_chunk)) * 2);
                 }
                 if (f_res1) {
 #pragma unroll
                     for (int j = j0; j < j0 + JB; ++j)
-                        rres1[j] = *reinterpret_cast<const half8*>(e.res1 + (p * e.res1_stride + (co[j] < e.cout ? co[j] : 0)) * 2);
+                        rres1[j] = *reinterpret_cast<const half8*>(e.res1 + (p * e.res1_stride + poff(j, e.res1_chunk)) * 2);
                 }
 #pragma unroll
                 for (int j = j0; j < j0 + JB; ++j) {
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void con
                         for (int r = 0; r < 8; ++r) h[r] = (half_t)v[r];
                         *reinterpret_cast<half8*>(base + idx * 2) = h;
                     };
-                    if (f_aux_mask && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + co[j]);
+                    if (f_aux_mask && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(j, e.out_chunk));
                     if (f_mask) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] *= ((float)rmask[j][r] > 0.f ? 1.f : e.slope);
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void con
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * e.slope;
                     }
-                    if (f_aux_res && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + co[j]);
+                    if (f_aux_res && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(j, e.out_chunk));
                     if (f_res0) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = v[r] * e.s0 + e.t0 * (float)rres0[j][r];
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void con
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] = fminf(fmaxf(v[r], 0.f), 1.f);
                         }
-                        if (ok) store8(e.out, p * e.out_stride + co[j]);
+                        if (ok) store8(e.out, p * e.out_stride + poff(j, e.out_chunk));
                     }
                 }
                 }

@@ -3,9 +3,11 @@
 //
 // HBM plan (T = f16 fast / f32 strict, all tensors pixel-major / NHWC):
 //   x_in              [N,h,w,CI]      input image, pixel-unshuffled, channels padded to 32/64
-//   ws[r], r=0..3B-1  [N,h,w,192]     one dense-block workspace per RDB: [x | o1 | o2 | o3 | o4];
-//                                     conv_k reads the channel prefix [0, 64+32(k-1)) and writes
-//                                     its 32-channel slice, conv5 writes x of ws[r+1]  -> the four
+//   ws[r], r=0..3B-1  [6][N,h,w,32]   one dense-block workspace per RDB, chunk-planar: planes [x0 x1 | o1 | o2 | o3 | o4]
+//                                     (a 32-channel chunk of a pixel = 64 B f16 = half an HBM line; planar, a pass
+//                                     consumes whole lines -- interleaved [N,h,w,192] fetched every line twice);
+//                                     conv_k reads the plane prefix [0, 2+(k-1)) and writes
+//                                     its 32-channel plane, conv5 writes x of ws[r+1]  -> the four
 //                                     torch.cat copies of model.py:91-94 never exist.
 //                                     Inference keeps 3 rotating workspaces, training keeps all
 //                                     (they are the saved activations: 192 ch/px/RDB, not 640).
@@ -13,6 +15,7 @@
 //   u1 [N,2h,2w,64], u2, c3 [N,4h,4w,64]   model.py:264-267 (nearest x2 folded into the conv's gather)
 //   y                 [N,3,4h,4w] fp32 planar (module surface) + 1 byte/elem clamp pass-mask
 // Backward-data runs the *mirrored* dense block: gradients are laid out [g_y | g_o4 | g_o3 | g_o2 | g_o1]
+// (g_y: [N,h,w,64]; the slab gS = [g_o4 | g_o3 | g_o2 | g_o1] chunk-planar [4][N,h,w,32])
 // so that every pass is again "3x3 conv over a channel prefix -> 32/64-channel slice" with the
 // transposed/flipped weights (pack.hip) -- no read-modify-write accumulation of partial input grads.
 #include <stdlib.h>
@@ -27,6 +30,7 @@ int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*,
 struct WgradConv {
     const void* x0; int cin, in0_stride, cin_real;
     const void* g; int cout, cout_pad, g_stride;
+    long x_chunk_stride, g_chunk_stride;  // elements between 32-channel chunks of X / G (0 = 32: interleaved)
     float* dw; float* db; float scale;
 };
 size_t wgrad_batch_partial_bytes(const WgradConv*, int, int);
@@ -169,7 +173,7 @@ void carve(const Plan& p, char* base, Bufs& b) {
     const int nws = p.d.training ? p.nrdb : 3;
     b.ws.resize(nws);
     for (int i = 0; i < nws; ++i) b.ws[i] = take(px * 192 * es);
-    if (p.d.training) { b.out1 = b.ws[0]; b.out1_stride = 192; }
+    if (p.d.training) { b.out1 = b.ws[0]; b.out1_stride = 32; }  // planes 0,1 of ws[0] (chunk-planar)
     else { b.out1 = take(px * 64 * es); b.out1_stride = 64; }  // rotating workspaces overwrite ws[0]
     b.trunk_out = take(px * 64 * es);
     b.feat = take(px * 64 * es);
@@ -350,16 +354,18 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
     const char* pk = (const char*)packed;
     const int N = d->n, h = p.h, w = p.w;
     const int nws = (int)b.ws.size();
+    const int plane = N * h * w * 32;  // elements per 32-channel plane of the chunk-planar trunk tensors
     auto W = [&](const ConvSpec& c) { return pk + c.pk_fwd * es; };
     auto Bias = [&](const ConvSpec& c) { return params + c.b_off; };
 
     RUN(nchw_to_nhwc_dispatch(x, b.x_in, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, nullptr, st));
     {   // conv1 -> ws[0][0:64]                                           model.py:259
         const ConvSpec& c = p.convs[p.i_conv1];
-        ResrConvDesc cd = conv_desc(p, N, h, w, p.ci_pad, p.ci_pad, p.ci_pad, 0, 64, 64, 192, 0);
+        ResrConvDesc cd = conv_desc(p, N, h, w, p.ci_pad, p.ci_pad, p.ci_pad, 0, 64, 64, 32, 0);
+        cd.out_chunk_stride = plane;
         RUN(conv3x3_dispatch(&cd, b.x_in, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.ws[0], nullptr, st));
         if (b.out1 != b.ws[0]) {  // inference: second copy of out1 (0.01 % of the FLOPs) instead of a pinned workspace
-            cd.out_stride = b.out1_stride;
+            cd.out_stride = b.out1_stride; cd.out_chunk_stride = 0;
             RUN(conv3x3_dispatch(&cd, b.x_in, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.out1, nullptr, st));
         }
     }
@@ -367,19 +373,22 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         char* cur = b.ws[r % nws];
         for (int k = 1; k <= 4; ++k) {  // model.py:90-93
             const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
-            ResrConvDesc cd = conv_desc(p, N, h, w, c.cin, c.cin, 192, 0, 32, 32, 192, RESR_CONV_LRELU);
+            ResrConvDesc cd = conv_desc(p, N, h, w, c.cin, c.cin, 32, 0, 32, 32, 32, RESR_CONV_LRELU);
+            cd.in0_chunk_stride = plane;
             RUN(conv3x3_dispatch(&cd, cur, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr,
-                                 cur + (size_t)(64 + 32 * (k - 1)) * es, nullptr, st));
+                                 cur + (size_t)(2 + (k - 1)) * plane * es, nullptr, st));
         }
         const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + 4];
         const bool last = r == p.nrdb - 1;
         char* dst = last ? b.trunk_out : b.ws[(r + 1) % nws];
-        ResrConvDesc cd = conv_desc(p, N, h, w, 192, 192, 192, 0, 64, 64, last ? 64 : 192, 0);
-        cd.s0 = 0.2f; cd.t0 = 1.f; cd.res0_stride = 192;  // model.py:95-96
+        ResrConvDesc cd = conv_desc(p, N, h, w, 192, 192, 32, 0, 64, 64, last ? 64 : 32, 0);
+        cd.in0_chunk_stride = plane;
+        cd.out_chunk_stride = last ? 0 : plane;
+        cd.s0 = 0.2f; cd.t0 = 1.f; cd.res0_stride = 32; cd.res0_chunk_stride = plane;  // model.py:95-96
         const char* res1 = nullptr;
         if (r % 3 == 2) {  // model.py:129-130
             res1 = b.ws[(r - 2) % nws];
-            cd.s1 = 0.2f; cd.t1 = 1.f; cd.res1_stride = 192;
+            cd.s1 = 0.2f; cd.t1 = 1.f; cd.res1_stride = 32; cd.res1_chunk_stride = plane;
         }
         RUN(conv3x3_dispatch(&cd, cur, nullptr, W(c), Bias(c), cur, res1, nullptr, dst, nullptr, st));
     }
@@ -387,6 +396,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         const ConvSpec& c = p.convs[p.i_conv2];
         ResrConvDesc cd = conv_desc(p, N, h, w, 64, 64, 64, 0, 64, 64, 64, 0);
         cd.res0_stride = b.out1_stride;
+        cd.res0_chunk_stride = b.out1 == b.ws[0] ? plane : 0;
         RUN(conv3x3_dispatch(&cd, b.trunk_out, nullptr, W(c), Bias(c), b.out1, nullptr, nullptr, b.feat, nullptr, st));
     }
     {   // model.py:264
@@ -428,11 +438,13 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     const char* pk = (const char*)packed;
     const int N = d->n, h = p.h, w = p.w;
     const int H4 = 4 * h, W4 = 4 * w, H2 = 2 * h, W2 = 2 * w;
+    const int plane = N * h * w * 32;  // elements per 32-channel plane of the chunk-planar trunk tensors (ws[], gS)
 
     auto wconv = [&](const ConvSpec& c, const void* x0, int cin, int s0, const void* g, int gstride, float scale) {
         WgradConv wc;
         wc.x0 = x0; wc.cin = cin; wc.in0_stride = s0; wc.cin_real = c.cin;
         wc.g = g; wc.cout = c.cout; wc.cout_pad = c.cout_pad; wc.g_stride = gstride;
+        wc.x_chunk_stride = wc.g_chunk_stride = 0;
         wc.dw = grad + c.w_off; wc.db = grad + c.b_off; wc.scale = scale;
         return wc;
     };
@@ -503,24 +515,28 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         const char* act = b.ws[r];
         const float fold = pos == 2 ? 0.04f : 0.2f;
         WgradConv wc[5];
-        wc[4] = wconv(p.convs[p.i_trunk0 + r * 5 + 4], act, 192, 192, gin, 64, fold);   // conv5: G = fold * gin
+        wc[4] = wconv(p.convs[p.i_trunk0 + r * 5 + 4], act, 192, 32, gin, 64, fold);   // conv5: G = fold * gin
+        wc[4].x_chunk_stride = plane;
         for (int ps = 0; ps < 4; ++ps) {   // g_o4, g_o3, g_o2, g_o1
             const int k = 4 - ps;           // conv index whose pre-activation gradient this pass yields
             const int cin = 64 + 32 * ps;
-            ResrConvDesc cd = dgrad(h, w, gin, 64, 64, b.gS, cin, 128, 0, 32, 32, nullptr, 128, RESR_CONV_MASK);
-            cd.mask_stride = 192;
-            char* out = b.gS + (size_t)(32 * ps) * es;
-            const char* mask = act + (size_t)(64 + 32 * (k - 1)) * es;
+            ResrConvDesc cd = dgrad(h, w, gin, 64, 64, b.gS, cin, 32, 0, 32, 32, nullptr, 32, RESR_CONV_MASK);
+            cd.in1_chunk_stride = plane;
+            cd.mask_stride = 32;
+            char* out = b.gS + (size_t)ps * plane * es;
+            const char* mask = act + (size_t)(2 + (k - 1)) * plane * es;
             RUN(conv3x3_dispatch(&cd, gin, b.gS, pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * es, nullptr, nullptr, nullptr,
                                  mask, out, nullptr, st));
             const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
-            wc[k - 1] = wconv(c, act, c.cin, 192, out, 128, 1.f);
+            wc[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f);
+            wc[k - 1].x_chunk_stride = plane;
         }
         RUN(wgrad_run(wc, 5, h, w, 0));   // all five weight gradients of the block in one launch pair
         {   // g_x = convT(all) + (skip terms)
             int nxt = (cur + 1) & 3;
             if (nxt == e_idx && pos != 2) nxt = (nxt + 1) & 3;
-            ResrConvDesc cd = dgrad(h, w, gin, 64, 64, b.gS, 192, 128, 0, 64, 64, nullptr, 64, 0);
+            ResrConvDesc cd = dgrad(h, w, gin, 64, 64, b.gS, 192, 32, 0, 64, 64, nullptr, 64, 0);
+            cd.in1_chunk_stride = plane;
             const char* res0 = gin;
             const char* res1 = nullptr;
             cd.res0_stride = 64; cd.s0 = 1.f;

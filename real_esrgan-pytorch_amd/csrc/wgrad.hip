@@ -313,6 +313,7 @@ static int launch_wgrad(WgradArgs& a, int njobs, hipStream_t stream) {
 struct WgradConv {
     const void* x0; int cin, in0_stride, cin_real;     // X: channel prefix [0,cin) of x0
     const void* g; int cout, cout_pad, g_stride;       // G: channels [0,cout_pad) of g
+    long x_chunk_stride, g_chunk_stride;               // elements between 32-channel chunks of X / G (0 = 32: interleaved)
     float* dw; float* db; float scale;
 };
 
@@ -345,8 +346,8 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
             for (int ck = 0; ck < c.cin / 32; ++ck) {
                 if (nj >= kMaxJobs) return fail(RESR_ERR_ARG, "wgrad: more than %d jobs in one batch", kMaxJobs);
                 WgradJob& j = a.jobs[nj];
-                j.x = (const char*)c.x0 + (size_t)ck * 32 * es;
-                j.g = (const char*)c.g + (size_t)ct * 32 * es;
+                j.x = (const char*)c.x0 + (size_t)ck * (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * es;
+                j.g = (const char*)c.g + (size_t)ct * (c.g_chunk_stride > 0 ? c.g_chunk_stride : 32) * es;
                 j.xstride_b = (unsigned)(c.in0_stride * es);
                 j.gstride_b = (unsigned)(c.g_stride * es);
                 j.slab_off = off;
@@ -382,6 +383,7 @@ int wgrad_dispatch(const ResrWgradDesc* d, const void* x0, const void* x1, const
     WgradConv c;
     c.x0 = x0; c.cin = d->cin; c.in0_stride = d->in0_stride; c.cin_real = d->cin_real;
     c.g = g; c.cout = d->cout; c.cout_pad = d->cout_pad; c.g_stride = d->g_stride;
+    c.x_chunk_stride = c.g_chunk_stride = 0;
     c.dw = dw; c.db = db; c.scale = d->scale;
     return wgrad_batch(&c, 1, d->n, d->h, d->w, d->dtype, d->flags, d->splits, partial, stream);
 }

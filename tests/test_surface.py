@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built):
 
 def test_struct_layouts_match_header(built):
     L = built._lib
-    assert ctypes.sizeof(L.ConvDesc) == 20 * 4
+    assert ctypes.sizeof(L.ConvDesc) == 26 * 4   # 20 original fields + 6 chunk strides
     assert ctypes.sizeof(L.WgradDesc) == 15 * 4
     assert ctypes.sizeof(L.PackChunk) == 64
     assert ctypes.sizeof(L.GeneratorDesc) == 10 * 4
