@@ -11,7 +11,8 @@
 //                                     torch.cat copies of model.py:91-94 never exist.
 //                                     Inference keeps 3 rotating workspaces, training keeps all
 //                                     (they are the saved activations: 192 ch/px/RDB, not 640).
-//   trunk_out, feat   [N,h,w,64]      model.py:260-262
+//   trunk_out         [2][N,h,w,32]   model.py:260 (chunk-planar, like the gT gradient ring of the backward pass)
+//   feat              [N,h,w,64]      model.py:261-262
 //   u1 [N,2h,2w,64], u2, c3 [N,4h,4w,64]   model.py:264-267 (nearest x2 folded into the conv's gather)
 //   y                 [N,3,4h,4w] fp32 planar (module surface) + 1 byte/elem clamp pass-mask
 // Backward-data runs the *mirrored* dense block: gradients are laid out [g_y | g_o4 | g_o3 | g_o2 | g_o1]
@@ -40,6 +41,7 @@ int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int
 int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t);
 int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int, float, hipStream_t);
 int add_inplace_dispatch(void*, const void*, long, int, hipStream_t);
+int add_planar64_dispatch(void*, const void*, long, int, hipStream_t);
 
 namespace {
 
@@ -381,9 +383,9 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + 4];
         const bool last = r == p.nrdb - 1;
         char* dst = last ? b.trunk_out : b.ws[(r + 1) % nws];
-        ResrConvDesc cd = conv_desc(p, N, h, w, 192, 192, 32, 0, 64, 64, last ? 64 : 32, 0);
+        ResrConvDesc cd = conv_desc(p, N, h, w, 192, 192, 32, 0, 64, 64, 32, 0);
         cd.in0_chunk_stride = plane;
-        cd.out_chunk_stride = last ? 0 : plane;
+        cd.out_chunk_stride = plane;
         cd.s0 = 0.2f; cd.t0 = 1.f; cd.res0_stride = 32; cd.res0_chunk_stride = plane;  // model.py:95-96
         const char* res1 = nullptr;
         if (r % 3 == 2) {  // model.py:129-130
@@ -394,7 +396,8 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
     }
     {   // conv2 + skip                                                   model.py:261-262
         const ConvSpec& c = p.convs[p.i_conv2];
-        ResrConvDesc cd = conv_desc(p, N, h, w, 64, 64, 64, 0, 64, 64, 64, 0);
+        ResrConvDesc cd = conv_desc(p, N, h, w, 64, 64, 32, 0, 64, 64, 64, 0);
+        cd.in0_chunk_stride = plane;
         cd.res0_stride = b.out1_stride;
         cd.res0_chunk_stride = b.out1 == b.ws[0] ? plane : 0;
         RUN(conv3x3_dispatch(&cd, b.trunk_out, nullptr, W(c), Bias(c), b.out1, nullptr, nullptr, b.feat, nullptr, st));
@@ -457,8 +460,9 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         return wgrad_batch(wc, nconv, N, hh, ww, d->dtype, flags, splits, b.partial, st);
     };
     auto wgrad = [&](const ConvSpec& c, int hh, int ww, const void* x0, int cin, int s0, const void* g, int gstride,
-                     int flags, float scale) -> int {
-        const WgradConv wc = wconv(c, x0, cin, s0, g, gstride, scale);
+                     int flags, float scale, long x_chunk = 0, long g_chunk = 0) -> int {
+        WgradConv wc = wconv(c, x0, cin, s0, g, gstride, scale);
+        wc.x_chunk_stride = x_chunk; wc.g_chunk_stride = g_chunk;
         return wgrad_run(&wc, 1, hh, ww, flags);
     };
     auto dgrad = [&](int hh, int ww, const void*, int cin0, int s0, const void*, int cin, int s1, size_t, int cout,
@@ -502,8 +506,9 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     int cur = 0;  // index into gT ring of the gradient wrt the current RDB's output chain
     {   // conv2                                                            model.py:261
         const ConvSpec& c = p.convs[p.i_conv2];
-        RUN(wgrad(c, h, w, b.trunk_out, 64, 64, b.gF, 64, 0, 1.f));
-        ResrConvDesc cd = dgrad(h, w, b.gF, 64, 64, nullptr, 64, 0, 0, 64, 64, b.gT[0], 64, 0);
+        RUN(wgrad(c, h, w, b.trunk_out, 64, 32, b.gF, 64, 0, 1.f, plane, 0));
+        ResrConvDesc cd = dgrad(h, w, b.gF, 64, 64, nullptr, 64, 0, 0, 64, 64, b.gT[0], 32, 0);
+        cd.out_chunk_stride = plane;   // the gT ring (gradient wrt the RDB chain) is chunk-planar [2][N,h,w,32]
         RUN(conv3x3_dispatch(&cd, b.gF, nullptr, pk + p.pk_bwd_conv2 * es, nullptr, nullptr, nullptr, nullptr, b.gT[0], nullptr, st));
     }
     // trunk, mirrored dense blocks.  gT ring: e (grad wrt RRDB output) must survive its three RDBs.
@@ -515,13 +520,13 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         const char* act = b.ws[r];
         const float fold = pos == 2 ? 0.04f : 0.2f;
         WgradConv wc[5];
-        wc[4] = wconv(p.convs[p.i_trunk0 + r * 5 + 4], act, 192, 32, gin, 64, fold);   // conv5: G = fold * gin
-        wc[4].x_chunk_stride = plane;
+        wc[4] = wconv(p.convs[p.i_trunk0 + r * 5 + 4], act, 192, 32, gin, 32, fold);   // conv5: G = fold * gin
+        wc[4].x_chunk_stride = plane; wc[4].g_chunk_stride = plane;
         for (int ps = 0; ps < 4; ++ps) {   // g_o4, g_o3, g_o2, g_o1
             const int k = 4 - ps;           // conv index whose pre-activation gradient this pass yields
             const int cin = 64 + 32 * ps;
-            ResrConvDesc cd = dgrad(h, w, gin, 64, 64, b.gS, cin, 32, 0, 32, 32, nullptr, 32, RESR_CONV_MASK);
-            cd.in1_chunk_stride = plane;
+            ResrConvDesc cd = dgrad(h, w, gin, 64, 32, b.gS, cin, 32, 0, 32, 32, nullptr, 32, RESR_CONV_MASK);
+            cd.in0_chunk_stride = plane; cd.in1_chunk_stride = plane;
             cd.mask_stride = 32;
             char* out = b.gS + (size_t)ps * plane * es;
             const char* mask = act + (size_t)(2 + (k - 1)) * plane * es;
@@ -535,13 +540,13 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         {   // g_x = convT(all) + (skip terms)
             int nxt = (cur + 1) & 3;
             if (nxt == e_idx && pos != 2) nxt = (nxt + 1) & 3;
-            ResrConvDesc cd = dgrad(h, w, gin, 64, 64, b.gS, 192, 32, 0, 64, 64, nullptr, 64, 0);
-            cd.in1_chunk_stride = plane;
+            ResrConvDesc cd = dgrad(h, w, gin, 64, 32, b.gS, 192, 32, 0, 64, 64, nullptr, 32, 0);
+            cd.in0_chunk_stride = plane; cd.in1_chunk_stride = plane; cd.out_chunk_stride = plane;
             const char* res0 = gin;
             const char* res1 = nullptr;
-            cd.res0_stride = 64; cd.s0 = 1.f;
+            cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.s0 = 1.f;
             cd.t0 = pos == 2 ? 0.2f : 1.f;       // d(rdb3_out*0.2 + x)/d(rdb3_out) reaches x3 scaled
-            if (pos == 0) { res1 = b.gT[e_idx]; cd.res1_stride = 64; cd.s1 = 1.f; cd.t1 = 1.f; }
+            if (pos == 0) { res1 = b.gT[e_idx]; cd.res1_stride = 32; cd.res1_chunk_stride = plane; cd.s1 = 1.f; cd.t1 = 1.f; }
             RUN(conv3x3_dispatch(&cd, gin, b.gS, pk + p.pk_bwd_trunk[(size_t)r * 5 + 4] * es, nullptr, res0, res1, nullptr,
                                  b.gT[nxt], nullptr, st));
             cur = nxt;
@@ -549,12 +554,13 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     }
     if (debug_stop() == 4) return RESR_OK;
     // gradient wrt out1 = trunk path + skip (model.py:262)
-    RUN(add_inplace_dispatch(b.gT[cur], b.gF, (long)N * h * w * 64, d->dtype, st));
+    RUN(add_planar64_dispatch(b.gT[cur], b.gF, (long)N * h * w, d->dtype, st));
     {   // conv1                                                            model.py:259
         const ConvSpec& c = p.convs[p.i_conv1];
-        RUN(wgrad(c, h, w, b.x_in, p.ci_pad, p.ci_pad, b.gT[cur], 64, 0, 1.f));
+        RUN(wgrad(c, h, w, b.x_in, p.ci_pad, p.ci_pad, b.gT[cur], 32, 0, 1.f, 0, plane));
         if (gx) {
-            ResrConvDesc cd = dgrad(h, w, b.gT[cur], 64, 64, nullptr, 64, 0, 0, p.ci_pad, p.ci_pad, b.gxin, p.ci_pad, 0);
+            ResrConvDesc cd = dgrad(h, w, b.gT[cur], 64, 32, nullptr, 64, 0, 0, p.ci_pad, p.ci_pad, b.gxin, p.ci_pad, 0);
+            cd.in0_chunk_stride = plane;
             RUN(conv3x3_dispatch(&cd, b.gT[cur], nullptr, pk + p.pk_bwd_conv1 * es, nullptr, nullptr, nullptr, nullptr, b.gxin, nullptr, st));
             RUN(nhwc_to_nchw_dispatch(b.gxin, gx, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, st));
         }
