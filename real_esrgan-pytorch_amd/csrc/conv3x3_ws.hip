@@ -79,7 +79,7 @@ __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
 // unconditional when set, absent when clear), bit 3 the rest (aux tensors, NCHW fp32 output, clamp; with bit 3 the
 // other features are run-time flags).  The dispatcher instantiates the combinations the networks use.
 template <typename T, int MT, int NT, int NWC, int EPI>
-__global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), 3) void conv3x3_ws_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCfg<T, MT, NT, NWC>::NP) / 4) void conv3x3_ws_kernel(const ConvArgs a) {
     using C = WsCfg<T, MT, NT, NWC>;
     constexpr int SPP = C::SPP, KS = C::KS, PB = C::PB, TH = C::TH, TW = C::TW, HW = C::HW, BUF = C::BUF;
     constexpr int NI = C::NI, NG = C::NG, NP = C::NP, NIP = C::NIP;
@@ -464,7 +464,9 @@ bool conv3x3_ws_supported(const ConvArgs& a) {
 int conv3x3_ws_f16(const ConvArgs& a, int mt, hipStream_t stream) {
     if (mt == 1) return launch_ws<half_t, 1, 4, 8>(a, stream);
     // cout 64: 3 rows per wave (24-row tiles) measured slower than 2 (123 vs 151 us for 192->64 at B=8, 256^2)
-    return launch_ws<half_t, 2, 2, 8>(a, stream);
+    static const char* v_env = getenv("RESR_CONV_WS_MT2");  // tuning knob: 'a' = 8 consumer waves x 2 rows
+    if (v_env && v_env[0] == 'a') return launch_ws<half_t, 2, 2, 8>(a, stream);
+    return launch_ws<half_t, 2, 4, 4>(a, stream);
 }
 
 }  // namespace resr

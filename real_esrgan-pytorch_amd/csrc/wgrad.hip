@@ -19,6 +19,8 @@
 // walks its share of the pixel tiles; at the end the 4 waves are summed through LDS and one fp32
 // slab [9][32][32] (+32 bias sums) per (job, split) is written.  A second launch reduces the slabs in
 // a fixed order (deterministic) into the OIHW fp32 gradient arena.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace resr {
@@ -40,6 +42,7 @@ struct WgradArgs {
     const char* zero;     // 16 zero bytes in global memory
     int n, h, w_, hs, ws;
     int up, splits, njobs;
+    int fast_addr;        // 1: every operand < 4 GB and < 2^24 pixels -> 32-bit lane offsets + uniform base (see stage())
     int tiles_x, tiles_y, ntiles;
 };
 
@@ -75,6 +78,12 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
 
 __device__ uint4 g_zero16 = {0, 0, 0, 0};
 
+// LDS-DMA with a uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset (asm: the builtin only takes per-lane
+// 64-bit pointers).  Not counted by the compiler: callers wait with s_waitcnt vmcnt(0) before the barrier.
+__device__ __forceinline__ void glds16_s(const char* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 // sum of the 8 f16 of a fragment in fp32: 4 x v_dot2_f32_f16 against (1,1)
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware work map.  Blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, each with its own
     // L2).  All jobs of one pixel split read the same X / G tiles, so they are placed on ONE XCD, adjacent in
     // dispatch order: the k-th block of XCD x takes job k % njobs of split x + 8 * (k / njobs).
@@ -114,7 +123,57 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     // Staging is LDS-DMA (global_load_lds, 16 B per lane): no staging VGPRs, no ds_write pass.  The LDS image is
     // lane-linear (slot s at byte 16*s), which is exactly the pixel-major tile the transpose reads want; lanes
     // whose pixel lies outside the image fetch from a 16-byte zero page instead.
-    auto stage = [&](int tile, int buf) {
+    // Tile-independent part of the lane -> slot map (the staging runs on the MFMA waves: every instruction it saves
+    // is an issue slot for the matrix pipe).  X: hy<<8 | hx | (piece*16)<<16, ~0u = no slot; G: row<<8 | px | (piece*16)<<16.
+    unsigned cx[NSX], cg[NSG];
+#pragma unroll
+    for (int i = 0; i < NSX; ++i) {
+        const unsigned s = i * 256 + tid;
+        const unsigned c16 = s % SPP, hp = s / SPP;
+        const unsigned hy = (hp * 61681u) >> 21;  // hp / 34, exact below 100000
+        cx[i] = s < (unsigned)XSLOT ? (hy << 8 | (hp - hy * HW) | (c16 << 20)) : ~0u;
+    }
+#pragma unroll
+    for (int i = 0; i < NSG; ++i) {
+        const unsigned s = i * 256 + tid;
+        const unsigned c16 = s % SPP, r = s / SPP;
+        cg[i] = (r >> 5) << 8 | (r & 31) | (c16 << 20);
+    }
+    auto stage_fast = [&](int tile, int buf) {
+        const int tx = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty = t2 % a.tiles_y;
+        const int n = t2 / a.tiles_y;
+        const int x0 = tx * 32, y0 = ty * TH;
+        const unsigned xl = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + buf * BUF) + wave * 1024;
+        const unsigned gl = xl + XBUF;
+        const unsigned xn = (unsigned)n * a.hs * a.ws, gn = (unsigned)n * a.h * a.w_;
+#pragma unroll
+        for (int i = 0; i < NSX; ++i) {
+            const unsigned c = cx[i];
+            const int iy = y0 - 1 + (int)((c >> 8) & 0xff), ix = x0 - 1 + (int)(c & 0xff);
+            if (c != ~0u) {
+                if ((unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w_) {
+                    const unsigned pix = xn + (unsigned)(iy >> a.up) * a.ws + (unsigned)(ix >> a.up);
+                    glds16_s(job.x, __umul24(pix, job.xstride_b) + (c >> 16), xl + i * 4096);
+                } else {
+                    glds16_s(a.zero, 0u, xl + i * 4096);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NSG; ++i) {
+            const unsigned c = cg[i];
+            const int iy = y0 + (int)((c >> 8) & 0xff), ix = x0 + (int)(c & 0xff);
+            if (iy < a.h && ix < a.w_) {
+                const unsigned pix = gn + (unsigned)iy * a.w_ + (unsigned)ix;
+                glds16_s(job.g, __umul24(pix, job.gstride_b) + (c >> 16), gl + i * 4096);
+            } else {
+                glds16_s(a.zero, 0u, gl + i * 4096);
+            }
+        }
+    };
+    auto stage_generic = [&](int tile, int buf) {
         const int tx = tile % a.tiles_x;
         const int t2 = tile / a.tiles_x;
         const int ty = t2 % a.tiles_y;
@@ -152,6 +211,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         }
     };
 
+    auto stage = [&](int tile, int buf) {
+        if (a.fast_addr) stage_fast(tile, buf);
+        else stage_generic(tile, buf);
+    };
+
     float16v acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -162,7 +226,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const int kh = lane >> 5;
     int tile = split;
     if (tile < a.ntiles) stage(tile, 0);
-    __syncthreads();                 // drains the LDS-DMA (vmcnt) before the barrier
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the asm LDS-DMA is not counted by the compiler
+    __syncthreads();
     int it = 0;
     for (; tile < a.ntiles; tile += a.splits, ++it) {
         const int next = tile + a.splits;
@@ -222,6 +287,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
                 }
             }
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's asm LDS-DMA has landed
         __syncthreads();
     }
 
@@ -360,6 +426,14 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
             }
     }
     a.partial = partial; r.partial = partial; r.splits = splits;
+    {   // 32-bit lane offsets are enough when every operand stays below 2^24 pixels and 4 GB
+        const size_t px = (size_t)n * h * w;
+        size_t smax = 0;
+        for (int i = 0; i < nj; ++i) smax = smax > a.jobs[i].xstride_b ? smax : a.jobs[i].xstride_b, smax = smax > a.jobs[i].gstride_b ? smax : a.jobs[i].gstride_b;
+        a.fast_addr = (px <= (1u << 24) && smax < (1u << 24) && px * smax + 64 < (1ull << 32)) ? 1 : 0;
+        static const char* env = getenv("RESR_WGRAD_GENERIC_ADDR");  // test knob: force the 64-bit addressing path
+        if (env) a.fast_addr = 0;
+    }
     a.n = n; a.h = h; a.w_ = w; a.hs = up ? h / 2 : h; a.ws = up ? w / 2 : w; a.up = up ? 1 : 0; a.splits = splits;
     int rc;
     if (dtype == RESR_F16) rc = launch_wgrad<half_t, 2>(a, nj, stream);
