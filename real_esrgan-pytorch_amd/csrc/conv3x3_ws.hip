@@ -116,14 +116,33 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         // LDS slot s = i*64 + lane (lane-linear destination) holds piece (s % SPP) ^ swz(hx) of halo pixel s / SPP: the
         // XOR swizzle of the consumers' conflict-free reads is applied on the source side.  Tile-independent part,
         // packed hy<<8 | hx | (piece*16)<<16; ~0u = slot beyond the tile (never read).
-        unsigned cst[NIP];
+        // Each slot of the very first stage is requested as soon as its index math is done (the fill phase is paid by
+        // every launch: the memory latency runs under the rest of the math instead of after it).
+        unsigned cst[NIP], pix[NIP], pixn[NIP];
+        {
+            const int tx = first % a.tiles_x;
+            const int t2 = first / a.tiles_x;
+            const int ty = t2 % a.tiles_y;
+            const int n = t2 / a.tiles_y;
+            const int x0 = tx * TW - 1, y0 = ty * TH - 1;
+            const unsigned nbase = (unsigned)n * a.hs * a.ws;
+            const unsigned dst0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 #pragma unroll
-        for (int i = 0; i < NIP; ++i) {
-            const unsigned s = (i * NP + pw) * 64 + lane;
-            const unsigned hp = s / SPP, cp = s % SPP;
-            const unsigned hy = (hp * 61681u) >> 21;  // hp / 34, exact below 100000
-            const unsigned hx = hp - hy * HW;
-            cst[i] = (i * NP + pw < NI && s < (unsigned)C::NSLOT) ? (hy << 8 | hx | ((cp ^ swz<SPP>((int)hx)) << 20)) : ~0u;
+            for (int i = 0; i < NIP; ++i) {
+                const unsigned s = (i * NP + pw) * 64 + lane;
+                const unsigned hp = s / SPP, cp = s % SPP;
+                const unsigned hy = (hp * 61681u) >> 21;  // hp / 34, exact below 100000
+                const unsigned hx = hp - hy * HW;
+                const unsigned c = (i * NP + pw < NI && s < (unsigned)C::NSLOT) ? (hy << 8 | hx | ((cp ^ swz<SPP>((int)hx)) << 20)) : ~0u;
+                cst[i] = c;
+                const int iy = y0 + (int)hy, ix = x0 + (int)hx;
+                const bool ok = c != ~0u && first < ntiles && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w_;
+                pix[i] = ok ? nbase + (unsigned)(iy >> ups) * a.ws + (unsigned)(ix >> ups) : ~0u;
+                if (first < ntiles) {
+                    if (pix[i] != ~0u) conv_glds16_s(a.in0, __umul24(pix[i], (unsigned)a.in0_stride_b) + (c >> 16), dst0 + (i * NP + pw) * 1024);
+                    else if (c != ~0u) conv_glds16_s(a.zero, 0u, dst0 + (i * NP + pw) * 1024);
+                }
+            }
         }
         // source pixel index per slot (< 2^24, host-checked); ~0u = zero (padding / outside the image)
         auto tile_pix = [&](int tile, unsigned (&pix)[NIP]) {
@@ -141,8 +160,6 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 pix[i] = ok ? nbase + (unsigned)(iy >> ups) * a.ws + (unsigned)(ix >> ups) : ~0u;
             }
         };
-        unsigned pix[NIP], pixn[NIP];
-        if (first < ntiles) tile_pix(first, pix);
         int par = 0;
         for (int tile = first; tile < ntiles; tile += G) {
             stamp(0);
@@ -152,6 +169,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
                 const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
                 const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + par * BUF);
+                if (tile != first || ck != 0)  // the first stage was requested above
 #pragma unroll
                 for (int i = 0; i < NIP; ++i) {
                     // uniform base + 32-bit lane offset (tensor < 4 GB, host-checked); padding lanes copy the zero page
