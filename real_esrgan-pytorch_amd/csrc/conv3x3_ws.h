@@ -1,0 +1,473 @@
+// conv3x3_ws.h -- the fast-mode (f16) 3x3 convolution: persistent workgroups, one producer wave + NWC consumer waves.
+//
+// Same GEMM view and LDS tile layout as conv3x3.hip (reference call sites: model.py:87-98, :123-132, :255-272 and
+// their autograd backward-data passes).  What differs is who moves the data:
+//
+//   producer wave   LDS-DMA (global_load_lds, 16 B per lane) of the (TH+2) x 34 x 32ch halo tile of the next stage
+//                   into the free LDS buffer, then waits for it and meets the consumers at the workgroup barrier.
+//   consumer waves  never touch activations in global memory.  They stream the packed weight fragments (global ->
+//                   registers, a 3-group ring) and feed the MFMAs from the LDS tile.
+//
+// On gfx950 the vector-memory counter retires in order.  In the one-role kernel a wave's weight loads queue behind
+// its own (HBM-latency) halo loads, so every chunk stalled two taps in until its prefetch had landed: memory time
+// and MFMA time added up instead of overlapping.  Splitting the roles gives each wave a counter that only tracks one
+// kind of traffic.  Workgroups are persistent (grid = one residency wave; tiles b, b+G, ...) so the producer runs
+// ahead across tile boundaries and the fill/drain phases are paid once per launch, not once per tile.
+//
+// A stage = (tile, 32-channel chunk).  Barrier protocol, one s_barrier per stage for every wave:
+//   producer:  for s: DMA(s -> buf s&1); wait vmcnt(0); barrier_s
+//   consumer:  for s: barrier_s; multiply(buf s&1)
+// barrier_{s+1} is passed only when all consumers are done with stage s, so DMA(s+2) may overwrite buf s&1.
+//
+// Consumer inner loop: per (k-step, dx) group the NT+2 halo rows are read once from LDS and reused by the three dy
+// taps (row t+dy of the tile is row t of tap dy): (NT+2) LDS reads per 3*NT*MT MFMAs instead of 3*NT.
+#pragma once
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv3x3.h"
+
+namespace resr {
+
+static __device__ uint4 g_conv_zero16 = {0, 0, 0, 0};  // one zero page per translation unit
+
+extern unsigned long long* g_conv_trace;  // debug timeline buffer [32 workgroups][2 roles][64 stamps] (conv3x3_ws.hip)
+
+template <typename T, int MT, int NT, int NWC>
+struct WsCfg {
+    static constexpr int E = 16 / (int)sizeof(T);
+    static constexpr int SPP = 32 / E;              // 16-byte slots per pixel per chunk
+    static constexpr int KS = SPP / 2;              // k-steps per chunk
+    static constexpr int PB = 32 * (int)sizeof(T);  // bytes per pixel per chunk
+    static constexpr int TH = NWC * NT, TW = 32, HH = TH + 2, HW = TW + 2;
+    static constexpr int NSLOT = HH * HW * SPP;
+    static constexpr int NI = (NSLOT + 63) / 64;    // LDS-DMA instructions per stage (1 KB each)
+    static constexpr int BUF = NSLOT * 16;          // one LDS buffer (the last DMA instruction's lanes beyond NSLOT are masked)
+    static constexpr int NG = KS * 3;               // (k-step, dx) weight groups per chunk
+    static constexpr int WTAP = KS * MT * 1024;     // packed weight bytes per (chunk, tap)
+    // 4 consumer + 4 producer waves: a workgroup's waves are dealt to the SIMDs round-robin from SIMD 0, so every SIMD
+    // gets one consumer and one producer; two workgroups per CU then need <= 128 VGPRs (4 waves per SIMD).
+    static constexpr int NP = 4;                    // producer waves (a single wave issues ~1 KB of LDS-DMA per 70 ns)
+    static constexpr int NIP = (NI + NP - 1) / NP;  // LDS-DMA instructions per producer wave per stage
+    static constexpr int NTHR = 64 * (NWC + NP);
+};
+
+__device__ __forceinline__ void conv_glds16(const char* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// LDS-DMA with a uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: no per-lane 64-bit address math.
+// Written as asm because the builtin only takes a per-lane 64-bit pointer; the producer waits with an explicit
+// s_waitcnt vmcnt(0) before the stage barrier (the compiler does not count these loads).
+__device__ __forceinline__ void conv_glds16_s(const char* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(sbase)
+                 : "memory", "m0");
+}
+
+// v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b`.  (asm: the builtin of this toolchain
+// returns its first result twice.)  The nops cover the VALU-write -> permlane-read wait states the compiler would
+// otherwise insert itself.
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
+// EPI: epilogue features of the instantiation -- bit 0 LeakyReLU-mask multiply, bit 1 residual 0, bit 2 residual 1 (each
+// unconditional when set, absent when clear), bit 3 the rest (aux tensors, NCHW fp32 output, clamp; with bit 3 the
+// other features are run-time flags).  The dispatcher instantiates the combinations the networks use.
+template <typename T, int MT, int NT, int NWC, int EPI>
+__global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCfg<T, MT, NT, NWC>::NP) / 4) void conv3x3_ws_kernel(const ConvArgs a) {
+    using C = WsCfg<T, MT, NT, NWC>;
+    constexpr int SPP = C::SPP, KS = C::KS, PB = C::PB, TH = C::TH, TW = C::TW, HW = C::HW, BUF = C::BUF;
+    constexpr int NI = C::NI, NG = C::NG, NP = C::NP, NIP = C::NIP;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = a.tiles_x * a.tiles_y * a.n;
+    const int G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G);
+    const int nchunks = a.cin >> 5;
+    int tk = 0;
+    auto stamp = [&](int role) {
+        // traced workgroups: blockIdx 16k .. 16k+0 for k < 32 (a sample across the whole grid)
+        if (a.trace && (blockIdx.x & 15) == 0 && blockIdx.x < 512 && lane == 0 && tk < 64 && wave <= NWC)
+            a.trace[((blockIdx.x >> 4) * 2 + role) * 64 + tk++] = __builtin_amdgcn_s_memrealtime();
+    };
+
+    if (wave == 0 || wave == NWC) stamp(wave == 0 ? 1 : 0);  // kernel entry
+
+    // The bias lives in LDS for the whole launch: re-read from global memory per tile it would queue behind the
+    // previous tile's stores on the in-order memory counter (measured: ~4 us per tile waiting for store acks).
+    float* bias_lds = reinterpret_cast<float*>(smem + 2 * BUF);
+    if (wave == 0) {
+        const bool f_bias = !(a.flags & RESR_CONV_NO_BIAS) && a.bias != nullptr;
+        bias_lds[lane] = (f_bias && lane < a.cout) ? a.bias[lane] : 0.f;
+    }
+    __syncthreads();
+    if (wave >= NWC) {
+        const int pw = wave - NWC;  // producer index: this wave issues DMA instructions pw, pw + NP, ...
+        // =============================== producer ===============================
+        const int ups = (a.flags & RESR_CONV_UPSAMPLE_IN) ? 1 : 0;
+        // LDS slot s = i*64 + lane (lane-linear destination) holds piece (s % SPP) ^ swz(hx) of halo pixel s / SPP: the
+        // XOR swizzle of the consumers' conflict-free reads is applied on the source side.  Tile-independent part,
+        // packed hy<<8 | hx | (piece*16)<<16; ~0u = slot beyond the tile (never read).
+        // Each slot of the very first stage is requested as soon as its index math is done (the fill phase is paid by
+        // every launch: the memory latency runs under the rest of the math instead of after it).
+        unsigned cst[NIP], pix[NIP], pixn[NIP];
+        {
+            const int tx = first % a.tiles_x;
+            const int t2 = first / a.tiles_x;
+            const int ty = t2 % a.tiles_y;
+            const int n = t2 / a.tiles_y;
+            const int x0 = tx * TW - 1, y0 = ty * TH - 1;
+            const unsigned nbase = (unsigned)n * a.hs * a.ws;
+            const unsigned dst0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+            for (int i = 0; i < NIP; ++i) {
+                const unsigned s = (i * NP + pw) * 64 + lane;
+                const unsigned hp = s / SPP, cp = s % SPP;
+                const unsigned hy = (hp * 61681u) >> 21;  // hp / 34, exact below 100000
+                const unsigned hx = hp - hy * HW;
+                const unsigned c = (i * NP + pw < NI && s < (unsigned)C::NSLOT) ? (hy << 8 | hx | ((cp ^ swz<SPP>((int)hx)) << 20)) : ~0u;
+                cst[i] = c;
+                const int iy = y0 + (int)hy, ix = x0 + (int)hx;
+                const bool ok = c != ~0u && first < ntiles && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w_;
+                pix[i] = ok ? nbase + (unsigned)(iy >> ups) * a.ws + (unsigned)(ix >> ups) : ~0u;
+                if (first < ntiles) {
+                    if (pix[i] != ~0u) conv_glds16_s(a.in0, __umul24(pix[i], (unsigned)a.in0_stride_b) + (c >> 16), dst0 + (i * NP + pw) * 1024);
+                    else if (c != ~0u) conv_glds16_s(a.zero, 0u, dst0 + (i * NP + pw) * 1024);
+                }
+            }
+        }
+        // source pixel index per slot (< 2^24, host-checked); ~0u = zero (padding / outside the image)
+        auto tile_pix = [&](int tile, unsigned (&pix)[NIP]) {
+            const int tx = tile % a.tiles_x;
+            const int t2 = tile / a.tiles_x;
+            const int ty = t2 % a.tiles_y;
+            const int n = t2 / a.tiles_y;
+            const int x0 = tx * TW - 1, y0 = ty * TH - 1;
+            const unsigned nbase = (unsigned)n * a.hs * a.ws;
+#pragma unroll
+            for (int i = 0; i < NIP; ++i) {
+                const unsigned c = cst[i];
+                const int iy = y0 + (int)((c >> 8) & 0xff), ix = x0 + (int)(c & 0xff);
+                const bool ok = c != ~0u && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w_;
+                pix[i] = ok ? nbase + (unsigned)(iy >> ups) * a.ws + (unsigned)(ix >> ups) : ~0u;
+            }
+        };
+        int par = 0;
+        for (int tile = first; tile < ntiles; tile += G) {
+            stamp(0);
+            for (int ck = 0; ck < nchunks; ++ck) {
+                const int c0 = ck * 32;
+                const bool seg1 = c0 >= a.cin0;
+                const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
+                const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
+                const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + par * BUF);
+                if (tile != first || ck != 0)  // the first stage was requested above
+#pragma unroll
+                for (int i = 0; i < NIP; ++i) {
+                    // uniform base + 32-bit lane offset (tensor < 4 GB, host-checked); padding lanes copy the zero page
+                    const unsigned ldst = dst + (i * NP + pw) * 1024;
+                    if (pix[i] != ~0u) {
+                        conv_glds16_s(base, __umul24(pix[i], stride_b) + (cst[i] >> 16), ldst);
+                    } else if (cst[i] != ~0u) {
+                        conv_glds16_s(a.zero, 0u, ldst);
+                    }
+                }
+                par ^= 1;
+                stamp(0);
+                // the next tile's index math runs while this tile's last chunk is in flight
+                if (ck == nchunks - 1 && tile + G < ntiles) tile_pix(tile + G, pixn);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                stamp(0);
+                __syncthreads();  // (vmcnt already 0: the DMA is asm) the stage barrier
+                stamp(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NIP; ++i) pix[i] = pixn[i];
+        }
+        return;
+    }
+
+    // =============================== consumers ===============================
+    const int lx = lane & 31, kh = lane >> 5;
+    const int row0 = wave * NT;
+    const unsigned lane16 = (unsigned)lane << 4;
+    // per-lane LDS byte offsets of the B fragment for (dx, k-step); rows add compile-time immediates
+    int boff[3][KS];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            boff[dx][ks] = row0 * (HW * PB) + (lx + dx) * PB + (((ks * 2 + kh) ^ swz<SPP>(lx + dx)) << 4);
+
+    // Accumulators start from the bias: register g*4+r of tile m holds cout m*32 + g*8 + kh*4 + r.
+    float16v acc[MT][NT];
+    auto init_acc = [&]() {
+        int kh_l = lane >> 5;
+        asm volatile("" : "+v"(kh_l));  // opaque: keeps the 16*MT bias values out of registers across the tile loop
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4v b = *reinterpret_cast<const float4v*>(bias_lds + m * 32 + g * 8 + kh_l * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[m][t][g * 4 + r] = b[r];
+            }
+    };
+    init_acc();
+
+    // Weight fragments: ring of (k-step, dx, dy) units -- one tap's MT fragments each -- in consumption order, fetched
+    // RING-1 units ahead.  NU is a multiple of RING, so the slot of a unit is static across chunks and tiles.
+    constexpr int NU = 9 * KS;
+    constexpr int RING = MT == 1 ? 6 : 3;
+    static_assert(NU % RING == 0, "ring slots must be static");
+    uint4 wr[RING][MT];
+    auto wload = [&](int slot, int ck, int u) {
+        const int ks = u / 9, dx = (u / 3) % 3, dy = u % 3;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            wr[slot][m] = *reinterpret_cast<const uint4*>(
+                a.w + ((size_t)((ck * 9 + dy * 3 + dx) * KS + ks) * MT + m) * 1024 + lane16);
+    };
+#pragma unroll
+    for (int u = 0; u < RING - 1; ++u) wload(u, 0, u);
+
+    int par = 0;
+    for (int tile = first; tile < ntiles; tile += G) {
+        for (int ck = 0; ck < nchunks; ++ck) {
+            // consumers only read LDS: a bare barrier (no vmcnt drain of the weight ring) is enough
+            if (wave == 0) stamp(1);
+            asm volatile("s_barrier" ::: "memory");
+            if (wave == 0) stamp(1);
+            const int nck = ck + 1 < nchunks ? ck + 1 : 0;  // next stage's chunk (first chunk of the next tile)
+            const char* lbuf = smem + par * BUF;
+            // halo rows of group gi+1 are read from LDS while the MFMAs of group gi run (ping-pong registers; NG is even)
+            // when the register budget allows (PP); otherwise each group reads its own rows first
+            constexpr int PP = (MT * NT * 16 + (NT + 2) * 8 <= 112) ? 1 : 0;
+            uint4 rowf[PP + 1][NT + 2];
+            auto rload = [&](int slot, int gi) {
+                const char* bp = lbuf + boff[gi % 3][gi / 3];
+#pragma unroll
+                for (int r = 0; r < NT + 2; ++r) rowf[slot][r] = *reinterpret_cast<const uint4*>(bp + r * (HW * PB));
+            };
+            if (PP) rload(0, 0);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (!PP) rload(0, gi);
+                else if (gi + 1 < NG) rload((gi + 1) & 1, gi + 1);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int u = gi * 3 + dy;
+                    wload((u + RING - 1) % RING, u + RING - 1 < NU ? ck : nck, (u + RING - 1) % NU);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[m][t] = Frag<T>::mma(wr[u % RING][m], rowf[PP ? (gi & 1) : 0][t + dy], acc[m][t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            par ^= 1;
+            if (wave == 0) stamp(1);
+        }
+
+        // ---- epilogue: lane owns pixel (row0+t, lx) and 4 consecutive couts per accumulator quad ----
+        const int x0 = (tile % a.tiles_x) * TW;
+        const int y0 = ((tile / a.tiles_x) % a.tiles_y) * TH;
+        const int n = tile / (a.tiles_x * a.tiles_y);
+        // The epilogue's arguments and per-lane indices are re-read / re-derived per tile through opaque copies:
+        // hoisted out of the tile loop they would sit in registers across the MFMA loop.
+        typedef const ConvArgs __attribute__((address_space(4))) * KernargPtr;
+        KernargPtr ep = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ep));
+        // one batch of scalar loads (one wait) instead of a reload at every use
+        struct {
+            const char *res0, *res1, *mask;
+            char* out;
+            uint8_t* aux;
+            int h, w_, cout, out_stride, res0_stride, res1_stride, mask_stride, flags;
+            int out_chunk, res0_chunk, res1_chunk, mask_chunk;
+            float s0, t0, s1, t1, slope;
+        } e;
+        e.res0 = ep->res0; e.res1 = ep->res1; e.mask = ep->mask; e.out = ep->out; e.aux = ep->aux;
+        e.h = ep->h; e.w_ = ep->w_; e.cout = ep->cout; e.out_stride = ep->out_stride;
+        e.res0_stride = ep->res0_stride; e.res1_stride = ep->res1_stride; e.mask_stride = ep->mask_stride;
+        e.out_chunk = ep->out_chunk; e.res0_chunk = ep->res0_chunk; e.res1_chunk = ep->res1_chunk; e.mask_chunk = ep->mask_chunk;
+        e.flags = ep->flags; e.s0 = ep->s0; e.t0 = ep->t0; e.s1 = ep->s1; e.t1 = ep->t1; e.slope = ep->slope;
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int lx_e = lane_e & 31, kh_e = lane_e >> 5;
+        constexpr bool EX = (EPI & 8) != 0, EM = (EPI & 1) != 0, ER = (EPI & 6) != 0;
+        const bool f_lrelu = e.flags & RESR_CONV_LRELU, f_clamp = EX && (e.flags & RESR_CONV_CLAMP01);
+        const bool f_nchw = EX && (e.flags & RESR_CONV_OUT_NCHW_F32);
+        const bool f_mask = EX ? (e.flags & RESR_CONV_MASK) != 0 : EM;
+        const bool f_aux_mask = EX && (e.flags & RESR_CONV_AUX_BEFORE_MASK) && e.aux && !f_nchw;
+        const bool f_aux_res = EX && (e.flags & RESR_CONV_AUX_BEFORE_RES) && e.aux && !f_nchw;
+        const bool f_res0 = EX ? e.res0 != nullptr : (EPI & 2) != 0, f_res1 = EX ? e.res1 != nullptr : (EPI & 4) != 0;
+        const int x = x0 + lx_e;
+        // MFMA results -> first non-MFMA reader: the swaps below are asm, so the compiler cannot count this hazard
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");
+        // MFMA leaves lane (lx, kh) with couts g*8 + kh*4 + 0..3 of each quad g.  v_permlane32_swap between lanes lx and
+        // lx+32 regroups a pair of quads (2j, 2j+1) into 8 consecutive couts per lane -- (2j + kh)*8 + 0..7 -- so masks,
+        // residuals and the result move as 16-byte pieces (half the L2 write transactions of 8-byte pieces).
+        // Per (row, cout tile): every epilogue input is requested before the first store, so the batch pays one
+        // memory latency instead of one per piece (loads behind stores wait for the stores).
+        static_assert(sizeof(T) == 2, "the 8-channel epilogue assumes f16 storage");
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int y = y0 + row0 + t;
+            const bool in_img = y < e.h && x < e.w_;
+            // pieces outside the image / beyond cout read a clamped (valid) address and are dropped at the store
+            const size_t p = ((size_t)n * e.h + (y < e.h ? y : e.h - 1)) * e.w_ + (x < e.w_ ? x : e.w_ - 1);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                // mask-only (the dense-block backward convs): both pieces' masks are requested before the first store;
+                // with residuals the batch is one piece (register budget)
+                constexpr int JB = (ER || EX) ? 1 : 2;
+                int co[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) co[j] = m * 32 + (2 * j + kh_e) * 8;
+                // element offset of piece j inside a pixel of an operand with chunk stride cs (clamped when beyond cout)
+                auto poff = [&](int j, int cs) { return co[j] < e.cout ? (size_t)m * cs + (2 * j + kh_e) * 8 : (size_t)0; };
+#pragma unroll
+                for (int j0 = 0; j0 < 2; j0 += JB) {
+                half8 rmask[2], rres0[2], rres1[2];
+                if (f_mask) {
+#pragma unroll
+                    for (int j = j0; j < j0 + JB; ++j)
+                        rmask[j] = *reinterpret_cast<const half8*>(e.mask + (p * e.mask_stride + poff(j, e.mask_chunk)) * 2);
+                }
+                if (f_res0) {
+#pragma unroll
+                    for (int j = j0; j < j0 + JB; ++j)
+                        rres0[j] = *reinterpret_cast<const half8*>(e.res0 + (p * e.res0_stride + poff(j, e.res0_chunk)) * 2);
+                }
+                if (f_res1) {
+#pragma unroll
+                    for (int j = j0; j < j0 + JB; ++j)
+                        rres1[j] = *reinterpret_cast<const half8*>(e.res1 + (p * e.res1_stride + poff(j, e.res1_chunk)) * 2);
+                }
+#pragma unroll
+                for (int j = j0; j < j0 + JB; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[m][t][(2 * j) * 4 + r];
+                        v[4 + r] = acc[m][t][(2 * j + 1) * 4 + r];
+                        permlane32_swap(v[r], v[4 + r]);
+                    }
+                    const bool ok = in_img && co[j] < e.cout;
+                    auto store8 = [&](char* base, size_t idx) {
+                        half8 h;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) h[r] = (half_t)v[r];
+                        *reinterpret_cast<half8*>(base + idx * 2) = h;
+                    };
+                    if (f_aux_mask && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(j, e.out_chunk));
+                    if (f_mask) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] *= ((float)rmask[j][r] > 0.f ? 1.f : e.slope);
+                    }
+                    if (f_lrelu) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * e.slope;
+                    }
+                    if (f_aux_res && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(j, e.out_chunk));
+                    if (f_res0) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = v[r] * e.s0 + e.t0 * (float)rres0[j][r];
+                    }
+                    if (f_res1) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = v[r] * e.s1 + e.t1 * (float)rres1[j][r];
+                    }
+                    if (f_nchw) {
+                        float* o = reinterpret_cast<float*>(e.out);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            if (!in_img || co[j] + r >= e.cout) continue;
+                            const size_t q = (((size_t)n * e.cout + co[j] + r) * e.h + y) * e.w_ + x;
+                            float u = v[r];
+                            if (f_clamp) {
+                                if (e.aux) e.aux[q] = (u >= 0.f && u <= 1.f) ? 1 : 0;
+                                u = fminf(fmaxf(u, 0.f), 1.f);
+                            }
+                            o[q] = u;
+                        }
+                    } else {
+                        if (f_clamp) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] = fminf(fmaxf(v[r], 0.f), 1.f);
+                        }
+                        if (ok) store8(e.out, p * e.out_stride + poff(j, e.out_chunk));
+                    }
+                }
+                }
+            }
+        }
+        init_acc();
+        if (wave == 0) stamp(1);  // tile done
+    }
+}
+
+template <typename T, int MT, int NT, int NWC, int EPI>
+static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
+    using C = WsCfg<T, MT, NT, NWC>;
+    ConvArgs args = a;
+    args.tiles_x = (a.w_ + 31) / 32;
+    args.tiles_y = (a.h + C::TH - 1) / C::TH;
+    const size_t lds = 2 * C::BUF + 64 * sizeof(float);  // two halo buffers + the bias
+    static int resident = 0;            // workgroups the device holds at once, per instantiation; benign race
+    static const char* zero = nullptr;
+    if (!resident) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_kernel<T, MT, NT, NWC, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        void* zp = nullptr;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_ws_kernel<T, MT, NT, NWC, EPI>, C::NTHR, lds) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu <= 0 ||
+            hipGetSymbolAddress(&zp, HIP_SYMBOL(g_conv_zero16)) != hipSuccess || !zp)
+            return fail(RESR_ERR_LAUNCH, "conv3x3: occupancy / zero-page query failed");
+        zero = (const char*)zp;
+        resident = per_cu * prop.multiProcessorCount;
+        if (getenv("RESR_DEBUG_OCC")) fprintf(stderr, "conv3x3_ws<%d,%d,%d,%d,%d>: %d workgroups/CU, lds %zu\n", (int)sizeof(T), MT, NT, NWC, EPI, per_cu, lds);
+    }
+    args.zero = zero;
+    args.trace = g_conv_trace;
+    const int ntiles = args.tiles_x * args.tiles_y * a.n;
+    const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
+    prof_before(stream);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<T, MT, NT, NWC, EPI>), dim3(grid), dim3(C::NTHR), lds, stream, args);
+    prof_after(stream, 20000 + MT * 100 + NT * 10 + NWC, 2.0 * 9 * a.cin * a.cout * (double)a.n * a.h * a.w_);
+    RESR_CHECK_LAUNCH("conv3x3_ws_kernel");
+    return RESR_OK;
+}
+
+template <typename T, int MT, int NT, int NWC>
+static int launch_ws(const ConvArgs& a, hipStream_t stream) {
+    const bool extras = a.aux || (a.flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_CLAMP01));
+    const int combo = ((a.flags & RESR_CONV_MASK) ? 1 : 0) | (a.res0 ? 2 : 0) | (a.res1 ? 4 : 0);
+    if (!extras) switch (combo) {
+        case 0: return launch_ws_epi<T, MT, NT, NWC, 0>(a, stream);  // forward convs 1-4, upsampling, D forward
+        case 1: return launch_ws_epi<T, MT, NT, NWC, 1>(a, stream);  // backward-data through a LeakyReLU
+        case 2: return launch_ws_epi<T, MT, NT, NWC, 2>(a, stream);  // conv5 of a dense block
+        case 6: return launch_ws_epi<T, MT, NT, NWC, 6>(a, stream);  // conv5 closing an RRDB / its backward
+        case 3: return launch_ws_epi<T, MT, NT, NWC, 3>(a, stream);  // masked backward with gradient accumulation
+        default: break;
+    }
+    return launch_ws_epi<T, MT, NT, NWC, 15>(a, stream);
+}
+
+
+}  // namespace resr
