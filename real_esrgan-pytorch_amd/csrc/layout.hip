@@ -15,17 +15,25 @@ template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
                                                            int n, int c, int h, int w, int r, int c_pad,
                                                            const uint8_t* __restrict__ mask) {
-    // output pixel grid is (h/r) x (w/r); output channel = ch*r*r + i*r + j  (torch pixel_unshuffle)
+    // output pixel grid is (h/r) x (w/r); output channel = ch*r*r + i*r + j  (torch pixel_unshuffle).
+    // One thread per 16-byte piece of an output pixel: consecutive threads write consecutive 16 bytes.
+    constexpr int E = 16 / (int)sizeof(T);
     const int ho = h / r, wo = w / r;
-    const long total = (long)n * ho * wo;
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= total) return;
+    const int pieces = c_pad / E;
+    const long total = (long)n * ho * wo * pieces;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long p = t / pieces;
+    const int piece = (int)(t - p * pieces);
     const int xo = (int)(p % wo);
     const int yo = (int)((p / wo) % ho);
     const int b = (int)(p / ((long)wo * ho));
-    T* o = dst + p * c_pad;
     const int creal = c * r * r;
-    for (int co = 0; co < c_pad; ++co) {
+    uint4 out;
+    T* o = reinterpret_cast<T*>(&out);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int co = piece * E + e;
         float v = 0.f;
         if (co < creal) {
             const int ch = co / (r * r), ij = co % (r * r), i = ij / r, j = ij % r;
@@ -33,8 +41,9 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
             v = src[q];
             if (mask) v = mask[q] ? v : 0.f;
         }
-        o[co] = (T)v;
+        o[e] = (T)v;
     }
+    *reinterpret_cast<uint4*>(dst + p * c_pad + piece * E) = out;
 }
 
 template <typename T>
@@ -132,9 +141,9 @@ static unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256);
 
 int nchw_to_nhwc_dispatch(const float* src, void* dst, int n, int c, int h, int w, int r, int c_pad, int dtype,
                           const uint8_t* mask, hipStream_t stream) {
-    if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || r <= 0 || (h % r) || (w % r) || c * r * r > c_pad)
+    if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || r <= 0 || (h % r) || (w % r) || c * r * r > c_pad || (c_pad & 7))
         return fail(RESR_ERR_ARG, "nchw_to_nhwc: bad argument (c=%d r=%d c_pad=%d h=%d w=%d)", c, r, c_pad, h, w);
-    const long total = (long)n * (h / r) * (w / r);
+    const long total = (long)n * (h / r) * (w / r) * (c_pad / (dtype == RESR_F16 ? 8 : 4));
     if (dtype == RESR_F16)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, src, (half_t*)dst, n, c, h, w, r, c_pad, mask);
     else
