@@ -19,7 +19,8 @@ from . import _lib
 
 __all__ = ["random_add_gaussian_noise_torch", "random_add_poisson_noise_torch", "random_mixed_kernels",
            "generate_sinc_kernel", "image_to_tensor", "tensor_to_image", "random_crop", "filter2d_torch",
-           "interpolate", "DiffJPEG", "USMSharp"]
+           "interpolate", "DiffJPEG", "USMSharp", "image_resize", "center_crop", "random_rotate",
+           "random_horizontally_flip", "random_vertically_flip", "rgb2ycbcr_torch", "read_image_rgb"]
 
 _MODES = {"area": 0, "bilinear": 1, "bicubic": 2}
 _seed_counter = [0x5EED]
@@ -322,3 +323,127 @@ def generate_sinc_kernel(cutoff: float, kernel_size: int, padding: int = 0) -> n
         p = (padding - kernel_size) // 2
         k = np.pad(k, ((p, p), (p, p)))
     return k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Host side of the data path: file-side augmentation and the MATLAB-style resize used for the
+# validation LR images.  CPU / numpy like the reference's DataLoader workers; no cv2.
+# ---------------------------------------------------------------------------------------------------------------
+def _cubic_kernel(x: np.ndarray) -> np.ndarray:
+    """Keys cubic, a = -0.5 (reference imgproc.py:52-69)."""
+    ax = np.abs(x)
+    ax2, ax3 = ax * ax, ax * ax * ax
+    return ((1.5 * ax3 - 2.5 * ax2 + 1) * (ax <= 1) + (-0.5 * ax3 + 2.5 * ax2 - 4 * ax + 2) * ((ax > 1) & (ax <= 2))).astype(np.float32)
+
+
+def _resize_matrix(in_length: int, out_length: int, scale: float, antialiasing: bool) -> np.ndarray:
+    """[out_length, in_length] float32 matrix of the 1-D MATLAB `imresize` bicubic pass, symmetric edge replication
+    folded in (reference imgproc.py:93-167 builds the same weights/indices and applies them row by row)."""
+    kernel_width = 4.0
+    aa = scale < 1 and antialiasing
+    if aa:
+        kernel_width = kernel_width / scale
+    x = np.linspace(1, out_length, out_length, dtype=np.float32)
+    u = (x / np.float32(scale) + np.float32(0.5 * (1 - 1 / scale))).astype(np.float32)
+    left = np.floor(u - np.float32(kernel_width / 2))
+    p = math.ceil(kernel_width) + 2
+    idx = left[:, None] + np.arange(p, dtype=np.float32)[None, :]           # 1-based input positions
+    dist = (u[:, None] - idx).astype(np.float32)
+    w = np.float32(scale) * _cubic_kernel(dist * np.float32(scale)) if aa else _cubic_kernel(dist)
+    w = (w / w.sum(1, keepdims=True)).astype(np.float32)
+    idx = idx.astype(np.int64)
+    idx = np.where(idx < 1, 1 - idx, idx)                                     # symmetric: 0 -> 1, -1 -> 2, ...
+    idx = np.where(idx > in_length, 2 * in_length + 1 - idx, idx)             # n+1 -> n, n+2 -> n-1, ...
+    m = np.zeros((out_length, in_length), dtype=np.float32)
+    np.add.at(m, (np.repeat(np.arange(out_length), p), (idx - 1).reshape(-1)), w.reshape(-1))
+    return m
+
+
+def image_resize(image: Any, scale_factor: float, antialiasing: bool = True) -> Any:
+    """MATLAB `imresize` (bicubic, optional antialiasing) -- reference imgproc.py:1599-1687.  numpy HWC / HW or
+    torch CHW / HW in, same kind out, float32, not rounded, output size ceil(in * scale)."""
+    is_np = isinstance(image, np.ndarray)
+    t = torch.from_numpy(np.ascontiguousarray(image)).float() if is_np else image.float()
+    squeeze = t.ndim == 2
+    if squeeze:
+        t = t.unsqueeze(-1) if is_np else t.unsqueeze(0)
+    if is_np:
+        t = t.permute(2, 0, 1)
+    _, in_h, in_w = t.shape
+    out_h, out_w = math.ceil(in_h * scale_factor), math.ceil(in_w * scale_factor)
+    mh = torch.from_numpy(_resize_matrix(in_h, out_h, scale_factor, antialiasing)).to(t.device)
+    mw = torch.from_numpy(_resize_matrix(in_w, out_w, scale_factor, antialiasing)).to(t.device)
+    out = torch.matmul(torch.matmul(mh, t), mw.t())                           # H pass, then W pass
+    if is_np:
+        out = out.permute(1, 2, 0)
+        out = out.squeeze(-1) if squeeze else out
+        return out.numpy()
+    return out.squeeze(0) if squeeze else out
+
+
+def center_crop(image: np.ndarray, image_size: int) -> np.ndarray:
+    """Reference imgproc.py:1871-1891."""
+    h, w = image.shape[:2]
+    top, left = (h - image_size) // 2, (w - image_size) // 2
+    return image[top:top + image_size, left:left + image_size, ...]
+
+
+def _rotate_right_angle(image: np.ndarray, angle: int) -> np.ndarray:
+    """What `cv2.warpAffine(image, cv2.getRotationMatrix2D((w//2, h//2), angle, 1), (w, h))` yields for the four
+    right angles (reference imgproc.py:1937-1963): an exact pixel permutation about the *integer* centre
+    (cx, cy) = (w//2, h//2), output size unchanged, pixels that fall outside are 0.  With an even side the centre is
+    half a pixel off, so a 90/180/270 rotation loses one row/column and gains a black one.  (cv2 is absent from the
+    image: pinned to the affine formula, unpinned vs OpenCV.)"""
+    angle %= 360
+    if angle == 0:
+        return image
+    h, w = image.shape[:2]
+    cx, cy = w // 2, h // 2
+    ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")           # destination coordinates
+    if angle == 90:       # dst = [[0, 1, cx - cy], [-1, 0, cx + cy]] . src
+        sx, sy = cx + cy - ys, xs - cx + cy
+    elif angle == 180:
+        sx, sy = 2 * cx - xs, 2 * cy - ys
+    else:                 # 270
+        sx, sy = ys - cy + cx, cx + cy - xs
+    ok = (sx >= 0) & (sx < w) & (sy >= 0) & (sy < h)
+    out = np.zeros_like(image)
+    out[ys[ok], xs[ok]] = image[sy[ok], sx[ok]]
+    return out
+
+
+def random_rotate(image: np.ndarray, angles: list, center: tuple = None, scale_factor: float = 1.0) -> np.ndarray:
+    """Reference imgproc.py:1937-1963 for right angles about the default centre (the only use, dataset.py:70)."""
+    angle = random.choice(angles)
+    if center is not None or scale_factor != 1.0 or angle % 90:
+        raise NotImplementedError("random_rotate: only right angles about the default centre (dataset.py:70)")
+    return _rotate_right_angle(image, int(angle))
+
+
+def random_horizontally_flip(image: np.ndarray, p: float) -> np.ndarray:
+    """Reference imgproc.py:1966-1982 (`cv2.flip(image, 1)`)."""
+    return image[:, ::-1].copy() if random.random() < p else image
+
+
+def random_vertically_flip(image: np.ndarray, p: float) -> np.ndarray:
+    """Reference imgproc.py:1985-2001 (`cv2.flip(image, 0)`)."""
+    return image[::-1].copy() if random.random() < p else image
+
+
+def rgb2ycbcr_torch(tensor: torch.Tensor, only_use_y_channel: bool) -> torch.Tensor:
+    """ITU-R BT.601 as MATLAB `rgb2ycbcr`, [N,3,H,W] in [0,1] (reference imgproc.py:1815-1840)."""
+    if only_use_y_channel:
+        w = torch.tensor([65.481, 128.553, 24.966], dtype=tensor.dtype, device=tensor.device).view(1, 3, 1, 1)
+        return ((tensor * w).sum(1, keepdim=True) + 16.0) / 255.0
+    m = torch.tensor([[65.481, -37.797, 112.0], [128.553, -74.203, -93.786], [24.966, 112.0, -18.214]],
+                     dtype=tensor.dtype, device=tensor.device)
+    b = torch.tensor([16.0, 128.0, 128.0], dtype=tensor.dtype, device=tensor.device).view(1, 3, 1, 1)
+    return (torch.einsum("nchw,cd->ndhw", tensor, m) + b) / 255.0
+
+
+def read_image_rgb(path: str) -> np.ndarray:
+    """File -> HWC float32 RGB in [0,1] (the reference reads BGR with cv2 and converts after the augmentation,
+    dataset.py:66-75; the augmentations are channel-agnostic, so reading RGB directly is equivalent)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"), dtype=np.float32) / 255.0

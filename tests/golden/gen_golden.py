@@ -152,7 +152,7 @@ def gen_ema(ref):
     save("ema", **arrs)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "imgproc"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("imgproc", "dataset", "niqe")):
     ref = ref_shim.load("model")
     gen_init(ref)
     gen_blocks(ref)
@@ -250,5 +250,42 @@ def gen_imgproc():
     save("imgproc_kernels", **arrs)
 
 
+def gen_dataset():
+    """Host data path (reference dataset.py:64-160, imgproc.py:1599-1687, 1871-2001): full `__getitem__` outputs of the
+    reference for a committed PNG under fixed seeds, plus `image_resize` cases."""
+    import random
+    from PIL import Image
+    rimg = ref_shim.load("imgproc")
+    rds = ref_shim.load("dataset")
+    rcfg = ref_shim.load("config")
+    rng = np.random.default_rng(7)
+    d = os.path.join(HERE, "dataset_images")
+    os.makedirs(d, exist_ok=True)
+    png = os.path.join(d, "sample_38x30.png")
+    Image.fromarray((rng.random((38, 30, 3)) * 255).astype(np.uint8)).save(png)
+    out = {}
+    ds = rds.TrainValidImageDataset(d, 16, 4, "Train", rcfg.degradation_model_parameters_dict)
+    for seed in range(6):
+        random.seed(seed); np.random.seed(seed)
+        item = ds[0]
+        for k, v in item.items():
+            out[f"train{seed}_{k}"] = v.numpy()
+    dv = rds.TrainValidImageDataset(d, 16, 4, "Valid", rcfg.degradation_model_parameters_dict)
+    item = dv[0]
+    out["valid_lr"], out["valid_hr"] = item["lr"].numpy(), item["hr"].numpy()
+    for i, (h, w, s) in enumerate([(37, 45, 0.25), (40, 40, 2.0), (33, 50, 0.3), (16, 21, 1.5)]):
+        img = rng.random((h, w, 3), dtype=np.float32)
+        out[f"resize{i}_in"], out[f"resize{i}_scale"] = img, np.float64(s)
+        out[f"resize{i}_out"] = rimg.image_resize(img.copy(), s)
+    x = torch.from_numpy(rng.random((2, 3, 8, 9), dtype=np.float32))
+    out["ycbcr_in"] = x.numpy()
+    out["ycbcr_y"] = rimg.rgb2ycbcr_torch(x.clone(), True).numpy()
+    out["ycbcr_full"] = rimg.rgb2ycbcr_torch(x.clone(), False).numpy()
+    np.savez_compressed(os.path.join(HERE, "dataset.npz"), **out)
+    print("wrote dataset.npz", len(out), "arrays")
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "imgproc":
     gen_imgproc()
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "dataset":
+    gen_dataset()

@@ -2,7 +2,8 @@
 
 Only usable where /root/reference exists (the build container).  Never imported by the
 `-m gpu` tests, smoke() or bench.py.  Three formulas are stand-ins for third-party
-libraries the image lacks -- parity for them is "pinned to formula":
+libraries the image lacks -- parity for them is "pinned to formula" (the file-side cv2 functions
+of dataset.py -- imread, cvtColor, flip, getRotationMatrix2D, warpAffine -- are stand-ins too, textbook forms):
   * torchvision rgb_to_grayscale  -> 0.2989 R + 0.587 G + 0.114 B
   * cv2.getGaussianKernel(k, s<=0) -> sigma = 0.3*((k-1)*0.5-1)+0.8, exp(-x^2/2s^2) normalised
   * torchvision to_tensor          -> HWC float ndarray -> CHW tensor
@@ -40,6 +41,51 @@ def install_stubs():
         cv2.IMREAD_UNCHANGED = -1
         cv2.COLOR_BGR2RGB = 4
         cv2.COLOR_RGB2BGR = 4
+
+        # file-side functions used by the reference's dataset.py (host data path goldens): generic textbook forms
+        def imread(path, flags=-1):
+            from PIL import Image
+            with Image.open(path) as im:
+                return np.asarray(im.convert("RGB"))[:, :, ::-1].copy()          # BGR uint8, like OpenCV
+
+        def cvtColor(img, code):
+            return np.ascontiguousarray(img[:, :, ::-1])
+
+        def flip(img, code):
+            return np.ascontiguousarray(img[:, ::-1] if code == 1 else img[::-1])
+
+        def getRotationMatrix2D(center, angle, scale):
+            a = np.deg2rad(angle)
+            al, be = scale * np.cos(a), scale * np.sin(a)
+            return np.array([[al, be, (1 - al) * center[0] - be * center[1]],
+                             [-be, al, be * center[0] + (1 - al) * center[1]]], dtype=np.float64)
+
+        def warpAffine(img, m, dsize):
+            # dst(x, y) = src(M^-1 (x, y)), bilinear, constant 0 border (OpenCV defaults)
+            w, h = dsize
+            mi = np.linalg.inv(np.vstack([m, [0, 0, 1]]))
+            ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+            sx = mi[0, 0] * xs + mi[0, 1] * ys + mi[0, 2]
+            sy = mi[1, 0] * xs + mi[1, 1] * ys + mi[1, 2]
+            sx, sy = np.round(sx * 1024) / 1024, np.round(sy * 1024) / 1024       # fixed-point coordinates
+            x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+            fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
+            src = img.astype(np.float64)
+            if src.ndim == 2:
+                src = src[..., None]
+
+            def tap(yy, xx):
+                ok = (xx >= 0) & (xx < src.shape[1]) & (yy >= 0) & (yy < src.shape[0])
+                out = np.zeros((h, w, src.shape[2]))
+                out[ok] = src[yy[ok], xx[ok]]
+                return out
+
+            out = (tap(y0, x0) * (1 - fx) * (1 - fy) + tap(y0, x0 + 1) * fx * (1 - fy) +
+                   tap(y0 + 1, x0) * (1 - fx) * fy + tap(y0 + 1, x0 + 1) * fx * fy)
+            return out.astype(img.dtype).reshape(h, w, *img.shape[2:])
+
+        cv2.imread, cv2.cvtColor, cv2.flip = imread, cvtColor, flip
+        cv2.getRotationMatrix2D, cv2.warpAffine = getRotationMatrix2D, warpAffine
     if "torchvision" not in sys.modules:
         tv = _stub("torchvision")
         tvm = _stub("torchvision.models")
