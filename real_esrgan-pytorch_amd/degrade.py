@@ -109,9 +109,10 @@ def run_plan(hr: torch.Tensor, plan: DegradationPlan, usm: imgproc.USMSharp, jpe
             trace[name] = t
         return t
 
-    k1 = torch.from_numpy(plan.kernel1).to(dev, non_blocking=True)
-    k2 = torch.from_numpy(plan.kernel2).to(dev, non_blocking=True)
-    ks = torch.from_numpy(plan.sinc_kernel).to(dev, non_blocking=True)
+    def dev_kernel(k):   # numpy from the plan's own sampler, or the tensors of a dataset batch (dataset.py)
+        return (k if torch.is_tensor(k) else torch.from_numpy(k)).to(dev, non_blocking=True)
+
+    k1, k2, ks = dev_kernel(plan.kernel1), dev_kernel(plan.kernel2), dev_kernel(plan.sinc_kernel)
     out = rec("usm", usm(hr, 0.5, 10))                                                              # :268
     if plan.blur1:
         out = rec("blur1", imgproc.filter2d_torch(out, k1))                                         # :276

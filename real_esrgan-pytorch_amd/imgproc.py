@@ -330,31 +330,33 @@ def generate_sinc_kernel(cutoff: float, kernel_size: int, padding: int = 0) -> n
 # validation LR images.  CPU / numpy like the reference's DataLoader workers; no cv2.
 # ---------------------------------------------------------------------------------------------------------------
 def _cubic_kernel(x: np.ndarray) -> np.ndarray:
-    """Keys cubic, a = -0.5 (reference imgproc.py:52-69)."""
+    """Keys cubic, a = -0.5 (reference imgproc.py:52-69), in the dtype of x."""
     ax = np.abs(x)
     ax2, ax3 = ax * ax, ax * ax * ax
-    return ((1.5 * ax3 - 2.5 * ax2 + 1) * (ax <= 1) + (-0.5 * ax3 + 2.5 * ax2 - 4 * ax + 2) * ((ax > 1) & (ax <= 2))).astype(np.float32)
+    return ((1.5 * ax3 - 2.5 * ax2 + 1) * (ax <= 1) + (-0.5 * ax3 + 2.5 * ax2 - 4 * ax + 2) * ((ax > 1) & (ax <= 2))).astype(x.dtype)
 
 
-def _resize_matrix(in_length: int, out_length: int, scale: float, antialiasing: bool) -> np.ndarray:
-    """[out_length, in_length] float32 matrix of the 1-D MATLAB `imresize` bicubic pass, symmetric edge replication
-    folded in (reference imgproc.py:93-167 builds the same weights/indices and applies them row by row)."""
+def _resize_matrix(in_length: int, out_length: int, scale: float, antialiasing: bool, dtype=np.float32) -> np.ndarray:
+    """[out_length, in_length] matrix of the 1-D MATLAB `imresize` bicubic pass, symmetric edge replication folded in
+    (reference imgproc.py:93-167 builds the same weights/indices in float32 and applies them row by row; NIQE's
+    half-size pass, image_quality_assessment.py:520-591, is the same construction in float64)."""
     kernel_width = 4.0
     aa = scale < 1 and antialiasing
     if aa:
         kernel_width = kernel_width / scale
-    x = np.linspace(1, out_length, out_length, dtype=np.float32)
-    u = (x / np.float32(scale) + np.float32(0.5 * (1 - 1 / scale))).astype(np.float32)
-    left = np.floor(u - np.float32(kernel_width / 2))
+    f = dtype
+    x = np.linspace(1, out_length, out_length, dtype=f)
+    u = (x / f(scale) + f(0.5 * (1 - 1 / scale))).astype(f)
+    left = np.floor(u - f(kernel_width / 2))
     p = math.ceil(kernel_width) + 2
-    idx = left[:, None] + np.arange(p, dtype=np.float32)[None, :]           # 1-based input positions
-    dist = (u[:, None] - idx).astype(np.float32)
-    w = np.float32(scale) * _cubic_kernel(dist * np.float32(scale)) if aa else _cubic_kernel(dist)
-    w = (w / w.sum(1, keepdims=True)).astype(np.float32)
+    idx = left[:, None] + np.arange(p, dtype=f)[None, :]                     # 1-based input positions
+    dist = (u[:, None] - idx).astype(f)
+    w = f(scale) * _cubic_kernel(dist * f(scale)) if aa else _cubic_kernel(dist)
+    w = (w / w.sum(1, keepdims=True)).astype(f)
     idx = idx.astype(np.int64)
     idx = np.where(idx < 1, 1 - idx, idx)                                     # symmetric: 0 -> 1, -1 -> 2, ...
     idx = np.where(idx > in_length, 2 * in_length + 1 - idx, idx)             # n+1 -> n, n+2 -> n-1, ...
-    m = np.zeros((out_length, in_length), dtype=np.float32)
+    m = np.zeros((out_length, in_length), dtype=f)
     np.add.at(m, (np.repeat(np.arange(out_length), p), (idx - 1).reshape(-1)), w.reshape(-1))
     return m
 
@@ -432,13 +434,14 @@ def random_vertically_flip(image: np.ndarray, p: float) -> np.ndarray:
 
 def rgb2ycbcr_torch(tensor: torch.Tensor, only_use_y_channel: bool) -> torch.Tensor:
     """ITU-R BT.601 as MATLAB `rgb2ycbcr`, [N,3,H,W] in [0,1] (reference imgproc.py:1815-1840)."""
+    nhwc = tensor.permute(0, 2, 3, 1)
     if only_use_y_channel:
-        w = torch.tensor([65.481, 128.553, 24.966], dtype=tensor.dtype, device=tensor.device).view(1, 3, 1, 1)
-        return ((tensor * w).sum(1, keepdim=True) + 16.0) / 255.0
+        w = torch.tensor([[65.481], [128.553], [24.966]], dtype=tensor.dtype, device=tensor.device)
+        return (torch.matmul(nhwc, w).permute(0, 3, 1, 2) + 16.0) / 255.0
     m = torch.tensor([[65.481, -37.797, 112.0], [128.553, -74.203, -93.786], [24.966, 112.0, -18.214]],
                      dtype=tensor.dtype, device=tensor.device)
     b = torch.tensor([16.0, 128.0, 128.0], dtype=tensor.dtype, device=tensor.device).view(1, 3, 1, 1)
-    return (torch.einsum("nchw,cd->ndhw", tensor, m) + b) / 255.0
+    return (torch.matmul(nhwc, m).permute(0, 3, 1, 2) + b) / 255.0
 
 
 def read_image_rgb(path: str) -> np.ndarray:

@@ -1,0 +1,253 @@
+"""RealESRNet training entry point behind the reference's `train_realesrnet.py` surface: same
+function names, epoch loop, checkpoint dictionary and file names, NIQE validation with the EMA weights applied.
+
+    python -m real_esrgan_pytorch_amd.train_realesrnet          # reads real_esrgan_pytorch_amd.config
+
+The step itself is `train.RealESRNetStep` (degradation -> generator forward/backward on the HIP kernels -> Adam ->
+EMA); the degradation uses the blur kernels the dataset sampled for each image (reference train_realesrnet.py:258-413).
+TensorBoard is absent from the image: scalars go to `samples/logs/<exp>/scalars.jsonl` through the same `add_scalar`.
+"""
+from __future__ import annotations
+
+import json
+import os
+import shutil
+import time
+from enum import Enum
+from typing import Any, List, Optional
+
+import numpy as np
+import torch
+from torch import nn, optim
+from torch.optim import lr_scheduler
+from torch.utils.data import DataLoader
+
+from . import config, imgproc
+from .dataset import CUDAPrefetcher, TestImageDataset, TrainValidImageDataset
+from .degrade import run_plan, sample_plan
+from .image_quality_assessment import NIQE
+from .model import EMA, Generator
+from .train import RealESRNetStep
+
+
+class ScalarWriter:
+    """`SummaryWriter.add_scalar` stand-in: one JSON line per scalar."""
+
+    def __init__(self, log_dir: str) -> None:
+        os.makedirs(log_dir, exist_ok=True)
+        self.path = os.path.join(log_dir, "scalars.jsonl")
+
+    def add_scalar(self, tag: str, value: float, step: int) -> None:
+        with open(self.path, "a") as f:
+            f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+
+
+def load_dataset() -> List[CUDAPrefetcher]:
+    """Reference train_realesrnet.py:131-172."""
+    train_datasets = TrainValidImageDataset(config.train_image_dir, config.image_size, config.upscale_factor, "Train",
+                                            config.degradation_model_parameters_dict)
+    valid_datasets = TrainValidImageDataset(config.valid_image_dir, config.image_size, config.upscale_factor, "Valid",
+                                            config.degradation_model_parameters_dict)
+    test_datasets = TestImageDataset(config.test_lr_image_dir, config.test_hr_image_dir)
+    workers = config.num_workers
+    train_dataloader = DataLoader(train_datasets, batch_size=config.batch_size, shuffle=True, num_workers=workers,
+                                  pin_memory=True, drop_last=True, persistent_workers=workers > 0)
+    valid_dataloader = DataLoader(valid_datasets, batch_size=1, shuffle=False, num_workers=min(1, workers),
+                                  pin_memory=True, drop_last=False, persistent_workers=workers > 0)
+    test_dataloader = DataLoader(test_datasets, batch_size=1, shuffle=False, num_workers=min(1, workers),
+                                 pin_memory=True, drop_last=False, persistent_workers=workers > 0)
+    return [CUDAPrefetcher(train_dataloader, config.device), CUDAPrefetcher(valid_dataloader, config.device),
+            CUDAPrefetcher(test_dataloader, config.device)]
+
+
+def build_model() -> List[nn.Module]:
+    """Reference train_realesrnet.py:175-183."""
+    model = Generator(config.in_channels, config.out_channels, config.upscale_factor,
+                      precision=getattr(config, "precision", "fast")).to(device=config.device)
+    ema_model = EMA(model, config.ema_model_weight_decay).to(device=config.device)
+    ema_model.register()
+    return [model, ema_model]
+
+
+def define_loss() -> nn.L1Loss:
+    return nn.L1Loss().to(device=config.device)
+
+
+def define_optimizer(model) -> optim.Adam:
+    return optim.Adam(model.parameters(), config.model_lr, config.model_betas)
+
+
+def define_scheduler(optimizer) -> lr_scheduler.StepLR:
+    return lr_scheduler.StepLR(optimizer, config.lr_scheduler_step_size, config.lr_scheduler_gamma)
+
+
+def load_checkpoint(path: str, model: nn.Module, ema_model: nn.Module, optimizer, scheduler) -> List[Any]:
+    """Reference train_realesrnet.py:60-83: keys present in the current modules are taken, the rest ignored."""
+    checkpoint = torch.load(path, map_location=lambda storage, loc: storage, weights_only=False)
+    for module, key in ((model, "state_dict"), (ema_model, "ema_state_dict")):
+        current = module.state_dict()
+        current.update({k: v for k, v in checkpoint[key].items() if k in current})
+        module.load_state_dict(current)
+    optimizer.load_state_dict(checkpoint["optimizer"])
+    scheduler.load_state_dict(checkpoint["scheduler"])
+    return [checkpoint["epoch"], checkpoint["best_niqe"]]
+
+
+def save_checkpoint(epoch: int, best_niqe: float, is_best: bool, model, ema_model, optimizer, scheduler,
+                    samples_dir: str, results_dir: str) -> str:
+    """Reference train_realesrnet.py:117-129: same dictionary, same file names."""
+    path = os.path.join(samples_dir, f"g_epoch_{epoch + 1}.pth.tar")
+    torch.save({"epoch": epoch + 1, "best_niqe": best_niqe, "state_dict": model.state_dict(),
+                "ema_state_dict": ema_model.state_dict(), "optimizer": optimizer.state_dict(),
+                "scheduler": scheduler.state_dict()}, path)
+    if is_best:
+        shutil.copyfile(path, os.path.join(results_dir, "g_best.pth.tar"))
+    if (epoch + 1) == config.epochs:
+        shutil.copyfile(path, os.path.join(results_dir, "g_last.pth.tar"))
+    return path
+
+
+def main() -> None:
+    start_epoch, best_niqe = 0, 100.0
+    train_prefetcher, valid_prefetcher, test_prefetcher = load_dataset()
+    model, ema_model = build_model()
+    pixel_criterion = define_loss()
+    optimizer = define_optimizer(model)
+    scheduler = define_scheduler(optimizer)
+    if config.resume:
+        start_epoch, best_niqe = load_checkpoint(config.resume, model, ema_model, optimizer, scheduler)
+        print("Loaded pretrained model weights.")
+    samples_dir = os.path.join("samples", config.exp_name)
+    results_dir = os.path.join("results", config.exp_name)
+    os.makedirs(samples_dir, exist_ok=True)
+    os.makedirs(results_dir, exist_ok=True)
+    writer = ScalarWriter(os.path.join("samples", "logs", config.exp_name))
+    scaler = torch.amp.GradScaler("cuda") if getattr(config, "precision", "fast") == "fast" else None
+    niqe_model = NIQE(config.upscale_factor, config.niqe_model_path).to(device=config.device)
+    for epoch in range(start_epoch, config.epochs):
+        train(model, ema_model, train_prefetcher, pixel_criterion, optimizer, epoch, scaler, writer)
+        _ = validate(model, ema_model, valid_prefetcher, epoch, writer, niqe_model, "Valid")
+        niqe = validate(model, ema_model, test_prefetcher, epoch, writer, niqe_model, "Test")
+        print("\n")
+        scheduler.step()
+        is_best = niqe < best_niqe
+        best_niqe = min(niqe, best_niqe)
+        save_checkpoint(epoch, best_niqe, is_best, model, ema_model, optimizer, scheduler, samples_dir, results_dir)
+
+
+def train(model: nn.Module, ema_model: nn.Module, train_prefetcher: CUDAPrefetcher, pixel_criterion: nn.L1Loss,
+          optimizer: optim.Adam, epoch: int, scaler: Optional["torch.amp.GradScaler"], writer: ScalarWriter) -> None:
+    """Reference train_realesrnet.py:218-413."""
+    jpeg_operation = imgproc.DiffJPEG(False)
+    usm_sharpener = imgproc.USMSharp(50, 0).to(device=config.device)
+    batches = len(train_prefetcher)
+    batch_time = AverageMeter("Time", ":6.3f")
+    data_time = AverageMeter("Data", ":6.3f")
+    losses = AverageMeter("Loss", ":6.6f")
+    progress = ProgressMeter(batches, [batch_time, data_time, losses], prefix=f"Epoch: [{epoch + 1}]")
+    model.train()
+
+    def degrade(hr):   # host draws in the reference's order, kernels from the dataset batch (:262-377)
+        plan = sample_plan(hr.shape[0], hr.shape[2], hr.shape[3], config.image_size, with_kernels=False)
+        plan.kernel1, plan.kernel2, plan.sinc_kernel = kernels
+        return run_plan(hr, plan, usm_sharpener, jpeg_operation, config.upscale_factor, config.image_size)
+
+    step = RealESRNetStep(model, ema_model, optimizer, scaler, degrade)
+    step.criterion = pixel_criterion
+    batch_index = 0
+    train_prefetcher.reset()
+    batch_data = train_prefetcher.next()
+    end = time.time()
+    while batch_data is not None:
+        data_time.update(time.time() - end)
+        hr = batch_data["hr"].to(device=config.device, non_blocking=True)
+        kernels = (batch_data["kernel1"], batch_data["kernel2"], batch_data["sinc_kernel"])
+        loss = step(hr)
+        losses.update(loss.item(), hr.size(0))
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if batch_index % config.print_frequency == 0:
+            writer.add_scalar("Train/Loss", loss.item(), batch_index + epoch * batches + 1)
+            progress.display(batch_index)
+        batch_data = train_prefetcher.next()
+        batch_index += 1
+
+
+def validate(model: nn.Module, ema_model: nn.Module, data_prefetcher: CUDAPrefetcher, epoch: int, writer: ScalarWriter,
+             niqe_model: Any, mode: str) -> float:
+    """Reference train_realesrnet.py:416-488: EMA weights applied for the evaluation, restored afterwards."""
+    batches = len(data_prefetcher)
+    batch_time = AverageMeter("Time", ":6.3f")
+    niqe_metrics = AverageMeter("NIQE", ":4.2f")
+    progress = ProgressMeter(batches, [batch_time, niqe_metrics], prefix=f"{mode}: ")
+    ema_model.apply_shadow()
+    model.eval()
+    batch_index = 0
+    data_prefetcher.reset()
+    batch_data = data_prefetcher.next()
+    end = time.time()
+    with torch.no_grad():
+        while batch_data is not None:
+            lr = batch_data["lr"].to(device=config.device, non_blocking=True)
+            sr = model(lr)
+            niqe = niqe_model(sr)
+            niqe_metrics.update(niqe.item(), lr.size(0))
+            batch_time.update(time.time() - end)
+            end = time.time()
+            if batch_index % max(1, batches // 5) == 0:
+                progress.display(batch_index)
+            batch_data = data_prefetcher.next()
+            batch_index += 1
+    ema_model.restore()
+    progress.display_summary()
+    if mode not in ("Valid", "Test"):
+        raise ValueError("Unsupported mode, please use `Valid` or `Test`.")
+    writer.add_scalar(f"{mode}/NIQE", niqe_metrics.avg, epoch + 1)
+    return niqe_metrics.avg
+
+
+class Summary(Enum):
+    NONE = 0
+    AVERAGE = 1
+    SUM = 2
+    COUNT = 3
+
+
+class AverageMeter(object):
+    def __init__(self, name, fmt=":f", summary_type=Summary.AVERAGE):
+        self.name, self.fmt, self.summary_type = name, fmt, summary_type
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+    def __str__(self):
+        return ("{name} {val" + self.fmt + "} ({avg" + self.fmt + "})").format(**self.__dict__)
+
+    def summary(self):
+        fmt = {Summary.NONE: "", Summary.AVERAGE: "{name} {avg:.2f}", Summary.SUM: "{name} {sum:.2f}",
+               Summary.COUNT: "{name} {count:.2f}"}[self.summary_type]
+        return fmt.format(**self.__dict__)
+
+
+class ProgressMeter(object):
+    def __init__(self, num_batches, meters, prefix=""):
+        num_digits = len(str(num_batches // 1))
+        self.batch_fmtstr = "[{:" + str(num_digits) + "d}/" + ("{:" + str(num_digits) + "d}").format(num_batches) + "]"
+        self.meters, self.prefix = meters, prefix
+
+    def display(self, batch):
+        print("\t".join([self.prefix + self.batch_fmtstr.format(batch)] + [str(m) for m in self.meters]))
+
+    def display_summary(self):
+        print(" ".join([" *"] + [m.summary() for m in self.meters]))
+
+
+if __name__ == "__main__":
+    main()

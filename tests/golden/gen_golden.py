@@ -285,7 +285,28 @@ def gen_dataset():
     print("wrote dataset.npz", len(out), "arrays")
 
 
+def gen_niqe():
+    """Reference NIQE (image_quality_assessment.py:1001-1032) on stored 8-bit images."""
+    import torch.nn.functional as F
+    riqa = ref_shim.load("image_quality_assessment")
+    path = os.path.join(HERE, "niqe_model.mat")    # copy of the reference's results/pretrained_models/niqe_model.mat
+    out = {}
+    for i, (seed, b, h, w, cb) in enumerate([(0, 1, 296, 296, 4), (1, 2, 200, 296, 0)]):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.rand(b, 3, h // 4, w // 4, generator=g)
+        x = F.interpolate(x, size=(h, w), mode="bicubic", align_corners=False).clamp(0, 1)
+        x = (x * 0.8 + 0.2 * torch.rand(b, 3, h, w, generator=g)).clamp(0, 1)
+        u8 = (x * 255).round().to(torch.uint8)
+        out[f"img{i}"] = u8.numpy()
+        out[f"crop{i}"] = np.int64(cb)
+        out[f"score{i}"] = np.atleast_1d(riqa.NIQE(cb, path)(u8.float() / 255.0).numpy())
+    np.savez_compressed(os.path.join(HERE, "niqe.npz"), **out)
+    print("wrote niqe.npz", {k: v for k, v in out.items() if k.startswith("score")})
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "imgproc":
     gen_imgproc()
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "niqe":
+    gen_niqe()
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "dataset":
     gen_dataset()
