@@ -45,7 +45,13 @@ enum {
     RESR_CONV_MASK = 1 << 4,         /* v *= (mask[p,c] > 0 ? 1 : slope): LeakyReLU backward                */
     RESR_CONV_NO_BIAS = 1 << 5,
     RESR_CONV_AUX_BEFORE_MASK = 1 << 6, /* aux_out (NHWC, out_stride) also receives v after bias, before the mask     */
-    RESR_CONV_AUX_BEFORE_RES = 1 << 7   /* aux_out (NHWC, out_stride) also receives v after LeakyReLU, before residuals */
+    RESR_CONV_AUX_BEFORE_RES = 1 << 7,  /* aux_out (NHWC, out_stride) also receives v after LeakyReLU, before residuals */
+    /* 1-bit LeakyReLU masks.  A sign tensor is uint32 [pixels][cout_pad/32]: bit c of word (p, m) = (out[p, 32m+c] > 0)
+     * for the value as stored.  A forward pass can emit it (aux_out; no mask / residuals / other aux use in the same
+     * pass); the matching backward-data pass reads it instead of re-reading the saved activation (64 B -> 4 B per
+     * pixel and 32 channels in f16).  MASK_BITS goes together with RESR_CONV_MASK, without residuals. */
+    RESR_CONV_WRITE_SIGNBITS = 1 << 8,
+    RESR_CONV_MASK_BITS = 1 << 9
 };
 
 /* One 3x3, stride 1, pad 1 convolution pass (forward conv or backward-data conv):

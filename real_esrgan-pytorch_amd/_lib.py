@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libresr_hip.so")
 RESR_F16, RESR_F32 = 0, 1
 CONV_LRELU, CONV_UPSAMPLE_IN, CONV_CLAMP01, CONV_OUT_NCHW_F32, CONV_MASK, CONV_NO_BIAS = 1, 2, 4, 8, 16, 32
 CONV_AUX_BEFORE_MASK, CONV_AUX_BEFORE_RES = 64, 128
+CONV_WRITE_SIGNBITS = 1 << 8
+CONV_MASK_BITS = 1 << 9
 
 
 class ConvDesc(C.Structure):

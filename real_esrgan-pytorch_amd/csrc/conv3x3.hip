@@ -180,6 +180,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
     const bool f_bias = !(a.flags & RESR_CONV_NO_BIAS) && a.bias != nullptr;
     const bool f_aux_mask = (a.flags & RESR_CONV_AUX_BEFORE_MASK) && a.aux && !f_nchw;
     const bool f_aux_res = (a.flags & RESR_CONV_AUX_BEFORE_RES) && a.aux && !f_nchw;
+    const bool f_sbits = (a.flags & RESR_CONV_WRITE_SIGNBITS) != 0, f_mbits = (a.flags & RESR_CONV_MASK_BITS) != 0;
     const int x = x0 + lx;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -188,6 +189,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
         const size_t p = ((size_t)n * a.h + y) * a.w_ + x;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            const size_t wi = p * (size_t)((a.cout + 31) >> 5) + m;   // sign word of (pixel, chunk m)
+            const unsigned mbits = f_mbits ? reinterpret_cast<const unsigned*>(a.mask)[wi] : 0u;
+            unsigned sbits = 0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cq = g * 8 + kh * 4, co = m * 32 + cq;  // cq: channel inside the 32-channel chunk m
@@ -201,7 +205,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
                         if (co + r < a.cout) v[r] += a.bias[co + r];
                 }
                 if (f_aux_mask) store4<T>(reinterpret_cast<char*>(a.aux), p * a.out_stride + (size_t)m * a.out_chunk + cq, v);
-                if (f_mask) {
+                if (f_mbits) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= ((mbits >> (cq + r)) & 1u) ? 1.f : a.slope;
+                } else if (f_mask) {
                     float mk[4];
                     load4<T>(a.mask, p * a.mask_stride + (size_t)m * a.mask_chunk + cq, mk);
 #pragma unroll
@@ -243,7 +250,15 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
                         for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], 0.f), 1.f);
                     }
                     store4<T>(a.out, p * a.out_stride + (size_t)m * a.out_chunk + cq, v);
+                    if (f_sbits) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sbits |= ((float)(T)v[r] > 0.f ? 1u : 0u) << (cq + r);
+                    }
                 }
+            }
+            if (f_sbits) {   // lanes lx and lx+32 hold complementary nibbles of the pixel's word: merge, lane kh = 0 stores
+                const unsigned word = sbits | (unsigned)__shfl_xor((int)sbits, 32);
+                if (kh == 0 && m * 32 < a.cout) reinterpret_cast<unsigned*>(a.aux)[wi] = word;
             }
         }
     }
@@ -291,6 +306,16 @@ int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, co
     if ((d->flags & RESR_CONV_UPSAMPLE_IN) && ((d->h | d->w) & 1))
         return fail(RESR_ERR_ARG, "conv3x3: upsampled input needs even h,w");
     if ((d->flags & RESR_CONV_MASK) && !mask) return fail(RESR_ERR_ARG, "conv3x3: mask missing");
+    if (d->flags & RESR_CONV_WRITE_SIGNBITS) {
+        if (!aux || (d->cout & 7) || res0 || res1 ||
+            (d->flags & (RESR_CONV_MASK | RESR_CONV_OUT_NCHW_F32 | RESR_CONV_CLAMP01 | RESR_CONV_AUX_BEFORE_MASK | RESR_CONV_AUX_BEFORE_RES)))
+            return fail(RESR_ERR_ARG, "conv3x3: WRITE_SIGNBITS needs aux_out, cout %% 8 == 0 and a plain (bias/LeakyReLU) epilogue");
+    }
+    if (d->flags & RESR_CONV_MASK_BITS) {
+        if (!(d->flags & RESR_CONV_MASK) || (d->cout & 7) || res0 || res1 || aux ||
+            (d->flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_CLAMP01 | RESR_CONV_WRITE_SIGNBITS)))
+            return fail(RESR_ERR_ARG, "conv3x3: MASK_BITS goes with MASK, cout %% 8 == 0, no residuals / aux");
+    }
     const size_t es = elem_size(d->dtype);
     ConvArgs a;
     memset(&a, 0, sizeof(a));

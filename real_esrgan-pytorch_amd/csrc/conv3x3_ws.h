@@ -77,7 +77,8 @@ __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
 
 // EPI: epilogue features of the instantiation -- bit 0 LeakyReLU-mask multiply, bit 1 residual 0, bit 2 residual 1 (each
 // unconditional when set, absent when clear), bit 3 the rest (aux tensors, NCHW fp32 output, clamp; with bit 3 the
-// other features are run-time flags).  The dispatcher instantiates the combinations the networks use.
+// other features are run-time flags), bit 4 also emit the 1-bit sign tensor (RESR_CONV_WRITE_SIGNBITS), bit 5 the mask is
+// such a sign tensor (RESR_CONV_MASK_BITS).  The dispatcher instantiates the combinations the networks use.
 template <typename T, int MT, int NT, int NWC, int EPI>
 __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCfg<T, MT, NT, NWC>::NP) / 4) void conv3x3_ws_kernel(const ConvArgs a) {
     using C = WsCfg<T, MT, NT, NWC>;
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         asm volatile("" : "+v"(lane_e));
         const int lx_e = lane_e & 31, kh_e = lane_e >> 5;
         constexpr bool EX = (EPI & 8) != 0, EM = (EPI & 1) != 0, ER = (EPI & 6) != 0;
+        constexpr bool ESB = (EPI & 16) != 0, EMB = (EPI & 32) != 0;   // write sign bits / mask given as sign bits
         const bool f_lrelu = e.flags & RESR_CONV_LRELU, f_clamp = EX && (e.flags & RESR_CONV_CLAMP01);
         const bool f_nchw = EX && (e.flags & RESR_CONV_OUT_NCHW_F32);
         const bool f_mask = EX ? (e.flags & RESR_CONV_MASK) != 0 : EM;
@@ -339,10 +341,14 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 for (int j = 0; j < 2; ++j) co[j] = m * 32 + (2 * j + kh_e) * 8;
                 // element offset of piece j inside a pixel of an operand with chunk stride cs (clamped when beyond cout)
                 auto poff = [&](int j, int cs) { return co[j] < e.cout ? (size_t)m * cs + (2 * j + kh_e) * 8 : (size_t)0; };
+                unsigned sbits = 0;   // ESB: this lane's bytes of the sign word
 #pragma unroll
                 for (int j0 = 0; j0 < 2; j0 += JB) {
                 half8 rmask[2], rres0[2], rres1[2];
-                if (f_mask) {
+                unsigned mbits = 0;   // EMB: the pixel's sign word of chunk m (bit c <-> channel 32m + c)
+                if (EMB) {
+                    mbits = reinterpret_cast<const unsigned*>(e.mask)[p * (size_t)((e.cout + 31) >> 5) + m];
+                } else if (f_mask) {
 #pragma unroll
                     for (int j = j0; j < j0 + JB; ++j)
                         rmask[j] = *reinterpret_cast<const half8*>(e.mask + (p * e.mask_stride + poff(j, e.mask_chunk)) * 2);
@@ -374,7 +380,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         *reinterpret_cast<half8*>(base + idx * 2) = h;
                     };
                     if (f_aux_mask && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(j, e.out_chunk));
-                    if (f_mask) {
+                    if (EMB) {
+                        const unsigned byte = mbits >> (8 * (2 * j + kh_e));
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] *= ((byte >> r) & 1u) ? 1.f : e.slope;
+                    } else if (f_mask) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] *= ((float)rmask[j][r] > 0.f ? 1.f : e.slope);
                     }
@@ -410,8 +420,19 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             for (int r = 0; r < 8; ++r) v[r] = fminf(fmaxf(v[r], 0.f), 1.f);
                         }
                         if (ok) store8(e.out, p * e.out_stride + poff(j, e.out_chunk));
+                        if (ESB) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) sbits |= ((float)(half_t)v[r] > 0.f ? 1u : 0u) << (8 * (2 * j + kh_e) + r);
+                        }
                     }
                 }
+                }
+                if (ESB) {   // the two lanes of a pixel hold complementary bytes: merge, lane kh = 0 stores the word
+                    float sa = __builtin_bit_cast(float, sbits), sb = sa;
+                    permlane32_swap(sa, sb);
+                    const unsigned word = __builtin_bit_cast(unsigned, sa) | __builtin_bit_cast(unsigned, sb);
+                    if (in_img && kh_e == 0 && m * 32 < e.cout)
+                        reinterpret_cast<unsigned*>(e.aux)[p * (size_t)((e.cout + 31) >> 5) + m] = word;
                 }
             }
         }
@@ -456,8 +477,12 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
 
 template <typename T, int MT, int NT, int NWC>
 static int launch_ws(const ConvArgs& a, hipStream_t stream) {
-    const bool extras = a.aux || (a.flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_CLAMP01));
     const int combo = ((a.flags & RESR_CONV_MASK) ? 1 : 0) | (a.res0 ? 2 : 0) | (a.res1 ? 4 : 0);
+    if (a.flags & RESR_CONV_WRITE_SIGNBITS) {   // forward conv + LeakyReLU that also emits its 1-bit mask (checked by the caller)
+        return launch_ws_epi<T, MT, NT, NWC, 16>(a, stream);
+    }
+    if (a.flags & RESR_CONV_MASK_BITS) return launch_ws_epi<T, MT, NT, NWC, 33>(a, stream);
+    const bool extras = a.aux || (a.flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_CLAMP01));
     if (!extras) switch (combo) {
         case 0: return launch_ws_epi<T, MT, NT, NWC, 0>(a, stream);  // forward convs 1-4, upsampling, D forward
         case 1: return launch_ws_epi<T, MT, NT, NWC, 1>(a, stream);  // backward-data through a LeakyReLU

@@ -11,6 +11,8 @@
 //                                     torch.cat copies of model.py:91-94 never exist.
 //                                     Inference keeps 3 rotating workspaces, training keeps all
 //                                     (they are the saved activations: 192 ch/px/RDB, not 640).
+//   bits[r]           [4][N,h,w] u32   training: 1-bit LeakyReLU masks of o1..o4, written by the forward convs and read by the
+//                                     mirrored backward passes instead of the saved activations (64 B -> 4 B per pixel)
 //   trunk_out         [2][N,h,w,32]   model.py:260 (chunk-planar, like the gT gradient ring of the backward pass)
 //   feat              [N,h,w,64]      model.py:261-262
 //   u1 [N,2h,2w,64], u2, c3 [N,4h,4w,64]   model.py:264-267 (nearest x2 folded into the conv's gather)
@@ -138,6 +140,8 @@ bool build_plan(const ResrGeneratorDesc* d, Plan& p) {
 struct Bufs {
     char* x_in;
     std::vector<char*> ws;
+    char *bits_u2, *bits_c3;   // training: sign words (2 per pixel) of the HR activations u2, c3
+    std::vector<char*> bits;   // training: per RDB, 4 sign planes (uint32 per pixel) = the 1-bit LeakyReLU masks of o1..o4
     char* out1;       // conv1 output kept for the skip of model.py:262 (aliases ws[0] when training)
     int out1_stride;
     char *trunk_out, *feat, *u1, *u2, *c3;
@@ -175,6 +179,11 @@ void carve(const Plan& p, char* base, Bufs& b) {
     const int nws = p.d.training ? p.nrdb : 3;
     b.ws.resize(nws);
     for (int i = 0; i < nws; ++i) b.ws[i] = take(px * 192 * es);
+    b.bits.clear();
+    if (p.d.training)
+        for (int i = 0; i < p.nrdb; ++i) b.bits.push_back(take(px * 4 * sizeof(uint32_t)));
+    b.bits_u2 = p.d.training ? take(px * 16 * 2 * sizeof(uint32_t)) : nullptr;
+    b.bits_c3 = p.d.training ? take(px * 16 * 2 * sizeof(uint32_t)) : nullptr;
     if (p.d.training) { b.out1 = b.ws[0]; b.out1_stride = 32; }  // planes 0,1 of ws[0] (chunk-planar)
     else { b.out1 = take(px * 64 * es); b.out1_stride = 64; }  // rotating workspaces overwrite ws[0]
     b.trunk_out = take(px * 64 * es);
@@ -377,8 +386,13 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
             const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
             ResrConvDesc cd = conv_desc(p, N, h, w, c.cin, c.cin, 32, 0, 32, 32, 32, RESR_CONV_LRELU);
             cd.in0_chunk_stride = plane;
+            char* signs = nullptr;
+            if (d->training) {   // the backward pass reads the 1-bit mask, not the activation
+                cd.flags |= RESR_CONV_WRITE_SIGNBITS;
+                signs = b.bits[r] + (size_t)(k - 1) * N * h * w * sizeof(uint32_t);
+            }
             RUN(conv3x3_dispatch(&cd, cur, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr,
-                                 cur + (size_t)(2 + (k - 1)) * plane * es, nullptr, st));
+                                 cur + (size_t)(2 + (k - 1)) * plane * es, signs, st));
         }
         const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + 4];
         const bool last = r == p.nrdb - 1;
@@ -410,12 +424,14 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
     {   // model.py:265
         const ConvSpec& c = p.convs[p.i_up2];
         ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 64, 0, 64, 64, 64, RESR_CONV_LRELU | RESR_CONV_UPSAMPLE_IN);
-        RUN(conv3x3_dispatch(&cd, b.u1, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.u2, nullptr, st));
+        if (d->training) cd.flags |= RESR_CONV_WRITE_SIGNBITS;
+        RUN(conv3x3_dispatch(&cd, b.u1, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.u2, b.bits_u2, st));
     }
     {   // model.py:267
         const ConvSpec& c = p.convs[p.i_conv3];
         ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 64, 0, 64, 64, 64, RESR_CONV_LRELU);
-        RUN(conv3x3_dispatch(&cd, b.u2, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.c3, nullptr, st));
+        if (d->training) cd.flags |= RESR_CONV_WRITE_SIGNBITS;
+        RUN(conv3x3_dispatch(&cd, b.u2, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.c3, b.bits_c3, st));
     }
     {   // model.py:268-270
         const ConvSpec& c = p.convs[p.i_conv4];
@@ -475,16 +491,14 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     {   // conv4                                                            model.py:268
         const ConvSpec& c = p.convs[p.i_conv4];
         RUN(wgrad(c, H4, W4, b.c3, 64, 64, b.g4, 32, 0, 1.f));
-        ResrConvDesc cd = dgrad(H4, W4, b.g4, 32, 32, nullptr, 32, 0, 0, 64, 64, b.gA, 64, RESR_CONV_MASK);
-        cd.mask_stride = 64;
-        RUN(conv3x3_dispatch(&cd, b.g4, nullptr, pk + p.pk_bwd_conv4 * es, nullptr, nullptr, nullptr, b.c3, b.gA, nullptr, st));
+        ResrConvDesc cd = dgrad(H4, W4, b.g4, 32, 32, nullptr, 32, 0, 0, 64, 64, b.gA, 64, RESR_CONV_MASK | RESR_CONV_MASK_BITS);
+        RUN(conv3x3_dispatch(&cd, b.g4, nullptr, pk + p.pk_bwd_conv4 * es, nullptr, nullptr, nullptr, b.bits_c3, b.gA, nullptr, st));
     }
     {   // conv3                                                            model.py:267
         const ConvSpec& c = p.convs[p.i_conv3];
         RUN(wgrad(c, H4, W4, b.u2, 64, 64, b.gA, 64, 0, 1.f));
-        ResrConvDesc cd = dgrad(H4, W4, b.gA, 64, 64, nullptr, 64, 0, 0, 64, 64, b.gB, 64, RESR_CONV_MASK);
-        cd.mask_stride = 64;
-        RUN(conv3x3_dispatch(&cd, b.gA, nullptr, pk + p.pk_bwd_conv3 * es, nullptr, nullptr, nullptr, b.u2, b.gB, nullptr, st));
+        ResrConvDesc cd = dgrad(H4, W4, b.gA, 64, 64, nullptr, 64, 0, 0, 64, 64, b.gB, 64, RESR_CONV_MASK | RESR_CONV_MASK_BITS);
+        RUN(conv3x3_dispatch(&cd, b.gA, nullptr, pk + p.pk_bwd_conv3 * es, nullptr, nullptr, nullptr, b.bits_u2, b.gB, nullptr, st));
     }
     if (debug_stop() == 1) return RESR_OK;
     {   // upsampling2                                                      model.py:265
@@ -525,11 +539,10 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         for (int ps = 0; ps < 4; ++ps) {   // g_o4, g_o3, g_o2, g_o1
             const int k = 4 - ps;           // conv index whose pre-activation gradient this pass yields
             const int cin = 64 + 32 * ps;
-            ResrConvDesc cd = dgrad(h, w, gin, 64, 32, b.gS, cin, 32, 0, 32, 32, nullptr, 32, RESR_CONV_MASK);
+            ResrConvDesc cd = dgrad(h, w, gin, 64, 32, b.gS, cin, 32, 0, 32, 32, nullptr, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS);
             cd.in0_chunk_stride = plane; cd.in1_chunk_stride = plane;
-            cd.mask_stride = 32;
             char* out = b.gS + (size_t)ps * plane * es;
-            const char* mask = act + (size_t)(2 + (k - 1)) * plane * es;
+            const char* mask = b.bits[r] + (size_t)(k - 1) * N * h * w * sizeof(uint32_t);   // sign plane of o_k
             RUN(conv3x3_dispatch(&cd, gin, b.gS, pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * es, nullptr, nullptr, nullptr,
                                  mask, out, nullptr, st));
             const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];

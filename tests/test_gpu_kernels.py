@@ -49,6 +49,11 @@ CONV_CASES = [
     ("mask_only", 64, 64, 64, "mask,nobias", 1, 40, 72),
     ("res0_only", 192, 192, 64, "res0", 1, 33, 40),
     ("two_seg_5chunks", 160, 64, 32, "lrelu", 1, 50, 33),
+    # 1-bit LeakyReLU masks: a forward pass emits the sign tensor, the backward-data pass reads it instead of the activation
+    ("signbits32", 64, 64, 32, "lrelu,signbits", 2, 37, 45),
+    ("signbits64", 96, 96, 64, "lrelu,signbits", 1, 40, 70),
+    ("maskbits32", 128, 64, 32, "mask,nobias,maskbits", 1, 33, 64),
+    ("maskbits64", 64, 64, 64, "mask,nobias,maskbits", 2, 20, 36),
 ]
 
 
@@ -81,8 +86,14 @@ def test_conv3x3(U, case, dtype_name, diag_dir):
         flags |= L.CONV_NO_BIAS
     if "mask" in fl:
         mk = U.quant(torch.randn(n, cout, h, w, generator=g), dtype)
-        mask = U.to_nhwc(mk, dtype, stride=cout + 32)
-        d.mask_stride = cout + 32
+        if "maskbits" in fl:   # sign tensor: uint32 [pixels][cout/32], bit c of word m = (mask[32m + c] > 0)
+            bits = (mk > 0).permute(0, 2, 3, 1).reshape(n, h, w, cout // 32, 32).to(torch.int64)
+            words = (bits << torch.arange(32)).sum(-1)
+            mask = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).cuda().contiguous()
+            flags |= L.CONV_MASK_BITS
+        else:
+            mask = U.to_nhwc(mk, dtype, stride=cout + 32)
+            d.mask_stride = cout + 32
         flags |= L.CONV_MASK
         ref = ref * torch.where(mk > 0, 1.0, 0.2)
     if "lrelu" in fl:
@@ -109,6 +120,9 @@ def test_conv3x3(U, case, dtype_name, diag_dir):
             ref = ref.clamp(0, 1)
     else:
         out = torch.full((n, h, w, cout_pad + 32), -7.0, dtype=U.tdtype(dtype), device="cuda")
+    if "signbits" in fl:
+        flags |= L.CONV_WRITE_SIGNBITS
+        aux = torch.zeros((n, h, w, cout_pad // 32), dtype=torch.int32, device="cuda")
     d.flags = flags
     bias_d = bias.cuda()
     L.check(L.lib().resr_conv3x3(C.byref(d), L.ptr(a), L.ptr(b) if b is None else U.sptr(b, 32), L.ptr(packed),
@@ -124,7 +138,11 @@ def test_conv3x3(U, case, dtype_name, diag_dir):
     with open(os.path.join(diag_dir, f"conv_{name}_{dtype_name}.json"), "w") as f:
         json.dump({"max_abs_err": err, "ref_absmax": ref.abs().max().item()}, f)
     assert err < _tol(dtype, U) * max(1.0, ref.abs().max().item()), f"{name}/{dtype_name}: max abs err {err}"
-    if aux is not None:
+    if "signbits" in fl:
+        words = aux.cpu().to(torch.int64) & 0xFFFFFFFF
+        got_bits = ((words.unsqueeze(-1) >> torch.arange(32)) & 1).reshape(n, h, w, cout_pad)[..., :cout].permute(0, 3, 1, 2).bool()
+        assert torch.equal(got_bits, got > 0), "sign tensor disagrees with the stored activation"
+    elif aux is not None:
         am = aux.cpu().bool()
         # pass-mask may differ only where the pre-clamp value is within rounding of 0 or 1
         assert (am != ref_mask).float().mean().item() < 1e-3
