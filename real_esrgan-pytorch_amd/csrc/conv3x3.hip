@@ -223,13 +223,13 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
                     float rr[4];
                     load4<T>(a.res0, p * a.res0_stride + (size_t)m * a.res0_chunk + cq, rr);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] * a.s0 + a.t0 * rr[r];
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], a.s0, a.t0 * rr[r]);   // explicit: one rounding, the same in every instantiation
                 }
                 if (a.res1) {
                     float rr[4];
                     load4<T>(a.res1, p * a.res1_stride + (size_t)m * a.res1_chunk + cq, rr);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] * a.s1 + a.t1 * rr[r];
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], a.s1, a.t1 * rr[r]);
                 }
                 if (f_nchw) {
                     float* o = reinterpret_cast<float*>(a.out);

@@ -395,11 +395,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     if (f_aux_res && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(j, e.out_chunk));
                     if (f_res0) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = v[r] * e.s0 + e.t0 * (float)rres0[j][r];
+                        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], e.s0, e.t0 * (float)rres0[j][r]);   // explicit: one rounding, the same in every instantiation
                     }
                     if (f_res1) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = v[r] * e.s1 + e.t1 * (float)rres1[j][r];
+                        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], e.s1, e.t1 * (float)rres1[j][r]);
                     }
                     if (f_nchw) {
                         float* o = reinterpret_cast<float*>(e.out);
