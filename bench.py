@@ -28,6 +28,7 @@ import torch.distributed as dist  # noqa: E402
 
 MAC_PER_LR_PX = 17_926_848          # generator x4 forward MACs per LR pixel
 PEAK_F16_TFLOPS = 2500.0            # dense f16/bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0              # HBM3E peak (spec; ~6300 achievable), MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
 
@@ -162,9 +163,10 @@ def roofline_in_situ(step_fn, precision, batch):
     n = int(lib.resr_profile_end(C.cast(buf, C.c_void_p), cap))
     by = {}
     for i in range(min(n, cap)):
-        b = by.setdefault(kernel_name(buf[i].kernel_id), {"t": 0.0, "f": 0.0, "n": 0})
+        b = by.setdefault(kernel_name(buf[i].kernel_id), {"t": 0.0, "f": 0.0, "n": 0, "b": 0.0})
         b["t"] += buf[i].ms
         b["f"] += buf[i].flop
+        b["b"] += buf[i].bytes
         b["n"] += 1
     name, b = max(by.items(), key=lambda kv: kv[1]["t"])
     achieved = b["f"] / b["t"] / 1e9
@@ -174,8 +176,12 @@ def roofline_in_situ(step_fn, precision, batch):
          "frac": round(achieved / peak, 4), "traffic": traffic,
          "avg_launch_ms": round(b["t"] / b["n"], 4), "launches_per_step": b["n"],
          "method": "HIP events around each launch of one extra train step (in situ, launch stream)",
+         # the same launches against the other roof: these passes sit under the 312 FLOP/B ridge
+         "hbm": {"algorithmic_bytes_per_launch": round(b["b"] / b["n"]), "achieved": round(b["b"] / b["t"] / 1e6, 1),
+                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(b["b"] / b["t"] / 1e6 / PEAK_HBM_GBS, 4)},
          "per_instance": {k: {"tflops": round(v["f"] / v["t"] / 1e9, 2), "ms_per_step": round(v["t"], 3), "launches": v["n"],
-                              "avg_launch_ms": round(v["t"] / v["n"], 4)} for k, v in by.items()}}
+                              "avg_launch_ms": round(v["t"] / v["n"], 4),
+                              "algorithmic_gbs": round(v["b"] / v["t"] / 1e6, 1)} for k, v in by.items()}}
     if src:
         r["traffic_source"] = "profiles/" + src
     return r

@@ -238,7 +238,8 @@ int resr_debug_tr_probe(float* out256, void* stream);
 typedef struct {
     int32_t kernel_id;
     float ms;
-    double flop; /* algorithmic FLOP of the launch: 2*9*cin*cout*pixels */
+    double flop;  /* algorithmic FLOP of the launch: 2*9*cin*cout*pixels */
+    double bytes; /* algorithmic HBM bytes of the launch: every operand plane read / written once (no halo, no re-reads) */
 } ResrProfEntry;
 int resr_profile_begin(void);
 int64_t resr_profile_end(ResrProfEntry* out, int64_t capacity);

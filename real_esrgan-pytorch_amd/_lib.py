@@ -44,7 +44,7 @@ class PackChunk(C.Structure):
 
 
 class ProfEntry(C.Structure):
-    _fields_ = [("kernel_id", C.c_int32), ("ms", C.c_float), ("flop", C.c_double)]
+    _fields_ = [("kernel_id", C.c_int32), ("ms", C.c_float), ("flop", C.c_double), ("bytes", C.c_double)]
 
 
 class GeneratorDesc(C.Structure):

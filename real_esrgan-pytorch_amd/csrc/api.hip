@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 
 // ---- in-situ profiling -------------------------------------------------------------------------------------
 namespace {
-struct ProfRec { hipEvent_t e0, e1; int id; double flop; };
+struct ProfRec { hipEvent_t e0, e1; int id; double flop, bytes; };
 std::vector<ProfRec> g_prof;
 bool g_prof_on = false;
 hipEvent_t g_prof_e0 = nullptr;
@@ -35,10 +35,10 @@ void prof_before(hipStream_t st) {
     (void)hipEventCreate(&g_prof_e0);
     (void)hipEventRecord(g_prof_e0, st);
 }
-void prof_after(hipStream_t st, int kernel_id, double flop) {
+void prof_after(hipStream_t st, int kernel_id, double flop, double bytes) {
     if (!g_prof_on || !g_prof_e0) return;
     ProfRec r;
-    r.e0 = g_prof_e0; r.id = kernel_id; r.flop = flop;
+    r.e0 = g_prof_e0; r.id = kernel_id; r.flop = flop; r.bytes = bytes;
     (void)hipEventCreate(&r.e1);
     (void)hipEventRecord(r.e1, st);
     g_prof.push_back(r);
@@ -261,7 +261,7 @@ int64_t resr_profile_end(ResrProfEntry* out, int64_t capacity) {
         (void)hipEventSynchronize(r.e1);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.e0, r.e1);
-        if (out && n < capacity) { out[n].kernel_id = r.id; out[n].ms = ms; out[n].flop = r.flop; }
+        if (out && n < capacity) { out[n].kernel_id = r.id; out[n].ms = ms; out[n].flop = r.flop; out[n].bytes = r.bytes; }
         ++n;
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);

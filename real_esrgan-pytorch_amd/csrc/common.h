@@ -29,7 +29,7 @@ int fail(int code, const char* fmt, ...);
 // optional in-situ kernel timing (resr_profile_begin/end): HIP events around individual launches on the launch stream
 bool prof_on();
 void prof_before(hipStream_t st);
-void prof_after(hipStream_t st, int kernel_id, double flop);
+void prof_after(hipStream_t st, int kernel_id, double flop, double bytes = 0.0);
 
 inline size_t elem_size(int dtype) { return dtype == RESR_F16 ? 2 : 4; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -29,6 +29,19 @@ struct ConvArgs {
     unsigned long long* trace;  // debug: per-workgroup s_memrealtime stamps (resr_debug_conv_trace), else null
 };
 
+// Algorithmic HBM bytes of one pass: input channels + output (+ mask, residuals, aux) once per pixel.
+inline double conv_algorithmic_bytes(const ConvArgs& a, size_t es) {
+    const double px_out = (double)a.n * a.h * a.w_, px_in = (double)a.n * a.hs * a.ws;
+    double b = px_in * a.cin * es;
+    const bool nchw = a.flags & RESR_CONV_OUT_NCHW_F32;
+    b += px_out * a.cout * (nchw ? 4 : es);
+    if (a.flags & RESR_CONV_MASK) b += px_out * ((a.flags & RESR_CONV_MASK_BITS) ? ((a.cout + 31) / 32) * 4.0 : a.cout * (double)es);
+    if (a.res0) b += px_out * a.cout * es;
+    if (a.res1) b += px_out * a.cout * es;
+    if (a.aux) b += px_out * ((a.flags & RESR_CONV_WRITE_SIGNBITS) ? ((a.cout + 31) / 32) * 4.0 : nchw ? a.cout : a.cout * (double)es);
+    return b;
+}
+
 template <int SPP>
 __device__ __forceinline__ int swz(int hx) {
     // SPP slots per pixel; 16/SPP consecutive pixels fill one 256-byte bank row.

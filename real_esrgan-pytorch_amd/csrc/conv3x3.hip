@@ -283,7 +283,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     prof_before(stream);
     hipLaunchKernelGGL((conv3x3_kernel<T, MT, NT, NW>), dim3(grid), dim3(64 * NW), lds, stream, args);
     prof_after(stream, (sizeof(T) == 2 ? 0 : 10000) + MT * 100 + NT * 10 + NW,
-               2.0 * 9 * a.cin * a.cout * (double)a.n * a.h * a.w_);
+               2.0 * 9 * a.cin * a.cout * (double)a.n * a.h * a.w_, conv_algorithmic_bytes(a, sizeof(T)));
     RESR_CHECK_LAUNCH("conv3x3_kernel");
     return RESR_OK;
 }

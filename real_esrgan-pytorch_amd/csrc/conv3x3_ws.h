@@ -470,7 +470,8 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
     prof_before(stream);
     hipLaunchKernelGGL((conv3x3_ws_kernel<T, MT, NT, NWC, EPI>), dim3(grid), dim3(C::NTHR), lds, stream, args);
-    prof_after(stream, 20000 + MT * 100 + NT * 10 + NWC, 2.0 * 9 * a.cin * a.cout * (double)a.n * a.h * a.w_);
+    prof_after(stream, 20000 + MT * 100 + NT * 10 + NWC, 2.0 * 9 * a.cin * a.cout * (double)a.n * a.h * a.w_,
+               conv_algorithmic_bytes(a, sizeof(T)));
     RESR_CHECK_LAUNCH("conv3x3_ws_kernel");
     return RESR_OK;
 }

@@ -369,7 +369,10 @@ static int launch_wgrad(WgradArgs& a, int njobs, hipStream_t stream) {
     const int splits8 = (a.splits + 7) / 8 * 8;
     prof_before(stream);
     hipLaunchKernelGGL((wgrad_kernel<T, RPW>), dim3(njobs * splits8), dim3(256), lds, stream, a);
-    prof_after(stream, 50000 + (sizeof(T) == 2 ? 0 : 100) + RPW, 2.0 * 9 * 32 * 32 * njobs * (double)a.n * a.h * a.w_);
+    // algorithmic bytes: each job's X chunk and G tile once (jobs that share a tile re-read it from L2, not counted twice
+    // would need the conv list; this is the upper, per-job figure)
+    prof_after(stream, 50000 + (sizeof(T) == 2 ? 0 : 100) + RPW, 2.0 * 9 * 32 * 32 * njobs * (double)a.n * a.h * a.w_,
+               (double)njobs * 2 * 32 * sizeof(T) * (double)a.n * a.h * a.w_);
     RESR_CHECK_LAUNCH("wgrad_kernel");
     return RESR_OK;
 }
