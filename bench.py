@@ -112,8 +112,8 @@ def probe_conv_kernels(batch, lr, dtype_name, reps=8):
         e1.synchronize()
         ms = e0.elapsed_time(e1) / reps
         flop = 2.0 * 9 * cin * cout * batch * h * w
-        big = ((w + 31) // 32) * ((h + 15) // 16) * batch >= 512
-        inst = f"conv3x3_kernel<{'f16' if dtype == L.RESR_F16 else 'f32'},{mt},2,{8 if (mt == 1 and big and dtype == L.RESR_F16) else 4}>"
+        # label only (the library picks the instantiation): fast mode = producer/consumer kernel, strict = one-role kernel
+        inst = f"conv3x3_ws_kernel<f16,mt={mt}>" if dtype == L.RESR_F16 else f"conv3x3_kernel<f32,{mt},2,4>"
         rows.append({"kernel": inst, "cin": cin, "cout": cout, "res": h, "launches_per_step": count,
                      "ms": ms, "tflops": flop / ms / 1e9, "flop": flop})
         del x, y, yn, packed

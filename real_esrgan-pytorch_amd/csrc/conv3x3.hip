@@ -1,4 +1,6 @@
-// conv3x3.hip -- 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on the gfx950 matrix cores.
+// conv3x3.hip -- 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on the gfx950 matrix cores: the C-ABI dispatch
+// and the one-role kernel (every wave stages and multiplies).  Strict (f32) mode runs on this kernel; fast (f16) mode
+// runs on the producer/consumer kernel of conv3x3_ws.h and falls back to this one when its preconditions fail.
 //
 // Replaces the F.conv2d + LeakyReLU + torch.cat + mul/add call sites of the reference generator
 // (model.py:87-98 dense block, :123-132 RRDB tail, :255-272 head/tail) and, with transposed
@@ -8,8 +10,8 @@
 //   A operand = packed weights (M = cout, 32 rows per MFMA tile), streamed from L2 in fragment order
 //   B operand = input pixels   (N = 32 pixels of one image row), read from an LDS halo tile
 //   K         = 9 taps x cin, walked as 32-channel chunks; "im2col" is only an LDS address offset.
-// A workgroup (4 waves) owns a (4*NT) x 32 pixel tile and all output channels; wave w owns rows
-// [w*NT, w*NT+NT).  The (4*NT+2) x 34 x 32ch halo tile of the next chunk is fetched while the
+// A workgroup (NW waves) owns a (NW*NT) x 32 pixel tile and all output channels; wave w owns rows
+// [w*NT, w*NT+NT).  The (NW*NT+2) x 34 x 32ch halo tile of the next chunk is fetched while the
 // current one is multiplied (double-buffered LDS, one barrier per chunk).
 //
 // f16 (fast) : v_mfma_f32_32x32x16_f16, fp32 accumulate.   f32 (strict): v_mfma_f32_32x32x2_f32.
@@ -337,26 +339,10 @@ int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, co
     const int mt = d->cout_pad / 32;
     // 16-row tiles only when that still yields enough workgroups to fill 256 CUs twice over
     const long tiles4 = (long)((d->w + 31) / 32) * ((d->h + 15) / 16) * d->n;
-    static const char* nt_env = getenv("RESR_CONV_NT");     // tuning knob: force rows-per-wave 2 or 4
-    const bool big = nt_env ? (nt_env[0] == '4') : tiles4 >= 512;
-    static const char* nw_env = getenv("RESR_CONV_NW");
+    const bool big = tiles4 >= 512;
     if (d->dtype == RESR_F16) {
-        static const char* old_env = getenv("RESR_CONV_ONE_ROLE");  // tuning knob: the register-staged kernel below
+        static const char* old_env = getenv("RESR_CONV_ONE_ROLE");  // test knob: fast mode on the one-role kernel below
         if (!old_env && conv3x3_ws_supported(a)) return conv3x3_ws_f16(a, mt, stream);
-        if (nw_env) {   // tuning knob "<mt1 cfg><mt2 cfg>", each one of: a=<2,4> b=<4,4> c=<2,8> d=<4,8> e=<1,8>
-            const char c = mt == 1 ? nw_env[0] : nw_env[1];
-            if (mt == 1) {
-                if (c == 'a') return launch_conv<half_t, 1, 2, 4>(a, stream);
-                if (c == 'b') return launch_conv<half_t, 1, 4, 4>(a, stream);
-                if (c == 'c') return launch_conv<half_t, 1, 2, 8>(a, stream);
-                if (c == 'd') return launch_conv<half_t, 1, 4, 8>(a, stream);
-            } else {
-                if (c == 'a') return launch_conv<half_t, 2, 2, 4>(a, stream);
-                if (c == 'b') return launch_conv<half_t, 2, 4, 4>(a, stream);
-                if (c == 'c') return launch_conv<half_t, 2, 2, 8>(a, stream);
-                if (c == 'e') return launch_conv<half_t, 2, 1, 8>(a, stream);
-            }
-        }
         // measured on MI355X (B=8, 256^2): cout 32 -> 8 waves x 2 rows (4 waves/SIMD, 2 workgroups/CU) beats
         // 4 waves x 4 rows by 5-16 %; cout 64 -> 4 waves x 2 rows (2 waves/SIMD) beats every 8-wave shape
         if (mt == 1) return big ? launch_conv<half_t, 1, 2, 8>(a, stream) : launch_conv<half_t, 1, 2, 4>(a, stream);
