@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             const char* lbuf = smem + par * BUF;
             // halo rows of group gi+1 are read from LDS while the MFMAs of group gi run (ping-pong registers; NG is even)
             // when the register budget allows (PP); otherwise each group reads its own rows first
-            constexpr int PP = (MT * NT * 16 + (NT + 2) * 8 <= 112) ? 1 : 0;
+            constexpr int PP = (NWC == 4 || MT * NT * 16 + (NT + 2) * 8 <= 112) ? 1 : 0;   // 4-consumer shapes have a 256-register budget
             uint4 rowf[PP + 1][NT + 2];
             auto rload = [&](int slot, int gi) {
                 const char* bp = lbuf + boff[gi % 3][gi / 3];
