@@ -14,8 +14,8 @@
 //   bits[r]           [4][N,h,w] u32   training: 1-bit LeakyReLU masks of o1..o4, written by the forward convs and read by the
 //                                     mirrored backward passes instead of the saved activations (64 B -> 4 B per pixel)
 //   trunk_out         [2][N,h,w,32]   model.py:260 (chunk-planar, like the gT gradient ring of the backward pass)
-//   feat              [N,h,w,64]      model.py:261-262
-//   u1 [N,2h,2w,64], u2, c3 [N,4h,4w,64]   model.py:264-267 (nearest x2 folded into the conv's gather)
+//   feat              [2][N,h,w,32]   model.py:261-262
+//   u1 [2][N,2h,2w,32], u2, c3 [2][N,4h,4w,32]   model.py:264-267 (nearest x2 folded into the conv's gather)
 //   y                 [N,3,4h,4w] fp32 planar (module surface) + 1 byte/elem clamp pass-mask
 // Backward-data runs the *mirrored* dense block: gradients are laid out [g_y | g_o4 | g_o3 | g_o2 | g_o1]
 // (g_y: [N,h,w,64]; the slab gS = [g_o4 | g_o3 | g_o2 | g_o1] chunk-planar [4][N,h,w,32])
@@ -43,7 +43,6 @@ int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int
 int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t);
 int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int, float, hipStream_t);
 int add_inplace_dispatch(void*, const void*, long, int, hipStream_t);
-int add_planar64_dispatch(void*, const void*, long, int, hipStream_t);
 
 namespace {
 
@@ -365,6 +364,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
     const char* pk = (const char*)packed;
     const int N = d->n, h = p.h, w = p.w;
     const int nws = (int)b.ws.size();
+    if ((long)N * h * w * 32 * 16 > 0x7fffffffL) return fail(RESR_ERR_ARG, "generator: batch x resolution too large for 32-bit chunk strides");
     const int plane = N * h * w * 32;  // elements per 32-channel plane of the chunk-planar trunk tensors
     auto W = [&](const ConvSpec& c) { return pk + c.pk_fwd * es; };
     auto Bias = [&](const ConvSpec& c) { return params + c.b_off; };
@@ -414,29 +414,34 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         cd.in0_chunk_stride = plane;
         cd.res0_stride = b.out1_stride;
         cd.res0_chunk_stride = b.out1 == b.ws[0] ? plane : 0;
+        cd.out_stride = 32; cd.out_chunk_stride = plane;        // feat and the whole HR tail are chunk-planar [2][N,H,W,32] too
         RUN(conv3x3_dispatch(&cd, b.trunk_out, nullptr, W(c), Bias(c), b.out1, nullptr, nullptr, b.feat, nullptr, st));
     }
     {   // model.py:264
         const ConvSpec& c = p.convs[p.i_up1];
-        ResrConvDesc cd = conv_desc(p, N, 2 * h, 2 * w, 64, 64, 64, 0, 64, 64, 64, RESR_CONV_LRELU | RESR_CONV_UPSAMPLE_IN);
+        ResrConvDesc cd = conv_desc(p, N, 2 * h, 2 * w, 64, 64, 32, 0, 64, 64, 32, RESR_CONV_LRELU | RESR_CONV_UPSAMPLE_IN);
+        cd.in0_chunk_stride = plane; cd.out_chunk_stride = 4 * plane;
         RUN(conv3x3_dispatch(&cd, b.feat, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.u1, nullptr, st));
     }
     {   // model.py:265
         const ConvSpec& c = p.convs[p.i_up2];
-        ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 64, 0, 64, 64, 64, RESR_CONV_LRELU | RESR_CONV_UPSAMPLE_IN);
+        ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 32, 0, 64, 64, 32, RESR_CONV_LRELU | RESR_CONV_UPSAMPLE_IN);
+        cd.in0_chunk_stride = 4 * plane; cd.out_chunk_stride = 16 * plane;
         if (d->training) cd.flags |= RESR_CONV_WRITE_SIGNBITS;
         RUN(conv3x3_dispatch(&cd, b.u1, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.u2, b.bits_u2, st));
     }
     {   // model.py:267
         const ConvSpec& c = p.convs[p.i_conv3];
-        ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 64, 0, 64, 64, 64, RESR_CONV_LRELU);
+        ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 32, 0, 64, 64, 32, RESR_CONV_LRELU);
+        cd.in0_chunk_stride = 16 * plane; cd.out_chunk_stride = 16 * plane;
         if (d->training) cd.flags |= RESR_CONV_WRITE_SIGNBITS;
         RUN(conv3x3_dispatch(&cd, b.u2, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.c3, b.bits_c3, st));
     }
     {   // model.py:268-270
         const ConvSpec& c = p.convs[p.i_conv4];
-        ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 64, 0, c.cout, c.cout_pad, 0,
+        ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 32, 0, c.cout, c.cout_pad, 0,
                                     RESR_CONV_CLAMP01 | RESR_CONV_OUT_NCHW_F32);
+        cd.in0_chunk_stride = 16 * plane;
         RUN(conv3x3_dispatch(&cd, b.c3, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, y, b.ymask, st));
     }
     return RESR_OK;
@@ -457,7 +462,9 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     const char* pk = (const char*)packed;
     const int N = d->n, h = p.h, w = p.w;
     const int H4 = 4 * h, W4 = 4 * w, H2 = 2 * h, W2 = 2 * w;
+    if ((long)N * h * w * 32 * 16 > 0x7fffffffL) return fail(RESR_ERR_ARG, "generator: batch x resolution too large for 32-bit chunk strides");
     const int plane = N * h * w * 32;  // elements per 32-channel plane of the chunk-planar trunk tensors (ws[], gS)
+    const int pl2 = 4 * plane, pl4 = 16 * plane;   // planes of the 2x / 4x resolution tensors
 
     auto wconv = [&](const ConvSpec& c, const void* x0, int cin, int s0, const void* g, int gstride, float scale) {
         WgradConv wc;
@@ -490,39 +497,46 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     RUN(nchw_to_nhwc_dispatch(gy, b.g4, N, d->out_channels, H4, W4, 1, 32, d->dtype, b.ymask, st));
     {   // conv4                                                            model.py:268
         const ConvSpec& c = p.convs[p.i_conv4];
-        RUN(wgrad(c, H4, W4, b.c3, 64, 64, b.g4, 32, 0, 1.f));
-        ResrConvDesc cd = dgrad(H4, W4, b.g4, 32, 32, nullptr, 32, 0, 0, 64, 64, b.gA, 64, RESR_CONV_MASK | RESR_CONV_MASK_BITS);
+        RUN(wgrad(c, H4, W4, b.c3, 64, 32, b.g4, 32, 0, 1.f, pl4, 0));
+        ResrConvDesc cd = dgrad(H4, W4, b.g4, 32, 32, nullptr, 32, 0, 0, 64, 64, b.gA, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS);
+        cd.out_chunk_stride = pl4;
         RUN(conv3x3_dispatch(&cd, b.g4, nullptr, pk + p.pk_bwd_conv4 * es, nullptr, nullptr, nullptr, b.bits_c3, b.gA, nullptr, st));
     }
     {   // conv3                                                            model.py:267
         const ConvSpec& c = p.convs[p.i_conv3];
-        RUN(wgrad(c, H4, W4, b.u2, 64, 64, b.gA, 64, 0, 1.f));
-        ResrConvDesc cd = dgrad(H4, W4, b.gA, 64, 64, nullptr, 64, 0, 0, 64, 64, b.gB, 64, RESR_CONV_MASK | RESR_CONV_MASK_BITS);
+        RUN(wgrad(c, H4, W4, b.u2, 64, 32, b.gA, 32, 0, 1.f, pl4, pl4));
+        ResrConvDesc cd = dgrad(H4, W4, b.gA, 64, 32, nullptr, 64, 0, 0, 64, 64, b.gB, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS);
+        cd.in0_chunk_stride = pl4; cd.out_chunk_stride = pl4;
         RUN(conv3x3_dispatch(&cd, b.gA, nullptr, pk + p.pk_bwd_conv3 * es, nullptr, nullptr, nullptr, b.bits_u2, b.gB, nullptr, st));
     }
     if (debug_stop() == 1) return RESR_OK;
     {   // upsampling2                                                      model.py:265
         const ConvSpec& c = p.convs[p.i_up2];
-        RUN(wgrad(c, H4, W4, b.u1, 64, 64, b.gB, 64, RESR_CONV_UPSAMPLE_IN, 1.f));
-        ResrConvDesc cd = dgrad(H4, W4, b.gB, 64, 64, nullptr, 64, 0, 0, 64, 64, b.gA, 64, 0);
+        RUN(wgrad(c, H4, W4, b.u1, 64, 32, b.gB, 32, RESR_CONV_UPSAMPLE_IN, 1.f, pl2, pl4));
+        ResrConvDesc cd = dgrad(H4, W4, b.gB, 64, 32, nullptr, 64, 0, 0, 64, 64, b.gA, 32, 0);
+        cd.in0_chunk_stride = pl4; cd.out_chunk_stride = pl4;
         RUN(conv3x3_dispatch(&cd, b.gB, nullptr, pk + p.pk_bwd_up2 * es, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
-        RUN(sumpool2x2_dispatch(b.gA, b.gM1, b.u1, N, H2, W2, 64, d->dtype, 0.2f, st));
+        for (int q = 0; q < 2; ++q)   // per 32-channel plane
+            RUN(sumpool2x2_dispatch(b.gA + (size_t)q * pl4 * es, b.gM1 + (size_t)q * pl2 * es, b.u1 + (size_t)q * pl2 * es,
+                                    N, H2, W2, 32, d->dtype, 0.2f, st));
     }
     if (debug_stop() == 2) return RESR_OK;
     {   // upsampling1                                                      model.py:264
         const ConvSpec& c = p.convs[p.i_up1];
-        RUN(wgrad(c, H2, W2, b.feat, 64, 64, b.gM1, 64, RESR_CONV_UPSAMPLE_IN, 1.f));
-        ResrConvDesc cd = dgrad(H2, W2, b.gM1, 64, 64, nullptr, 64, 0, 0, 64, 64, b.gA, 64, 0);
+        RUN(wgrad(c, H2, W2, b.feat, 64, 32, b.gM1, 32, RESR_CONV_UPSAMPLE_IN, 1.f, plane, pl2));
+        ResrConvDesc cd = dgrad(H2, W2, b.gM1, 64, 32, nullptr, 64, 0, 0, 64, 64, b.gA, 32, 0);
+        cd.in0_chunk_stride = pl2; cd.out_chunk_stride = pl2;
         RUN(conv3x3_dispatch(&cd, b.gM1, nullptr, pk + p.pk_bwd_up1 * es, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
-        RUN(sumpool2x2_dispatch(b.gA, b.gF, nullptr, N, h, w, 64, d->dtype, 0.2f, st));
+        for (int q = 0; q < 2; ++q)
+            RUN(sumpool2x2_dispatch(b.gA + (size_t)q * pl2 * es, b.gF + (size_t)q * plane * es, nullptr, N, h, w, 32, d->dtype, 0.2f, st));
     }
     if (debug_stop() == 3) return RESR_OK;
     int cur = 0;  // index into gT ring of the gradient wrt the current RDB's output chain
     {   // conv2                                                            model.py:261
         const ConvSpec& c = p.convs[p.i_conv2];
-        RUN(wgrad(c, h, w, b.trunk_out, 64, 32, b.gF, 64, 0, 1.f, plane, 0));
-        ResrConvDesc cd = dgrad(h, w, b.gF, 64, 64, nullptr, 64, 0, 0, 64, 64, b.gT[0], 32, 0);
-        cd.out_chunk_stride = plane;   // the gT ring (gradient wrt the RDB chain) is chunk-planar [2][N,h,w,32]
+        RUN(wgrad(c, h, w, b.trunk_out, 64, 32, b.gF, 32, 0, 1.f, plane, plane));
+        ResrConvDesc cd = dgrad(h, w, b.gF, 64, 32, nullptr, 64, 0, 0, 64, 64, b.gT[0], 32, 0);
+        cd.in0_chunk_stride = plane; cd.out_chunk_stride = plane;   // the gT ring (gradient wrt the RDB chain) is chunk-planar [2][N,h,w,32]
         RUN(conv3x3_dispatch(&cd, b.gF, nullptr, pk + p.pk_bwd_conv2 * es, nullptr, nullptr, nullptr, nullptr, b.gT[0], nullptr, st));
     }
     // trunk, mirrored dense blocks.  gT ring: e (grad wrt RRDB output) must survive its three RDBs.
@@ -567,7 +581,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     }
     if (debug_stop() == 4) return RESR_OK;
     // gradient wrt out1 = trunk path + skip (model.py:262)
-    RUN(add_planar64_dispatch(b.gT[cur], b.gF, (long)N * h * w, d->dtype, st));
+    RUN(add_inplace_dispatch(b.gT[cur], b.gF, (long)N * h * w * 64, d->dtype, st));   // both chunk-planar [2][N,h,w,32]
     {   // conv1                                                            model.py:259
         const ConvSpec& c = p.convs[p.i_conv1];
         RUN(wgrad(c, h, w, b.x_in, p.ci_pad, p.ci_pad, b.gT[cur], 32, 0, 1.f, 0, plane));

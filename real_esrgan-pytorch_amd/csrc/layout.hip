@@ -5,7 +5,7 @@
 //   nhwc_to_nchw : the inverse (gradient wrt the input image), PixelShuffle folded in
 //   sumpool2x2   : backward of F.interpolate(scale_factor=2, mode="nearest") (model.py:264-265)
 //                  fused with the LeakyReLU backward of the producer
-//   add_inplace  : skip-connection gradient merge (model.py:262); add_planar64: same, into a chunk-planar tensor
+//   add_inplace  : skip-connection gradient merge (model.py:262)
 // All are one-pass, 16-byte vectorised where the layout allows; each thread owns one pixel.
 #include "common.h"
 
@@ -118,25 +118,6 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ dst, c
     *reinterpret_cast<uint4*>(dst + i) = a;
 }
 
-// dst: chunk-planar [2][npix][32];  src: interleaved [npix][64];  dst += src
-template <typename T>
-__global__ __launch_bounds__(256) void add_planar64_kernel(T* __restrict__ dst, const T* __restrict__ src, long npix) {
-    constexpr int E = 16 / (int)sizeof(T);
-    constexpr int VP = 32 / E;                       // 16-byte vectors per 32-channel chunk of a pixel
-    const long v = (long)blockIdx.x * 256 + threadIdx.x;
-    if (v >= npix * 2 * VP) return;
-    const long chunk = v / (npix * VP), rem = v - chunk * npix * VP;
-    const long pix = rem / VP, piece = rem - pix * VP;
-    T* d = dst + (chunk * npix + pix) * 32 + piece * E;
-    uint4 a = *reinterpret_cast<const uint4*>(d);
-    const uint4 b = *reinterpret_cast<const uint4*>(src + pix * 64 + chunk * 32 + piece * E);
-    T* pa = reinterpret_cast<T*>(&a);
-    const T* pb = reinterpret_cast<const T*>(&b);
-#pragma unroll
-    for (int e = 0; e < E; ++e) pa[e] = (T)((float)pa[e] + (float)pb[e]);
-    *reinterpret_cast<uint4*>(d) = a;
-}
-
 static unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
 
 int nchw_to_nhwc_dispatch(const float* src, void* dst, int n, int c, int h, int w, int r, int c_pad, int dtype,
@@ -188,17 +169,6 @@ int add_inplace_dispatch(void* dst, const void* src, long count, int dtype, hipS
     else
         hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, (float*)dst, (const float*)src, count);
     RESR_CHECK_LAUNCH("add_inplace_kernel");
-    return RESR_OK;
-}
-
-int add_planar64_dispatch(void* dst, const void* src, long npix, int dtype, hipStream_t stream) {
-    if (!dst || !src || npix <= 0) return fail(RESR_ERR_ARG, "add_planar64: bad argument");
-    const long total = npix * 2 * (dtype == RESR_F16 ? 4 : 8);
-    if (dtype == RESR_F16)
-        hipLaunchKernelGGL(add_planar64_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, (half_t*)dst, (const half_t*)src, npix);
-    else
-        hipLaunchKernelGGL(add_planar64_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, (float*)dst, (const float*)src, npix);
-    RESR_CHECK_LAUNCH("add_planar64_kernel");
     return RESR_OK;
 }
 
