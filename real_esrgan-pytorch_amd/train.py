@@ -86,9 +86,10 @@ class RealESRGANStep:
 
     def __init__(self, generator, discriminator, ema, g_optimizer, d_optimizer, scaler=None, degrade=None,
                  pixel_weight: float = 1.0, adversarial_weight: float = 0.1, content_criterion=None,
-                 content_weight=(0.1, 0.1, 1.0, 1.0, 1.0)) -> None:
+                 content_weight=(0.1, 0.1, 1.0, 1.0, 1.0), return_probabilities: bool = False) -> None:
         from . import imgproc
         self.g, self.d, self.ema = generator, discriminator, ema
+        self.return_probabilities = return_probabilities
         self.g_opt, self.d_opt, self.scaler, self.degrade = g_optimizer, d_optimizer, scaler, degrade
         self.pixel_weight, self.adversarial_weight = pixel_weight, adversarial_weight
         self.content, self.content_weight = content_criterion, content_weight
@@ -146,4 +147,7 @@ class RealESRGANStep:
                "d_loss_hr": d_loss_hr.detach(), "d_loss_sr": d_loss_sr.detach()}
         if content_loss is not None:
             out["content_loss"] = content_loss
+        if self.return_probabilities:                                                      # :524-525 (logging only)
+            out["d_hr_probability"] = torch.sigmoid(hr_out.detach().float().mean())
+            out["d_sr_probability"] = torch.sigmoid(sr_out.detach().float().mean())
         return out

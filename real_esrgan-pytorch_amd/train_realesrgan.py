@@ -1,0 +1,201 @@
+"""RealESRGAN training entry point behind the reference's `train_realesrgan.py` surface: same
+function names, epoch loop, the two checkpoint dictionaries and their file names (`d_epoch_N` / `g_epoch_N`,
+`d_best` / `g_best`, `d_last` / `g_last`), the three ways of resuming, NIQE validation under the EMA weights.
+
+    RESR_MODE=train_realesrgan python -m real_esrgan_pytorch_amd.train_realesrgan
+
+The step is `train.RealESRGANStep` (degradation -> generator update with the discriminator frozen -> two discriminator
+backwards -> EMA; reference train_realesrgan.py:459-521) on the HIP kernels; the degradation uses the blur kernels the
+dataset sampled for each image, USM-sharpened ground truth included (reference :330-452).  Scalars go to
+`samples/logs/<exp>/scalars.jsonl` under the reference's tags.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import time
+from typing import Any, List, Optional
+
+import torch
+from torch import nn, optim
+from torch.optim import lr_scheduler
+
+from . import config, imgproc
+from .content_loss import ContentLoss
+from .dataset import CUDAPrefetcher
+from .degrade import run_plan, sample_plan
+from .discriminator import Discriminator
+from .image_quality_assessment import NIQE
+from .model import EMA, Generator
+from .train import RealESRGANStep
+from .train_realesrnet import AverageMeter, ProgressMeter, ScalarWriter, load_dataset, validate  # noqa: F401
+
+
+def build_model() -> List[nn.Module]:
+    """Reference train_realesrgan.py:223-237."""
+    precision = getattr(config, "precision", "fast")
+    discriminator = Discriminator(precision=precision).to(device=config.device)
+    generator = Generator(config.in_channels, config.out_channels, config.upscale_factor,
+                          precision=precision).to(device=config.device)
+    ema_model = EMA(generator, config.ema_model_weight_decay).to(device=config.device)
+    ema_model.register()
+    return [discriminator, generator, ema_model]
+
+
+def define_loss() -> List[nn.Module]:
+    """Reference train_realesrgan.py:240-253.  The VGG19 weights are torchvision's in the reference (a download);
+    here they are whatever `content_criterion.load_state_dict` is given, random otherwise -- the term is logged only
+    (see `train.RealESRGANStep`)."""
+    pixel_criterion = nn.L1Loss().to(device=config.device)
+    content_criterion = ContentLoss(config.feature_model_extractor_nodes, config.feature_model_normalize_mean,
+                                    config.feature_model_normalize_std,
+                                    precision=getattr(config, "precision", "fast")).to(device=config.device)
+    adversarial_criterion = nn.BCEWithLogitsLoss().to(device=config.device)
+    return [pixel_criterion, content_criterion, adversarial_criterion]
+
+
+def define_optimizer(discriminator: nn.Module, generator: nn.Module) -> List[optim.Adam]:
+    return [optim.Adam(discriminator.parameters(), config.model_lr, config.model_betas),
+            optim.Adam(generator.parameters(), config.model_lr, config.model_betas)]
+
+
+def define_scheduler(d_optimizer: optim.Adam, g_optimizer: optim.Adam) -> List[lr_scheduler.MultiStepLR]:
+    return [lr_scheduler.MultiStepLR(d_optimizer, config.lr_scheduler_milestones, config.lr_scheduler_gamma),
+            lr_scheduler.MultiStepLR(g_optimizer, config.lr_scheduler_milestones, config.lr_scheduler_gamma)]
+
+
+def _load(path: str) -> dict:
+    return torch.load(path, map_location=lambda storage, loc: storage, weights_only=False)
+
+
+def _update_state(module: nn.Module, saved: dict) -> None:
+    """Keys present in the current module are taken, the rest ignored (reference :75-79, :93-104)."""
+    current = module.state_dict()
+    current.update({k: v for k, v in saved.items() if k in current})
+    module.load_state_dict(current)
+
+
+def main() -> None:
+    start_epoch, best_niqe = 0, 100.0
+    train_prefetcher, valid_prefetcher, test_prefetcher = load_dataset()
+    discriminator, generator, ema_model = build_model()
+    pixel_criterion, content_criterion, adversarial_criterion = define_loss()
+    d_optimizer, g_optimizer = define_optimizer(discriminator, generator)
+    d_scheduler, g_scheduler = define_scheduler(d_optimizer, g_optimizer)
+    if config.resume:                                     # RealESRNet weights into the generator (:60-65)
+        generator.load_state_dict(_load(config.resume)["state_dict"])
+        print("Loaded RealESRNet model weights.")
+    if getattr(config, "resume_d", ""):                   # :68-84
+        checkpoint = _load(config.resume_d)
+        start_epoch, best_niqe = checkpoint["epoch"], checkpoint["best_niqe"]
+        _update_state(discriminator, checkpoint["state_dict"])
+        d_optimizer.load_state_dict(checkpoint["optimizer"])
+        d_scheduler.load_state_dict(checkpoint["scheduler"])
+        print("Loaded pretrained discriminator model weights.")
+    if getattr(config, "resume_g", ""):                   # :87-110
+        checkpoint = _load(config.resume_g)
+        start_epoch, best_niqe = checkpoint["epoch"], checkpoint["best_niqe"]
+        _update_state(generator, checkpoint["state_dict"])
+        _update_state(ema_model, checkpoint["ema_state_dict"])
+        g_optimizer.load_state_dict(checkpoint["optimizer"])
+        g_scheduler.load_state_dict(checkpoint["scheduler"])
+        print("Loaded pretrained generator model weights.")
+    samples_dir = os.path.join("samples", config.exp_name)
+    results_dir = os.path.join("results", config.exp_name)
+    os.makedirs(samples_dir, exist_ok=True)
+    os.makedirs(results_dir, exist_ok=True)
+    writer = ScalarWriter(os.path.join("samples", "logs", config.exp_name))
+    scaler = torch.amp.GradScaler("cuda") if getattr(config, "precision", "fast") == "fast" else None
+    niqe_model = NIQE(config.upscale_factor, config.niqe_model_path).to(device=config.device)
+    for epoch in range(start_epoch, config.epochs):
+        train(discriminator, generator, ema_model, train_prefetcher, pixel_criterion, content_criterion,
+              adversarial_criterion, d_optimizer, g_optimizer, epoch, scaler, writer)
+        _ = validate(generator, ema_model, valid_prefetcher, epoch, writer, niqe_model, "Valid")
+        niqe = validate(generator, ema_model, test_prefetcher, epoch, writer, niqe_model, "Test")
+        print("\n")
+        d_scheduler.step()
+        g_scheduler.step()
+        is_best = niqe < best_niqe
+        best_niqe = min(niqe, best_niqe)
+        d_path = os.path.join(samples_dir, f"d_epoch_{epoch + 1}.pth.tar")
+        g_path = os.path.join(samples_dir, f"g_epoch_{epoch + 1}.pth.tar")
+        torch.save({"epoch": epoch + 1, "best_niqe": best_niqe, "state_dict": discriminator.state_dict(),
+                    "optimizer": d_optimizer.state_dict(), "scheduler": d_scheduler.state_dict()}, d_path)
+        torch.save({"epoch": epoch + 1, "best_niqe": best_niqe, "state_dict": generator.state_dict(),
+                    "ema_state_dict": ema_model.state_dict(), "optimizer": g_optimizer.state_dict(),
+                    "scheduler": g_scheduler.state_dict()}, g_path)
+        if is_best:
+            shutil.copyfile(d_path, os.path.join(results_dir, "d_best.pth.tar"))
+            shutil.copyfile(g_path, os.path.join(results_dir, "g_best.pth.tar"))
+        if (epoch + 1) == config.epochs:
+            shutil.copyfile(d_path, os.path.join(results_dir, "d_last.pth.tar"))
+            shutil.copyfile(g_path, os.path.join(results_dir, "g_last.pth.tar"))
+
+
+def train(discriminator: nn.Module, generator: nn.Module, ema_model: nn.Module, train_prefetcher: CUDAPrefetcher,
+          pixel_criterion: nn.L1Loss, content_criterion: Optional[ContentLoss],
+          adversarial_criterion: nn.BCEWithLogitsLoss, d_optimizer: optim.Adam, g_optimizer: optim.Adam, epoch: int,
+          scaler: Optional["torch.amp.GradScaler"], writer: Any) -> None:
+    """Reference train_realesrgan.py:282-553."""
+    jpeg_operation = imgproc.DiffJPEG(False)
+    usm_sharpener = imgproc.USMSharp(50, 0).to(device=config.device)
+    batches = len(train_prefetcher)
+    batch_time = AverageMeter("Time", ":6.3f")
+    data_time = AverageMeter("Data", ":6.3f")
+    pixel_losses = AverageMeter("Pixel loss", ":6.6f")
+    content_losses = AverageMeter("Content loss", ":6.6f")
+    adversarial_losses = AverageMeter("Adversarial loss", ":6.6f")
+    d_hr_probabilities = AverageMeter("D(HR)", ":6.3f")
+    d_sr_probabilities = AverageMeter("D(SR)", ":6.3f")
+    progress = ProgressMeter(batches, [batch_time, data_time, pixel_losses, content_losses, adversarial_losses,
+                                       d_hr_probabilities, d_sr_probabilities], prefix=f"Epoch: [{epoch + 1}]")
+    discriminator.train()
+    generator.train()
+
+    def degrade(hr):   # host draws in the reference's order, kernels from the dataset batch (:330-452)
+        plan = sample_plan(hr.shape[0], hr.shape[2], hr.shape[3], config.image_size, with_kernels=False)
+        plan.kernel1, plan.kernel2, plan.sinc_kernel = kernels
+        return run_plan(hr, plan, usm_sharpener, jpeg_operation, config.upscale_factor, config.image_size)
+
+    step = RealESRGANStep(generator, discriminator, ema_model, g_optimizer, d_optimizer, scaler, degrade,
+                          config.pixel_weight, config.adversarial_weight, content_criterion, config.content_weight,
+                          return_probabilities=True)
+    step.pixel, step.adv = pixel_criterion, adversarial_criterion
+    batch_index = 0
+    train_prefetcher.reset()
+    batch_data = train_prefetcher.next()
+    end = time.time()
+    while batch_data is not None:
+        data_time.update(time.time() - end)
+        hr = batch_data["hr"].to(device=config.device, non_blocking=True)
+        kernels = (batch_data["kernel1"], batch_data["kernel2"], batch_data["sinc_kernel"])
+        out = step(hr)
+        # one D2H transfer for everything the meters and the log need (the reference does 5-12 `.item()` syncs)
+        names = ["pixel_loss", "content_loss", "adversarial_loss", "d_loss_hr", "d_loss_sr", "d_hr_probability",
+                 "d_sr_probability"]
+        zero = out["pixel_loss"].new_zeros(())
+        vals = dict(zip(names, torch.stack([out.get(k, zero).float() for k in names]).tolist()))
+        n = hr.size(0)
+        pixel_losses.update(vals["pixel_loss"], n)
+        content_losses.update(vals["content_loss"], n)
+        adversarial_losses.update(vals["adversarial_loss"], n)
+        d_hr_probabilities.update(vals["d_hr_probability"], n)
+        d_sr_probabilities.update(vals["d_sr_probability"], n)
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if batch_index % config.print_frequency == 0:
+            iters = batch_index + epoch * batches + 1
+            writer.add_scalar("Train/D_Loss", vals["d_loss_hr"] + vals["d_loss_sr"], iters)
+            writer.add_scalar("Train/G_Loss", vals["pixel_loss"] + vals["content_loss"] + vals["adversarial_loss"], iters)
+            writer.add_scalar("Train/Pixel_Loss", vals["pixel_loss"], iters)
+            writer.add_scalar("Train/Content_Loss", vals["content_loss"], iters)
+            writer.add_scalar("Train/Adversarial_Loss", vals["adversarial_loss"], iters)
+            writer.add_scalar("Train/D(HR)_Probability", vals["d_hr_probability"], iters)
+            writer.add_scalar("Train/D(SR)_Probability", vals["d_sr_probability"], iters)
+            progress.display(batch_index)
+        batch_data = train_prefetcher.next()
+        batch_index += 1
+
+
+if __name__ == "__main__":
+    main()

@@ -20,10 +20,8 @@ def _smooth_png(path, size, seed):
     Image.fromarray((x[0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)).save(path)
 
 
-def test_train_validate_checkpoint_resume(tmp_path, monkeypatch):
-    import real_esrgan_pytorch_amd as R
+def _tiny_dataset(tmp_path, monkeypatch, **extra):
     from real_esrgan_pytorch_amd import config, imgproc
-    from real_esrgan_pytorch_amd import train_realesrnet as T
     for sub, n in (("train", 4), ("valid", 2), ("test_hr", 2)):
         os.makedirs(tmp_path / sub)
         for i in range(n):
@@ -40,9 +38,16 @@ def test_train_validate_checkpoint_resume(tmp_path, monkeypatch):
                      image_size=208, batch_size=2, num_workers=0, epochs=1, print_frequency=1, resume="",
                      lr_scheduler_step_size=1, exp_name="harness_test",
                      niqe_model_path=os.path.join(here, "golden", "niqe_model.mat"),
-                     device=torch.device("cuda", 0)).items():
+                     device=torch.device("cuda", 0), **extra).items():
         monkeypatch.setattr(config, k, v, raising=False)
     monkeypatch.chdir(tmp_path)
+
+
+def test_train_validate_checkpoint_resume(tmp_path, monkeypatch):
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd import config
+    from real_esrgan_pytorch_amd import train_realesrnet as T
+    _tiny_dataset(tmp_path, monkeypatch)
     T.main()
     ck1 = tmp_path / "samples" / "harness_test" / "g_epoch_1.pth.tar"
     assert ck1.exists() and (tmp_path / "results" / "harness_test" / "g_last.pth.tar").exists()
@@ -62,3 +67,54 @@ def test_train_validate_checkpoint_resume(tmp_path, monkeypatch):
     # the reference's inference loader reads it: strip "model." (inference.py:33)
     g = R.Generator(3, 3, 4).cuda()
     g.load_state_dict({k[len("model."):]: v for k, v in ck2["ema_state_dict"].items()})
+
+
+def test_gan_train_checkpoints_resume_and_directory_test(tmp_path, monkeypatch):
+    """`train_realesrgan.main()` from a RealESRNet checkpoint, its two checkpoint families, resume_d / resume_g, and
+    `test.main()` over the LR folder with the resulting EMA weights."""
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd import config
+    from real_esrgan_pytorch_amd import test as E
+    from real_esrgan_pytorch_amd import train_realesrgan as T
+    _tiny_dataset(tmp_path, monkeypatch, resume_d="", resume_g="", pixel_weight=1.0, adversarial_weight=0.1,
+                  content_weight=[0.1, 0.1, 1.0, 1.0, 1.0], lr_scheduler_milestones=[1], lr_scheduler_gamma=0.5,
+                  model_lr=1e-4, model_betas=(0.9, 0.99), ema_model_weight_decay=0.999,
+                  feature_model_extractor_nodes=["features.2", "features.7", "features.16", "features.25", "features.34"],
+                  feature_model_normalize_mean=[0.485, 0.456, 0.406], feature_model_normalize_std=[0.229, 0.224, 0.225])
+    torch.manual_seed(3)
+    net = R.Generator(3, 3, 4)
+    torch.save({"state_dict": net.state_dict()}, tmp_path / "esrnet.pth.tar")            # what train_realesrnet leaves (g_last)
+    monkeypatch.setattr(config, "resume", str(tmp_path / "esrnet.pth.tar"))
+    T.main()
+    samples, results = tmp_path / "samples" / "harness_test", tmp_path / "results" / "harness_test"
+    for name in ("d_best", "g_best", "d_last", "g_last"):
+        assert (results / f"{name}.pth.tar").exists()
+    d1 = torch.load(samples / "d_epoch_1.pth.tar", weights_only=False)
+    g1 = torch.load(samples / "g_epoch_1.pth.tar", weights_only=False)
+    assert set(d1) == {"epoch", "best_niqe", "state_dict", "optimizer", "scheduler"}
+    assert set(g1) == {"epoch", "best_niqe", "state_dict", "ema_state_dict", "optimizer", "scheduler"}
+    assert any(k.endswith("weight_orig") for k in d1["state_dict"])                      # spectral-norm parametrisation kept
+    w0, w1 = net.state_dict()["conv1.weight"], g1["state_dict"]["conv1.weight"].cpu()
+    assert not torch.equal(w0, w1) and (w0 - w1).abs().max() < 1e-2                      # started from the RealESRNet weights, then moved
+    tags = {json.loads(l)["tag"] for l in open(tmp_path / "samples" / "logs" / "harness_test" / "scalars.jsonl")}
+    assert {"Train/D_Loss", "Train/G_Loss", "Train/Pixel_Loss", "Train/Content_Loss", "Train/Adversarial_Loss",
+            "Train/D(HR)_Probability", "Train/D(SR)_Probability", "Valid/NIQE", "Test/NIQE"} <= tags
+    # resume both networks for one more epoch
+    for k, v in dict(resume="", resume_d=str(samples / "d_epoch_1.pth.tar"), resume_g=str(samples / "g_epoch_1.pth.tar"),
+                     epochs=2).items():
+        monkeypatch.setattr(config, k, v)
+    T.main()
+    d2 = torch.load(samples / "d_epoch_2.pth.tar", weights_only=False)
+    g2 = torch.load(samples / "g_epoch_2.pth.tar", weights_only=False)
+    assert d2["epoch"] == g2["epoch"] == 2
+    assert d2["optimizer"]["state"][0]["step"] == 4 and g2["optimizer"]["state"][0]["step"] == 4
+    assert g2["optimizer"]["param_groups"][0]["lr"] == pytest.approx(5e-5)        # 1e-4, milestone 1 passed once
+    # directory evaluation with the EMA weights (reference test.py)
+    for k, v in dict(lr_dir=str(tmp_path / "test_lr"), sr_dir=str(tmp_path / "sr"), hr_dir=str(tmp_path / "test_hr"),
+                     model_path=str(results / "g_last.pth.tar")).items():
+        monkeypatch.setattr(config, k, v, raising=False)
+    score = E.main()
+    assert 0 < score <= 100 and sorted(os.listdir(tmp_path / "sr")) == ["0.png", "1.png"]
+    from PIL import Image
+    assert Image.open(tmp_path / "sr" / "0.png").size == (224, 224)                     # 56x56 LR, x4
+

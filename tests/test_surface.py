@@ -112,3 +112,9 @@ def test_discriminator_surface_matches_reference_init(built):
     assert torch.allclose(sums, torch.from_numpy(z["total_sum"]), rtol=0, atol=1e-9), "init RNG stream differs"
     with pytest.raises(RuntimeError, match="no CPU path"):
         d(torch.rand(1, 3, 16, 16))
+
+
+def test_natural_sort():
+    from real_esrgan_pytorch_amd.test import natural_sorted
+    assert natural_sorted(["img10.png", "img2.png", "a.png", "img1.png", "10.png", "9.png"]) == \
+        ["9.png", "10.png", "a.png", "img1.png", "img2.png", "img10.png"]
