@@ -139,6 +139,8 @@ def pmc_traffic(kernel, batch):
 def kernel_name(kid):
     if kid >= 50000:
         k = kid - 50000
+        if k == 200:
+            return "wgrad_quad_kernel<f16>"
         return f"wgrad_kernel<{'f32' if k >= 100 else 'f16'},{k % 100}>"
     if kid >= 20000:  # fast-mode producer/consumer kernel: <f16, MT, NT, consumer waves>
         k = kid - 20000

@@ -152,15 +152,24 @@ struct Bufs {
     size_t total;
 };
 
-// pixel splits of a batched weight-gradient launch: enough workgroups (jobs x splits) to fill 256 CUs
-// about three times over, but never fewer than two pixel tiles per workgroup
-int splits_for(const Plan& p, int njobs, int h, int w) {
+// pixel splits of a batched weight-gradient launch (`npairs` = (X chunk, G tile) products), never fewer than two pixel
+// tiles per workgroup.  strict: one workgroup per product and split, 256 CUs filled about three times over.  fast: the
+// quad kernel runs one 8-wave workgroup per CU on npairs/4 jobs -- two rounds of 256, in whole groups of 8 splits
+// (a split's jobs share one XCD).
+int splits_for(const Plan& p, int npairs, int h, int w) {
     if (p.d.wgrad_splits > 0) return p.d.wgrad_splits;
     const int th = wgrad_tile_rows(p.d.dtype);
     const long tiles = (long)((w + 31) / 32) * ((h + th - 1) / th) * p.d.n;
-    long s = 768 / njobs;
+    long s;
+    if (p.d.dtype == RESR_F16) {
+        s = 512 / ((npairs + 3) / 4);
+        if (s >= 16) s &= ~7L;
+        if (s > 256) s = 256;
+    } else {
+        s = 768 / npairs;
+        if (s > 128) s = 128;
+    }
     if (s > tiles / 2) s = tiles / 2;
-    if (s > 128) s = 128;
     if (s < 1) s = 1;
     return (int)s;
 }

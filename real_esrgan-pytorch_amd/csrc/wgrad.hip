@@ -25,7 +25,8 @@
 
 namespace resr {
 
-constexpr int kMaxJobs = 40;
+constexpr int kMaxJobs = 80;    // (X chunk, G tile) pairs per launch
+constexpr int kMaxQuads = 40;   // 2x2 jobs per launch of the quad kernel
 constexpr int kSlab = 9 * 1024 + 32;   // floats per (job, split): 9 taps x 32 co x 32 ci, then 32 bias sums
 
 struct WgradJob {
@@ -321,6 +322,224 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// f16 quad kernel: one job = up to 2 X chunks x 2 G tiles (four 32x32x9 products) on one staged pixel tile.
+//
+// The pair kernel above stages 128 B per pixel for one product and is bound by the L2 -> LDS delivery rate of a CU
+// (~25 GB/s), not by the matrix pipe.  Here the same 8 waves of a CU form ONE workgroup that shares a staged tile of
+// 2 x 64 B (X) + 2 x 64 B (G) per pixel between four products: half the staged bytes per FLOP.  Wave w computes product
+// p = w >> 1 (X chunk p & 1, G tile p >> 1) on rows [4 (w & 1), +4) of the 8 x 32 tile.  The LDS-DMA of the next tile
+// is issued one instruction at a time between the MFMAs of the current one, so a wave that stalls on the memory
+// pipe's back-pressure leaves the matrix pipe to its SIMD partner instead of stalling a whole staging phase.
+// Products a job does not need (slab_off == ~0u) are computed by their two waves all the same and not written.
+struct WgradQuad {
+    const char* x[2];
+    const char* g[2];
+    unsigned xstride_b[2], gstride_b[2];
+    unsigned slab_off[4];   // float offset of product p's [splits][kSlab] slabs, ~0u = product not wanted
+    unsigned bias_mask;     // bit p: product p also yields sum_p G (one product per G tile does)
+    unsigned pad_;
+};
+
+struct WgradQuadArgs {
+    WgradQuad jobs[kMaxQuads];
+    float* partial;
+    const char* zero;
+    int n, h, w_, hs, ws;
+    int up, splits, njobs;
+    int tiles_x, tiles_y, ntiles;
+};
+
+constexpr int kQXW = 22;                          // waves of LDS-DMA lanes per X chunk (10 x 34 px x 4 pieces = 1360 slots)
+constexpr int kQXCH = kQXW * 1024;                // bytes per X chunk image in LDS
+constexpr int kQGT = 16 * 1024;                   // bytes per G tile image (8 x 32 px x 64 B)
+constexpr int kQBUF = 2 * kQXCH + 2 * kQGT;       // one stage: 77,824 B; two stages = 152 KB of the 160 KB LDS
+
+__global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs a) {
+    constexpr int PB = 64, HW = 34;
+    constexpr int NSX = 6, NSG = 4;               // LDS-DMA instructions per wave per tile: 44 X waves / 8, 32 G waves / 8
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bx = blockIdx.x & 7, bk = blockIdx.x >> 3;   // all jobs of one pixel split on one XCD (see wgrad_kernel)
+    const int split = bx + 8 * (bk / a.njobs);
+    if (split >= a.splits) return;
+    const WgradQuad& job = a.jobs[bk % a.njobs];
+    // scalar copies: a field read inside the MFMA loop would be an s_load + lgkmcnt(0) in the middle of the LDS reads
+    const char* const jx0 = job.x[0]; const char* const jx1 = job.x[1];
+    const char* const jg0 = job.g[0]; const char* const jg1 = job.g[1];
+    const unsigned sx0 = job.xstride_b[0], sx1 = job.xstride_b[1], sg0 = job.gstride_b[0], sg1 = job.gstride_b[1];
+    const char* const zero = a.zero;
+    const int img_h = a.h, img_w = a.w_, src_w = a.ws, up = a.up;
+    const bool two_x = jx1 != nullptr, two_g = jg1 != nullptr;
+
+    // lane -> slot maps (tile independent).  X wave ws = i*8 + wave: chunk ws >= 22, slot (ws % 22)*64 + lane.
+    unsigned cx[NSX], cg[NSG];
+#pragma unroll
+    for (int i = 0; i < NSX; ++i) {
+        const int ws = i * 8 + wave;
+        const int chunk = ws >= kQXW ? 1 : 0;
+        const unsigned s = (unsigned)(ws - kQXW * chunk) * 64 + lane;
+        const unsigned c16 = s & 3, hp = s >> 2;
+        const unsigned hy = (hp * 61681u) >> 21;  // hp / 34, exact below 100000
+        const bool ok = ws < 2 * kQXW && s < 1360u && (chunk == 0 || two_x);
+        cx[i] = ok ? (hy << 8 | (hp - hy * HW) | (c16 << 20)) : ~0u;
+    }
+#pragma unroll
+    for (int i = 0; i < NSG; ++i) {
+        const unsigned s = (unsigned)(((i & 1) * 8 + wave) * 64 + lane);   // tile = i >> 1
+        const unsigned c16 = s & 3, r = s >> 2;
+        cg[i] = (i < 2 || two_g) ? ((r >> 5) << 8 | (r & 31) | (c16 << 20)) : ~0u;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    struct TileAt { int x0, y0; unsigned xn, gn; };
+    auto tile_at = [&](int tile) {
+        const int tx = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty = t2 % a.tiles_y;
+        const int n = t2 / a.tiles_y;
+        TileAt t;
+        t.x0 = tx * 32; t.y0 = ty * 8;
+        t.xn = (unsigned)n * a.hs * a.ws; t.gn = (unsigned)n * a.h * a.w_;
+        return t;
+    };
+    // Branch-free staging (the MFMA loop stays one basic block): lanes outside the image read the zero page through a
+    // per-lane address select; lanes / waves without a slot are masked off inside the asm by narrowing EXEC.
+    auto dma = [&](const char* src, unsigned dst, bool on) {
+        const unsigned long long mask = __ballot(on);
+        unsigned long long save;
+        asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %3, off\n\ts_mov_b64 exec, %0"
+                     : "=&s"(save) : "s"(mask), "s"(dst), "v"(src) : "memory", "m0");
+    };
+    auto stage_x = [&](int i, const TileAt& t, int buf, bool go) {
+        const unsigned c = cx[i];
+        const int ws = i * 8 + wave;
+        const int chunk = ws >= kQXW ? 1 : 0;                                  // wave-uniform
+        const int iy = t.y0 - 1 + (int)((c >> 8) & 0xff), ix = t.x0 - 1 + (int)(c & 0xff);
+        const bool in = (unsigned)iy < (unsigned)img_h && (unsigned)ix < (unsigned)img_w;
+        const unsigned pix = t.xn + (unsigned)(iy >> up) * src_w + (unsigned)(ix >> up);
+        const char* src = (chunk ? jx1 : jx0) + (__umul24(pix, chunk ? sx1 : sx0) + ((c >> 16) & 0xfff));
+        src = in ? src : zero;
+        dma(src, lds0 + buf * kQBUF + ws * 1024, go && c != ~0u);
+    };
+    auto stage_g = [&](int i, const TileAt& t, int buf, bool go) {
+        const unsigned c = cg[i];
+        const int gt = i >> 1;
+        const int iy = t.y0 + (int)((c >> 8) & 0xff), ix = t.x0 + (int)(c & 0xff);
+        const bool in = iy < img_h && ix < img_w;
+        const unsigned pix = t.gn + (unsigned)iy * img_w + (unsigned)ix;
+        const char* src = (gt ? jg1 : jg0) + (__umul24(pix, gt ? sg1 : sg0) + ((c >> 16) & 0xfff));
+        src = in ? src : zero;
+        dma(src, lds0 + buf * kQBUF + 2 * kQXCH + (i * 8 + wave) * 1024, go && c != ~0u);
+    };
+    auto stage_slot = [&](int k, const TileAt& t, int buf, bool go) {   // k = 0..9
+        if (k < NSX) stage_x(k, t, buf, go);
+        else stage_g(k - NSX, t, buf, go);
+    };
+
+    float16v acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+
+    const int prod = wave >> 1, khalf = wave & 1;
+    const int xi = prod & 1, gi = prod >> 1;
+    const int kh = lane >> 5, a16 = lane & 15;
+    const int chb = ((((lane >> 4) & 1) << 4) + ((a16 & 3) << 2)) * 2;
+    const int pxl = (kh << 3) + (a16 >> 2);
+    const int goff = 2 * kQXCH + gi * kQGT + ((khalf * 4 * 32 + pxl) * PB) + chb;
+    const int xoff = xi * kQXCH + ((khalf * 4 * HW + pxl) * PB) + chb;
+
+    int tile = split;
+    {
+        const TileAt t0 = tile_at(tile < a.ntiles ? tile : 0);
+#pragma unroll
+        for (int k = 0; k < NSX + NSG; ++k) stage_slot(k, t0, 0, tile < a.ntiles);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the asm LDS-DMA is not counted by the compiler
+    __syncthreads();
+    int it = 0;
+    for (; tile < a.ntiles; tile += a.splits, ++it) {
+        const int next = tile + a.splits;
+        const bool has_next = next < a.ntiles;
+        const TileAt tn = tile_at(has_next ? next : tile);
+        const int nb = (it + 1) & 1;
+        const char* gbase = smem + (it & 1) * kQBUF + goff;
+        const char* xbase = smem + (it & 1) * kQBUF + xoff;
+        // X-row-major walk: halo row j of the wave's 6 serves output rows j (dy 0), j-1 (dy 1), j-2 (dy 2), so every
+        // X fragment is read from LDS once (88 transpose reads per tile instead of 160 -- the LDS pipe, not the
+        // matrix pipe, was the limit); the G fragments of the last three output rows stay in registers.
+        // Software pipeline: the transpose reads of step st+1 are issued before the MFMAs of step st (a step = one
+        // halo row j of one 16-pixel half kbh), so the matrix pipe never waits for an LDS round trip inside a tile.
+        uint4 fg[2][4], fb[2][3];
+        auto fload = [&](int st) {
+            const int kbh = st / 6, j = st % 6;
+            if (j < 4) {
+                const char* ga = gbase + (j * 32 + kbh * 16) * PB;
+                const uint2 alo = tr_read(ga), ahi = tr_read(ga + 4 * PB);
+                fg[kbh][j] = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
+            }
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const char* xa = xbase + (j * HW + kbh * 16 + dx) * PB;
+                const uint2 lo = tr_read(xa), hi = tr_read(xa + 4 * PB);
+                fb[st & 1][dx] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        };
+        fload(0);
+#pragma unroll
+        for (int st = 0; st < 12; ++st) {
+            const int kbh = st / 6, j = st % 6;
+            if (st + 1 < 12) fload(st + 1);
+            if (j < 4) bsum += sum8_f16(fg[kbh][j]);     // 4 dot instructions; only written where a bias is wanted
+            bool staged = false;
+#pragma unroll
+            for (int dy = 2; dy >= 0; --dy) {    // descending: the accumulators the previous step touched last come last
+                const int r = j - dy;
+                if (r < 0 || r > 3) continue;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fg[kbh][r]),
+                                                                              __builtin_bit_cast(half8, fb[st & 1][dx]), acc[dy * 3 + dx], 0, 0, 0);
+                if (!staged && st < NSX + NSG) { stage_slot(st, tn, nb, has_next); staged = true; }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's asm LDS-DMA has landed
+        __syncthreads();
+    }
+
+    // ---- sum the two row-halves of every product through LDS, write the slabs ---------------------------------
+    float* red = reinterpret_cast<float*>(smem);               // [8 waves][16 regs][64 lanes]
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[tap][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + i * 512;
+            const int p = e >> 10, q = e & 1023;                 // p is wave-uniform (512 | 1024)
+            const int r = q >> 6, l = q & 63;
+            const float s = red[(2 * p) * 1024 + q] + red[(2 * p + 1) * 1024 + q];
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ci = l & 31;
+            if (job.slab_off[p] != ~0u) a.partial[job.slab_off[p] + (size_t)split * kSlab + tap * 1024 + co * 32 + ci] = s;
+        }
+        __syncthreads();
+    }
+    red[wave * 64 + lane] = bsum;
+    __syncthreads();
+    if (tid < 128) {
+        const int p = tid >> 5, c = tid & 31;
+        const float s = (red[(2 * p) * 64 + c] + red[(2 * p) * 64 + 32 + c]) + (red[(2 * p + 1) * 64 + c] + red[(2 * p + 1) * 64 + 32 + c]);
+        if (((job.bias_mask >> p) & 1) && job.slab_off[p] != ~0u)
+            a.partial[job.slab_off[p] + (size_t)split * kSlab + 9 * 1024 + c] = s;
+    }
+}
+
 // deterministic slab reduction -> OIHW fp32 gradient (+ bias gradient)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     const ReduceJob job = a.jobs[blockIdx.x];
@@ -374,6 +593,101 @@ static int launch_wgrad(WgradArgs& a, int njobs, hipStream_t stream) {
     prof_after(stream, 50000 + (sizeof(T) == 2 ? 0 : 100) + RPW, 2.0 * 9 * 32 * 32 * njobs * (double)a.n * a.h * a.w_,
                (double)njobs * 2 * 32 * sizeof(T) * (double)a.n * a.h * a.w_);
     RESR_CHECK_LAUNCH("wgrad_kernel");
+    return RESR_OK;
+}
+
+// Group the (X chunk, G tile) pairs of a launch into 2x2 quads: greedily take the pair of X chunks and pair of G tiles
+// that covers the most still-unassigned products (ties: fewer staged operands).  A dense block's 26 products become 6 full
+// quads + one diagonal (2 products); a single 64->64 conv is one quad.
+static int build_quads(const WgradArgs& a, int nj, WgradQuadArgs& q) {
+    const char* xs[kMaxJobs]; const char* gs[kMaxJobs];
+    unsigned xstr[kMaxJobs], gstr[kMaxJobs];
+    int nx = 0, ng = 0;
+    static thread_local short need[kMaxJobs][kMaxJobs];   // pair index + 1, 0 = not wanted / already assigned
+    int jx[kMaxJobs], jg[kMaxJobs];
+    for (int i = 0; i < nj; ++i) {
+        int xi = 0, gi = 0;
+        while (xi < nx && xs[xi] != a.jobs[i].x) ++xi;
+        if (xi == nx) { xs[nx] = a.jobs[i].x; xstr[nx] = a.jobs[i].xstride_b; ++nx; }
+        while (gi < ng && gs[gi] != a.jobs[i].g) ++gi;
+        if (gi == ng) { gs[ng] = a.jobs[i].g; gstr[ng] = a.jobs[i].gstride_b; ++ng; }
+        jx[i] = xi; jg[i] = gi;
+    }
+    for (int x = 0; x < nx; ++x)
+        for (int g = 0; g < ng; ++g) need[x][g] = 0;
+    for (int i = 0; i < nj; ++i) {
+        if (need[jx[i]][jg[i]]) return -1;                 // the same product twice: keep the pair kernel
+        need[jx[i]][jg[i]] = (short)(i + 1);
+    }
+    int nq = 0, left = nj;
+    while (left > 0) {
+        int best = -1, bxa = 0, bxb = 0, bga = 0, bgb = 0;
+        for (int xa = 0; xa < nx; ++xa)
+            for (int xb = xa; xb < nx; ++xb)
+                for (int ga = 0; ga < ng; ++ga)
+                    for (int gb = ga; gb < ng; ++gb) {
+                        int cnt = (need[xa][ga] != 0);
+                        if (xb != xa) cnt += (need[xb][ga] != 0);
+                        if (gb != ga) cnt += (need[xa][gb] != 0);
+                        if (xb != xa && gb != ga) cnt += (need[xb][gb] != 0);
+                        if (!cnt) continue;
+                        const int score = cnt * 8 - (xb != xa) - (gb != ga);
+                        if (score > best) { best = score; bxa = xa; bxb = xb; bga = ga; bgb = gb; }
+                    }
+        if (best < 0 || nq >= kMaxQuads) return -1;
+        WgradQuad& w = q.jobs[nq++];
+        memset(&w, 0, sizeof(w));
+        w.x[0] = xs[bxa]; w.xstride_b[0] = xstr[bxa];
+        if (bxb != bxa) { w.x[1] = xs[bxb]; w.xstride_b[1] = xstr[bxb]; }
+        w.g[0] = gs[bga]; w.gstride_b[0] = gstr[bga];
+        if (bgb != bga) { w.g[1] = gs[bgb]; w.gstride_b[1] = gstr[bgb]; }
+        const int qx[2] = {bxa, bxb}, qg[2] = {bga, bgb};
+        for (int p = 0; p < 4; ++p) {
+            const int xi = p & 1, gi = p >> 1;
+            w.slab_off[p] = ~0u;
+            if ((xi && bxb == bxa) || (gi && bgb == bga)) continue;
+            short& n = need[qx[xi]][qg[gi]];
+            if (!n) continue;
+            const WgradJob& j = a.jobs[n - 1];
+            w.slab_off[p] = j.slab_off;
+            if (j.want_bias) w.bias_mask |= 1u << p;
+            n = 0;
+            --left;
+        }
+    }
+    return nq;
+}
+
+static int launch_wgrad_quad(const WgradArgs& a, int nj, hipStream_t stream, bool* done) {
+    static thread_local WgradQuadArgs q;
+    *done = false;
+    const int nq = build_quads(a, nj, q);
+    if (nq <= 0) return RESR_OK;
+    q.partial = a.partial;
+    q.n = a.n; q.h = a.h; q.w_ = a.w_; q.hs = a.hs; q.ws = a.ws; q.up = a.up; q.splits = a.splits; q.njobs = nq;
+    q.tiles_x = (a.w_ + 31) / 32;
+    q.tiles_y = (a.h + 7) / 8;
+    q.ntiles = q.tiles_x * q.tiles_y * a.n;
+    const size_t lds = 2 * kQBUF;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_quad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return fail(RESR_ERR_LAUNCH, "wgrad: cannot reserve %zu B of LDS", lds);
+        attr_done = true;
+    }
+    void* zp = nullptr;
+    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess || !zp) return fail(RESR_ERR_LAUNCH, "wgrad: zero page");
+    q.zero = (const char*)zp;
+    const int splits8 = (a.splits + 7) / 8 * 8;
+    double staged = 0;
+    for (int i = 0; i < nq; ++i) staged += 1 + (q.jobs[i].x[1] != nullptr) + 1 + (q.jobs[i].g[1] != nullptr);
+    prof_before(stream);
+    hipLaunchKernelGGL(wgrad_quad_kernel, dim3(nq * splits8), dim3(512), lds, stream, q);
+    // algorithmic bytes: every quad's X chunks and G tiles once (quads that share an operand find it in their XCD's L2)
+    prof_after(stream, 50200, 2.0 * 9 * 32 * 32 * nj * (double)a.n * a.h * a.w_, staged * 64.0 * (double)a.n * a.h * a.w_);
+    RESR_CHECK_LAUNCH("wgrad_quad_kernel");
+    *done = true;
     return RESR_OK;
 }
 
@@ -439,7 +753,14 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
     }
     a.n = n; a.h = h; a.w_ = w; a.hs = up ? h / 2 : h; a.ws = up ? w / 2 : w; a.up = up ? 1 : 0; a.splits = splits;
     int rc;
-    if (dtype == RESR_F16) rc = launch_wgrad<half_t, 2>(a, nj, stream);
+    bool quad_done = false;
+    static const char* pair_env = getenv("RESR_WGRAD_PAIR_KERNEL");   // test knob: keep the f16 pair kernel
+    if (dtype == RESR_F16 && a.fast_addr && !pair_env) {
+        rc = launch_wgrad_quad(a, nj, stream, &quad_done);
+        if (rc) return rc;
+    }
+    if (quad_done) rc = RESR_OK;
+    else if (dtype == RESR_F16) rc = launch_wgrad<half_t, 2>(a, nj, stream);
     else if (dtype == RESR_F32) rc = launch_wgrad<float, 1>(a, nj, stream);
     else return fail(RESR_ERR_ARG, "wgrad: dtype=%d", dtype);
     if (rc) return rc;

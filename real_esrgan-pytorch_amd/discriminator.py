@@ -200,7 +200,7 @@ class Discriminator(nn.Module):
         """dW[cout][cin_real][3][3] (+db) = wgrad(X = first cin_pad channels of x, G = first cout channels of g)."""
         L, lib = _lib, _lib.lib()
         chunks = cin_pad // 32
-        step = 64 if chunks * 2 <= 40 else 32
+        step = 64 if chunks * 2 <= 80 else 32          # wgrad.hip kMaxJobs products per launch
         th = 8 if self._dtype == L.RESR_F16 else 4
         tiles = ((w + 31) // 32) * ((h + th - 1) // th) * n
         st = _lib.stream_ptr()
@@ -210,7 +210,12 @@ class Discriminator(nn.Module):
                 continue
             cp = _r32(co)
             jobs = chunks * (cp // 32)
-            splits = max(1, min(128, 768 // jobs, max(1, tiles // 2)))
+            if self._dtype == L.RESR_F16:               # quad kernel: jobs/4 workgroups per split, one per CU (generator.hip splits_for)
+                splits = 512 // ((jobs + 3) // 4)
+                splits = min(256, splits & ~7 if splits >= 16 else splits)
+            else:
+                splits = min(128, 768 // jobs)
+            splits = max(1, min(splits, max(1, tiles // 2)))
             d = L.WgradDesc(n, h, w, cin_pad, cin_pad, x.shape[-1], 0, cin_real, co, cp, g.shape[-1], self._dtype, 0, splits, 1.0)
             nbytes = lib.resr_wgrad_partial_bytes(C.byref(d))
             part = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)

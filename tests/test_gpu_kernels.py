@@ -166,6 +166,8 @@ WGRAD_CASES = [
     ("w_up", 64, 64, 1, 1, 16, 64),
     ("w_cout3", 64, 3, 0, 1, 17, 33),
     ("w_cin3", 3, 64, 0, 2, 12, 36),
+    ("w_160_32", 160, 32, 0, 1, 21, 70),      # odd chunk count: 2 full quad jobs + a half one
+    ("w_many_tiles", 64, 64, 0, 3, 40, 96),   # several tiles per workgroup (double-buffer reuse)
 ]
 
 
@@ -205,6 +207,18 @@ def test_wgrad(U, case, dtype_name, diag_dir):
     tol = 2e-3 if dtype == L.RESR_F16 else 2e-4
     assert err_w < tol * scale, f"dW max abs err {err_w} (ref max {scale})"
     assert err_b < tol * max(1.0, ref_b.abs().max().item()), f"db max abs err {err_b}"
+
+
+@pytest.mark.parametrize("knob", ["RESR_WGRAD_PAIR_KERNEL", "RESR_WGRAD_GENERIC_ADDR"])
+def test_wgrad_fallback_kernels(knob):
+    """The f16 pair kernel (used when the quad kernel's grouping or 32-bit addressing preconditions fail) and its 64-bit
+    addressing path stay correct: re-run the wgrad cases in a subprocess with the knob set (read once per process)."""
+    import subprocess, sys
+    env = dict(os.environ, **{knob: "1"})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_wgrad and not fallback"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_layout_and_pool(U):

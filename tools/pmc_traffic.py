@@ -18,6 +18,8 @@ def short(name):
     m = re.search(r"conv3x3_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)E", name)
     if m:
         return f"conv3x3_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'},{m.group(2)},{m.group(3)},{m.group(4)}>"
+    if "wgrad_quad_kernel" in name:
+        return "wgrad_quad_kernel<f16>"
     m = re.search(r"wgrad_kernelI(DF16_|f)Li(\d)E", name)
     if m:
         return f"wgrad_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'},{m.group(2)}>"
