@@ -51,6 +51,16 @@ struct WsCfg {
     static constexpr int NP = 4;                    // producer waves (a single wave issues ~1 KB of LDS-DMA per 70 ns)
     static constexpr int NIP = (NI + NP - 1) / NP;  // LDS-DMA instructions per producer wave per stage
     static constexpr int NTHR = 64 * (NWC + NP);
+    // cout 64 (MT = 2): the chunk's packed weights (36 KB) go through LDS as well -- one LDS-DMA copy per stage shared by
+    // the four consumers instead of four register streams from L2 (which were 4/5 of the workgroup's load traffic and
+    // set the stage time: 186 KB per stage at ~35 GB/s per CU).  cout <= 32 keeps the register stream: two 74 KB halo
+    // buffers leave no room for a second pair of buffers.
+    static constexpr bool WL = MT == 2;
+    static constexpr int WBUF = 9 * KS * MT * 1024;  // packed weight bytes per chunk
+    static constexpr int NWI = WBUF / 1024;          // LDS-DMA instructions per chunk of weights
+    static constexpr int NWIP = (NWI + NP - 1) / NP;
+    static constexpr int WOFF = 2 * BUF + 256;       // after the halo buffers and the bias
+    static constexpr int LDS_BYTES = WOFF + (WL ? 2 * WBUF : 0);
 };
 
 __device__ __forceinline__ void conv_glds16(const char* gsrc, char* lds_wave_base) {
@@ -145,6 +155,18 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 }
             }
         }
+        const unsigned wdst0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + C::WOFF);
+        auto stage_weights = [&](int ck, int par) {   // chunk ck's packed weights, lane-linear = fragment order
+            if constexpr (C::WL) {
+                const char* wbase = a.w + (size_t)ck * C::WBUF;
+#pragma unroll
+                for (int i = 0; i < C::NWIP; ++i) {
+                    const int idx = i * NP + pw;
+                    if (idx < C::NWI) conv_glds16_s(wbase, (unsigned)(idx * 1024) + ((unsigned)lane << 4), wdst0 + par * C::WBUF + idx * 1024);
+                }
+            }
+        };
+        if (first < ntiles) stage_weights(0, 0);
         // source pixel index per slot (< 2^24, host-checked); ~0u = zero (padding / outside the image)
         auto tile_pix = [&](int tile, unsigned (&pix)[NIP]) {
             const int tx = tile % a.tiles_x;
@@ -170,16 +192,18 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
                 const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
                 const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + par * BUF);
-                if (tile != first || ck != 0)  // the first stage was requested above
+                if (tile != first || ck != 0) {  // the first stage was requested above
 #pragma unroll
-                for (int i = 0; i < NIP; ++i) {
-                    // uniform base + 32-bit lane offset (tensor < 4 GB, host-checked); padding lanes copy the zero page
-                    const unsigned ldst = dst + (i * NP + pw) * 1024;
-                    if (pix[i] != ~0u) {
-                        conv_glds16_s(base, __umul24(pix[i], stride_b) + (cst[i] >> 16), ldst);
-                    } else if (cst[i] != ~0u) {
-                        conv_glds16_s(a.zero, 0u, ldst);
+                    for (int i = 0; i < NIP; ++i) {
+                        // uniform base + 32-bit lane offset (tensor < 4 GB, host-checked); padding lanes copy the zero page
+                        const unsigned ldst = dst + (i * NP + pw) * 1024;
+                        if (pix[i] != ~0u) {
+                            conv_glds16_s(base, __umul24(pix[i], stride_b) + (cst[i] >> 16), ldst);
+                        } else if (cst[i] != ~0u) {
+                            conv_glds16_s(a.zero, 0u, ldst);
+                        }
                     }
+                    stage_weights(ck, par);
                 }
                 par ^= 1;
                 stamp(0);
@@ -232,15 +256,22 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     constexpr int RING = MT == 1 ? 6 : 3;
     static_assert(NU % RING == 0, "ring slots must be static");
     uint4 wr[RING][MT];
+    const char* wlds = smem + C::WOFF + lane16;   // WL: this lane's piece of every fragment of weight buffer 0
     auto wload = [&](int slot, int ck, int u) {
         const int ks = u / 9, dx = (u / 3) % 3, dy = u % 3;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-            wr[slot][m] = *reinterpret_cast<const uint4*>(
-                a.w + ((size_t)((ck * 9 + dy * 3 + dx) * KS + ks) * MT + m) * 1024 + lane16);
+        for (int m = 0; m < MT; ++m) {
+            if constexpr (C::WL)   // `ck` is the LDS buffer parity here
+                wr[slot][m] = *reinterpret_cast<const uint4*>(wlds + ck * C::WBUF + (((dy * 3 + dx) * KS + ks) * MT + m) * 1024);
+            else
+                wr[slot][m] = *reinterpret_cast<const uint4*>(
+                    a.w + ((size_t)((ck * 9 + dy * 3 + dx) * KS + ks) * MT + m) * 1024 + lane16);
+        }
     };
+    if constexpr (!C::WL) {
 #pragma unroll
-    for (int u = 0; u < RING - 1; ++u) wload(u, 0, u);
+        for (int u = 0; u < RING - 1; ++u) wload(u, 0, u);
+    }
 
     int par = 0;
     for (int tile = first; tile < ntiles; tile += G) {
@@ -260,6 +291,10 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                 for (int r = 0; r < NT + 2; ++r) rowf[slot][r] = *reinterpret_cast<const uint4*>(bp + r * (HW * PB));
             };
+            if constexpr (C::WL) {   // the stage's weights are in LDS once the barrier is passed: no prefetch across stages
+#pragma unroll
+                for (int u = 0; u < RING - 1; ++u) wload(u, par, u);
+            }
             if (PP) rload(0, 0);
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
@@ -268,7 +303,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const int u = gi * 3 + dy;
-                    wload((u + RING - 1) % RING, u + RING - 1 < NU ? ck : nck, (u + RING - 1) % NU);
+                    if constexpr (C::WL) {
+                        if (u + RING - 1 < NU) wload((u + RING - 1) % RING, par, u + RING - 1);
+                    } else {
+                        wload((u + RING - 1) % RING, u + RING - 1 < NU ? ck : nck, (u + RING - 1) % NU);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
@@ -331,38 +370,52 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             const bool in_img = y < e.h && x < e.w_;
             // pieces outside the image / beyond cout read a clamped (valid) address and are dropped at the store
             const size_t p = ((size_t)n * e.h + (y < e.h ? y : e.h - 1)) * e.w_ + (x < e.w_ ? x : e.w_ - 1);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                // mask-only (the dense-block backward convs): both pieces' masks are requested before the first store;
-                // with residuals the batch is one piece (register budget)
-                constexpr int JB = (ER || EX) ? 1 : 2;
-                int co[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) co[j] = m * 32 + (2 * j + kh_e) * 8;
-                // element offset of piece j inside a pixel of an operand with chunk stride cs (clamped when beyond cout)
-                auto poff = [&](int j, int cs) { return co[j] < e.cout ? (size_t)m * cs + (2 * j + kh_e) * 8 : (size_t)0; };
-                unsigned sbits = 0;   // ESB: this lane's bytes of the sign word
-#pragma unroll
-                for (int j0 = 0; j0 < 2; j0 += JB) {
-                half8 rmask[2], rres0[2], rres1[2];
-                unsigned mbits = 0;   // EMB: the pixel's sign word of chunk m (bit c <-> channel 32m + c)
+            // Every epilogue input of a batch is requested before the batch's first store (loads behind stores wait for
+            // the stores' acks on the in-order counter, one memory round trip per batch).  cout 64: the whole row -- four
+            // pieces with up to two residuals, 32 registers that are free once the MFMA loop is over (16 round trips
+            // per tile were 3.3 us); cout <= 32 (168-register budget): both pieces when there is only a mask, one
+            // piece with residuals.
+            constexpr bool RB = MT == 2 && !EX;
+            constexpr int JB = (RB || !(ER || EX)) ? 2 : 1;
+            constexpr int MA = RB ? MT : 1;   // without row batching one m tile's inputs are live at a time
+            half8 rmask[MA][2], rres0[MA][2], rres1[MA][2];
+            unsigned mbits[MA];   // EMB: the pixel's sign word of chunk m (bit c <-> channel 32m + c)
+            // element offset of piece (m, j) inside a pixel of an operand with chunk stride cs (clamped when beyond cout)
+            auto poff = [&](int m, int j, int cs) {
+                return m * 32 + (2 * j + kh_e) * 8 < e.cout ? (size_t)m * cs + (2 * j + kh_e) * 8 : (size_t)0;
+            };
+            auto request = [&](int m, int j0) {
                 if (EMB) {
-                    mbits = reinterpret_cast<const unsigned*>(e.mask)[p * (size_t)((e.cout + 31) >> 5) + m];
+                    if (j0 == 0) mbits[m % MA] = reinterpret_cast<const unsigned*>(e.mask)[p * (size_t)((e.cout + 31) >> 5) + m];
                 } else if (f_mask) {
 #pragma unroll
                     for (int j = j0; j < j0 + JB; ++j)
-                        rmask[j] = *reinterpret_cast<const half8*>(e.mask + (p * e.mask_stride + poff(j, e.mask_chunk)) * 2);
+                        rmask[m % MA][j] = *reinterpret_cast<const half8*>(e.mask + (p * e.mask_stride + poff(m, j, e.mask_chunk)) * 2);
                 }
                 if (f_res0) {
 #pragma unroll
                     for (int j = j0; j < j0 + JB; ++j)
-                        rres0[j] = *reinterpret_cast<const half8*>(e.res0 + (p * e.res0_stride + poff(j, e.res0_chunk)) * 2);
+                        rres0[m % MA][j] = *reinterpret_cast<const half8*>(e.res0 + (p * e.res0_stride + poff(m, j, e.res0_chunk)) * 2);
                 }
                 if (f_res1) {
 #pragma unroll
                     for (int j = j0; j < j0 + JB; ++j)
-                        rres1[j] = *reinterpret_cast<const half8*>(e.res1 + (p * e.res1_stride + poff(j, e.res1_chunk)) * 2);
+                        rres1[m % MA][j] = *reinterpret_cast<const half8*>(e.res1 + (p * e.res1_stride + poff(m, j, e.res1_chunk)) * 2);
                 }
+            };
+            if (RB) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) request(m, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                int co[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) co[j] = m * 32 + (2 * j + kh_e) * 8;
+                unsigned sbits = 0;   // ESB: this lane's bytes of the sign word
+#pragma unroll
+                for (int j0 = 0; j0 < 2; j0 += JB) {
+                if (!RB) request(m, j0);
 #pragma unroll
                 for (int j = j0; j < j0 + JB; ++j) {
                     float v[8];
@@ -379,27 +432,27 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         for (int r = 0; r < 8; ++r) h[r] = (half_t)v[r];
                         *reinterpret_cast<half8*>(base + idx * 2) = h;
                     };
-                    if (f_aux_mask && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(j, e.out_chunk));
+                    if (f_aux_mask && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(m, j, e.out_chunk));
                     if (EMB) {
-                        const unsigned byte = mbits >> (8 * (2 * j + kh_e));
+                        const unsigned byte = mbits[m % MA] >> (8 * (2 * j + kh_e));
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] *= ((byte >> r) & 1u) ? 1.f : e.slope;
                     } else if (f_mask) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] *= ((float)rmask[j][r] > 0.f ? 1.f : e.slope);
+                        for (int r = 0; r < 8; ++r) v[r] *= ((float)rmask[m % MA][j][r] > 0.f ? 1.f : e.slope);
                     }
                     if (f_lrelu) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * e.slope;
                     }
-                    if (f_aux_res && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(j, e.out_chunk));
+                    if (f_aux_res && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(m, j, e.out_chunk));
                     if (f_res0) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], e.s0, e.t0 * (float)rres0[j][r]);   // explicit: one rounding, the same in every instantiation
+                        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], e.s0, e.t0 * (float)rres0[m % MA][j][r]);   // explicit: one rounding, the same in every instantiation
                     }
                     if (f_res1) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], e.s1, e.t1 * (float)rres1[j][r]);
+                        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], e.s1, e.t1 * (float)rres1[m % MA][j][r]);
                     }
                     if (f_nchw) {
                         float* o = reinterpret_cast<float*>(e.out);
@@ -419,7 +472,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] = fminf(fmaxf(v[r], 0.f), 1.f);
                         }
-                        if (ok) store8(e.out, p * e.out_stride + poff(j, e.out_chunk));
+                        if (ok) store8(e.out, p * e.out_stride + poff(m, j, e.out_chunk));
                         if (ESB) {
 #pragma unroll
                             for (int r = 0; r < 8; ++r) sbits |= ((float)(half_t)v[r] > 0.f ? 1u : 0u) << (8 * (2 * j + kh_e) + r);
@@ -447,7 +500,7 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     ConvArgs args = a;
     args.tiles_x = (a.w_ + 31) / 32;
     args.tiles_y = (a.h + C::TH - 1) / C::TH;
-    const size_t lds = 2 * C::BUF + 64 * sizeof(float);  // two halo buffers + the bias
+    const size_t lds = C::LDS_BYTES;  // two halo buffers + the bias (+ two weight buffers for cout 64)
     static int resident = 0;            // workgroups the device holds at once, per instantiation; benign race
     static const char* zero = nullptr;
     if (!resident) {

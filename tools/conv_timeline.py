@@ -10,6 +10,7 @@ ap.add_argument("--res", type=int, default=256)
 ap.add_argument("--shape", default="160:32")
 ap.add_argument("--wgs", default="0,1,8,9")
 ap.add_argument("--stride", type=int, default=0)
+ap.add_argument("--planar", action="store_true", help="chunk-planar input [C/32][N,H,W,32] as the generator uses")
 a = ap.parse_args()
 lib = L.lib()
 cin, cout = map(int, a.shape.split(":"))
@@ -21,6 +22,12 @@ x = (torch.rand(a.batch, a.res, a.res, xs, device="cuda", generator=gen) - 0.5).
 y = torch.empty(a.batch, a.res, a.res, cout_pad, device="cuda", dtype=torch.float16)
 w = ((torch.rand((cin // 32) * 9 * mt * 1024 + 8192, device="cuda", generator=gen) - 0.5) * 0.1).half()
 d = L.ConvDesc(a.batch, a.res, a.res, cin, cin, xs, 0, cout, cout_pad, cout_pad, 0, 0, 0, L.RESR_F16, L.CONV_LRELU, 1, 1, 1, 1, 0.2)
+if a.planar:
+    x = (torch.rand(cin // 32, a.batch, a.res, a.res, 32, device="cuda", generator=gen) - 0.5).half()
+    y = torch.empty(cout_pad // 32, a.batch, a.res, a.res, 32, device="cuda", dtype=torch.float16)
+    d.in0_stride = 32; d.out_stride = 32
+    d.in0_chunk_stride = a.batch * a.res * a.res * 32
+    d.out_chunk_stride = a.batch * a.res * a.res * 32
 def launch():
     L.check(lib.resr_conv3x3(C.byref(d), L.ptr(x), None, L.ptr(w), None, None, None, None, L.ptr(y), None, L.stream_ptr()))
 for _ in range(3): launch()
