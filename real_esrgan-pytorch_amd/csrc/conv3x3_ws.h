@@ -1,23 +1,27 @@
-// conv3x3_ws.h -- the fast-mode (f16) 3x3 convolution: persistent workgroups, one producer wave + NWC consumer waves.
+// conv3x3_ws.h -- the fast-mode (f16) 3x3 convolution: persistent workgroups, 4 producer waves + NWC consumer waves.
 //
 // Same GEMM view and LDS tile layout as conv3x3.hip (reference call sites: model.py:87-98, :123-132, :255-272 and
 // their autograd backward-data passes).  What differs is who moves the data:
 //
-//   producer wave   LDS-DMA (global_load_lds, 16 B per lane) of the (TH+2) x 34 x 32ch halo tile of the next stage
-//                   into the free LDS buffer, then waits for it and meets the consumers at the workgroup barrier.
-//   consumer waves  never touch activations in global memory.  They stream the packed weight fragments (global ->
-//                   registers, a 3-group ring) and feed the MFMAs from the LDS tile.
+//   producer waves  LDS-DMA (global_load_lds, 16 B per lane) of the next stage's (TH+2) x 34 x 32ch halo tile and of the
+//                   chunk's packed weights into free LDS buffers; they wait for the copy and meet the consumers at the
+//                   workgroup barrier.
+//   consumer waves  never touch global memory before the epilogue: weight fragments (a 3- or 6-unit register ring) and
+//                   halo rows both come from LDS and feed the MFMAs.
 //
-// On gfx950 the vector-memory counter retires in order.  In the one-role kernel a wave's weight loads queue behind
+// On gfx950 the vector-memory counter retires in order.  In the one-role kernel a wave's weight loads queued behind
 // its own (HBM-latency) halo loads, so every chunk stalled two taps in until its prefetch had landed: memory time
 // and MFMA time added up instead of overlapping.  Splitting the roles gives each wave a counter that only tracks one
-// kind of traffic.  Workgroups are persistent (grid = one residency wave; tiles b, b+G, ...) so the producer runs
+// kind of traffic.  Workgroups are persistent (grid = one residency wave; tiles b, b+G, ...) so the producers run
 // ahead across tile boundaries and the fill/drain phases are paid once per launch, not once per tile.
 //
-// A stage = (tile, 32-channel chunk).  Barrier protocol, one s_barrier per stage for every wave:
+// A stage = (tile, 32-channel chunk).  Barrier protocol, one s_barrier per stage for every wave (two halo buffers):
 //   producer:  for s: DMA(s -> buf s&1); wait vmcnt(0); barrier_s
 //   consumer:  for s: barrier_s; multiply(buf s&1)
 // barrier_{s+1} is passed only when all consumers are done with stage s, so DMA(s+2) may overwrite buf s&1.
+// With three halo buffers (16-row tiles of cout <= 32) the halo of stage s+2 is requested right after barrier_s, behind
+// the weights of stage s+1, and `s_waitcnt vmcnt(<instructions of that halo>)` on the in-order counter says that
+// everything older has landed.
 //
 // Consumer inner loop: per (k-step, dx) group the NT+2 halo rows are read once from LDS and reused by the three dy
 // taps (row t+dy of the tile is row t of tap dy): (NT+2) LDS reads per 3*NT*MT MFMAs instead of 3*NT.
@@ -51,16 +55,18 @@ struct WsCfg {
     static constexpr int NP = 4;                    // producer waves (a single wave issues ~1 KB of LDS-DMA per 70 ns)
     static constexpr int NIP = (NI + NP - 1) / NP;  // LDS-DMA instructions per producer wave per stage
     static constexpr int NTHR = 64 * (NWC + NP);
-    // cout 64 (MT = 2): the chunk's packed weights (36 KB) go through LDS as well -- one LDS-DMA copy per stage shared by
-    // the four consumers instead of four register streams from L2 (which were 4/5 of the workgroup's load traffic and
-    // set the stage time: 186 KB per stage at ~35 GB/s per CU).  cout <= 32 keeps the register stream: two 74 KB halo
-    // buffers leave no room for a second pair of buffers.
-    static constexpr bool WL = MT == 2;
+    // The chunk's packed weights (18 KB per 32 output channels) go through LDS as well: one LDS-DMA copy per stage shared
+    // by all consumers instead of one register stream from L2 per consumer wave (for cout 64 those streams were 4/5 of
+    // the workgroup's load traffic and set the stage time; for cout 32 they queued behind the halo requests).
+    // 16-row tiles of cout <= 32: three 39 KB halo buffers, so the request for stage s+2 is in flight while stage s+1
+    // lands and stage s is multiplied (with two buffers the memory pipe drains at every stage of a memory-bound launch:
+    // measured 4.2 us of back-pressured issue, then 1.1 us with nothing in flight, per 5.5 us stage of a 32-row tile).
+    static constexpr int NHB = (MT == 1 && NT * NWC == 16) ? 3 : 2;
     static constexpr int WBUF = 9 * KS * MT * 1024;  // packed weight bytes per chunk
     static constexpr int NWI = WBUF / 1024;          // LDS-DMA instructions per chunk of weights
     static constexpr int NWIP = (NWI + NP - 1) / NP;
-    static constexpr int WOFF = 2 * BUF + 256;       // after the halo buffers and the bias
-    static constexpr int LDS_BYTES = WOFF + (WL ? 2 * WBUF : 0);
+    static constexpr int WOFF = NHB * BUF + 256;     // after the halo buffers and the bias
+    static constexpr int LDS_BYTES = WOFF + 2 * WBUF;
 };
 
 __device__ __forceinline__ void conv_glds16(const char* gsrc, char* lds_wave_base) {
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 
     // The bias lives in LDS for the whole launch: re-read from global memory per tile it would queue behind the
     // previous tile's stores on the in-order memory counter (measured: ~4 us per tile waiting for store acks).
-    float* bias_lds = reinterpret_cast<float*>(smem + 2 * BUF);
+    float* bias_lds = reinterpret_cast<float*>(smem + C::NHB * BUF);
     if (wave == 0) {
         const bool f_bias = !(a.flags & RESR_CONV_NO_BIAS) && a.bias != nullptr;
         bias_lds[lane] = (f_bias && lane < a.cout) ? a.bias[lane] : 0.f;
@@ -123,6 +129,133 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     if (wave >= NWC) {
         const int pw = wave - NWC;  // producer index: this wave issues DMA instructions pw, pw + NP, ...
         // =============================== producer ===============================
+        if constexpr (C::NHB == 3) {
+            // ---- three halo buffers, weights through LDS: H(s+2) is requested right after barrier s, behind W(s+1) ----
+            // Every wave issues a static number of LDS-DMA instructions per stage (lanes outside the image read the zero
+            // page through a per-lane address select, lanes beyond the tile are masked off inside the asm), so "W(s+1) and
+            // H(s+1) have landed" is `s_waitcnt vmcnt(<my instructions of H(s+2)>)` on the in-order counter.
+            const int ups3 = (a.flags & RESR_CONV_UPSAMPLE_IN) ? 1 : 0;
+            constexpr int REM = NI - (NIP - 1) * NP;   // waves pw < REM own NIP halo instructions, the rest NIP-1
+            static_assert(NIP < 64, "vmcnt is 6 bits");
+            unsigned cst[NIP], pix[NIP];
+            unsigned long long val[NIP], inb[NIP];   // per instruction: lanes that own a slot / whose pixel is inside the image
+            const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+            // One instruction per slot group whatever the tile (static count).  The common case -- every lane inside the
+            // image -- is the lean scalar-base form (the producers share their SIMDs' issue ports with the MFMA waves:
+            // every VALU instruction here queues behind them); edge tiles select the zero page per lane.
+            auto dma_s = [&](const char* sbase, unsigned voff, unsigned dst, unsigned long long mask) {
+                unsigned long long save;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %3, %4\n\ts_mov_b64 exec, %0"
+                             : "=&s"(save) : "s"(mask), "s"(dst), "v"(voff), "s"(sbase) : "memory", "m0");
+            };
+            auto dma_v = [&](const char* src, unsigned dst, unsigned long long mask) {
+                unsigned long long save;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %3, off\n\ts_mov_b64 exec, %0"
+                             : "=&s"(save) : "s"(mask), "s"(dst), "v"(src) : "memory", "m0");
+            };
+#pragma unroll
+            for (int i = 0; i < NIP; ++i) {
+                const unsigned s = (i * NP + pw) * 64 + lane;
+                const unsigned hp = s / SPP, cp = s % SPP;
+                const unsigned hy = (hp * 61681u) >> 21;  // hp / 34, exact below 100000
+                const unsigned hx = hp - hy * HW;
+                cst[i] = (i * NP + pw < NI && s < (unsigned)C::NSLOT) ? (hy << 8 | hx | ((cp ^ swz<SPP>((int)hx)) << 20)) : ~0u;
+                val[i] = __ballot(cst[i] != ~0u);
+            }
+            auto tile_pix = [&](int tile) {
+                const int tx = tile % a.tiles_x;
+                const int t2 = tile / a.tiles_x;
+                const int ty = t2 % a.tiles_y;
+                const int n = t2 / a.tiles_y;
+                const int x0 = tx * TW - 1, y0 = ty * TH - 1;
+                const unsigned nbase = (unsigned)n * a.hs * a.ws;
+#pragma unroll
+                for (int i = 0; i < NIP; ++i) {
+                    const unsigned c = cst[i];
+                    const int iy = y0 + (int)((c >> 8) & 0xff), ix = x0 + (int)(c & 0xff);
+                    const bool ok = c != ~0u && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w_;
+                    pix[i] = ok ? nbase + (unsigned)(iy >> ups3) * a.ws + (unsigned)(ix >> ups3) : ~0u;
+                    inb[i] = __ballot(ok);
+                }
+            };
+            const char* const zero = a.zero;
+            auto issue_h = [&](int ck, int hb) {   // halo of (current pix, chunk ck) -> halo buffer hb
+                const int c0 = ck * 32;
+                const bool seg1 = c0 >= a.cin0;
+                const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
+                const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
+#pragma unroll
+                for (int i = 0; i < NIP; ++i) {
+                    if (i * NP + pw < NI) {   // wave-uniform; false only for i = NIP-1 of the waves pw >= REM
+                        const unsigned dst = lds_base + hb * BUF + (i * NP + pw) * 1024;
+                        const unsigned voff = __umul24(pix[i], stride_b) + ((cst[i] >> 16) & 0xfff0u);   // tensor < 4 GB (host-checked)
+                        if (inb[i] == val[i]) {
+                            dma_s(base, voff, dst, val[i]);
+                        } else {
+                            const char* src = pix[i] != ~0u ? base + voff : zero;
+                            dma_v(src, dst, val[i]);
+                        }
+                    }
+                }
+            };
+            auto issue_w = [&](int ck, int par) {   // chunk ck's packed weights, lane-linear = fragment order
+                const char* wbase = a.w + (size_t)ck * C::WBUF;
+#pragma unroll
+                for (int i = 0; i < C::NWIP; ++i) {
+                    const int idx = i * NP + pw;
+                    if (idx < C::NWI) conv_glds16_s(wbase, (unsigned)(idx * 1024) + ((unsigned)lane << 4), lds_base + C::WOFF + par * C::WBUF + idx * 1024);
+                }
+            };
+            auto wait_all_but_h = [&]() {   // everything but the halo stage issued last has landed
+                constexpr int K1 = NIP, K0 = NIP - 1;
+                if (pw < REM) __builtin_amdgcn_s_waitcnt((K1 & 15) | 0x0F70 | ((K1 >> 4) << 14));
+                else __builtin_amdgcn_s_waitcnt((K0 & 15) | 0x0F70 | ((K0 >> 4) << 14));
+            };
+            if (first >= ntiles) return;
+            int it = first, ick = 0;   // the stage whose halo was requested last
+            int hb = 0;                // ... and its buffer
+            tile_pix(it);
+            issue_w(0, 0);
+            issue_h(0, 0);
+            int ck_next = 0;           // chunk of stage s+1 (valid when have_next)
+            bool have_next;            // stage s+1 exists (its halo is in flight)
+            if (++ick == nchunks) { ick = 0; it += G; }
+            have_next = it < ntiles;
+            if (have_next) {
+                if (ick == 0) tile_pix(it);
+                hb = 1;
+                issue_h(ick, hb);
+                ck_next = ick;
+                wait_all_but_h();
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            stamp(0);
+            __syncthreads();           // barrier 0
+            for (int s = 0; have_next; ++s) {   // stage s is being multiplied; H(s+1) is in flight
+                stamp(0);
+                issue_w(ck_next, (s + 1) & 1);           // its buffer was read by stage s-1: free past barrier s
+                if (++ick == nchunks) { ick = 0; it += G; }
+                const bool have_next2 = it < ntiles;
+                if (have_next2) {
+                    if (ick == 0) tile_pix(it);
+                    hb = hb == 2 ? 0 : hb + 1;
+                    issue_h(ick, hb);                    // buffer of stage s-1 as well
+                    stamp(0);
+                    wait_all_but_h();
+                } else {
+                    stamp(0);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
+                stamp(0);
+                __syncthreads();       // barrier s+1
+                ck_next = ick;
+                have_next = have_next2;
+            }
+            return;
+        }
         const int ups = (a.flags & RESR_CONV_UPSAMPLE_IN) ? 1 : 0;
         // LDS slot s = i*64 + lane (lane-linear destination) holds piece (s % SPP) ^ swz(hx) of halo pixel s / SPP: the
         // XOR swizzle of the consumers' conflict-free reads is applied on the source side.  Tile-independent part,
@@ -157,13 +290,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         }
         const unsigned wdst0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + C::WOFF);
         auto stage_weights = [&](int ck, int par) {   // chunk ck's packed weights, lane-linear = fragment order
-            if constexpr (C::WL) {
-                const char* wbase = a.w + (size_t)ck * C::WBUF;
+            const char* wbase = a.w + (size_t)ck * C::WBUF;
 #pragma unroll
-                for (int i = 0; i < C::NWIP; ++i) {
-                    const int idx = i * NP + pw;
-                    if (idx < C::NWI) conv_glds16_s(wbase, (unsigned)(idx * 1024) + ((unsigned)lane << 4), wdst0 + par * C::WBUF + idx * 1024);
-                }
+            for (int i = 0; i < C::NWIP; ++i) {
+                const int idx = i * NP + pw;
+                if (idx < C::NWI) conv_glds16_s(wbase, (unsigned)(idx * 1024) + ((unsigned)lane << 4), wdst0 + par * C::WBUF + idx * 1024);
             }
         };
         if (first < ntiles) stage_weights(0, 0);
@@ -256,32 +387,22 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     constexpr int RING = MT == 1 ? 6 : 3;
     static_assert(NU % RING == 0, "ring slots must be static");
     uint4 wr[RING][MT];
-    const char* wlds = smem + C::WOFF + lane16;   // WL: this lane's piece of every fragment of weight buffer 0
-    auto wload = [&](int slot, int ck, int u) {
+    const char* wlds = smem + C::WOFF + lane16;   // this lane's piece of every fragment of weight buffer 0
+    auto wload = [&](int slot, int par, int u) {
         const int ks = u / 9, dx = (u / 3) % 3, dy = u % 3;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            if constexpr (C::WL)   // `ck` is the LDS buffer parity here
-                wr[slot][m] = *reinterpret_cast<const uint4*>(wlds + ck * C::WBUF + (((dy * 3 + dx) * KS + ks) * MT + m) * 1024);
-            else
-                wr[slot][m] = *reinterpret_cast<const uint4*>(
-                    a.w + ((size_t)((ck * 9 + dy * 3 + dx) * KS + ks) * MT + m) * 1024 + lane16);
-        }
+        for (int m = 0; m < MT; ++m)
+            wr[slot][m] = *reinterpret_cast<const uint4*>(wlds + par * C::WBUF + (((dy * 3 + dx) * KS + ks) * MT + m) * 1024);
     };
-    if constexpr (!C::WL) {
-#pragma unroll
-        for (int u = 0; u < RING - 1; ++u) wload(u, 0, u);
-    }
 
-    int par = 0;
+    int par = 0, hbc = 0;   // weight-buffer parity / halo buffer of the current stage
     for (int tile = first; tile < ntiles; tile += G) {
         for (int ck = 0; ck < nchunks; ++ck) {
             // consumers only read LDS: a bare barrier (no vmcnt drain of the weight ring) is enough
             if (wave == 0) stamp(1);
             asm volatile("s_barrier" ::: "memory");
             if (wave == 0) stamp(1);
-            const int nck = ck + 1 < nchunks ? ck + 1 : 0;  // next stage's chunk (first chunk of the next tile)
-            const char* lbuf = smem + par * BUF;
+            const char* lbuf = smem + hbc * BUF;
             // halo rows of group gi+1 are read from LDS while the MFMAs of group gi run (ping-pong registers; NG is even)
             // when the register budget allows (PP); otherwise each group reads its own rows first
             constexpr int PP = (NWC == 4 || MT * NT * 16 + (NT + 2) * 8 <= 112) ? 1 : 0;   // 4-consumer shapes have a 256-register budget
@@ -291,10 +412,9 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                 for (int r = 0; r < NT + 2; ++r) rowf[slot][r] = *reinterpret_cast<const uint4*>(bp + r * (HW * PB));
             };
-            if constexpr (C::WL) {   // the stage's weights are in LDS once the barrier is passed: no prefetch across stages
+            // the stage's weights are in LDS once the barrier is passed: no prefetch across stages
 #pragma unroll
-                for (int u = 0; u < RING - 1; ++u) wload(u, par, u);
-            }
+            for (int u = 0; u < RING - 1; ++u) wload(u, par, u);
             if (PP) rload(0, 0);
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
@@ -303,11 +423,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const int u = gi * 3 + dy;
-                    if constexpr (C::WL) {
-                        if (u + RING - 1 < NU) wload((u + RING - 1) % RING, par, u + RING - 1);
-                    } else {
-                        wload((u + RING - 1) % RING, u + RING - 1 < NU ? ck : nck, (u + RING - 1) % NU);
-                    }
+                    if (u + RING - 1 < NU) wload((u + RING - 1) % RING, par, u + RING - 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
@@ -318,6 +434,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 }
             }
             par ^= 1;
+            hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;
             if (wave == 0) stamp(1);
         }
 

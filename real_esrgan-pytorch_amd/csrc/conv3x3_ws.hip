@@ -39,8 +39,8 @@ static int pick_rows(const ConvArgs& a, const int* rows, int nrows) {
 }
 
 int conv3x3_ws_f16(const ConvArgs& a, int mt, hipStream_t stream) {
-    static const int rows1[] = {32, 16, 8}, rows2[] = {16, 8};
-    if (mt == 1) return conv3x3_ws_mt1(a, pick_rows(a, rows1, 3), stream);
+    static const int rows1[] = {16, 8}, rows2[] = {16, 8};
+    if (mt == 1) return conv3x3_ws_mt1(a, pick_rows(a, rows1, 2), stream);
     return conv3x3_ws_mt2(a, pick_rows(a, rows2, 2), stream);
 }
 

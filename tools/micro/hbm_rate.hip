@@ -32,10 +32,10 @@ __global__ __launch_bounds__(256) void k_dma(const char* __restrict__ src, size_
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + wave * 16384;
     const size_t blk = 64 * 1024;                              // per workgroup per iteration
-    const size_t nblk = TILE ? 32768 : bytes / blk;
+    const size_t nblk = TILE == 1 ? 32768 : bytes / blk;
     for (size_t b = blockIdx.x; b < nblk; b += gridDim.x) {
         const char* base = src + b * blk;
-        if (TILE) {
+        if (TILE == 1) {
             // block b = a 34-row tile: row r at pitch 16 KB (wraps inside a 64 MB plane), 2176 B per row -> 72.25 KB; waves split rows
             // tile b of a [32 planes][16 images][256][256] x 64 B tensor: plane-major, 32x32-pixel tiles with a 1-pixel halo
             const size_t t = b % 1024, plane_i = (b / 1024) % 32;
@@ -57,6 +57,10 @@ __global__ __launch_bounds__(256) void k_dma(const char* __restrict__ src, size_
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) glds(base, (unsigned)((i * 4 + wave) * 1024 + lane * 16), lds0 + (i & 7) * 1024);
+            if (TILE == 2) {   // + 32 KB that every workgroup re-reads (L2 hits), like a chunk's packed weights
+#pragma unroll
+                for (int i = 0; i < 8; ++i) glds(src, (unsigned)((i * 4 + wave) * 1024 + lane * 16), lds0 + (i & 7) * 1024);
+            }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
     }
@@ -86,11 +90,12 @@ int main() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dma<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dma<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     auto time = [&](const char* name, double moved, auto launch) {
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep == 2) printf("%-44s %8.3f ms  %7.2f TB/s\n", name, ms, moved / ms * 1e-9);
+            if (rep == 2) printf("%-62s %8.3f ms  %7.2f TB/s\n", name, ms, moved / ms * 1e-9);
         }
     };
     for (int wgs : {512, 1024, 2048}) {
@@ -105,6 +110,8 @@ int main() {
         snprintf(nm, sizeof nm, "read  LDS-DMA 34x2176 B tiles, %d wgs", wgs);
         time(nm, 32768.0 * 73984.0, [&] { hipLaunchKernelGGL(k_dma<1>, dim3(wgs), dim3(256), 65536, 0, a, bytes, out); });
     }
+    time("read  LDS-DMA 64 KB HBM + 32 KB L2-hit, 256 wgs (HBM part)", (double)bytes, [&] { hipLaunchKernelGGL(k_dma<2>, dim3(256), dim3(256), 65536, 0, a, bytes, out); });
+    time("read  LDS-DMA 64 KB HBM + 32 KB L2-hit, 512 wgs (HBM part)", (double)bytes, [&] { hipLaunchKernelGGL(k_dma<2>, dim3(512), dim3(256), 65536, 0, a, bytes, out); });
     time("copy  1 read : 1 write, 2048 wgs", 2.0 * bytes, [&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, (const uint4*)a, (uint4*)b, bytes / 16, 1); });
     time("copy  2 reads : 1 write, 2048 wgs", 3.0 * bytes, [&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, (const uint4*)a, (uint4*)b, bytes / 16, 2); });
     return 0;
