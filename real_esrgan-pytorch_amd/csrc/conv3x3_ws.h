@@ -164,6 +164,10 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 cst[i] = (i * NP + pw < NI && s < (unsigned)C::NSLOT) ? (hy << 8 | hx | ((cp ^ swz<SPP>((int)hx)) << 20)) : ~0u;
                 val[i] = __ballot(cst[i] != ~0u);
             }
+            // Per-lane byte offsets are computed once per tile (and pixel stride), not per stage: the producers share their
+            // SIMDs' VALU port with the MFMA waves, and a stage's requests should be scalar + vector-memory instructions only.
+            unsigned voff[NIP];
+            unsigned voff_stride = 0;   // pixel stride the offsets were computed for (0: stale)
             auto tile_pix = [&](int tile) {
                 const int tx = tile % a.tiles_x;
                 const int t2 = tile / a.tiles_x;
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     pix[i] = ok ? nbase + (unsigned)(iy >> ups3) * a.ws + (unsigned)(ix >> ups3) : ~0u;
                     inb[i] = __ballot(ok);
                 }
+                voff_stride = 0;
             };
             const char* const zero = a.zero;
             auto issue_h = [&](int ck, int hb) {   // halo of (current pix, chunk ck) -> halo buffer hb
@@ -186,15 +191,19 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 const bool seg1 = c0 >= a.cin0;
                 const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
                 const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
+                if (stride_b != voff_stride) {
+#pragma unroll
+                    for (int i = 0; i < NIP; ++i) voff[i] = __umul24(pix[i], stride_b) + ((cst[i] >> 16) & 0xfff0u);   // tensor < 4 GB (host-checked)
+                    voff_stride = stride_b;
+                }
 #pragma unroll
                 for (int i = 0; i < NIP; ++i) {
                     if (i * NP + pw < NI) {   // wave-uniform; false only for i = NIP-1 of the waves pw >= REM
                         const unsigned dst = lds_base + hb * BUF + (i * NP + pw) * 1024;
-                        const unsigned voff = __umul24(pix[i], stride_b) + ((cst[i] >> 16) & 0xfff0u);   // tensor < 4 GB (host-checked)
                         if (inb[i] == val[i]) {
-                            dma_s(base, voff, dst, val[i]);
+                            dma_s(base, voff[i], dst, val[i]);
                         } else {
-                            const char* src = pix[i] != ~0u ? base + voff : zero;
+                            const char* src = pix[i] != ~0u ? base + voff[i] : zero;
                             dma_v(src, dst, val[i]);
                         }
                     }

@@ -67,6 +67,51 @@ __global__ __launch_bounds__(256) void k_dma(const char* __restrict__ src, size_
     if (smem[threadIdx.x] == 0x5a && bytes == 1) out[0] = 1;
 }
 
+
+// LDS-DMA streaming (waves 0-3) while waves 4-11 keep the matrix pipe busy with random f16 operands: what the
+// memory pipe delivers under the power state of a convolution.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(768) void k_dma_mfma(const char* __restrict__ src, size_t bytes, unsigned* out, int mfma_on) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(smem + 65536);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) *flag = 0;
+    __syncthreads();
+    if (wave < 4) {
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + wave * 16384;
+        const size_t blk = 64 * 1024, nblk = bytes / blk;
+        for (size_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+            const char* base = src + b * blk;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) glds(base, (unsigned)((i * 4 + wave) * 1024 + lane * 16), lds0 + (i & 7) * 1024);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        if (lane == 0) atomicAdd((unsigned*)flag, 1u);
+    } else if (mfma_on) {
+        unsigned h = threadIdx.x * 2654435761u + blockIdx.x; h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+        uint4 fa = make_uint4((h & 0x8fff8fffu) | 0x30003000u, (h * 3 & 0x8fff8fffu) | 0x30003000u, (h * 5 & 0x8fff8fffu) | 0x30003000u, (h * 7 & 0x8fff8fffu) | 0x30003000u);
+        uint4 fb = make_uint4((h * 11 & 0x8fff8fffu) | 0x30003000u, (h * 13 & 0x8fff8fffu) | 0x30003000u, (h * 17 & 0x8fff8fffu) | 0x30003000u, (h * 19 & 0x8fff8fffu) | 0x30003000u);
+        float16v acc[4];
+        for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        const char* lp = smem + (wave - 4) * 8192 + lane * 16;   // reads the DMA destination area (no data dependence on it)
+        while (*flag < 4u) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (mfma_on & 2) {   // a consumer's LDS diet: ~1.2 KB of ds_read_b128 per MFMA
+                    uint4 v; asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) char*)(lp + (u & 7) * 1024)) : "memory");
+                    fb.x ^= v.x & 1u;
+                    if (u & 1) { uint4 w; asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) char*)(lp + 512)) : "memory"); fa.y ^= w.y & 1u; }
+                }
+                acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa), __builtin_bit_cast(half8, fb), acc[u & 3], 0, 0, 0);
+            }
+        }
+        float s = 0.f;
+        for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
+        if (s == 1.2345f) out[1] = 1;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, int reads_per_write) {
     const size_t stride = (size_t)gridDim.x * 4096;
     for (size_t b = (size_t)blockIdx.x * 4096; b < n16; b += stride) {
@@ -95,7 +140,7 @@ int main() {
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep == 2) printf("%-62s %8.3f ms  %7.2f TB/s\n", name, ms, moved / ms * 1e-9);
+            if (rep == 2) printf("%-76s %8.3f ms  %7.2f TB/s\n", name, ms, moved / ms * 1e-9);
         }
     };
     for (int wgs : {512, 1024, 2048}) {
@@ -112,6 +157,10 @@ int main() {
     }
     time("read  LDS-DMA 64 KB HBM + 32 KB L2-hit, 256 wgs (HBM part)", (double)bytes, [&] { hipLaunchKernelGGL(k_dma<2>, dim3(256), dim3(256), 65536, 0, a, bytes, out); });
     time("read  LDS-DMA 64 KB HBM + 32 KB L2-hit, 512 wgs (HBM part)", (double)bytes, [&] { hipLaunchKernelGGL(k_dma<2>, dim3(512), dim3(256), 65536, 0, a, bytes, out); });
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dma_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 64));
+    time("read  LDS-DMA 64 KB blocks, 256 wgs, 8 idle waves", (double)bytes, [&] { hipLaunchKernelGGL(k_dma_mfma, dim3(256), dim3(768), 65536 + 64, 0, a, bytes, out, 0); });
+    time("read  LDS-DMA 64 KB blocks, 256 wgs, 8 MFMA waves (random data)", (double)bytes, [&] { hipLaunchKernelGGL(k_dma_mfma, dim3(256), dim3(768), 65536 + 64, 0, a, bytes, out, 1); });
+    time("read  LDS-DMA 64 KB blocks, 256 wgs, 8 MFMA waves + ds_read_b128 streams", (double)bytes, [&] { hipLaunchKernelGGL(k_dma_mfma, dim3(256), dim3(768), 65536 + 64, 0, a, bytes, out, 3); });
     time("copy  1 read : 1 write, 2048 wgs", 2.0 * bytes, [&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, (const uint4*)a, (uint4*)b, bytes / 16, 1); });
     time("copy  2 reads : 1 write, 2048 wgs", 3.0 * bytes, [&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, (const uint4*)a, (uint4*)b, bytes / 16, 2); });
     return 0;
