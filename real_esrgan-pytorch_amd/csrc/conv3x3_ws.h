@@ -52,7 +52,9 @@ struct WsCfg {
     static constexpr int WTAP = KS * MT * 1024;     // packed weight bytes per (chunk, tap)
     // 4 consumer + 4 producer waves: a workgroup's waves are dealt to the SIMDs round-robin from SIMD 0, so every SIMD
     // gets one consumer and one producer; two workgroups per CU then need <= 128 VGPRs (4 waves per SIMD).
-    static constexpr int NP = 4;                    // producer waves (a single wave issues ~1 KB of LDS-DMA per 70 ns)
+    // producer waves (a single wave issues ~1 KB of LDS-DMA per 70 ns); 8 where 16 waves fit the register file (<= 128
+    // VGPRs): with three buffers more requests can be outstanding, and 8 waves hold them (835 -> 880 TFLOP/s)
+    static constexpr int NP = (MT == 1 && NT * NWC == 16) ? 8 : 4;
     static constexpr int NIP = (NI + NP - 1) / NP;  // LDS-DMA instructions per producer wave per stage
     static constexpr int NTHR = 64 * (NWC + NP);
     // The chunk's packed weights (18 KB per 32 output channels) go through LDS as well: one LDS-DMA copy per stage shared
