@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (the reference trains 16 per GPU; 8..32 measured: 104..110 images/s)")
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (the reference trains 16 per GPU; 8..32 measured within 5 % of each other)")
     ap.add_argument("--lr-size", type=int, default=256, help="LR tile edge; HR = 4x (headline: 256 -> 1024)")
     ap.add_argument("--precision", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-degradation", action="store_true", help="debug only: feed pre-degraded LR tiles")

@@ -540,15 +540,21 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
     }
 }
 
-// deterministic slab reduction -> OIHW fp32 gradient (+ bias gradient)
+// deterministic slab reduction -> OIHW fp32 gradient (+ bias gradient).  64 slab elements per workgroup, the splits dealt to
+// four thread groups (more loads in flight: the slabs of a dense block are 69 MB) and summed in a fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
+    __shared__ float red[4][64];
     const ReduceJob job = a.jobs[blockIdx.x];
-    const int e = blockIdx.y * 256 + threadIdx.x;
-    if (e >= kSlab) return;
-    const float* p = a.partial + job.slab_off + e;
+    const int e = blockIdx.y * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     float s = 0.f;
-    for (int k = 0; k < a.splits; ++k) s += p[(size_t)k * kSlab];
-    s *= job.scale;
+    if (e < kSlab) {
+        const float* p = a.partial + job.slab_off + e;
+        for (int k = g; k < a.splits; k += 4) s += p[(size_t)k * kSlab];
+    }
+    red[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g != 0 || e >= kSlab) return;
+    s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * job.scale;
     if (e < 9 * 1024) {
         const int tap = e >> 10, co = job.co_base + ((e >> 5) & 31), ci = job.ci_base + (e & 31);
         if (co < job.cout && ci < job.cin_real) job.dw[((size_t)co * job.cin_real + ci) * 9 + tap] = s;
@@ -764,7 +770,7 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
     else if (dtype == RESR_F32) rc = launch_wgrad<float, 1>(a, nj, stream);
     else return fail(RESR_ERR_ARG, "wgrad: dtype=%d", dtype);
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nj, (kSlab + 255) / 256), dim3(256), 0, stream, r);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nj, (kSlab + 63) / 64), dim3(256), 0, stream, r);
     RESR_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RESR_OK;
 }
