@@ -492,48 +492,59 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         // Per (row, cout tile): every epilogue input is requested before the first store, so the batch pays one
         // memory latency instead of one per piece (loads behind stores wait for the stores).
         static_assert(sizeof(T) == 2, "the 8-channel epilogue assumes f16 storage");
+        // Every epilogue input of a batch is requested before the batch's first store (loads behind stores wait for the
+        // stores' acks on the in-order counter, one memory round trip per batch).  cout 64: the batch is a whole row -- four
+        // pieces with up to two residuals -- and row t+1 is requested before row t is processed (64 registers that are free
+        // once the MFMA loop is over; 16 exposed round trips per tile were 3.3 us); cout <= 32 (tighter register budget): both
+        // pieces when there is only a mask, one piece with residuals.
+        constexpr bool RB = MT == 2 && !EX;
+        constexpr int JB = (RB || !(ER || EX)) ? 2 : 1;
+        constexpr int MA = RB ? MT : 1;   // without row batching one m tile's inputs are live at a time
+        constexpr int NB = RB ? 2 : 1;    // row double buffer
+        half8 rmask[NB][MA][2], rres0[NB][MA][2], rres1[NB][MA][2];
+        unsigned mbits[NB][MA];   // EMB: the pixel's sign word of chunk m (bit c <-> channel 32m + c)
+        // pieces outside the image / beyond cout read a clamped (valid) address and are dropped at the store
+        auto row_p = [&](int t) {
+            const int y = y0 + row0 + t;
+            return ((size_t)n * e.h + (y < e.h ? y : e.h - 1)) * e.w_ + (x < e.w_ ? x : e.w_ - 1);
+        };
+        // element offset of piece (m, j) inside a pixel of an operand with chunk stride cs (clamped when beyond cout)
+        auto poff = [&](int m, int j, int cs) {
+            return m * 32 + (2 * j + kh_e) * 8 < e.cout ? (size_t)m * cs + (2 * j + kh_e) * 8 : (size_t)0;
+        };
+        auto request = [&](int b, size_t p, int m, int j0) {
+            if (EMB) {
+                if (j0 == 0) mbits[b][m % MA] = reinterpret_cast<const unsigned*>(e.mask)[p * (size_t)((e.cout + 31) >> 5) + m];
+            } else if (f_mask) {
+#pragma unroll
+                for (int j = j0; j < j0 + JB; ++j)
+                    rmask[b][m % MA][j] = *reinterpret_cast<const half8*>(e.mask + (p * e.mask_stride + poff(m, j, e.mask_chunk)) * 2);
+            }
+            if (f_res0) {
+#pragma unroll
+                for (int j = j0; j < j0 + JB; ++j)
+                    rres0[b][m % MA][j] = *reinterpret_cast<const half8*>(e.res0 + (p * e.res0_stride + poff(m, j, e.res0_chunk)) * 2);
+            }
+            if (f_res1) {
+#pragma unroll
+                for (int j = j0; j < j0 + JB; ++j)
+                    rres1[b][m % MA][j] = *reinterpret_cast<const half8*>(e.res1 + (p * e.res1_stride + poff(m, j, e.res1_chunk)) * 2);
+            }
+        };
+        if (RB) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) request(0, row_p(0), m, 0);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int y = y0 + row0 + t;
             const bool in_img = y < e.h && x < e.w_;
-            // pieces outside the image / beyond cout read a clamped (valid) address and are dropped at the store
-            const size_t p = ((size_t)n * e.h + (y < e.h ? y : e.h - 1)) * e.w_ + (x < e.w_ ? x : e.w_ - 1);
-            // Every epilogue input of a batch is requested before the batch's first store (loads behind stores wait for
-            // the stores' acks on the in-order counter, one memory round trip per batch).  cout 64: the whole row -- four
-            // pieces with up to two residuals, 32 registers that are free once the MFMA loop is over (16 round trips
-            // per tile were 3.3 us); cout <= 32 (168-register budget): both pieces when there is only a mask, one
-            // piece with residuals.
-            constexpr bool RB = MT == 2 && !EX;
-            constexpr int JB = (RB || !(ER || EX)) ? 2 : 1;
-            constexpr int MA = RB ? MT : 1;   // without row batching one m tile's inputs are live at a time
-            half8 rmask[MA][2], rres0[MA][2], rres1[MA][2];
-            unsigned mbits[MA];   // EMB: the pixel's sign word of chunk m (bit c <-> channel 32m + c)
-            // element offset of piece (m, j) inside a pixel of an operand with chunk stride cs (clamped when beyond cout)
-            auto poff = [&](int m, int j, int cs) {
-                return m * 32 + (2 * j + kh_e) * 8 < e.cout ? (size_t)m * cs + (2 * j + kh_e) * 8 : (size_t)0;
-            };
-            auto request = [&](int m, int j0) {
-                if (EMB) {
-                    if (j0 == 0) mbits[m % MA] = reinterpret_cast<const unsigned*>(e.mask)[p * (size_t)((e.cout + 31) >> 5) + m];
-                } else if (f_mask) {
+            const size_t p = row_p(t);
+            constexpr int bsel = 0;
+            const int b = RB ? (t & 1) : bsel;
+            if (RB && t + 1 < NT) {
 #pragma unroll
-                    for (int j = j0; j < j0 + JB; ++j)
-                        rmask[m % MA][j] = *reinterpret_cast<const half8*>(e.mask + (p * e.mask_stride + poff(m, j, e.mask_chunk)) * 2);
-                }
-                if (f_res0) {
-#pragma unroll
-                    for (int j = j0; j < j0 + JB; ++j)
-                        rres0[m % MA][j] = *reinterpret_cast<const half8*>(e.res0 + (p * e.res0_stride + poff(m, j, e.res0_chunk)) * 2);
-                }
-                if (f_res1) {
-#pragma unroll
-                    for (int j = j0; j < j0 + JB; ++j)
-                        rres1[m % MA][j] = *reinterpret_cast<const half8*>(e.res1 + (p * e.res1_stride + poff(m, j, e.res1_chunk)) * 2);
-                }
-            };
-            if (RB) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) request(m, 0);
+                for (int m = 0; m < MT; ++m) request((t + 1) & 1, row_p(t + 1), m, 0);
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 unsigned sbits = 0;   // ESB: this lane's bytes of the sign word
 #pragma unroll
                 for (int j0 = 0; j0 < 2; j0 += JB) {
-                if (!RB) request(m, j0);
+                if (!RB) request(0, p, m, j0);
 #pragma unroll
                 for (int j = j0; j < j0 + JB; ++j) {
                     float v[8];
@@ -562,12 +573,12 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     };
                     if (f_aux_mask && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(m, j, e.out_chunk));
                     if (EMB) {
-                        const unsigned byte = mbits[m % MA] >> (8 * (2 * j + kh_e));
+                        const unsigned byte = mbits[b][m % MA] >> (8 * (2 * j + kh_e));
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] *= ((byte >> r) & 1u) ? 1.f : e.slope;
                     } else if (f_mask) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] *= ((float)rmask[m % MA][j][r] > 0.f ? 1.f : e.slope);
+                        for (int r = 0; r < 8; ++r) v[r] *= ((float)rmask[b][m % MA][j][r] > 0.f ? 1.f : e.slope);
                     }
                     if (f_lrelu) {
 #pragma unroll
@@ -576,11 +587,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     if (f_aux_res && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(m, j, e.out_chunk));
                     if (f_res0) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], e.s0, e.t0 * (float)rres0[m % MA][j][r]);   // explicit: one rounding, the same in every instantiation
+                        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], e.s0, e.t0 * (float)rres0[b][m % MA][j][r]);   // explicit: one rounding, the same in every instantiation
                     }
                     if (f_res1) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], e.s1, e.t1 * (float)rres1[m % MA][j][r]);
+                        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], e.s1, e.t1 * (float)rres1[b][m % MA][j][r]);
                     }
                     if (f_nchw) {
                         float* o = reinterpret_cast<float*>(e.out);
