@@ -496,7 +496,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
             const int kbh = st / 6, j = st % 6;
             if (st + 1 < 12) fload(st + 1);
             if (j < 4) bsum += sum8_f16(fg[kbh][j]);     // 4 dot instructions; only written where a bias is wanted
-            bool staged = false;
+            // the next tile's ten requests go out during the first five steps, two per step, each behind a group of MFMAs:
+            // the last one then has seven steps (~2.5 us) to land before the tile barrier
+            int slot = 2 * st;
 #pragma unroll
             for (int dy = 2; dy >= 0; --dy) {    // descending: the accumulators the previous step touched last come last
                 const int r = j - dy;
@@ -505,8 +507,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
                 for (int dx = 0; dx < 3; ++dx)
                     acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fg[kbh][r]),
                                                                               __builtin_bit_cast(half8, fb[st & 1][dx]), acc[dy * 3 + dx], 0, 0, 0);
-                if (!staged && st < NSX + NSG) { stage_slot(st, tn, nb, has_next); staged = true; }
+                if (slot < 2 * st + 2 && slot < NSX + NSG) { stage_slot(slot, tn, nb, has_next); ++slot; }
             }
+            if (slot < 2 * st + 2 && slot < NSX + NSG) { stage_slot(slot, tn, nb, has_next); ++slot; }   // one-group steps
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's asm LDS-DMA has landed
         __syncthreads();
