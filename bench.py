@@ -35,8 +35,8 @@ PEAK_F32_TFLOPS = 157.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (the reference trains 16 per GPU; 8..32 measured within 5 % of each other)")
     ap.add_argument("--lr-size", type=int, default=256, help="LR tile edge; HR = 4x (headline: 256 -> 1024)")
     ap.add_argument("--precision", default="fast", choices=["fast", "strict"])

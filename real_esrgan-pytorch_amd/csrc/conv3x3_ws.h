@@ -54,7 +54,7 @@ struct WsCfg {
     // gets one consumer and one producer; two workgroups per CU then need <= 128 VGPRs (4 waves per SIMD).
     // producer waves (a single wave issues ~1 KB of LDS-DMA per 70 ns); 8 where 16 waves fit the register file (<= 128
     // VGPRs): with three buffers more requests can be outstanding, and 8 waves hold them (835 -> 880 TFLOP/s)
-    static constexpr int NP = (MT == 1 && NT * NWC == 16) ? 8 : 4;
+    static constexpr int NP = (MT == 1 && NT * NWC <= 16) ? 8 : 4;
     static constexpr int NIP = (NI + NP - 1) / NP;  // LDS-DMA instructions per producer wave per stage
     static constexpr int NTHR = 64 * (NWC + NP);
     // The chunk's packed weights (18 KB per 32 output channels) go through LDS as well: one LDS-DMA copy per stage shared
@@ -63,7 +63,7 @@ struct WsCfg {
     // 16-row tiles of cout <= 32: three 39 KB halo buffers, so the request for stage s+2 is in flight while stage s+1
     // lands and stage s is multiplied (with two buffers the memory pipe drains at every stage of a memory-bound launch:
     // measured 4.2 us of back-pressured issue, then 1.1 us with nothing in flight, per 5.5 us stage of a 32-row tile).
-    static constexpr int NHB = (MT == 1 && NT * NWC == 16) ? 3 : 2;
+    static constexpr int NHB = (MT == 1 && NT * NWC <= 16) ? 3 : 2;
     static constexpr int WBUF = 9 * KS * MT * 1024;  // packed weight bytes per chunk
     static constexpr int NWI = WBUF / 1024;          // LDS-DMA instructions per chunk of weights
     static constexpr int NWIP = (NWI + NP - 1) / NP;
