@@ -228,6 +228,11 @@ int resr_ema_update(float* shadow, const float* params, int64_t count, double de
 
 /* Debug: per-workgroup timeline of the fast-mode conv kernel (32 workgroups x 2 roles x 64 uint64 stamps, 100 MHz). */
 int resr_debug_conv_trace(void* dev_buf);
+/* Host logic of the f16 weight-gradient launch, no GPU needed: how the (X chunk, G tile) products of `nconv` convolutions
+ * that read one channel-prefix workspace (conv i: the first cin[i] channels; its own cout_pad[i] gradient channels) are
+ * grouped into 2x2 jobs of the quad kernel.  out[q*4 + p] = index of the product computed by slot p of job q (products are
+ * numbered conv-major, then G tile, then X chunk), -1 = slot unused.  Returns the number of jobs (<= max_jobs) or < 0. */
+int resr_debug_wgrad_plan(const int32_t* cin, const int32_t* cout_pad, int32_t nconv, int32_t* out, int32_t max_jobs);
 /* test probe: lane/element map of ds_read_b64_tr_b16 (256 floats out) */
 int resr_debug_tr_probe(float* out256, void* stream);
 

@@ -50,6 +50,7 @@ int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*,
                      const void*, const void*, void*, void*, hipStream_t);
 int wgrad_dispatch(const ResrWgradDesc*, const void*, const void*, const void*, float*, float*, float*, hipStream_t);
 size_t wgrad_partial_bytes(const ResrWgradDesc*);
+int wgrad_debug_plan(const int*, const int*, int, int*, int);
 int pack_dispatch(const ResrPackChunk*, int, const float*, void*, int, hipStream_t);
 int ema_dispatch(float*, const float*, long, double, hipStream_t);
 int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t);
@@ -268,6 +269,11 @@ int64_t resr_profile_end(ResrProfEntry* out, int64_t capacity) {
     }
     g_prof.clear();
     return n;
+}
+
+// host logic probe (no GPU): 2x2 grouping of a weight-gradient launch's products
+int resr_debug_wgrad_plan(const int32_t* cin, const int32_t* cout_pad, int32_t nconv, int32_t* out, int32_t max_jobs) {
+    return wgrad_debug_plan(cin, cout_pad, nconv, out, max_jobs);
 }
 
 // debug: device buffer of 32*2*64 uint64 receiving s_memrealtime stamps of the next conv launches (null = off)

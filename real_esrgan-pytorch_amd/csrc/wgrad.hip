@@ -700,6 +700,33 @@ static int launch_wgrad_quad(const WgradArgs& a, int nj, hipStream_t stream, boo
     return RESR_OK;
 }
 
+// resr_debug_wgrad_plan (include/resr.h): the grouping above on synthetic operand addresses
+int wgrad_debug_plan(const int* cin, const int* cout_pad, int nconv, int* out, int max_jobs) {
+    if (!cin || !cout_pad || !out || nconv <= 0 || max_jobs <= 0) return fail(RESR_ERR_ARG, "wgrad plan: null argument");
+    static thread_local WgradArgs a;
+    static thread_local WgradQuadArgs q;
+    memset(&a, 0, sizeof(a));
+    const char* xbase = reinterpret_cast<const char*>(0x10000000);   // never dereferenced
+    const char* gbase = reinterpret_cast<const char*>(0x20000000);
+    int nj = 0, gt = 0;
+    for (int i = 0; i < nconv; ++i) {
+        if (cin[i] <= 0 || (cin[i] & 31) || (cout_pad[i] != 32 && cout_pad[i] != 64)) return fail(RESR_ERR_ARG, "wgrad plan: cin=%d cout_pad=%d", cin[i], cout_pad[i]);
+        for (int ct = 0; ct < cout_pad[i] / 32; ++ct, ++gt)
+            for (int ck = 0; ck < cin[i] / 32; ++ck) {
+                if (nj >= kMaxJobs) return fail(RESR_ERR_ARG, "wgrad plan: more than %d products", kMaxJobs);
+                a.jobs[nj].x = xbase + ck * 64;
+                a.jobs[nj].g = gbase + gt * 64;
+                a.jobs[nj].slab_off = (unsigned)nj;     // product index
+                ++nj;
+            }
+    }
+    const int nq = build_quads(a, nj, q);
+    if (nq < 0 || nq > max_jobs) return fail(RESR_ERR_ARG, "wgrad plan: %d jobs", nq);
+    for (int i = 0; i < nq; ++i)
+        for (int p = 0; p < 4; ++p) out[i * 4 + p] = q.jobs[i].slab_off[p] == ~0u ? -1 : (int)q.jobs[i].slab_off[p];
+    return nq;
+}
+
 // One batched launch pair.  `convs` describes up to a dense block's worth of convolutions that share
 // n/h/w/flags; jobs are generated as (conv, ci chunk, co tile).
 struct WgradConv {

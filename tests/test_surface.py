@@ -118,3 +118,42 @@ def test_natural_sort():
     from real_esrgan_pytorch_amd.test import natural_sorted
     assert natural_sorted(["img10.png", "img2.png", "a.png", "img1.png", "10.png", "9.png"]) == \
         ["9.png", "10.png", "a.png", "img1.png", "img2.png", "img10.png"]
+
+
+def test_wgrad_quad_plan_host_logic():
+    """Host side of the f16 weight-gradient launch (csrc/wgrad.hip build_quads, no GPU): every (X chunk, G tile) product of a
+    launch lands in exactly one slot of one 2x2 job; a dense block's 26 products need 7 jobs (6 full + one diagonal)."""
+    import ctypes as C
+    from real_esrgan_pytorch_amd import _lib as L
+    lib = L.lib()
+
+    def plan(cins, couts):
+        n = len(cins)
+        out = (C.c_int32 * (40 * 4))()
+        nq = lib.resr_debug_wgrad_plan((C.c_int32 * n)(*cins), (C.c_int32 * n)(*couts), n, out, 40)
+        assert nq > 0, L.last_error() if hasattr(L, "last_error") else nq
+        return [[out[q * 4 + p] for p in range(4)] for q in range(nq)]
+
+    def products(cins, couts):
+        return sum((ci // 32) * (co // 32) for ci, co in zip(cins, couts))
+
+    # reference ResidualDenseBlock (model.py:73-85): convs 64->32, 96->32, 128->32, 160->32, 192->64 on one workspace
+    rdb = ([64, 96, 128, 160, 192], [32, 32, 32, 32, 64])
+    jobs = plan(*rdb)
+    used = sorted(p for j in jobs for p in j if p >= 0)
+    assert used == list(range(products(*rdb))) == list(range(26))
+    assert len(jobs) == 7 and sum(1 for j in jobs if all(p >= 0 for p in j)) == 6
+    assert sorted(sum(p >= 0 for p in j) for j in jobs)[0] == 2              # the diagonal job
+    # single convolutions of the generator's head / tail and of the discriminator
+    for cins, couts, njobs in (([64], [64], 1), ([32], [64], 1), ([64], [32], 1), ([32], [32], 1), ([1024], [64], 16),
+                               ([160], [32], 3)):
+        jobs = plan(cins, couts)
+        assert len(jobs) == njobs, (cins, couts, jobs)
+        used = sorted(p for j in jobs for p in j if p >= 0)
+        assert used == list(range(products(cins, couts)))
+    # slot p of a job is (X chunk p & 1, G tile p >> 1): the two slots of a row share the G tile, of a column the X chunk
+    j = plan([64], [64])[0]          # products numbered conv-major, then G tile, then X chunk: (g0,x0)=0 (g0,x1)=1 (g1,x0)=2 (g1,x1)=3
+    assert j == [0, 1, 2, 3]
+    # argument errors come back as negative status, not as a crash
+    bad = (C.c_int32 * 4)()
+    assert lib.resr_debug_wgrad_plan((C.c_int32 * 1)(48), (C.c_int32 * 1)(32), 1, bad, 1) < 0
