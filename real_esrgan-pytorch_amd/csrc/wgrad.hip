@@ -11,14 +11,19 @@
 //   f32: v_mfma_f32_32x32x2_f32 takes one element per lane, so a plain ds_read_b32 (32 consecutive
 //        channels of one pixel per half-wave) is already fragment-shaped.
 //
-// Work decomposition.  A *job* is one (conv, 32-channel chunk of X, 32-channel tile of G) pair; a
-// launch takes a list of jobs that share the pixel geometry -- all five convs of a dense block go in
-// one launch (26 jobs), because they read the same workspace and are individually too small to fill
-// 256 CUs.  grid = (jobs, pixel splits).  The 4 waves of a workgroup split a (4*RPW) x 32 pixel tile
-// by rows (K-split) and each keeps all 9 taps' 32x32 accumulators (144 VGPRs) while the workgroup
-// walks its share of the pixel tiles; at the end the 4 waves are summed through LDS and one fp32
-// slab [9][32][32] (+32 bias sums) per (job, split) is written.  A second launch reduces the slabs in
-// a fixed order (deterministic) into the OIHW fp32 gradient arena.
+// Work decomposition.  A *product* is one (conv, 32-channel chunk of X, 32-channel tile of G) pair; a
+// launch takes the products of convolutions that share the pixel geometry -- all five convs of a dense
+// block go in one launch (26 products), because they read the same workspace and are individually too
+// small to fill 256 CUs.  Two kernels compute them:
+//   wgrad_kernel<T,RPW>  "pair" kernel, one product per workgroup: grid = (products, pixel splits).  The 4
+//                        waves of a workgroup split a (4*RPW) x 32 pixel tile by rows (K-split) and each keeps
+//                        all 9 taps' 32x32 accumulators (144 VGPRs) while the workgroup walks its share of the
+//                        pixel tiles.  Strict (f32) mode, and f16 when the quad kernel's preconditions fail.
+//   wgrad_quad_kernel    f16: four products (2 X chunks x 2 G tiles) per 8-wave workgroup on one staged tile
+//                        (see its own comment); the host groups a launch's products into such 2x2 jobs.
+// Either way the waves of a workgroup are summed through LDS at the end and one fp32 slab [9][32][32] (+32 bias
+// sums) per (product, split) is written; a second launch reduces the slabs in a fixed order (deterministic) into
+// the OIHW fp32 gradient arena.
 #include <stdlib.h>
 
 #include "common.h"
