@@ -157,3 +157,30 @@ def test_wgrad_quad_plan_host_logic():
     # argument errors come back as negative status, not as a crash
     bad = (C.c_int32 * 4)()
     assert lib.resr_debug_wgrad_plan((C.c_int32 * 1)(48), (C.c_int32 * 1)(32), 1, bad, 1) < 0
+
+
+def test_entry_points_keep_the_reference_function_names(built):
+    """The train / test entry points expose the functions a user of the reference's scripts calls or patches
+    (train_realesrnet.py, train_realesrgan.py, test.py, inference.py: main / load_dataset / build_model / define_* / train /
+    validate and the meters)."""
+    import importlib
+    import inspect
+    want = {
+        "train_realesrnet": ["main", "load_dataset", "build_model", "define_loss", "define_optimizer", "define_scheduler",
+                             "load_checkpoint", "save_checkpoint", "train", "validate", "Summary", "AverageMeter", "ProgressMeter"],
+        "train_realesrgan": ["main", "load_dataset", "build_model", "define_loss", "define_optimizer", "define_scheduler",
+                             "train", "validate", "AverageMeter", "ProgressMeter"],
+        "test": ["main"],
+        "inference": ["main"],
+    }
+    for mod, names in want.items():
+        m = importlib.import_module(f"real_esrgan_pytorch_amd.{mod}")
+        for n in names:
+            assert hasattr(m, n), f"{mod}.{n} missing"
+    g = importlib.import_module("real_esrgan_pytorch_amd.train_realesrgan")
+    # argument order of the reference's GAN train() (train_realesrgan.py:282-294)
+    assert list(inspect.signature(g.train).parameters)[:12] == [
+        "discriminator", "generator", "ema_model", "train_prefetcher", "pixel_criterion", "content_criterion",
+        "adversarial_criterion", "d_optimizer", "g_optimizer", "epoch", "scaler", "writer"]
+    n = importlib.import_module("real_esrgan_pytorch_amd.train_realesrnet")
+    assert list(inspect.signature(n.validate).parameters) == ["model", "ema_model", "data_prefetcher", "epoch", "writer", "niqe_model", "mode"]
