@@ -54,6 +54,10 @@ CONV_CASES = [
     ("signbits64", 96, 96, 64, "lrelu,signbits", 1, 40, 70),
     ("maskbits32", 128, 64, 32, "mask,nobias,maskbits", 1, 33, 64),
     ("maskbits64", 64, 64, 64, "mask,nobias,maskbits", 2, 20, 36),
+    # 16-row tile shapes (three halo buffers for cout <= 32) with ragged last tile row / column and several tiles per workgroup
+    ("rows16_ragged32", 96, 96, 32, "lrelu,signbits", 8, 200, 200),
+    ("rows16_ragged64", 64, 64, 64, "res0", 8, 200, 200),
+    ("rows16_maskbits_2seg", 160, 64, 32, "mask,nobias,maskbits", 6, 184, 216),
 ]
 
 
