@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--precision", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-degradation", action="store_true", help="debug only: feed pre-degraded LR tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-tensor-adam", action="store_true", help="optimizer over the 702 per-tensor Parameters instead of the flat arena")
     ap.add_argument("--no-probe", action="store_true", help="skip the in-situ roofline step")
     ap.add_argument("--isolated-probe", action="store_true", help="also time every conv shape back-to-back in isolation")
     return ap.parse_args()
@@ -285,7 +286,10 @@ def main():
     dp.attach(model)
     ema = R.EMA(model, 0.999)                             # config.py:102
     ema.register()
-    opt = torch.optim.Adam(model.parameters(), 2e-4, (0.9, 0.99), fused=True)   # config.py:100-101
+    # config.py:100-101.  Default: Adam over the one Parameter that aliases the flat arena (same update, one launch);
+    # --per-tensor-adam: over the 702 per-tensor Parameters like the reference's script
+    opt_params = model.parameters() if args.per_tensor_adam else [model.flat_parameter()]
+    opt = torch.optim.Adam(opt_params, 2e-4, (0.9, 0.99), fused=True)
     scaler = torch.amp.GradScaler("cuda") if args.precision == "fast" else None  # train_realesrnet.py:97
 
     B, lr_edge = args.batch, args.lr_size

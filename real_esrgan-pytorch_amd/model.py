@@ -148,6 +148,7 @@ class Generator(nn.Module):
         self._table_dev: Dict[int, tuple] = {}
         self._workspaces: Dict[tuple, List[_Workspace]] = {}
         self.grad_hook = None   # callable(flat_grad) run after backward wrote the arena (data-parallel all-reduce)
+        self.__dict__["_flat_param"] = None   # see flat_parameter(); kept out of nn.Module's parameter registry
 
     # ---- flat arena ---------------------------------------------------------------------------
     def _ordered_params(self) -> List[nn.Parameter]:
@@ -190,6 +191,22 @@ class Generator(nn.Module):
 
     def flat_grad(self) -> Optional[torch.Tensor]:
         return self._flat_grad
+
+    def flat_parameter(self) -> nn.Parameter:
+        """One leaf Parameter that aliases the whole fp32 arena, for an optimizer that should see a single tensor:
+        `optim.Adam([g.flat_parameter()], ..., fused=True)` is one elementwise launch (and one GradScaler unscale /
+        inf-check) instead of multi-tensor launches over 702 views.  After this call backward hands the gradient arena
+        to this Parameter's `.grad` (overwritten, not accumulated) and returns no per-tensor gradients.  The per-tensor
+        Parameters stay valid views of the same storage; `state_dict()` is unchanged, the optimizer's own state_dict
+        then holds one tensor (not loadable into the reference's per-tensor Adam state)."""
+        flat = self.flat_parameters()
+        fp = self.__dict__["_flat_param"]
+        if fp is None:
+            fp = nn.Parameter(flat, requires_grad=True)
+            self.__dict__["_flat_param"] = fp
+        elif fp.data_ptr() != flat.data_ptr():
+            fp.data = flat
+        return fp
 
     # ---- C-ABI plumbing -------------------------------------------------------------------------
     def _desc(self, x: torch.Tensor, training: bool) -> _lib.GeneratorDesc:
@@ -264,6 +281,12 @@ class Generator(nn.Module):
                    "resr_generator_backward")
         if self.grad_hook is not None:
             self.grad_hook(self._flat_grad)
+        fp = self.__dict__["_flat_param"]
+        if fp is not None:                       # flat_parameter() mode: the arena is the gradient of the alias
+            if fp.data_ptr() != flat.data_ptr():
+                fp.data = flat
+            fp.grad = self._flat_grad
+            return [None] * len(self._ordered_params()), gx
         grads, off = [], 0
         for p in self._ordered_params():
             n = p.numel()

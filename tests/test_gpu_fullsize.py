@@ -85,3 +85,31 @@ def test_training_reduces_the_loss():
     # EMA(0.9) after 60 steps sits close to the trained weights, far from the initial ones
     flat, shadow = g.flat_parameters(), ema._flat_shadow
     assert (flat - shadow).norm() < 0.5 * flat.norm() and torch.isfinite(shadow).all()
+
+
+def test_flat_parameter_adam_matches_per_tensor_adam():
+    """`Generator.flat_parameter()` mode (one Parameter aliasing the arena, gradient arena handed over as its `.grad`): three
+    GradScaler + fused-Adam steps give the same weights as the per-tensor optimizer of the reference's script."""
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd.train import RealESRNetStep
+
+    def run(flat_mode):
+        torch.manual_seed(11)
+        g = R.Generator(3, 3, 4, n_blocks=2).cuda().train()
+        params = [g.flat_parameter()] if flat_mode else g.parameters()
+        opt = torch.optim.Adam(params, 2e-4, (0.9, 0.99), fused=True)
+        scaler = torch.amp.GradScaler("cuda")
+        step = RealESRNetStep(g, None, opt, scaler, None)
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        losses = []
+        for _ in range(3):
+            lr = torch.rand(2, 3, 32, 48, device="cuda", generator=gen)
+            hr = torch.rand(2, 3, 128, 192, device="cuda", generator=gen)
+            losses.append(step(hr, lr).item())
+        assert len(g.state_dict()) == len(list(g.parameters())) == 2 * (2 * 15 + 6)      # the alias is not a module parameter
+        return g.flat_parameters().clone(), losses
+
+    w_ref, l_ref = run(False)
+    w_flat, l_flat = run(True)
+    assert l_ref == l_flat
+    assert torch.equal(w_ref, w_flat), (w_ref - w_flat).abs().max().item()
