@@ -247,7 +247,9 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             __syncthreads();           // barrier 0
             for (int s = 0; have_next; ++s) {   // stage s is being multiplied; H(s+1) is in flight
                 stamp(0);
-                issue_w(ck_next, (s + 1) & 1);           // its buffer was read by stage s-1: free past barrier s
+                // its buffer was read by stage s-1: free past barrier s.  With one or two chunks the two weight buffers hold
+                // every chunk after stages 0 and 1 (stage s uses buffer s & 1 = chunk s % nchunks): nothing to reload
+                if (nchunks > 2 || s + 1 < 2) issue_w(ck_next, (s + 1) & 1);
                 if (++ick == nchunks) { ick = 0; it += G; }
                 const bool have_next2 = it < ntiles;
                 if (have_next2) {
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             }
         };
         int par = 0;
+        int nstage = 0;   // index of the stage this iteration requests
         for (int tile = first; tile < ntiles; tile += G) {
             stamp(0);
             for (int ck = 0; ck < nchunks; ++ck) {
@@ -345,9 +348,10 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             conv_glds16_s(a.zero, 0u, ldst);
                         }
                     }
-                    stage_weights(ck, par);
+                    if (nchunks > 2 || nstage < 2) stage_weights(ck, par);   // <= 2 chunks: both buffers stay valid (buffer s & 1 = chunk s % nchunks)
                 }
                 par ^= 1;
+                ++nstage;
                 stamp(0);
                 // the next tile's index math runs while this tile's last chunk is in flight
                 if (ck == nchunks - 1 && tile + G < ntiles) tile_pix(tile + G, pixn);
