@@ -68,7 +68,10 @@ struct WsCfg {
     static constexpr int NWI = WBUF / 1024;          // LDS-DMA instructions per chunk of weights
     static constexpr int NWIP = (NWI + NP - 1) / NP;
     static constexpr int WOFF = NHB * BUF + 256;     // after the halo buffers and the bias
-    static constexpr int LDS_BYTES = WOFF + 2 * WBUF;
+    // weight buffers: as many as fit next to the halo buffers (at least the ring of two).  A launch whose chunks all fit
+    // keeps them resident (buffer = chunk, loaded during the first tile only); otherwise the two-buffer ring by stage parity.
+    static constexpr int NWB = (160 * 1024 - WOFF) / WBUF < 2 ? 2 : (160 * 1024 - WOFF) / WBUF;
+    static constexpr int LDS_BYTES = WOFF + NWB * WBUF;
 };
 
 __device__ __forceinline__ void conv_glds16(const char* gsrc, char* lds_wave_base) {
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 else __builtin_amdgcn_s_waitcnt((K0 & 15) | 0x0F70 | ((K0 >> 4) << 14));
             };
             if (first >= ntiles) return;
+            const bool wres = nchunks <= C::NWB;
             int it = first, ick = 0;   // the stage whose halo was requested last
             int hb = 0;                // ... and its buffer
             tile_pix(it);
@@ -247,9 +251,9 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             __syncthreads();           // barrier 0
             for (int s = 0; have_next; ++s) {   // stage s is being multiplied; H(s+1) is in flight
                 stamp(0);
-                // its buffer was read by stage s-1: free past barrier s.  With one or two chunks the two weight buffers hold
-                // every chunk after stages 0 and 1 (stage s uses buffer s & 1 = chunk s % nchunks): nothing to reload
-                if (nchunks > 2 || s + 1 < 2) issue_w(ck_next, (s + 1) & 1);
+                // ring: its buffer was read by stage s-1, free past barrier s; resident: loaded during the first tile only
+                if (!wres) issue_w(ck_next, (s + 1) & 1);
+                else if (s + 1 < nchunks) issue_w(ck_next, ck_next);
                 if (++ick == nchunks) { ick = 0; it += G; }
                 const bool have_next2 = it < ntiles;
                 if (have_next2) {
@@ -329,6 +333,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         };
         int par = 0;
         int nstage = 0;   // index of the stage this iteration requests
+        const bool wres2 = nchunks <= C::NWB;
         for (int tile = first; tile < ntiles; tile += G) {
             stamp(0);
             for (int ck = 0; ck < nchunks; ++ck) {
@@ -348,7 +353,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             conv_glds16_s(a.zero, 0u, ldst);
                         }
                     }
-                    if (nchunks > 2 || nstage < 2) stage_weights(ck, par);   // <= 2 chunks: both buffers stay valid (buffer s & 1 = chunk s % nchunks)
+                    if (!wres2) stage_weights(ck, par);                    // ring of two by stage parity
+                    else if (nstage < nchunks) stage_weights(ck, ck);    // resident: buffer = chunk, first tile only
                 }
                 par ^= 1;
                 ++nstage;
@@ -418,6 +424,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             asm volatile("s_barrier" ::: "memory");
             if (wave == 0) stamp(1);
             const char* lbuf = smem + hbc * BUF;
+            const int wsel = nchunks <= C::NWB ? ck : par;   // resident weights: buffer = chunk; else the ring of two
             // halo rows of group gi+1 are read from LDS while the MFMAs of group gi run (ping-pong registers; NG is even)
             // when the register budget allows (PP); otherwise each group reads its own rows first
             constexpr int PP = (NWC == 4 || MT * NT * 16 + (NT + 2) * 8 <= 112) ? 1 : 0;   // 4-consumer shapes have a 256-register budget
@@ -429,7 +436,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             };
             // the stage's weights are in LDS once the barrier is passed: no prefetch across stages
 #pragma unroll
-            for (int u = 0; u < RING - 1; ++u) wload(u, par, u);
+            for (int u = 0; u < RING - 1; ++u) wload(u, wsel, u);
             if (PP) rload(0, 0);
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const int u = gi * 3 + dy;
-                    if (u + RING - 1 < NU) wload((u + RING - 1) % RING, par, u + RING - 1);
+                    if (u + RING - 1 < NU) wload((u + RING - 1) % RING, wsel, u + RING - 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
