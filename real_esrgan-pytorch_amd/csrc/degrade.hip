@@ -14,6 +14,8 @@
 
 #include <mutex>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace resr {
@@ -64,11 +66,129 @@ __global__ __launch_bounds__(256) void filter2d_kernel(const float* __restrict__
     }
 }
 
+// 21 x 21 taps (every blur / sinc kernel of the degradation is zero-padded to 21 x 21, dataset.py:101-103): the generic
+// kernel above reads LDS once per FMA and is LDS-bound at ~28 % of the vector rate.  Here a thread owns 4 consecutive
+// outputs of one row: per tap row it reads its 24-float window (6 x ds_read_b128) and the 21 taps (broadcast reads) once
+// for 84 FMAs.  Same tile, same accumulation order (dy, then dx) as the generic kernel.
+__global__ __launch_bounds__(256) void filter2d21_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         const float* __restrict__ kern, int c, int h, int w, int per_sample) {
+    constexpr int K = 21, R = 10, TW = 32 + 2 * R, TH = 32 + 2 * R;   // 52 x 52 tile
+    __shared__ __attribute__((aligned(16))) float tile[TH * TW];
+    __shared__ __attribute__((aligned(16))) float taps[K * 24];        // rows padded to 24 floats (b128 reads)
+    const int plane = blockIdx.z;                       // n * c + ch
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const float* sp = src + (size_t)plane * h * w;
+    const float* kp = kern + (per_sample ? (size_t)(plane / c) * K * K : 0);
+    for (int i = threadIdx.x; i < TW * TH; i += 256) {
+        const int ty = i / TW, tx = i - ty * TW;
+        const int iy = reflect(y0 + ty - R, h), ix = reflect(x0 + tx - R, w);
+        tile[i] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? sp[(size_t)iy * w + ix] : 0.f;
+    }
+    for (int i = threadIdx.x; i < K * 24; i += 256) {
+        const int r = i / 24, q = i - r * 24;
+        taps[i] = q < K ? kp[r * K + q] : 0.f;
+    }
+    __syncthreads();
+    const int cg = threadIdx.x & 7, row = threadIdx.x >> 3;   // 8 column groups of 4 x 32 rows
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int dy = 0; dy < K; ++dy) {
+        float win[24], tp[24];
+        const float4* wp = reinterpret_cast<const float4*>(tile + (row + dy) * TW + cg * 4);
+        const float4* tq = reinterpret_cast<const float4*>(taps + dy * 24);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float4 v = wp[q], t = tq[q];
+            win[q * 4] = v.x; win[q * 4 + 1] = v.y; win[q * 4 + 2] = v.z; win[q * 4 + 3] = v.w;
+            tp[q * 4] = t.x; tp[q * 4 + 1] = t.y; tp[q * 4 + 2] = t.z; tp[q * 4 + 3] = t.w;
+        }
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += tp[dx] * win[j + dx];
+    }
+    const int y = y0 + row;
+    if (y < h) {
+        float* dp = dst + ((size_t)plane * h + y) * w + x0 + cg * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x0 + cg * 4 + j < w) dp[j] = acc[j];
+    }
+}
+
+// 1 x K / K x 1 taps (the two passes of USMSharp's separable 51-tap Gaussian): a thread owns 4 consecutive outputs along the
+// filter axis and reads its K+3 window once for 4K FMAs (the generic kernel reads LDS once per FMA).
+template <int K, int AXIS>   // AXIS 0: taps along x, 1: taps along y
+__global__ __launch_bounds__(256) void filter1d_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       const float* __restrict__ kern, int h, int w) {
+    constexpr int R = K / 2, WIN = K + 3, WIN4 = (WIN + 3) / 4 * 4;
+    constexpr int TW = AXIS == 0 ? 32 + WIN4 - 4 + 4 : 32, TH = AXIS == 0 ? 32 : 32 + K - 1;   // x pass: row padded for whole float4 windows
+    __shared__ __attribute__((aligned(16))) float tile[TH * TW];
+    __shared__ __attribute__((aligned(16))) float taps[WIN4];
+    const int plane = blockIdx.z;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const float* sp = src + (size_t)plane * h * w;
+    for (int i = threadIdx.x; i < TW * TH; i += 256) {
+        const int ty = i / TW, tx = i - ty * TW;
+        const int iy = reflect(y0 + ty - (AXIS == 1 ? R : 0), h), ix = reflect(x0 + tx - (AXIS == 0 ? R : 0), w);
+        tile[i] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? sp[(size_t)iy * w + ix] : 0.f;
+    }
+    for (int i = threadIdx.x; i < WIN4; i += 256) taps[i] = i < K ? kern[i] : 0.f;
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float win[WIN4], tp[WIN4];
+#pragma unroll
+    for (int q = 0; q < WIN4 / 4; ++q) {
+        const float4 t = reinterpret_cast<const float4*>(taps)[q];
+        tp[q * 4] = t.x; tp[q * 4 + 1] = t.y; tp[q * 4 + 2] = t.z; tp[q * 4 + 3] = t.w;
+    }
+    int ox, oy;
+    if (AXIS == 0) {
+        const int cg = threadIdx.x & 7, row = threadIdx.x >> 3;
+        const float4* wp = reinterpret_cast<const float4*>(tile + row * TW + cg * 4);
+#pragma unroll
+        for (int q = 0; q < WIN4 / 4; ++q) {
+            const float4 v = wp[q];
+            win[q * 4] = v.x; win[q * 4 + 1] = v.y; win[q * 4 + 2] = v.z; win[q * 4 + 3] = v.w;
+        }
+        ox = x0 + cg * 4; oy = y0 + row;
+    } else {
+        const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+#pragma unroll
+        for (int q = 0; q < WIN; ++q) win[q] = tile[(rg * 4 + q) * TW + col];
+        ox = x0 + col; oy = y0 + rg * 4;
+    }
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += tp[t] * win[j + t];
+    float* dp = dst + (size_t)plane * h * w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = AXIS == 0 ? ox + j : ox, y = AXIS == 0 ? oy : oy + j;
+        if (y < h && x < w) dp[(size_t)y * w + x] = acc[j];
+    }
+}
+
 int filter2d_dispatch(const float* src, float* dst, const float* kern, int n, int c, int h, int w, int kh, int kw,
                       int per_sample, hipStream_t st) {
     if (!src || !dst || !kern || n <= 0 || c <= 0 || h <= 0 || w <= 0) return fail(RESR_ERR_ARG, "filter2d: bad argument");
     if (!(kh & 1) || !(kw & 1) || kh > 63 || kw > 63) return fail(RESR_ERR_ARG, "Wrong kernel size.");   // imgproc.py:1106
     if (kh / 2 >= h || kw / 2 >= w) return fail(RESR_ERR_ARG, "filter2d: reflect padding needs pad < image size");
+    static const char* generic_env = getenv("RESR_FILTER_GENERIC");   // test knob: every size on the generic kernel
+    if (kh == 21 && kw == 21 && !generic_env) {
+        hipLaunchKernelGGL(filter2d21_kernel, dim3((w + 31) / 32, (h + 31) / 32, n * c), dim3(256), 0, st, src, dst, kern, c, h, w,
+                           per_sample);
+        RESR_CHECK_LAUNCH("filter2d21_kernel");
+        return RESR_OK;
+    }
+    if (!per_sample && !generic_env && ((kh == 1 && kw == 51) || (kh == 51 && kw == 1))) {   // USMSharp(50, 0): imgproc.py:1514-1526
+        const dim3 grid((w + 31) / 32, (h + 31) / 32, n * c);
+        if (kh == 1) hipLaunchKernelGGL((filter1d_kernel<51, 0>), grid, dim3(256), 0, st, src, dst, kern, h, w);
+        else hipLaunchKernelGGL((filter1d_kernel<51, 1>), grid, dim3(256), 0, st, src, dst, kern, h, w);
+        RESR_CHECK_LAUNCH("filter1d_kernel");
+        return RESR_OK;
+    }
     const size_t lds = ((size_t)(32 + 2 * (kw / 2)) * (32 + 2 * (kh / 2)) + (size_t)kh * kw) * sizeof(float);
     hipLaunchKernelGGL(filter2d_kernel, dim3((w + 31) / 32, (h + 31) / 32, n * c), dim3(256), lds, st, src, dst, kern, c,
                        h, w, kh, kw, per_sample);

@@ -170,3 +170,16 @@ def test_pipeline_prefix_parity_and_prefetcher(ip):
         assert a.shape == (2, 3, 16, 16) and b.shape == (2, 3, 64, 64)
     torch.cuda.synchronize()
     assert torch.isfinite(a).all()
+
+
+def test_generic_filter_kernel_knob():
+    """21x21 and 1x51 / 51x1 filters have register-tiled kernels; the generic kernel they replace stays correct for those sizes
+    too: re-run the golden comparison in a subprocess with RESR_FILTER_GENERIC=1 (the knob is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RESR_FILTER_GENERIC="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_degrade.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "usm_and_filter2d or pipeline_prefix"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
