@@ -152,6 +152,66 @@ def test_conv3x3(U, case, dtype_name, diag_dir):
         assert (am != ref_mask).float().mean().item() < 1e-3
 
 
+PLANAR_CASES = [
+    # name, cin, cout, residual, n, h, w -- operands laid out chunk-planar [C/32][N,H,W,32] as the generator's workspaces are
+    ("planar_rdb_conv3", 128, 32, False, 5, 120, 100),
+    ("planar_rdb_conv5", 192, 64, True, 3, 100, 72),
+    ("planar_small", 64, 32, False, 1, 20, 24),
+]
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "f16"])
+@pytest.mark.parametrize("case", PLANAR_CASES, ids=[c[0] for c in PLANAR_CASES])
+def test_conv3x3_chunk_planar(U, case, dtype_name):
+    """`ResrConvDesc.*_chunk_stride`: input, output, residual and the emitted sign tensor in the chunk-planar layout
+     -- the addressing every dense-block pass of the generator uses."""
+    L = U.L
+    dtype = L.RESR_F16 if dtype_name == "f16" else L.RESR_F32
+    name, cin, cout, with_res, n, h, w = case
+    g = torch.Generator().manual_seed(len(name))
+    x = U.quant(torch.randn(n, cin, h, w, generator=g), dtype)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+
+    def planar(t):   # [N,C,H,W] cpu -> [C/32][N,H,W,32] device
+        nn_, c, hh, ww = t.shape
+        return t.reshape(nn_, c // 32, 32, hh, ww).permute(1, 0, 3, 4, 2).contiguous().to(U.tdtype(dtype)).cuda()
+
+    def unplanar(t, c):
+        return t.float().cpu().permute(1, 0, 4, 2, 3).reshape(n, c, h, w)
+
+    plane = n * h * w * 32
+    xin = planar(x)
+    out = torch.full((cout // 32, n, h, w, 32), -7.0, dtype=U.tdtype(dtype), device="cuda")
+    d = L.ConvDesc(n, h, w, cin, cin, 32, 0, cout, cout, 32, 0, 0, 0, dtype, 0, 1.0, 1.0, 1.0, 1.0, 0.2)
+    d.in0_chunk_stride = plane
+    d.out_chunk_stride = plane
+    ref = F.conv2d(x, U.quant(wt, dtype), bias, padding=1)
+    res0 = aux = None
+    if with_res:
+        r0 = U.quant(torch.randn(n, cout, h, w, generator=g), dtype)
+        res0 = planar(r0)
+        d.res0_stride, d.res0_chunk_stride, d.s0, d.t0 = 32, plane, 0.2, 1.0
+        ref = ref * 0.2 + r0
+        d.flags = 0
+    else:
+        ref = F.leaky_relu(ref, 0.2)
+        aux = torch.zeros((n, h, w, cout // 32), dtype=torch.int32, device="cuda")
+        d.flags = L.CONV_LRELU | L.CONV_WRITE_SIGNBITS
+    packed = U.pack_conv(wt, dtype)
+    bias_d = bias.cuda()
+    L.check(L.lib().resr_conv3x3(C.byref(d), L.ptr(xin), None, L.ptr(packed), L.ptr(bias_d), L.ptr(res0), None, None,
+                                 L.ptr(out), L.ptr(aux), L.stream_ptr()), "resr_conv3x3")
+    torch.cuda.synchronize()
+    got = unplanar(out, cout)
+    err = (got - ref).abs().max().item()
+    assert err < _tol(dtype, U) * max(1.0, ref.abs().max().item()), f"{name}/{dtype_name}: max abs err {err}"
+    if aux is not None:
+        words = aux.cpu().to(torch.int64) & 0xFFFFFFFF
+        bits = ((words.unsqueeze(-1) >> torch.arange(32)) & 1).reshape(n, h, w, cout).permute(0, 3, 1, 2).bool()
+        assert torch.equal(bits, got > 0), "sign tensor disagrees with the stored activation"
+
+
 def test_conv3x3_one_role_fallback():
     """The register-staged f16 kernel (used when the producer/consumer kernel's preconditions fail) stays correct:
     re-run the f16 conv cases in a subprocess with RESR_CONV_ONE_ROLE=1 (the knob is read once per process)."""
