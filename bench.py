@@ -266,11 +266,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU; wraps only in the single-GPU control-flow test
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RESR_BENCH_BACKEND", "nccl")     # "gloo": ranks sharing one GPU (tests/test_gpu_dp.py)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if rank == 0:
         ensure_built()
     if world > 1:
@@ -334,6 +339,19 @@ def main():
         dt = tt.item()
     loss_v = float(loss)
 
+    # The in-situ roofline probe is one more (untimed) train step.  With several ranks that step contains the gradient
+    # all-reduce, so every rank runs it; only rank 0 brackets its launches with events and reports.
+    roofline = None
+    if not args.no_probe:
+        if rank == 0:
+            try:
+                roofline = roofline_in_situ(one, args.precision, B)
+            except Exception as e:  # pragma: no cover
+                roofline = {"error": repr(e)}
+        else:
+            one()
+            torch.cuda.synchronize()
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         images = B * world * args.steps
@@ -350,11 +368,8 @@ def main():
             "generator_tflops_per_gpu": round(value / world * flop_per_image / 1e12, 2),
             "loss": loss_v,
         }
-        if not args.no_probe:
-            try:
-                out["roofline"] = roofline_in_situ(one, args.precision, B)
-            except Exception as e:  # pragma: no cover
-                out["roofline"] = {"error": repr(e)}
+        if roofline is not None:
+            out["roofline"] = roofline
         if args.isolated_probe:
             rows = probe_conv_kernels(B, lr_edge, args.precision)
             out["conv_probe_isolated"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "flop"}

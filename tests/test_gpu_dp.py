@@ -71,3 +71,25 @@ def test_two_rank_dp_matches_single_process():
     assert torch.equal(res[0][0], res[1][0])                                                            # same reduced gradient
     rel = ((res[0][0] - ref).norm() / ref.norm()).item()
     assert rel < 1e-5, rel                    # fp32: mean of two half-batch gradients == whole-batch gradient
+
+
+def test_bench_two_ranks_prints_one_line():
+    """The driver's multi-GPU launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) with two
+    ranks sharing the test box's one GPU (gloo): warm-up, timed steps, the in-situ roofline step (a collective step: every
+    rank must run it) and the teardown complete, and rank 0 prints exactly one JSON line with the aggregate rate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RESR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--lr-size", "64"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["scaling"] == "weak" and "roofline" in out and "cpu_baseline" not in out
+    assert "error" not in out["roofline"], out["roofline"]
