@@ -37,11 +37,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (the reference trains 16 per GPU; 8..32 measured within 5 % of each other)")
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (the reference trains 16 per GPU; 8..32 measured within 5 %% of each other)")
     ap.add_argument("--lr-size", type=int, default=256, help="LR tile edge; HR = 4x (headline: 256 -> 1024)")
     ap.add_argument("--precision", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-degradation", action="store_true", help="debug only: feed pre-degraded LR tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--noise-data", action="store_true",
+                    help="uniform-noise HR tiles (SURVEY 8d's literal torch.rand tiles) instead of the image-like default: on those the "
+                         "first Adam step saturates the output clamp, the backward pass carries zero gradients and the matrix kernels "
+                         "run 10-20 %% faster than on real gradients (DESIGN.md section 5)")
     ap.add_argument("--per-tensor-adam", action="store_true", help="optimizer over the 702 per-tensor Parameters instead of the flat arena")
     ap.add_argument("--no-probe", action="store_true", help="skip the in-situ roofline step")
     ap.add_argument("--isolated-probe", action="store_true", help="also time every conv shape back-to-back in isolation")
@@ -301,6 +305,11 @@ def main():
     hr_edge = lr_edge * 4
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
     hr = torch.round(torch.rand(B, 3, hr_edge, hr_edge, device="cuda", generator=g) * 255.0) / 255.0
+    if not args.noise_data:   # image-like tiles (bicubic-upsampled noise + grain): keeps the output off the clamp, so the backward
+        # pass carries dense gradients (on uniform-noise tiles the first Adam step saturates the clamp, model.py:270)
+        base = torch.rand(B, 3, hr_edge // 16, hr_edge // 16, device="cuda", generator=g)
+        hr = torch.nn.functional.interpolate(base, size=(hr_edge, hr_edge), mode="bicubic").clamp(0, 1)
+        hr = torch.round((0.9 * hr + 0.1 * torch.rand(B, 3, hr_edge, hr_edge, device="cuda", generator=g)) * 255.0) / 255.0
 
     degrade = None
     degradation = "none"
@@ -362,6 +371,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.precision == "fast" else "f32", "data": "synthetic",
+            "data_detail": "uniform-noise HR tiles" if args.noise_data else "image-like HR tiles (bicubic-upsampled noise + 10 % grain, quantised to k/255)",
             "config": {"workload": f"RealESRNet x4 L1 train step, RRDBNet 23 blocks, LR {lr_edge}^2 -> HR {hr_edge}^2, "
                                    f"batch {B}/GPU, degradation={degradation}, Adam+EMA, GradScaler",
                        "global_batch": B * world, "parallelism": f"dp{world}"},
