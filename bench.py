@@ -361,6 +361,12 @@ def main():
             one()
             torch.cuda.synchronize()
 
+    unclamped = None
+    if rank == 0:
+        with torch.no_grad():
+            sr_probe = model(torch.nn.functional.interpolate(hr[:2], scale_factor=0.25, mode="area"))
+            unclamped = round(float(((sr_probe > 0) & (sr_probe < 1)).float().mean()), 4)
+            del sr_probe
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         images = B * world * args.steps
@@ -377,6 +383,9 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "generator_tflops_per_gpu": round(value / world * flop_per_image / 1e12, 2),
             "loss": loss_v,
+            # health of the timed regime: the share of output values strictly inside the training-time clamp (model.py:270).
+            # Near 0 the backward pass multiplies (almost) only zeros and runs faster than on real gradients (see --noise-data)
+            "unclamped_output_fraction": unclamped,
         }
         if roofline is not None:
             out["roofline"] = roofline
