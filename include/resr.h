@@ -34,7 +34,14 @@ typedef enum {
     RESR_ERR_WORKSPACE = -3 /* workspace too small */
 } resr_status;
 
-typedef enum { RESR_F16 = 0, RESR_F32 = 1 } resr_dtype;
+/* RESR_F16X2 ("exact16" mode): every activation tensor is a PAIR of f16 tensors of identical shape and strides,
+ *   value = hi + lo * 2^-12,   hi = f16(value),   lo = f16((value - hi) * 2^12)
+ * (about 22 significand bits, the scaled lo keeps clear of the f16 subnormal range), addressed as `ptr` (hi) and
+ * `ptr + *_lo_offset` elements (lo).  Packed weights hold three f16 blocks per 32-channel chunk -- f16(w*2^12),
+ * its remainder, and f16(w) -- and a conv pass runs three v_mfma_f32_32x32x16_f16 per product into one fp32
+ * accumulator (x_hi*W0 + x_hi*W1 + x_lo*W2, descaled by 2^-12 in the epilogue): fp32-class results on the f16
+ * matrix pipe (the x_lo*w_lo term, 2^-22 relative, is dropped).  |w| must stay below 16. */
+typedef enum { RESR_F16 = 0, RESR_F32 = 1, RESR_F16X2 = 2 } resr_dtype;
 
 /* epilogue / gather flags of resr_conv3x3 */
 enum {
@@ -78,6 +85,9 @@ typedef struct {
      * HBM lines are consumed whole (the generator keeps its dense-block workspaces this way). */
     int32_t in0_chunk_stride, in1_chunk_stride, out_chunk_stride;
     int32_t res0_chunk_stride, res1_chunk_stride, mask_chunk_stride;
+    /* RESR_F16X2 only: element offset from the hi tensor of an operand to its lo tensor (a mask given as an f16
+     * activation is read from its hi tensor alone; AUX_BEFORE_* is not available in this mode). */
+    int64_t in0_lo_offset, in1_lo_offset, out_lo_offset, res0_lo_offset, res1_lo_offset;
 } ResrConvDesc;
 
 int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const void* w_packed,
@@ -97,6 +107,7 @@ typedef struct {
     int32_t dtype, flags;                      /* RESR_CONV_UPSAMPLE_IN honoured for X            */
     int32_t splits;                            /* pixel splits (partial slabs)                    */
     float scale;
+    int64_t x_lo_offset, g_lo_offset;          /* RESR_F16X2: hi -> lo element offsets of X and G */
 } ResrWgradDesc;
 
 size_t resr_wgrad_partial_bytes(const ResrWgradDesc* d);

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libresr_hip.so")
 
-RESR_F16, RESR_F32 = 0, 1
+RESR_F16, RESR_F32, RESR_F16X2 = 0, 1, 2
 CONV_LRELU, CONV_UPSAMPLE_IN, CONV_CLAMP01, CONV_OUT_NCHW_F32, CONV_MASK, CONV_NO_BIAS = 1, 2, 4, 8, 16, 32
 CONV_AUX_BEFORE_MASK, CONV_AUX_BEFORE_RES = 64, 128
 CONV_WRITE_SIGNBITS = 1 << 8
@@ -26,14 +26,17 @@ class ConvDesc(C.Structure):
                 ("dtype", C.c_int32), ("flags", C.c_int32),
                 ("s0", C.c_float), ("t0", C.c_float), ("s1", C.c_float), ("t1", C.c_float), ("slope", C.c_float),
                 ("in0_chunk_stride", C.c_int32), ("in1_chunk_stride", C.c_int32), ("out_chunk_stride", C.c_int32),
-                ("res0_chunk_stride", C.c_int32), ("res1_chunk_stride", C.c_int32), ("mask_chunk_stride", C.c_int32)]
+                ("res0_chunk_stride", C.c_int32), ("res1_chunk_stride", C.c_int32), ("mask_chunk_stride", C.c_int32),
+                ("in0_lo_offset", C.c_int64), ("in1_lo_offset", C.c_int64), ("out_lo_offset", C.c_int64),
+                ("res0_lo_offset", C.c_int64), ("res1_lo_offset", C.c_int64)]
 
 
 class WgradDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
                 ("cin", C.c_int32), ("cin0", C.c_int32), ("in0_stride", C.c_int32), ("in1_stride", C.c_int32),
                 ("cin_real", C.c_int32), ("cout", C.c_int32), ("cout_pad", C.c_int32), ("g_stride", C.c_int32),
-                ("dtype", C.c_int32), ("flags", C.c_int32), ("splits", C.c_int32), ("scale", C.c_float)]
+                ("dtype", C.c_int32), ("flags", C.c_int32), ("splits", C.c_int32), ("scale", C.c_float),
+                ("x_lo_offset", C.c_int64), ("g_lo_offset", C.c_int64)]
 
 
 class PackChunk(C.Structure):

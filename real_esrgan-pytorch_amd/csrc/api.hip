@@ -53,9 +53,9 @@ size_t wgrad_partial_bytes(const ResrWgradDesc*);
 int wgrad_debug_plan(const int*, const int*, int, int*, int);
 int pack_dispatch(const ResrPackChunk*, int, const float*, void*, int, hipStream_t);
 int ema_dispatch(float*, const float*, long, double, hipStream_t);
-int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t);
-int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t);
-int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int, float, hipStream_t);
+int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long);
+int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t, long);
+int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int, float, hipStream_t, long, long);
 size_t generator_param_count(const ResrGeneratorDesc*);
 size_t generator_packed_bytes(const ResrGeneratorDesc*, int);
 size_t generator_workspace_bytes(const ResrGeneratorDesc*);
@@ -127,17 +127,17 @@ int resr_pack_weights(const ResrPackChunk* chunks_dev, int32_t n_chunks, const f
 
 int resr_nchw_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t unshuffle,
                       int32_t c_pad, int32_t dtype, const uint8_t* mask, void* stream) {
-    return nchw_to_nhwc_dispatch(src, dst, n, c, h, w, unshuffle, c_pad, dtype, mask, (hipStream_t)stream);
+    return nchw_to_nhwc_dispatch(src, dst, n, c, h, w, unshuffle, c_pad, dtype, mask, (hipStream_t)stream, -1L);
 }
 
 int resr_nhwc_to_nchw(const void* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t shuffle,
                       int32_t src_stride, int32_t dtype, void* stream) {
-    return nhwc_to_nchw_dispatch(src, dst, n, c, h, w, shuffle, src_stride, dtype, (hipStream_t)stream);
+    return nhwc_to_nchw_dispatch(src, dst, n, c, h, w, shuffle, src_stride, dtype, (hipStream_t)stream, -1L);
 }
 
 int resr_sumpool2x2(const void* src, void* dst, const void* mask, int32_t n, int32_t h_out, int32_t w_out, int32_t c,
                     int32_t dtype, float slope, void* stream) {
-    return sumpool2x2_dispatch(src, dst, mask, n, h_out, w_out, c, dtype, slope, (hipStream_t)stream);
+    return sumpool2x2_dispatch(src, dst, mask, n, h_out, w_out, c, dtype, slope, (hipStream_t)stream, -1L, -1L);
 }
 
 size_t resr_generator_param_count(const ResrGeneratorDesc* d) { return generator_param_count(d); }

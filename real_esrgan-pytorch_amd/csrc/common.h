@@ -31,7 +31,12 @@ bool prof_on();
 void prof_before(hipStream_t st);
 void prof_after(hipStream_t st, int kernel_id, double flop, double bytes = 0.0);
 
-inline size_t elem_size(int dtype) { return dtype == RESR_F16 ? 2 : 4; }
+// bytes per stored element (RESR_F16X2: of one f16 tensor of the hi/lo pair) / tensors per activation
+inline size_t elem_size(int dtype) { return dtype == RESR_F32 ? 4 : 2; }
+inline size_t act_tensors(int dtype) { return dtype == RESR_F16X2 ? 2 : 1; }
+// RESR_F16X2: value = hi + lo * kLoInv, lo = (value - hi) * kLoScale; packed weights carry the factor kLoScale
+constexpr float kLoScale = 4096.f, kLoInv = 1.f / 4096.f;
+constexpr int kMaxDevices = 16;   // per-device caches (occupancy, zero pages, CU counts) are indexed by hipGetDevice()
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // MI355X: blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8).  Give every XCD a

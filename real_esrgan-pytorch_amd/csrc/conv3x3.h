@@ -25,6 +25,9 @@ struct ConvArgs {
     int flags;
     float s0, t0, s1, t1, slope;
     int tiles_x, tiles_y;
+    // RESR_F16X2: byte offsets hi -> lo of the two input segments, element offsets hi -> lo of out / residuals
+    size_t in0_lo_b, in1_lo_b;
+    long out_lo, res0_lo, res1_lo;
     const char* zero;  // 16 zero bytes in device memory (source of out-of-image LDS-DMA lanes)
     unsigned long long* trace;  // debug: per-workgroup s_memrealtime stamps (resr_debug_conv_trace), else null
 };

@@ -290,7 +290,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     return RESR_OK;
 }
 
-int conv3x3_ws_f16(const ConvArgs& a, int mt, hipStream_t stream);  // conv3x3_ws.hip
+int conv3x3_ws_f16(const ConvArgs& a, int mt, bool x2, hipStream_t stream);  // conv3x3_ws.hip
 bool conv3x3_ws_supported(const ConvArgs& a);
 
 int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, const void* w,
@@ -337,12 +337,26 @@ int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, co
     a.res1_chunk = chunk(d->res1_chunk_stride); a.mask_chunk = chunk(d->mask_chunk_stride);
     a.flags = d->flags; a.s0 = d->s0; a.t0 = d->t0; a.s1 = d->s1; a.t1 = d->t1; a.slope = d->slope;
     const int mt = d->cout_pad / 32;
+    if (d->dtype == RESR_F16X2) {
+        // hi/lo pairs: only the producer/consumer kernel has the mode
+        if (d->flags & (RESR_CONV_AUX_BEFORE_MASK | RESR_CONV_AUX_BEFORE_RES))
+            return fail(RESR_ERR_ARG, "conv3x3: AUX_BEFORE_* is not available with RESR_F16X2");
+        const bool nchw = d->flags & RESR_CONV_OUT_NCHW_F32;
+        if (d->in0_lo_offset == 0 || (in1 && d->cin0 < d->cin && d->in1_lo_offset == 0) || (!nchw && d->out_lo_offset == 0) ||
+            (res0 && d->res0_lo_offset == 0) || (res1 && d->res1_lo_offset == 0))
+            return fail(RESR_ERR_ARG, "conv3x3: RESR_F16X2 needs the hi -> lo offset of every operand");
+        a.in0_lo_b = (size_t)d->in0_lo_offset * es; a.in1_lo_b = (size_t)d->in1_lo_offset * es;
+        a.out_lo = (long)d->out_lo_offset; a.res0_lo = (long)d->res0_lo_offset; a.res1_lo = (long)d->res1_lo_offset;
+        if (!conv3x3_ws_supported(a))
+            return fail(RESR_ERR_ARG, "conv3x3: RESR_F16X2 needs tensors below 4 GB / 2^24 pixels and cout %% 8 == 0");
+        return conv3x3_ws_f16(a, mt, true, stream);
+    }
     // 16-row tiles only when that still yields enough workgroups to fill 256 CUs twice over
     const long tiles4 = (long)((d->w + 31) / 32) * ((d->h + 15) / 16) * d->n;
     const bool big = tiles4 >= 512;
     if (d->dtype == RESR_F16) {
         static const char* old_env = getenv("RESR_CONV_ONE_ROLE");  // test knob: fast mode on the one-role kernel below
-        if (!old_env && conv3x3_ws_supported(a)) return conv3x3_ws_f16(a, mt, stream);
+        if (!old_env && conv3x3_ws_supported(a)) return conv3x3_ws_f16(a, mt, false, stream);
         // measured on MI355X (B=8, 256^2): cout 32 -> 8 waves x 2 rows (4 waves/SIMD, 2 workgroups/CU) beats
         // 4 waves x 4 rows by 5-16 %; cout 64 -> 4 waves x 2 rows (2 waves/SIMD) beats every 8-wave shape
         if (mt == 1) return big ? launch_conv<half_t, 1, 2, 8>(a, stream) : launch_conv<half_t, 1, 2, 4>(a, stream);

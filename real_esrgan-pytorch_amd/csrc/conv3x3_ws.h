@@ -100,7 +100,12 @@ __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
 // unconditional when set, absent when clear), bit 3 the rest (aux tensors, NCHW fp32 output, clamp; with bit 3 the
 // other features are run-time flags), bit 4 also emit the 1-bit sign tensor (RESR_CONV_WRITE_SIGNBITS), bit 5 the mask is
 // such a sign tensor (RESR_CONV_MASK_BITS).  The dispatcher instantiates the combinations the networks use.
-template <typename T, int MT, int NT, int NWC, int EPI>
+//
+// X2 (RESR_F16X2, "exact16"): every real 32-channel chunk is three ordinary stages -- (x_hi, W0 = f16(w*2^12)),
+// (x_hi, W1 = remainder of W0), (x_lo, W2 = f16(w)) with x_lo stored times 2^12 -- accumulated into the same fp32
+// registers; the packed weights are laid out in that stage order, so only the producers' chunk -> address map and the
+// epilogue (descale, hi/lo split of the result, hi + lo residuals) know about the mode.
+template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false>
 __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCfg<T, MT, NT, NWC>::NP) / 4) void conv3x3_ws_kernel(const ConvArgs a) {
     using C = WsCfg<T, MT, NT, NWC>;
     constexpr int SPP = C::SPP, KS = C::KS, PB = C::PB, TH = C::TH, TW = C::TW, HW = C::HW, BUF = C::BUF;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     const int ntiles = a.tiles_x * a.tiles_y * a.n;
     const int G = gridDim.x;
     const int first = xcd_remap(blockIdx.x, G);
-    const int nchunks = a.cin >> 5;
+    const int nchunks = X2 ? 3 * (a.cin >> 5) : a.cin >> 5;   // stages per tile
     int tk = 0;
     auto stamp = [&](int role) {
         // traced workgroups: blockIdx 16k .. 16k+0 for k < 32 (a sample across the whole grid)
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     float* bias_lds = reinterpret_cast<float*>(smem + C::NHB * BUF);
     if (wave == 0) {
         const bool f_bias = !(a.flags & RESR_CONV_NO_BIAS) && a.bias != nullptr;
-        bias_lds[lane] = (f_bias && lane < a.cout) ? a.bias[lane] : 0.f;
+        bias_lds[lane] = (f_bias && lane < a.cout) ? a.bias[lane] * (X2 ? kLoScale : 1.f) : 0.f;
     }
     __syncthreads();
     if (wave >= NWC) {
@@ -192,9 +197,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             };
             const char* const zero = a.zero;
             auto issue_h = [&](int ck, int hb) {   // halo of (current pix, chunk ck) -> halo buffer hb
-                const int c0 = ck * 32;
+                const int ckr = X2 ? ck / 3 : ck;   // X2: stage ck = (real chunk ck / 3, part ck % 3); part 2 reads the lo tensor
+                const int c0 = ckr * 32;
                 const bool seg1 = c0 >= a.cin0;
                 const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
+                if (X2 && ck - ckr * 3 == 2) base += seg1 ? a.in1_lo_b : a.in0_lo_b;
                 const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
                 if (stride_b != voff_stride) {
 #pragma unroll
@@ -337,9 +344,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         for (int tile = first; tile < ntiles; tile += G) {
             stamp(0);
             for (int ck = 0; ck < nchunks; ++ck) {
-                const int c0 = ck * 32;
+                const int ckr = X2 ? ck / 3 : ck;
+                const int c0 = ckr * 32;
                 const bool seg1 = c0 >= a.cin0;
                 const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
+                if (X2 && ck - ckr * 3 == 2) base += seg1 ? a.in1_lo_b : a.in0_lo_b;
                 const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
                 const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + par * BUF);
                 if (tile != first || ck != 0) {  // the first stage was requested above
@@ -477,11 +486,13 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             int h, w_, cout, out_stride, res0_stride, res1_stride, mask_stride, flags;
             int out_chunk, res0_chunk, res1_chunk, mask_chunk;
             float s0, t0, s1, t1, slope;
+            long out_lo, res0_lo, res1_lo;
         } e;
         e.res0 = ep->res0; e.res1 = ep->res1; e.mask = ep->mask; e.out = ep->out; e.aux = ep->aux;
         e.h = ep->h; e.w_ = ep->w_; e.cout = ep->cout; e.out_stride = ep->out_stride;
         e.res0_stride = ep->res0_stride; e.res1_stride = ep->res1_stride; e.mask_stride = ep->mask_stride;
         e.out_chunk = ep->out_chunk; e.res0_chunk = ep->res0_chunk; e.res1_chunk = ep->res1_chunk; e.mask_chunk = ep->mask_chunk;
+        if constexpr (X2) { e.out_lo = ep->out_lo; e.res0_lo = ep->res0_lo; e.res1_lo = ep->res1_lo; }
         e.flags = ep->flags; e.s0 = ep->s0; e.t0 = ep->t0; e.s1 = ep->s1; e.t1 = ep->t1; e.slope = ep->slope;
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
@@ -508,11 +519,12 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         // pieces with up to two residuals -- and row t+1 is requested before row t is processed (64 registers that are free
         // once the MFMA loop is over; 16 exposed round trips per tile were 3.3 us); cout <= 32 (tighter register budget): both
         // pieces when there is only a mask, one piece with residuals.
-        constexpr bool RB = MT == 2 && !EX;
+        constexpr bool RB = MT == 2 && !EX && !X2;
         constexpr int JB = (RB || !(ER || EX)) ? 2 : 1;
         constexpr int MA = RB ? MT : 1;   // without row batching one m tile's inputs are live at a time
         constexpr int NB = RB ? 2 : 1;    // row double buffer
         half8 rmask[NB][MA][2], rres0[NB][MA][2], rres1[NB][MA][2];
+        half8 rres0l[NB][MA][2], rres1l[NB][MA][2];   // X2: the residuals' lo tensors
         unsigned mbits[NB][MA];   // EMB: the pixel's sign word of chunk m (bit c <-> channel 32m + c)
         // pieces outside the image / beyond cout read a clamped (valid) address and are dropped at the store
         auto row_p = [&](int t) {
@@ -535,11 +547,21 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                 for (int j = j0; j < j0 + JB; ++j)
                     rres0[b][m % MA][j] = *reinterpret_cast<const half8*>(e.res0 + (p * e.res0_stride + poff(m, j, e.res0_chunk)) * 2);
+                if constexpr (X2) {
+#pragma unroll
+                    for (int j = j0; j < j0 + JB; ++j)
+                        rres0l[b][m % MA][j] = *reinterpret_cast<const half8*>(e.res0 + (p * e.res0_stride + poff(m, j, e.res0_chunk) + e.res0_lo) * 2);
+                }
             }
             if (f_res1) {
 #pragma unroll
                 for (int j = j0; j < j0 + JB; ++j)
                     rres1[b][m % MA][j] = *reinterpret_cast<const half8*>(e.res1 + (p * e.res1_stride + poff(m, j, e.res1_chunk)) * 2);
+                if constexpr (X2) {
+#pragma unroll
+                    for (int j = j0; j < j0 + JB; ++j)
+                        rres1l[b][m % MA][j] = *reinterpret_cast<const half8*>(e.res1 + (p * e.res1_stride + poff(m, j, e.res1_chunk) + e.res1_lo) * 2);
+                }
             }
         };
         if (RB) {
@@ -575,12 +597,22 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         v[4 + r] = acc[m][t][(2 * j + 1) * 4 + r];
                         permlane32_swap(v[r], v[4 + r]);
                     }
+                    if constexpr (X2) {   // the packed weights (and the bias) carry 2^12
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] *= kLoInv;
+                    }
                     const bool ok = in_img && co[j] < e.cout;
                     auto store8 = [&](char* base, size_t idx) {
                         half8 h;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) h[r] = (half_t)v[r];
                         *reinterpret_cast<half8*>(base + idx * 2) = h;
+                        if constexpr (X2) {
+                            half8 l;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) l[r] = (half_t)((v[r] - (float)h[r]) * kLoScale);
+                            *reinterpret_cast<half8*>(base + (idx + e.out_lo) * 2) = l;
+                        }
                     };
                     if (f_aux_mask && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(m, j, e.out_chunk));
                     if (EMB) {
@@ -598,11 +630,19 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     if (f_aux_res && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(m, j, e.out_chunk));
                     if (f_res0) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], e.s0, e.t0 * (float)rres0[b][m % MA][j][r]);   // explicit: one rounding, the same in every instantiation
+                        for (int r = 0; r < 8; ++r) {
+                            float rv = (float)rres0[b][m % MA][j][r];
+                            if constexpr (X2) rv = __builtin_fmaf((float)rres0l[b][m % MA][j][r], kLoInv, rv);
+                            v[r] = __builtin_fmaf(v[r], e.s0, e.t0 * rv);   // explicit: one rounding, the same in every instantiation
+                        }
                     }
                     if (f_res1) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], e.s1, e.t1 * (float)rres1[b][m % MA][j][r]);
+                        for (int r = 0; r < 8; ++r) {
+                            float rv = (float)rres1[b][m % MA][j][r];
+                            if constexpr (X2) rv = __builtin_fmaf((float)rres1l[b][m % MA][j][r], kLoInv, rv);
+                            v[r] = __builtin_fmaf(v[r], e.s1, e.t1 * rv);
+                        }
                     }
                     if (f_nchw) {
                         float* o = reinterpret_cast<float*>(e.out);
@@ -625,7 +665,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         if (ok) store8(e.out, p * e.out_stride + poff(m, j, e.out_chunk));
                         if (ESB) {
 #pragma unroll
-                            for (int r = 0; r < 8; ++r) sbits |= ((float)(half_t)v[r] > 0.f ? 1u : 0u) << (8 * (2 * j + kh_e) + r);
+                            for (int r = 0; r < 8; ++r) sbits |= ((X2 ? v[r] : (float)(half_t)v[r]) > 0.f ? 1u : 0u) << (8 * (2 * j + kh_e) + r);
                         }
                     }
                 }
@@ -644,23 +684,29 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     }
 }
 
-template <typename T, int MT, int NT, int NWC, int EPI>
+template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false>
 static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     using C = WsCfg<T, MT, NT, NWC>;
     ConvArgs args = a;
     args.tiles_x = (a.w_ + 31) / 32;
     args.tiles_y = (a.h + C::TH - 1) / C::TH;
     const size_t lds = C::LDS_BYTES;  // two halo buffers + the bias (+ two weight buffers for cout 64)
-    static int resident = 0;            // workgroups the device holds at once, per instantiation; benign race
-    static const char* zero = nullptr;
+    // per device (the boundary is callable with any current device): workgroups the device holds at once and the
+    // address of this translation unit's zero page there; idempotent, so a race between two first calls is benign
+    static int resident_dev[kMaxDevices] = {0};
+    static const char* zero_dev[kMaxDevices] = {nullptr};
+    int cur_dev = 0;
+    if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= kMaxDevices) return fail(RESR_ERR_LAUNCH, "conv3x3: hipGetDevice");
+    int& resident = resident_dev[cur_dev];
+    const char*& zero = zero_dev[cur_dev];
     if (!resident) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_kernel<T, MT, NT, NWC, EPI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int per_cu = 0, dev = 0;
+        int per_cu = 0;
         hipDeviceProp_t prop;
         void* zp = nullptr;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_ws_kernel<T, MT, NT, NWC, EPI>, C::NTHR, lds) != hipSuccess ||
-            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu <= 0 ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2>, C::NTHR, lds) != hipSuccess ||
+            hipGetDeviceProperties(&prop, cur_dev) != hipSuccess || per_cu <= 0 ||
             hipGetSymbolAddress(&zp, HIP_SYMBOL(g_conv_zero16)) != hipSuccess || !zp)
             return fail(RESR_ERR_LAUNCH, "conv3x3: occupancy / zero-page query failed");
         zero = (const char*)zp;
@@ -672,30 +718,30 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     const int ntiles = args.tiles_x * args.tiles_y * a.n;
     const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
     prof_before(stream);
-    hipLaunchKernelGGL((conv3x3_ws_kernel<T, MT, NT, NWC, EPI>), dim3(grid), dim3(C::NTHR), lds, stream, args);
-    prof_after(stream, 20000 + MT * 100 + NT * 10 + NWC, 2.0 * 9 * a.cin * a.cout * (double)a.n * a.h * a.w_,
-               conv_algorithmic_bytes(a, sizeof(T)));
+    hipLaunchKernelGGL((conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2>), dim3(grid), dim3(C::NTHR), lds, stream, args);
+    prof_after(stream, (X2 ? 25000 : 20000) + MT * 100 + NT * 10 + NWC, 2.0 * 9 * a.cin * a.cout * (double)a.n * a.h * a.w_,
+               conv_algorithmic_bytes(a, sizeof(T) * (X2 ? 2 : 1)));
     RESR_CHECK_LAUNCH("conv3x3_ws_kernel");
     return RESR_OK;
 }
 
-template <typename T, int MT, int NT, int NWC>
+template <typename T, int MT, int NT, int NWC, bool X2 = false>
 static int launch_ws(const ConvArgs& a, hipStream_t stream) {
     const int combo = ((a.flags & RESR_CONV_MASK) ? 1 : 0) | (a.res0 ? 2 : 0) | (a.res1 ? 4 : 0);
     if (a.flags & RESR_CONV_WRITE_SIGNBITS) {   // forward conv + LeakyReLU that also emits its 1-bit mask (checked by the caller)
-        return launch_ws_epi<T, MT, NT, NWC, 16>(a, stream);
+        return launch_ws_epi<T, MT, NT, NWC, 16, X2>(a, stream);
     }
-    if (a.flags & RESR_CONV_MASK_BITS) return launch_ws_epi<T, MT, NT, NWC, 33>(a, stream);
+    if (a.flags & RESR_CONV_MASK_BITS) return launch_ws_epi<T, MT, NT, NWC, 33, X2>(a, stream);
     const bool extras = a.aux || (a.flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_CLAMP01));
     if (!extras) switch (combo) {
-        case 0: return launch_ws_epi<T, MT, NT, NWC, 0>(a, stream);  // forward convs 1-4, upsampling, D forward
-        case 1: return launch_ws_epi<T, MT, NT, NWC, 1>(a, stream);  // backward-data through a LeakyReLU
-        case 2: return launch_ws_epi<T, MT, NT, NWC, 2>(a, stream);  // conv5 of a dense block
-        case 6: return launch_ws_epi<T, MT, NT, NWC, 6>(a, stream);  // conv5 closing an RRDB / its backward
-        case 3: return launch_ws_epi<T, MT, NT, NWC, 3>(a, stream);  // masked backward with gradient accumulation
+        case 0: return launch_ws_epi<T, MT, NT, NWC, 0, X2>(a, stream);  // forward convs 1-4, upsampling, D forward
+        case 1: return launch_ws_epi<T, MT, NT, NWC, 1, X2>(a, stream);  // backward-data through a LeakyReLU
+        case 2: return launch_ws_epi<T, MT, NT, NWC, 2, X2>(a, stream);  // conv5 of a dense block
+        case 6: return launch_ws_epi<T, MT, NT, NWC, 6, X2>(a, stream);  // conv5 closing an RRDB / its backward
+        case 3: return launch_ws_epi<T, MT, NT, NWC, 3, X2>(a, stream);  // masked backward with gradient accumulation
         default: break;
     }
-    return launch_ws_epi<T, MT, NT, NWC, 15>(a, stream);
+    return launch_ws_epi<T, MT, NT, NWC, 15, X2>(a, stream);
 }
 
 

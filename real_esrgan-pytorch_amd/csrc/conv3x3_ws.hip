@@ -11,6 +11,8 @@ void conv_trace_set(void* p) { g_conv_trace = (unsigned long long*)p; }
 
 int conv3x3_ws_mt1(const ConvArgs& a, int tile_rows, hipStream_t stream);
 int conv3x3_ws_mt2(const ConvArgs& a, int tile_rows, hipStream_t stream);
+int conv3x3_ws_x2_mt1(const ConvArgs& a, int tile_rows, hipStream_t stream);   // RESR_F16X2 instantiations
+int conv3x3_ws_x2_mt2(const ConvArgs& a, int tile_rows, hipStream_t stream);
 
 // Preconditions of the producer's 24 x 24-bit offsets and of the 8-channel epilogue; otherwise the caller uses the
 // one-role kernel.
@@ -25,11 +27,13 @@ bool conv3x3_ws_supported(const ConvArgs& a) {
 // Tile height: the tallest tile (least halo, most weight reuse) that still gives every CU a workgroup; small images
 // (GAN crops, the discriminator's coarse levels) fall back to shorter tiles instead of leaving CUs idle.
 static int pick_rows(const ConvArgs& a, const int* rows, int nrows) {
-    static int cus = 0;
+    static int cus_dev[kMaxDevices] = {0};   // per device; idempotent
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    int& cus = cus_dev[dev];
     if (!cus) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
     }
     for (int i = 0; i < nrows; ++i) {
         const long tiles = (long)((a.w_ + 31) / 32) * ((a.h + rows[i] - 1) / rows[i]) * a.n;
@@ -38,8 +42,12 @@ static int pick_rows(const ConvArgs& a, const int* rows, int nrows) {
     return rows[nrows - 1];
 }
 
-int conv3x3_ws_f16(const ConvArgs& a, int mt, hipStream_t stream) {
+int conv3x3_ws_f16(const ConvArgs& a, int mt, bool x2, hipStream_t stream) {
     static const int rows1[] = {16, 8}, rows2[] = {16, 8};
+    if (x2) {
+        if (mt == 1) return conv3x3_ws_x2_mt1(a, pick_rows(a, rows1, 2), stream);
+        return conv3x3_ws_x2_mt2(a, pick_rows(a, rows2, 2), stream);
+    }
     if (mt == 1) return conv3x3_ws_mt1(a, pick_rows(a, rows1, 2), stream);
     return conv3x3_ws_mt2(a, pick_rows(a, rows2, 2), stream);
 }

@@ -1,6 +1,8 @@
 // generator.hip -- whole-RRDBNet passes enqueued natively (reference model.py:206-275 and its
 // autograd backward).  No kernels here: this file owns the HBM plan and the launch order.
 //
+// RESR_F16X2 ("exact16"): every activation / gradient tensor below is a (hi, lo) pair of f16 tensors -- the lo tensor
+// directly follows the hi tensor of the same buffer -- and packed weights take three blocks per chunk (include/resr.h).
 // HBM plan (T = f16 fast / f32 strict, all tensors pixel-major / NHWC):
 //   x_in              [N,h,w,CI]      input image, pixel-unshuffled, channels padded to 32/64
 //   ws[r], r=0..3B-1  [6][N,h,w,32]   one dense-block workspace per RDB, chunk-planar: planes [x0 x1 | o1 | o2 | o3 | o4]
@@ -25,24 +27,19 @@
 #include <vector>
 
 #include "common.h"
+#include "wgrad.h"
 
 namespace resr {
 
 int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*, const float*, const void*,
                      const void*, const void*, void*, void*, hipStream_t);
-struct WgradConv {
-    const void* x0; int cin, in0_stride, cin_real;
-    const void* g; int cout, cout_pad, g_stride;
-    long x_chunk_stride, g_chunk_stride;  // elements between 32-channel chunks of X / G (0 = 32: interleaved)
-    float* dw; float* db; float scale;
-};
-size_t wgrad_batch_partial_bytes(const WgradConv*, int, int);
+size_t wgrad_batch_partial_bytes(const WgradConv*, int, int, int);
 int wgrad_batch(const WgradConv*, int, int, int, int, int, int, int, float*, hipStream_t);
 int wgrad_tile_rows(int dtype);
-int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t);
-int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t);
-int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int, float, hipStream_t);
-int add_inplace_dispatch(void*, const void*, long, int, hipStream_t);
+int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long);
+int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t, long);
+int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int, float, hipStream_t, long, long);
+int add_inplace_dispatch(void*, const void*, long, int, hipStream_t, long, long);
 
 namespace {
 
@@ -161,7 +158,7 @@ int splits_for(const Plan& p, int npairs, int h, int w) {
     const int th = wgrad_tile_rows(p.d.dtype);
     const long tiles = (long)((w + 31) / 32) * ((h + th - 1) / th) * p.d.n;
     long s;
-    if (p.d.dtype == RESR_F16) {
+    if (p.d.dtype != RESR_F32) {
         s = 512 / ((npairs + 3) / 4);
         if (s >= 16) s &= ~7L;
         if (s > 256) s = 256;
@@ -175,7 +172,8 @@ int splits_for(const Plan& p, int npairs, int h, int w) {
 }
 
 void carve(const Plan& p, char* base, Bufs& b) {
-    const size_t es = elem_size(p.d.dtype);
+    const size_t es = elem_size(p.d.dtype) * act_tensors(p.d.dtype);   // bytes per activation element (hi + lo)
+    const int wm = p.d.dtype == RESR_F16X2 ? 3 : 1;                     // weight-gradient jobs per product
     const size_t px = (size_t)p.d.n * p.h * p.w;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -211,11 +209,11 @@ void carve(const Plan& p, char* base, Bufs& b) {
         b.gxin = take(px * p.ci_pad * es);
         // wgrad slabs: largest batch (a dense block = 26 jobs at LR; single 64->64 convs = 4 jobs at 1x/2x/4x)
         const size_t slab = (9 * 1024 + 32) * sizeof(float);
-        size_t pb = (size_t)26 * splits_for(p, 26, p.h, p.w) * slab;
+        size_t pb = (size_t)26 * wm * splits_for(p, 26 * wm, p.h, p.w) * slab;
         for (int m = 1; m <= 4; m *= 2) {
-            const size_t q = (size_t)4 * splits_for(p, 4, p.h * m, p.w * m) * slab;
+            const size_t q = (size_t)4 * wm * splits_for(p, 4 * wm, p.h * m, p.w * m) * slab;
             if (q > pb) pb = q;
-            const size_t q2 = (size_t)2 * splits_for(p, 2, p.h * m, p.w * m) * slab;
+            const size_t q2 = (size_t)2 * wm * splits_for(p, 2 * wm, p.h * m, p.w * m) * slab;
             if (q2 > pb) pb = q2;
         }
         b.partial_bytes = pb;
@@ -250,7 +248,7 @@ size_t generator_packed_bytes(const ResrGeneratorDesc* d, int backward) {
     Plan p;
     if (!build_plan(d, p)) return 0;
     // + two dummy (chunk,tap) of slack: conv3x3_kernel prefetches two taps past the end
-    return (backward ? p.pk_total_elems : p.pk_fwd_elems) * elem_size(d->dtype) + 16384;
+    return (backward ? p.pk_total_elems : p.pk_fwd_elems) * elem_size(d->dtype) * (d->dtype == RESR_F16X2 ? 3 : 1) + 16384;
 }
 
 size_t generator_workspace_bytes(const ResrGeneratorDesc* d) {
@@ -370,22 +368,29 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
     carve(p, (char*)workspace, b);
     if (b.total > workspace_bytes) return fail(RESR_ERR_WORKSPACE, "generator_forward: workspace %zu < %zu", workspace_bytes, b.total);
     const size_t es = elem_size(d->dtype);
+    const bool x2 = d->dtype == RESR_F16X2;
+    const size_t wes = es * (x2 ? 3 : 1);   // bytes per element of the plain packed layout
     const char* pk = (const char*)packed;
     const int N = d->n, h = p.h, w = p.w;
     const int nws = (int)b.ws.size();
     if ((long)N * h * w * 32 * 16 > 0x7fffffffL) return fail(RESR_ERR_ARG, "generator: batch x resolution too large for 32-bit chunk strides");
     const int plane = N * h * w * 32;  // elements per 32-channel plane of the chunk-planar trunk tensors
-    auto W = [&](const ConvSpec& c) { return pk + c.pk_fwd * es; };
+    // RESR_F16X2: element offset hi -> lo of a buffer holding `planes` 32-channel planes of `pl` elements
+    auto LO = [&](long planes, long pl) -> int64_t { return x2 ? planes * pl : 0; };
+    const int64_t lo_ws = LO(6, plane), lo_t = LO(2, plane), lo_xin = x2 ? (int64_t)N * h * w * p.ci_pad : 0;
+    const int64_t lo_out1 = b.out1 == b.ws[0] ? lo_ws : LO(2, plane);
+    auto W = [&](const ConvSpec& c) { return pk + c.pk_fwd * wes; };
     auto Bias = [&](const ConvSpec& c) { return params + c.b_off; };
 
-    RUN(nchw_to_nhwc_dispatch(x, b.x_in, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, nullptr, st));
+    RUN(nchw_to_nhwc_dispatch(x, b.x_in, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, nullptr, st, (long)lo_xin));
     {   // conv1 -> ws[0][0:64]                                           model.py:259
         const ConvSpec& c = p.convs[p.i_conv1];
         ResrConvDesc cd = conv_desc(p, N, h, w, p.ci_pad, p.ci_pad, p.ci_pad, 0, 64, 64, 32, 0);
         cd.out_chunk_stride = plane;
+        cd.in0_lo_offset = lo_xin; cd.out_lo_offset = lo_ws;
         RUN(conv3x3_dispatch(&cd, b.x_in, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.ws[0], nullptr, st));
         if (b.out1 != b.ws[0]) {  // inference: second copy of out1 (0.01 % of the FLOPs) instead of a pinned workspace
-            cd.out_stride = b.out1_stride; cd.out_chunk_stride = 0;
+            cd.out_stride = b.out1_stride; cd.out_chunk_stride = 0; cd.out_lo_offset = lo_out1;
             RUN(conv3x3_dispatch(&cd, b.x_in, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.out1, nullptr, st));
         }
     }
@@ -395,6 +400,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
             const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
             ResrConvDesc cd = conv_desc(p, N, h, w, c.cin, c.cin, 32, 0, 32, 32, 32, RESR_CONV_LRELU);
             cd.in0_chunk_stride = plane;
+            cd.in0_lo_offset = lo_ws; cd.out_lo_offset = lo_ws;
             char* signs = nullptr;
             if (d->training) {   // the backward pass reads the 1-bit mask, not the activation
                 cd.flags |= RESR_CONV_WRITE_SIGNBITS;
@@ -409,11 +415,12 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         ResrConvDesc cd = conv_desc(p, N, h, w, 192, 192, 32, 0, 64, 64, 32, 0);
         cd.in0_chunk_stride = plane;
         cd.out_chunk_stride = plane;
-        cd.s0 = 0.2f; cd.t0 = 1.f; cd.res0_stride = 32; cd.res0_chunk_stride = plane;  // model.py:95-96
+        cd.in0_lo_offset = lo_ws; cd.out_lo_offset = last ? lo_t : lo_ws;
+        cd.s0 = 0.2f; cd.t0 = 1.f; cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.res0_lo_offset = lo_ws;  // model.py:95-96
         const char* res1 = nullptr;
         if (r % 3 == 2) {  // model.py:129-130
             res1 = b.ws[(r - 2) % nws];
-            cd.s1 = 0.2f; cd.t1 = 1.f; cd.res1_stride = 32; cd.res1_chunk_stride = plane;
+            cd.s1 = 0.2f; cd.t1 = 1.f; cd.res1_stride = 32; cd.res1_chunk_stride = plane; cd.res1_lo_offset = lo_ws;
         }
         RUN(conv3x3_dispatch(&cd, cur, nullptr, W(c), Bias(c), cur, res1, nullptr, dst, nullptr, st));
     }
@@ -424,18 +431,21 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         cd.res0_stride = b.out1_stride;
         cd.res0_chunk_stride = b.out1 == b.ws[0] ? plane : 0;
         cd.out_stride = 32; cd.out_chunk_stride = plane;        // feat and the whole HR tail are chunk-planar [2][N,H,W,32] too
+        cd.in0_lo_offset = lo_t; cd.res0_lo_offset = lo_out1; cd.out_lo_offset = lo_t;
         RUN(conv3x3_dispatch(&cd, b.trunk_out, nullptr, W(c), Bias(c), b.out1, nullptr, nullptr, b.feat, nullptr, st));
     }
     {   // model.py:264
         const ConvSpec& c = p.convs[p.i_up1];
         ResrConvDesc cd = conv_desc(p, N, 2 * h, 2 * w, 64, 64, 32, 0, 64, 64, 32, RESR_CONV_LRELU | RESR_CONV_UPSAMPLE_IN);
         cd.in0_chunk_stride = plane; cd.out_chunk_stride = 4 * plane;
+        cd.in0_lo_offset = lo_t; cd.out_lo_offset = LO(2, 4L * plane);
         RUN(conv3x3_dispatch(&cd, b.feat, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.u1, nullptr, st));
     }
     {   // model.py:265
         const ConvSpec& c = p.convs[p.i_up2];
         ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 32, 0, 64, 64, 32, RESR_CONV_LRELU | RESR_CONV_UPSAMPLE_IN);
         cd.in0_chunk_stride = 4 * plane; cd.out_chunk_stride = 16 * plane;
+        cd.in0_lo_offset = LO(2, 4L * plane); cd.out_lo_offset = LO(2, 16L * plane);
         if (d->training) cd.flags |= RESR_CONV_WRITE_SIGNBITS;
         RUN(conv3x3_dispatch(&cd, b.u1, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.u2, b.bits_u2, st));
     }
@@ -443,6 +453,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         const ConvSpec& c = p.convs[p.i_conv3];
         ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 32, 0, 64, 64, 32, RESR_CONV_LRELU);
         cd.in0_chunk_stride = 16 * plane; cd.out_chunk_stride = 16 * plane;
+        cd.in0_lo_offset = LO(2, 16L * plane); cd.out_lo_offset = LO(2, 16L * plane);
         if (d->training) cd.flags |= RESR_CONV_WRITE_SIGNBITS;
         RUN(conv3x3_dispatch(&cd, b.u2, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.c3, b.bits_c3, st));
     }
@@ -451,6 +462,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         ResrConvDesc cd = conv_desc(p, N, 4 * h, 4 * w, 64, 64, 32, 0, c.cout, c.cout_pad, 0,
                                     RESR_CONV_CLAMP01 | RESR_CONV_OUT_NCHW_F32);
         cd.in0_chunk_stride = 16 * plane;
+        cd.in0_lo_offset = LO(2, 16L * plane);
         RUN(conv3x3_dispatch(&cd, b.c3, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, y, b.ymask, st));
     }
     return RESR_OK;
@@ -468,85 +480,98 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     carve(p, (char*)workspace, b);
     if (b.total > workspace_bytes) return fail(RESR_ERR_WORKSPACE, "generator_backward: workspace %zu < %zu", workspace_bytes, b.total);
     const size_t es = elem_size(d->dtype);
+    const bool x2 = d->dtype == RESR_F16X2;
+    const size_t wes = es * (x2 ? 3 : 1);
+    const int wm = x2 ? 3 : 1;
     const char* pk = (const char*)packed;
     const int N = d->n, h = p.h, w = p.w;
     const int H4 = 4 * h, W4 = 4 * w, H2 = 2 * h, W2 = 2 * w;
     if ((long)N * h * w * 32 * 16 > 0x7fffffffL) return fail(RESR_ERR_ARG, "generator: batch x resolution too large for 32-bit chunk strides");
     const int plane = N * h * w * 32;  // elements per 32-channel plane of the chunk-planar trunk tensors (ws[], gS)
     const int pl2 = 4 * plane, pl4 = 16 * plane;   // planes of the 2x / 4x resolution tensors
+    // RESR_F16X2: element offsets hi -> lo (the lo tensor follows the hi tensor of the same buffer)
+    auto LO = [&](long planes, long pl) -> long { return x2 ? planes * pl : 0; };
+    const long lo_ws = LO(6, plane), lo_t = LO(2, plane), lo_gs = LO(4, plane), lo_2 = LO(2, pl2), lo_4 = LO(2, pl4), lo_g4 = LO(1, pl4);
+    const long lo_xin = x2 ? (long)N * h * w * p.ci_pad : 0;
 
-    auto wconv = [&](const ConvSpec& c, const void* x0, int cin, int s0, const void* g, int gstride, float scale) {
+    auto wconv = [&](const ConvSpec& c, const void* x0, int cin, int s0, const void* g, int gstride, float scale,
+                     long x_lo, long g_lo) {
         WgradConv wc;
         wc.x0 = x0; wc.cin = cin; wc.in0_stride = s0; wc.cin_real = c.cin;
         wc.g = g; wc.cout = c.cout; wc.cout_pad = c.cout_pad; wc.g_stride = gstride;
         wc.x_chunk_stride = wc.g_chunk_stride = 0;
+        wc.x_lo_off = x_lo; wc.g_lo_off = g_lo;
         wc.dw = grad + c.w_off; wc.db = grad + c.b_off; wc.scale = scale;
         return wc;
     };
     auto wgrad_run = [&](const WgradConv* wc, int nconv, int hh, int ww, int flags) -> int {
         int njobs = 0;
         for (int i = 0; i < nconv; ++i) njobs += (wc[i].cin / 32) * (wc[i].cout_pad / 32);
-        const int splits = splits_for(p, njobs, hh, ww);
-        if (wgrad_batch_partial_bytes(wc, nconv, splits) > b.partial_bytes)
+        const int splits = splits_for(p, njobs * wm, hh, ww);
+        if (wgrad_batch_partial_bytes(wc, nconv, splits, d->dtype) > b.partial_bytes)
             return fail(RESR_ERR_WORKSPACE, "wgrad slab buffer too small");
         return wgrad_batch(wc, nconv, N, hh, ww, d->dtype, flags, splits, b.partial, st);
     };
     auto wgrad = [&](const ConvSpec& c, int hh, int ww, const void* x0, int cin, int s0, const void* g, int gstride,
-                     int flags, float scale, long x_chunk = 0, long g_chunk = 0) -> int {
-        WgradConv wc = wconv(c, x0, cin, s0, g, gstride, scale);
+                     int flags, float scale, long x_chunk, long g_chunk, long x_lo, long g_lo) -> int {
+        WgradConv wc = wconv(c, x0, cin, s0, g, gstride, scale, x_lo, g_lo);
         wc.x_chunk_stride = x_chunk; wc.g_chunk_stride = g_chunk;
         return wgrad_run(&wc, 1, hh, ww, flags);
     };
-    auto dgrad = [&](int hh, int ww, const void*, int cin0, int s0, const void*, int cin, int s1, size_t, int cout,
-                     int cout_pad, void*, int out_stride, int flags) {
-        return conv_desc(p, N, hh, ww, cin, cin0, s0, s1, cout, cout_pad, out_stride, flags | RESR_CONV_NO_BIAS);
+    // backward-data pass descriptor: in0 (cin0 channels, lo offset lo0) [+ in1 (lo offset lo1)] -> out (lo offset lo_out)
+    auto dgrad = [&](int hh, int ww, int cin0, int s0, int cin, int s1, int cout, int cout_pad, int out_stride, int flags,
+                     long lo0, long lo1, long lo_out) {
+        ResrConvDesc cd = conv_desc(p, N, hh, ww, cin, cin0, s0, s1, cout, cout_pad, out_stride, flags | RESR_CONV_NO_BIAS);
+        cd.in0_lo_offset = lo0; cd.in1_lo_offset = lo1; cd.out_lo_offset = lo_out;
+        return cd;
     };
 
     // clamp_ backward + layout                                              model.py:270
-    RUN(nchw_to_nhwc_dispatch(gy, b.g4, N, d->out_channels, H4, W4, 1, 32, d->dtype, b.ymask, st));
+    RUN(nchw_to_nhwc_dispatch(gy, b.g4, N, d->out_channels, H4, W4, 1, 32, d->dtype, b.ymask, st, lo_g4));
     {   // conv4                                                            model.py:268
         const ConvSpec& c = p.convs[p.i_conv4];
-        RUN(wgrad(c, H4, W4, b.c3, 64, 32, b.g4, 32, 0, 1.f, pl4, 0));
-        ResrConvDesc cd = dgrad(H4, W4, b.g4, 32, 32, nullptr, 32, 0, 0, 64, 64, b.gA, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS);
+        RUN(wgrad(c, H4, W4, b.c3, 64, 32, b.g4, 32, 0, 1.f, pl4, 0, lo_4, lo_g4));
+        ResrConvDesc cd = dgrad(H4, W4, 32, 32, 32, 0, 64, 64, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS, lo_g4, 0, lo_4);
         cd.out_chunk_stride = pl4;
-        RUN(conv3x3_dispatch(&cd, b.g4, nullptr, pk + p.pk_bwd_conv4 * es, nullptr, nullptr, nullptr, b.bits_c3, b.gA, nullptr, st));
+        RUN(conv3x3_dispatch(&cd, b.g4, nullptr, pk + p.pk_bwd_conv4 * wes, nullptr, nullptr, nullptr, b.bits_c3, b.gA, nullptr, st));
     }
     {   // conv3                                                            model.py:267
         const ConvSpec& c = p.convs[p.i_conv3];
-        RUN(wgrad(c, H4, W4, b.u2, 64, 32, b.gA, 32, 0, 1.f, pl4, pl4));
-        ResrConvDesc cd = dgrad(H4, W4, b.gA, 64, 32, nullptr, 64, 0, 0, 64, 64, b.gB, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS);
+        RUN(wgrad(c, H4, W4, b.u2, 64, 32, b.gA, 32, 0, 1.f, pl4, pl4, lo_4, lo_4));
+        ResrConvDesc cd = dgrad(H4, W4, 64, 32, 64, 0, 64, 64, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS, lo_4, 0, lo_4);
         cd.in0_chunk_stride = pl4; cd.out_chunk_stride = pl4;
-        RUN(conv3x3_dispatch(&cd, b.gA, nullptr, pk + p.pk_bwd_conv3 * es, nullptr, nullptr, nullptr, b.bits_u2, b.gB, nullptr, st));
+        RUN(conv3x3_dispatch(&cd, b.gA, nullptr, pk + p.pk_bwd_conv3 * wes, nullptr, nullptr, nullptr, b.bits_u2, b.gB, nullptr, st));
     }
     if (debug_stop() == 1) return RESR_OK;
     {   // upsampling2                                                      model.py:265
         const ConvSpec& c = p.convs[p.i_up2];
-        RUN(wgrad(c, H4, W4, b.u1, 64, 32, b.gB, 32, RESR_CONV_UPSAMPLE_IN, 1.f, pl2, pl4));
-        ResrConvDesc cd = dgrad(H4, W4, b.gB, 64, 32, nullptr, 64, 0, 0, 64, 64, b.gA, 32, 0);
+        RUN(wgrad(c, H4, W4, b.u1, 64, 32, b.gB, 32, RESR_CONV_UPSAMPLE_IN, 1.f, pl2, pl4, lo_2, lo_4));
+        ResrConvDesc cd = dgrad(H4, W4, 64, 32, 64, 0, 64, 64, 32, 0, lo_4, 0, lo_4);
         cd.in0_chunk_stride = pl4; cd.out_chunk_stride = pl4;
-        RUN(conv3x3_dispatch(&cd, b.gB, nullptr, pk + p.pk_bwd_up2 * es, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
+        RUN(conv3x3_dispatch(&cd, b.gB, nullptr, pk + p.pk_bwd_up2 * wes, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
         for (int q = 0; q < 2; ++q)   // per 32-channel plane
             RUN(sumpool2x2_dispatch(b.gA + (size_t)q * pl4 * es, b.gM1 + (size_t)q * pl2 * es, b.u1 + (size_t)q * pl2 * es,
-                                    N, H2, W2, 32, d->dtype, 0.2f, st));
+                                    N, H2, W2, 32, d->dtype, 0.2f, st, lo_4, lo_2));
     }
     if (debug_stop() == 2) return RESR_OK;
     {   // upsampling1                                                      model.py:264
         const ConvSpec& c = p.convs[p.i_up1];
-        RUN(wgrad(c, H2, W2, b.feat, 64, 32, b.gM1, 32, RESR_CONV_UPSAMPLE_IN, 1.f, plane, pl2));
-        ResrConvDesc cd = dgrad(H2, W2, b.gM1, 64, 32, nullptr, 64, 0, 0, 64, 64, b.gA, 32, 0);
+        RUN(wgrad(c, H2, W2, b.feat, 64, 32, b.gM1, 32, RESR_CONV_UPSAMPLE_IN, 1.f, plane, pl2, lo_t, lo_2));
+        ResrConvDesc cd = dgrad(H2, W2, 64, 32, 64, 0, 64, 64, 32, 0, lo_2, 0, lo_2);
         cd.in0_chunk_stride = pl2; cd.out_chunk_stride = pl2;
-        RUN(conv3x3_dispatch(&cd, b.gM1, nullptr, pk + p.pk_bwd_up1 * es, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
+        RUN(conv3x3_dispatch(&cd, b.gM1, nullptr, pk + p.pk_bwd_up1 * wes, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
         for (int q = 0; q < 2; ++q)
-            RUN(sumpool2x2_dispatch(b.gA + (size_t)q * pl2 * es, b.gF + (size_t)q * plane * es, nullptr, N, h, w, 32, d->dtype, 0.2f, st));
+            RUN(sumpool2x2_dispatch(b.gA + (size_t)q * pl2 * es, b.gF + (size_t)q * plane * es, nullptr, N, h, w, 32, d->dtype, 0.2f, st,
+                                    lo_2, lo_t));
     }
     if (debug_stop() == 3) return RESR_OK;
     int cur = 0;  // index into gT ring of the gradient wrt the current RDB's output chain
     {   // conv2                                                            model.py:261
         const ConvSpec& c = p.convs[p.i_conv2];
-        RUN(wgrad(c, h, w, b.trunk_out, 64, 32, b.gF, 32, 0, 1.f, plane, plane));
-        ResrConvDesc cd = dgrad(h, w, b.gF, 64, 32, nullptr, 64, 0, 0, 64, 64, b.gT[0], 32, 0);
+        RUN(wgrad(c, h, w, b.trunk_out, 64, 32, b.gF, 32, 0, 1.f, plane, plane, lo_t, lo_t));
+        ResrConvDesc cd = dgrad(h, w, 64, 32, 64, 0, 64, 64, 32, 0, lo_t, 0, lo_t);
         cd.in0_chunk_stride = plane; cd.out_chunk_stride = plane;   // the gT ring (gradient wrt the RDB chain) is chunk-planar [2][N,h,w,32]
-        RUN(conv3x3_dispatch(&cd, b.gF, nullptr, pk + p.pk_bwd_conv2 * es, nullptr, nullptr, nullptr, nullptr, b.gT[0], nullptr, st));
+        RUN(conv3x3_dispatch(&cd, b.gF, nullptr, pk + p.pk_bwd_conv2 * wes, nullptr, nullptr, nullptr, nullptr, b.gT[0], nullptr, st));
     }
     // trunk, mirrored dense blocks.  gT ring: e (grad wrt RRDB output) must survive its three RDBs.
     int e_idx = 0;
@@ -557,48 +582,48 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         const char* act = b.ws[r];
         const float fold = pos == 2 ? 0.04f : 0.2f;
         WgradConv wc[5];
-        wc[4] = wconv(p.convs[p.i_trunk0 + r * 5 + 4], act, 192, 32, gin, 32, fold);   // conv5: G = fold * gin
+        wc[4] = wconv(p.convs[p.i_trunk0 + r * 5 + 4], act, 192, 32, gin, 32, fold, lo_ws, lo_t);   // conv5: G = fold * gin
         wc[4].x_chunk_stride = plane; wc[4].g_chunk_stride = plane;
         for (int ps = 0; ps < 4; ++ps) {   // g_o4, g_o3, g_o2, g_o1
             const int k = 4 - ps;           // conv index whose pre-activation gradient this pass yields
             const int cin = 64 + 32 * ps;
-            ResrConvDesc cd = dgrad(h, w, gin, 64, 32, b.gS, cin, 32, 0, 32, 32, nullptr, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS);
+            ResrConvDesc cd = dgrad(h, w, 64, 32, cin, 32, 32, 32, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS, lo_t, lo_gs, lo_gs);
             cd.in0_chunk_stride = plane; cd.in1_chunk_stride = plane;
             char* out = b.gS + (size_t)ps * plane * es;
             const char* mask = b.bits[r] + (size_t)(k - 1) * N * h * w * sizeof(uint32_t);   // sign plane of o_k
-            RUN(conv3x3_dispatch(&cd, gin, b.gS, pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * es, nullptr, nullptr, nullptr,
+            RUN(conv3x3_dispatch(&cd, gin, b.gS, pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * wes, nullptr, nullptr, nullptr,
                                  mask, out, nullptr, st));
             const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
-            wc[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f);
+            wc[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f, lo_ws, lo_gs);
             wc[k - 1].x_chunk_stride = plane;
         }
         RUN(wgrad_run(wc, 5, h, w, 0));   // all five weight gradients of the block in one launch pair
         {   // g_x = convT(all) + (skip terms)
             int nxt = (cur + 1) & 3;
             if (nxt == e_idx && pos != 2) nxt = (nxt + 1) & 3;
-            ResrConvDesc cd = dgrad(h, w, gin, 64, 32, b.gS, 192, 32, 0, 64, 64, nullptr, 32, 0);
+            ResrConvDesc cd = dgrad(h, w, 64, 32, 192, 32, 64, 64, 32, 0, lo_t, lo_gs, lo_t);
             cd.in0_chunk_stride = plane; cd.in1_chunk_stride = plane; cd.out_chunk_stride = plane;
             const char* res0 = gin;
             const char* res1 = nullptr;
-            cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.s0 = 1.f;
+            cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.s0 = 1.f; cd.res0_lo_offset = lo_t;
             cd.t0 = pos == 2 ? 0.2f : 1.f;       // d(rdb3_out*0.2 + x)/d(rdb3_out) reaches x3 scaled
-            if (pos == 0) { res1 = b.gT[e_idx]; cd.res1_stride = 32; cd.res1_chunk_stride = plane; cd.s1 = 1.f; cd.t1 = 1.f; }
-            RUN(conv3x3_dispatch(&cd, gin, b.gS, pk + p.pk_bwd_trunk[(size_t)r * 5 + 4] * es, nullptr, res0, res1, nullptr,
+            if (pos == 0) { res1 = b.gT[e_idx]; cd.res1_stride = 32; cd.res1_chunk_stride = plane; cd.s1 = 1.f; cd.t1 = 1.f; cd.res1_lo_offset = lo_t; }
+            RUN(conv3x3_dispatch(&cd, gin, b.gS, pk + p.pk_bwd_trunk[(size_t)r * 5 + 4] * wes, nullptr, res0, res1, nullptr,
                                  b.gT[nxt], nullptr, st));
             cur = nxt;
         }
     }
     if (debug_stop() == 4) return RESR_OK;
     // gradient wrt out1 = trunk path + skip (model.py:262)
-    RUN(add_inplace_dispatch(b.gT[cur], b.gF, (long)N * h * w * 64, d->dtype, st));   // both chunk-planar [2][N,h,w,32]
+    RUN(add_inplace_dispatch(b.gT[cur], b.gF, (long)N * h * w * 64, d->dtype, st, lo_t, lo_t));   // both chunk-planar [2][N,h,w,32]
     {   // conv1                                                            model.py:259
         const ConvSpec& c = p.convs[p.i_conv1];
-        RUN(wgrad(c, h, w, b.x_in, p.ci_pad, p.ci_pad, b.gT[cur], 32, 0, 1.f, 0, plane));
+        RUN(wgrad(c, h, w, b.x_in, p.ci_pad, p.ci_pad, b.gT[cur], 32, 0, 1.f, 0, plane, lo_xin, lo_t));
         if (gx) {
-            ResrConvDesc cd = dgrad(h, w, b.gT[cur], 64, 32, nullptr, 64, 0, 0, p.ci_pad, p.ci_pad, b.gxin, p.ci_pad, 0);
+            ResrConvDesc cd = dgrad(h, w, 64, 32, 64, 0, p.ci_pad, p.ci_pad, p.ci_pad, 0, lo_t, 0, lo_xin);
             cd.in0_chunk_stride = plane;
-            RUN(conv3x3_dispatch(&cd, b.gT[cur], nullptr, pk + p.pk_bwd_conv1 * es, nullptr, nullptr, nullptr, nullptr, b.gxin, nullptr, st));
-            RUN(nhwc_to_nchw_dispatch(b.gxin, gx, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, st));
+            RUN(conv3x3_dispatch(&cd, b.gT[cur], nullptr, pk + p.pk_bwd_conv1 * wes, nullptr, nullptr, nullptr, nullptr, b.gxin, nullptr, st));
+            RUN(nhwc_to_nchw_dispatch(b.gxin, gx, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, st, lo_xin));
         }
     }
     return RESR_OK;

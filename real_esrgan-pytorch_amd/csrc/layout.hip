@@ -11,10 +11,17 @@
 
 namespace resr {
 
+// RESR_F16X2 (lo_off != 0 with T = f16): every tensor of T is a (hi, lo) pair, lo at element offset lo_off; values are
+// split / recombined in fp32 (see include/resr.h).
+__device__ __forceinline__ void split_f16(float v, half_t& hi, half_t& lo) {
+    hi = (half_t)v;
+    lo = (half_t)((v - (float)hi) * kLoScale);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
                                                            int n, int c, int h, int w, int r, int c_pad,
-                                                           const uint8_t* __restrict__ mask) {
+                                                           const uint8_t* __restrict__ mask, long lo_off) {
     // output pixel grid is (h/r) x (w/r); output channel = ch*r*r + i*r + j  (torch pixel_unshuffle).
     // One thread per 16-byte piece of an output pixel: consecutive threads write consecutive 16 bytes.
     constexpr int E = 16 / (int)sizeof(T);
@@ -29,8 +36,9 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     const int yo = (int)((p / wo) % ho);
     const int b = (int)(p / ((long)wo * ho));
     const int creal = c * r * r;
-    uint4 out;
+    uint4 out, outl;
     T* o = reinterpret_cast<T*>(&out);
+    T* ol = reinterpret_cast<T*>(&outl);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int co = piece * E + e;
@@ -41,14 +49,20 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
             v = src[q];
             if (mask) v = mask[q] ? v : 0.f;
         }
-        o[e] = (T)v;
+        if constexpr (sizeof(T) == 2) {
+            if (lo_off) split_f16(v, o[e], ol[e]);
+            else o[e] = (T)v;
+        } else {
+            o[e] = (T)v;
+        }
     }
     *reinterpret_cast<uint4*>(dst + p * c_pad + piece * E) = out;
+    if (sizeof(T) == 2 && lo_off) *reinterpret_cast<uint4*>(dst + lo_off + p * c_pad + piece * E) = outl;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst,
-                                                           int n, int c, int h, int w, int r, int src_stride) {
+                                                           int n, int c, int h, int w, int r, int src_stride, long lo_off) {
     // src pixel grid (h/r) x (w/r) with c*r*r channels; dst [n,c,h,w]
     const long total = (long)n * c * h * w;
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
@@ -60,13 +74,15 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
     const int ho = h / r, wo = w / r;
     const int co = ch * r * r + (y % r) * r + (x % r);
     const size_t p = ((size_t)b * ho + y / r) * wo + x / r;
-    dst[q] = (float)src[p * src_stride + co];
+    float v = (float)src[p * src_stride + co];
+    if (sizeof(T) == 2 && lo_off) v = __builtin_fmaf((float)src[lo_off + p * src_stride + co], kLoInv, v);
+    dst[q] = v;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ src, T* __restrict__ dst,
                                                          const T* __restrict__ mask, int n, int ho, int wo, int c,
-                                                         float slope) {
+                                                         float slope, long src_lo, long dst_lo) {
     constexpr int E = 16 / (int)sizeof(T);
     const int groups = c / E;
     const long total = (long)n * ho * wo * groups;
@@ -90,6 +106,12 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ s
             const T* v = reinterpret_cast<const T*>(&raw);
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] += (float)v[e];
+            if (sizeof(T) == 2 && src_lo) {
+                const uint4 rawl = *reinterpret_cast<const uint4*>(s + src_lo + ((size_t)dy * wi + dx) * c);
+                const T* vl = reinterpret_cast<const T*>(&rawl);
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] = __builtin_fmaf((float)vl[e], kLoInv, acc[e]);
+            }
         }
     if (mask) {
         const uint4 raw = *reinterpret_cast<const uint4*>(mask + p * c + g * E);
@@ -97,15 +119,25 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ s
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] *= ((float)v[e] > 0.f ? 1.f : slope);
     }
-    uint4 outv;
+    uint4 outv, outl;
     T* o = reinterpret_cast<T*>(&outv);
+    T* ol = reinterpret_cast<T*>(&outl);
 #pragma unroll
-    for (int e = 0; e < E; ++e) o[e] = (T)acc[e];
+    for (int e = 0; e < E; ++e) {
+        if constexpr (sizeof(T) == 2) {
+            if (dst_lo) split_f16(acc[e], o[e], ol[e]);
+            else o[e] = (T)acc[e];
+        } else {
+            o[e] = (T)acc[e];
+        }
+    }
     *reinterpret_cast<uint4*>(dst + p * c + g * E) = outv;
+    if (sizeof(T) == 2 && dst_lo) *reinterpret_cast<uint4*>(dst + dst_lo + p * c + g * E) = outl;
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ src, long count) {
+__global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ src, long count,
+                                                          long dst_lo, long src_lo) {
     constexpr int E = 16 / (int)sizeof(T);
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * E;
     if (i >= count) return;
@@ -113,6 +145,22 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ dst, c
     const uint4 b = *reinterpret_cast<const uint4*>(src + i);
     T* pa = reinterpret_cast<T*>(&a);
     const T* pb = reinterpret_cast<const T*>(&b);
+    if constexpr (sizeof(T) == 2) {
+        if (dst_lo) {   // hi/lo pairs: add in fp32, split again
+            uint4 al = *reinterpret_cast<const uint4*>(dst + dst_lo + i);
+            const uint4 bl = *reinterpret_cast<const uint4*>(src + src_lo + i);
+            T* pal = reinterpret_cast<T*>(&al);
+            const T* pbl = reinterpret_cast<const T*>(&bl);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float v = ((float)pa[e] + (float)pb[e]) + ((float)pal[e] + (float)pbl[e]) * kLoInv;
+                split_f16(v, pa[e], pal[e]);
+            }
+            *reinterpret_cast<uint4*>(dst + i) = a;
+            *reinterpret_cast<uint4*>(dst + dst_lo + i) = al;
+            return;
+        }
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) pa[e] = (T)((float)pa[e] + (float)pb[e]);
     *reinterpret_cast<uint4*>(dst + i) = a;
@@ -120,54 +168,64 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ dst, c
 
 static unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
 
+// RESR_F16X2: lo_off < 0 selects the C-ABI default -- the lo tensor directly follows the hi tensor
 int nchw_to_nhwc_dispatch(const float* src, void* dst, int n, int c, int h, int w, int r, int c_pad, int dtype,
-                          const uint8_t* mask, hipStream_t stream) {
+                          const uint8_t* mask, hipStream_t stream, long lo_off) {
     if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || r <= 0 || (h % r) || (w % r) || c * r * r > c_pad || (c_pad & 7))
         return fail(RESR_ERR_ARG, "nchw_to_nhwc: bad argument (c=%d r=%d c_pad=%d h=%d w=%d)", c, r, c_pad, h, w);
-    const long total = (long)n * (h / r) * (w / r) * (c_pad / (dtype == RESR_F16 ? 8 : 4));
-    if (dtype == RESR_F16)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, src, (half_t*)dst, n, c, h, w, r, c_pad, mask);
+    const long total = (long)n * (h / r) * (w / r) * (c_pad / (dtype != RESR_F32 ? 8 : 4));
+    if (dtype == RESR_F16X2 && lo_off < 0) lo_off = (long)n * (h / r) * (w / r) * c_pad;
+    if (dtype != RESR_F16X2) lo_off = 0;
+    if (dtype != RESR_F32)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, src, (half_t*)dst, n, c, h, w, r, c_pad, mask, lo_off);
     else
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, src, (float*)dst, n, c, h, w, r, c_pad, mask);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, src, (float*)dst, n, c, h, w, r, c_pad, mask, 0L);
     RESR_CHECK_LAUNCH("nchw_to_nhwc_kernel");
     return RESR_OK;
 }
 
 int nhwc_to_nchw_dispatch(const void* src, float* dst, int n, int c, int h, int w, int r, int src_stride, int dtype,
-                          hipStream_t stream) {
+                          hipStream_t stream, long lo_off) {
     if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || r <= 0 || (h % r) || (w % r))
         return fail(RESR_ERR_ARG, "nhwc_to_nchw: bad argument");
     const long total = (long)n * c * h * w;
-    if (dtype == RESR_F16)
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, (const half_t*)src, dst, n, c, h, w, r, src_stride);
+    if (dtype == RESR_F16X2 && lo_off < 0) lo_off = (long)n * (h / r) * (w / r) * src_stride;
+    if (dtype != RESR_F16X2) lo_off = 0;
+    if (dtype != RESR_F32)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, (const half_t*)src, dst, n, c, h, w, r, src_stride, lo_off);
     else
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, (const float*)src, dst, n, c, h, w, r, src_stride);
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, (const float*)src, dst, n, c, h, w, r, src_stride, 0L);
     RESR_CHECK_LAUNCH("nhwc_to_nchw_kernel");
     return RESR_OK;
 }
 
 int sumpool2x2_dispatch(const void* src, void* dst, const void* mask, int n, int ho, int wo, int c, int dtype,
-                        float slope, hipStream_t stream) {
-    const int E = dtype == RESR_F16 ? 8 : 4;
+                        float slope, hipStream_t stream, long src_lo, long dst_lo) {
+    const int E = dtype != RESR_F32 ? 8 : 4;
+    if (dtype == RESR_F16X2 && src_lo < 0) src_lo = (long)n * ho * wo * 4 * c;
+    if (dtype == RESR_F16X2 && dst_lo < 0) dst_lo = (long)n * ho * wo * c;
+    if (dtype != RESR_F16X2) src_lo = dst_lo = 0;
     if (!src || !dst || n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || (c % E))
         return fail(RESR_ERR_ARG, "sumpool2x2: bad argument");
     const long total = (long)n * ho * wo * (c / E);
-    if (dtype == RESR_F16)
-        hipLaunchKernelGGL(sumpool2x2_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, (const half_t*)src, (half_t*)dst, (const half_t*)mask, n, ho, wo, c, slope);
+    if (dtype != RESR_F32)
+        hipLaunchKernelGGL(sumpool2x2_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, (const half_t*)src, (half_t*)dst, (const half_t*)mask, n, ho, wo, c, slope, src_lo, dst_lo);
     else
-        hipLaunchKernelGGL(sumpool2x2_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, (const float*)src, (float*)dst, (const float*)mask, n, ho, wo, c, slope);
+        hipLaunchKernelGGL(sumpool2x2_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, (const float*)src, (float*)dst, (const float*)mask, n, ho, wo, c, slope, 0L, 0L);
     RESR_CHECK_LAUNCH("sumpool2x2_kernel");
     return RESR_OK;
 }
 
-int add_inplace_dispatch(void* dst, const void* src, long count, int dtype, hipStream_t stream) {
-    const int E = dtype == RESR_F16 ? 8 : 4;
+int add_inplace_dispatch(void* dst, const void* src, long count, int dtype, hipStream_t stream, long dst_lo, long src_lo) {
+    const int E = dtype != RESR_F32 ? 8 : 4;
+    if (dtype == RESR_F16X2 && (dst_lo <= 0 || src_lo <= 0)) return fail(RESR_ERR_ARG, "add_inplace: RESR_F16X2 needs the lo offsets");
+    if (dtype != RESR_F16X2) dst_lo = src_lo = 0;
     if (!dst || !src || count <= 0 || (count % E)) return fail(RESR_ERR_ARG, "add_inplace: bad argument");
     const long total = count / E;
-    if (dtype == RESR_F16)
-        hipLaunchKernelGGL(add_inplace_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, (half_t*)dst, (const half_t*)src, count);
+    if (dtype != RESR_F32)
+        hipLaunchKernelGGL(add_inplace_kernel<half_t>, dim3(blocks_for(total)), dim3(256), 0, stream, (half_t*)dst, (const half_t*)src, count, dst_lo, src_lo);
     else
-        hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, (float*)dst, (const float*)src, count);
+        hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, (float*)dst, (const float*)src, count, 0L, 0L);
     RESR_CHECK_LAUNCH("add_inplace_kernel");
     return RESR_OK;
 }

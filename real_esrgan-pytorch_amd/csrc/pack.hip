@@ -11,14 +11,19 @@
 
 namespace resr {
 
-template <typename T>
+//
+// RESR_F16X2 (X2 = true): a chunk becomes THREE consecutive f16 blocks of the plain chunk's size, in the stage order of
+// the conv kernel: W0 = f16(w * 2^12) (multiplies x_hi), W1 = f16(w * 2^12 - W0) (x_hi again), W2 = f16(W0 * 2^-12)
+// (multiplies x_lo, which is stored times 2^12).  The table's dst_off counts elements of the *plain* layout; the
+// kernel triples it.
+template <typename T, bool X2 = false>
 __global__ __launch_bounds__(256) void pack_kernel(const ResrPackChunk* __restrict__ chunks,
                                                    const float* __restrict__ arena, T* __restrict__ packed) {
     constexpr int E = 16 / (int)sizeof(T);
     constexpr int KS = 32 / E / 2;
     const ResrPackChunk c = chunks[blockIdx.x];
     const int total = 9 * c.mt * 1024;
-    T* dst = packed + c.dst_off;
+    T* dst = packed + c.dst_off * (X2 ? 3 : 1);
     const float* src = arena + c.src_off;
     const float sc = c.scale * (c.scale_ptr ? *c.scale_ptr : 1.f);
     for (int idx = threadIdx.x; idx < total; idx += 256) {
@@ -45,7 +50,15 @@ __global__ __launch_bounds__(256) void pack_kernel(const ResrPackChunk* __restri
             }
             v *= sc;
         }
-        dst[idx] = (T)v;
+        if constexpr (X2) {
+            const float t = v * kLoScale;
+            const T w0 = (T)t;
+            dst[idx] = w0;
+            dst[total + idx] = (T)(t - (float)w0);
+            dst[2 * total + idx] = (T)((float)w0 * kLoInv);
+        } else {
+            dst[idx] = (T)v;
+        }
     }
 }
 
@@ -56,6 +69,8 @@ int pack_dispatch(const ResrPackChunk* chunks_dev, int n_chunks, const float* ar
         hipLaunchKernelGGL(pack_kernel<half_t>, dim3(n_chunks), dim3(256), 0, stream, chunks_dev, arena, (half_t*)packed);
     else if (dtype == RESR_F32)
         hipLaunchKernelGGL(pack_kernel<float>, dim3(n_chunks), dim3(256), 0, stream, chunks_dev, arena, (float*)packed);
+    else if (dtype == RESR_F16X2)
+        hipLaunchKernelGGL((pack_kernel<half_t, true>), dim3(n_chunks), dim3(256), 0, stream, chunks_dev, arena, (half_t*)packed);
     else
         return fail(RESR_ERR_ARG, "pack_weights: dtype=%d", dtype);
     RESR_CHECK_LAUNCH("pack_kernel");

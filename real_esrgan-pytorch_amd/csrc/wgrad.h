@@ -1,0 +1,15 @@
+// wgrad.h -- host-side description of one convolution of a batched weight-gradient launch (wgrad.hip); shared with
+// the whole-network planners (generator.hip, disc_native.hip).
+#pragma once
+
+namespace resr {
+
+struct WgradConv {
+    const void* x0; int cin, in0_stride, cin_real;     // X: channel prefix [0,cin) of x0
+    const void* g; int cout, cout_pad, g_stride;       // G: channels [0,cout_pad) of g
+    long x_chunk_stride, g_chunk_stride;               // elements between 32-channel chunks of X / G (0 = 32: interleaved)
+    long x_lo_off, g_lo_off;                           // RESR_F16X2: element offsets hi -> lo tensor of X / G (else 0)
+    float* dw; float* db; float scale;
+};
+
+}  // namespace resr

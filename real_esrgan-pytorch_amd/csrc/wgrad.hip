@@ -26,7 +26,12 @@
 // the OIHW fp32 gradient arena.
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "common.h"
+#include "wgrad.h"
 
 namespace resr {
 
@@ -52,13 +57,16 @@ struct WgradArgs {
     int tiles_x, tiles_y, ntiles;
 };
 
+// RESR_F16X2: a product's slabs come in three -- (x_hi, g_hi) at slab_off, (x_hi, g_lo) at slab_b, (x_lo, g_hi) at
+// slab_c, the last two carrying the lo tensors' 2^12 -- and dW = A + (B + C) * 2^-12, db = bias(A) + bias(B) * 2^-12.
 struct ReduceJob {
     float* dw;            // OIHW fp32 gradient of the conv
     float* db;            // bias gradient or nullptr
-    unsigned slab_off;
-    int co_base, ci_base, cout, cin_real;
+    unsigned slab_off, slab_b, slab_c;   // slab_b / slab_c = ~0u outside RESR_F16X2
+    short co_base, ci_base;
+    int cout, cin_real;
     float scale;
-    int want_bias;
+    short want_bias, pad_;
 };
 
 struct ReduceArgs {
@@ -558,6 +566,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     if (e < kSlab) {
         const float* p = a.partial + job.slab_off + e;
         for (int k = g; k < a.splits; k += 4) s += p[(size_t)k * kSlab];
+        if (job.slab_b != ~0u) {   // RESR_F16X2: the two cross products (bias sums: only the g_lo one)
+            float s2 = 0.f;
+            const float* pb = a.partial + job.slab_b + e;
+            for (int k = g; k < a.splits; k += 4) s2 += pb[(size_t)k * kSlab];
+            if (e < 9 * 1024) {
+                const float* pc = a.partial + job.slab_c + e;
+                for (int k = g; k < a.splits; k += 4) s2 += pc[(size_t)k * kSlab];
+            }
+            s = __builtin_fmaf(s2, kLoInv, s);
+        }
     }
     red[g][threadIdx.x & 63] = s;
     __syncthreads();
@@ -575,7 +593,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-int wgrad_tile_rows(int dtype) { return dtype == RESR_F16 ? 8 : 4; }
+int wgrad_tile_rows(int dtype) { return dtype != RESR_F32 ? 8 : 4; }
 
 template <typename T, int RPW>
 static int launch_wgrad(WgradArgs& a, int njobs, hipStream_t stream) {
@@ -612,12 +630,66 @@ static int launch_wgrad(WgradArgs& a, int njobs, hipStream_t stream) {
 
 // Group the (X chunk, G tile) pairs of a launch into 2x2 quads: greedily take the pair of X chunks and pair of G tiles
 // that covers the most still-unassigned products (ties: fewer staged operands).  A dense block's 26 products become 6 full
-// quads + one diagonal (2 products); a single 64->64 conv is one quad.
+// quads + one diagonal (2 products); a single 64->64 conv is one quad.  The search only depends on which (X, G) index
+// pairs are wanted, so its result is cached per pattern (a RESR_F16X2 dense block has 78 products over 12 x 12 operands:
+// ~10^5 candidate evaluations, once).
+struct QuadIdx { short xa, xb, ga, gb; short prod[4]; };   // operand indices; job index per slot or -1
+
+static const std::vector<QuadIdx>* plan_quads(const int* jx, const int* jg, int nj, int nx, int ng) {
+    static std::mutex mu;
+    static std::map<std::vector<short>, std::vector<QuadIdx>> cache;
+    std::vector<short> key;
+    key.reserve(2 * nj + 2);
+    key.push_back((short)nx); key.push_back((short)ng);
+    for (int i = 0; i < nj; ++i) { key.push_back((short)jx[i]); key.push_back((short)jg[i]); }
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second.empty() ? nullptr : &it->second;
+    std::vector<QuadIdx>& out = cache[key];
+    std::vector<short> need((size_t)nx * ng, 0);   // job index + 1, 0 = not wanted / already assigned
+    auto N = [&](int x, int g) -> short& { return need[(size_t)x * ng + g]; };
+    for (int i = 0; i < nj; ++i) {
+        if (N(jx[i], jg[i])) return nullptr;                 // the same product twice: keep the pair kernel (cached as empty)
+        N(jx[i], jg[i]) = (short)(i + 1);
+    }
+    int left = nj;
+    while (left > 0) {
+        int best = -1, bxa = 0, bxb = 0, bga = 0, bgb = 0;
+        for (int xa = 0; xa < nx; ++xa)
+            for (int xb = xa; xb < nx; ++xb)
+                for (int ga = 0; ga < ng; ++ga)
+                    for (int gb = ga; gb < ng; ++gb) {
+                        int cnt = (N(xa, ga) != 0);
+                        if (xb != xa) cnt += (N(xb, ga) != 0);
+                        if (gb != ga) cnt += (N(xa, gb) != 0);
+                        if (xb != xa && gb != ga) cnt += (N(xb, gb) != 0);
+                        if (!cnt) continue;
+                        const int score = cnt * 8 - (xb != xa) - (gb != ga);
+                        if (score > best) { best = score; bxa = xa; bxb = xb; bga = ga; bgb = gb; }
+                    }
+        if (best < 0 || (int)out.size() >= kMaxQuads) { out.clear(); return nullptr; }
+        QuadIdx q;
+        q.xa = (short)bxa; q.xb = (short)bxb; q.ga = (short)bga; q.gb = (short)bgb;
+        const int qx[2] = {bxa, bxb}, qg[2] = {bga, bgb};
+        for (int p = 0; p < 4; ++p) {
+            const int xi = p & 1, gi = p >> 1;
+            q.prod[p] = -1;
+            if ((xi && bxb == bxa) || (gi && bgb == bga)) continue;
+            short& n = N(qx[xi], qg[gi]);
+            if (!n) continue;
+            q.prod[p] = (short)(n - 1);
+            n = 0;
+            --left;
+        }
+        out.push_back(q);
+    }
+    return &out;
+}
+
 static int build_quads(const WgradArgs& a, int nj, WgradQuadArgs& q) {
     const char* xs[kMaxJobs]; const char* gs[kMaxJobs];
     unsigned xstr[kMaxJobs], gstr[kMaxJobs];
     int nx = 0, ng = 0;
-    static thread_local short need[kMaxJobs][kMaxJobs];   // pair index + 1, 0 = not wanted / already assigned
     int jx[kMaxJobs], jg[kMaxJobs];
     for (int i = 0; i < nj; ++i) {
         int xi = 0, gi = 0;
@@ -627,46 +699,22 @@ static int build_quads(const WgradArgs& a, int nj, WgradQuadArgs& q) {
         if (gi == ng) { gs[ng] = a.jobs[i].g; gstr[ng] = a.jobs[i].gstride_b; ++ng; }
         jx[i] = xi; jg[i] = gi;
     }
-    for (int x = 0; x < nx; ++x)
-        for (int g = 0; g < ng; ++g) need[x][g] = 0;
-    for (int i = 0; i < nj; ++i) {
-        if (need[jx[i]][jg[i]]) return -1;                 // the same product twice: keep the pair kernel
-        need[jx[i]][jg[i]] = (short)(i + 1);
-    }
-    int nq = 0, left = nj;
-    while (left > 0) {
-        int best = -1, bxa = 0, bxb = 0, bga = 0, bgb = 0;
-        for (int xa = 0; xa < nx; ++xa)
-            for (int xb = xa; xb < nx; ++xb)
-                for (int ga = 0; ga < ng; ++ga)
-                    for (int gb = ga; gb < ng; ++gb) {
-                        int cnt = (need[xa][ga] != 0);
-                        if (xb != xa) cnt += (need[xb][ga] != 0);
-                        if (gb != ga) cnt += (need[xa][gb] != 0);
-                        if (xb != xa && gb != ga) cnt += (need[xb][gb] != 0);
-                        if (!cnt) continue;
-                        const int score = cnt * 8 - (xb != xa) - (gb != ga);
-                        if (score > best) { best = score; bxa = xa; bxb = xb; bga = ga; bgb = gb; }
-                    }
-        if (best < 0 || nq >= kMaxQuads) return -1;
+    const std::vector<QuadIdx>* plan = plan_quads(jx, jg, nj, nx, ng);
+    if (!plan) return -1;
+    int nq = 0;
+    for (const QuadIdx& qi : *plan) {
         WgradQuad& w = q.jobs[nq++];
         memset(&w, 0, sizeof(w));
-        w.x[0] = xs[bxa]; w.xstride_b[0] = xstr[bxa];
-        if (bxb != bxa) { w.x[1] = xs[bxb]; w.xstride_b[1] = xstr[bxb]; }
-        w.g[0] = gs[bga]; w.gstride_b[0] = gstr[bga];
-        if (bgb != bga) { w.g[1] = gs[bgb]; w.gstride_b[1] = gstr[bgb]; }
-        const int qx[2] = {bxa, bxb}, qg[2] = {bga, bgb};
+        w.x[0] = xs[qi.xa]; w.xstride_b[0] = xstr[qi.xa];
+        if (qi.xb != qi.xa) { w.x[1] = xs[qi.xb]; w.xstride_b[1] = xstr[qi.xb]; }
+        w.g[0] = gs[qi.ga]; w.gstride_b[0] = gstr[qi.ga];
+        if (qi.gb != qi.ga) { w.g[1] = gs[qi.gb]; w.gstride_b[1] = gstr[qi.gb]; }
         for (int p = 0; p < 4; ++p) {
-            const int xi = p & 1, gi = p >> 1;
             w.slab_off[p] = ~0u;
-            if ((xi && bxb == bxa) || (gi && bgb == bga)) continue;
-            short& n = need[qx[xi]][qg[gi]];
-            if (!n) continue;
-            const WgradJob& j = a.jobs[n - 1];
+            if (qi.prod[p] < 0) continue;
+            const WgradJob& j = a.jobs[qi.prod[p]];
             w.slab_off[p] = j.slab_off;
             if (j.want_bias) w.bias_mask |= 1u << p;
-            n = 0;
-            --left;
         }
     }
     return nq;
@@ -732,19 +780,12 @@ int wgrad_debug_plan(const int* cin, const int* cout_pad, int nconv, int* out, i
     return nq;
 }
 
-// One batched launch pair.  `convs` describes up to a dense block's worth of convolutions that share
-// n/h/w/flags; jobs are generated as (conv, ci chunk, co tile).
-struct WgradConv {
-    const void* x0; int cin, in0_stride, cin_real;     // X: channel prefix [0,cin) of x0
-    const void* g; int cout, cout_pad, g_stride;       // G: channels [0,cout_pad) of g
-    long x_chunk_stride, g_chunk_stride;               // elements between 32-channel chunks of X / G (0 = 32: interleaved)
-    float* dw; float* db; float scale;
-};
-
-size_t wgrad_batch_partial_bytes(const WgradConv* convs, int nconv, int splits) {
+// One batched launch pair.  `convs` (wgrad.h) describes up to a dense block's worth of convolutions that share
+// n/h/w/flags; jobs are generated as (conv, ci chunk, co tile) -- three per product with RESR_F16X2.
+size_t wgrad_batch_partial_bytes(const WgradConv* convs, int nconv, int splits, int dtype) {
     size_t jobs = 0;
     for (int i = 0; i < nconv; ++i) jobs += (size_t)(convs[i].cin / 32) * (convs[i].cout_pad / 32);
-    return jobs * splits * kSlab * sizeof(float);
+    return jobs * (dtype == RESR_F16X2 ? 3 : 1) * splits * kSlab * sizeof(float);
 }
 
 int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtype, int flags, int splits,
@@ -758,29 +799,39 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
     ReduceArgs r;
     memset(&a, 0, sizeof(a));
     memset(&r, 0, sizeof(r));
-    int nj = 0;
+    int nj = 0, nr = 0;
     unsigned off = 0;
+    const bool x2 = dtype == RESR_F16X2;
     for (int i = 0; i < nconv; ++i) {
         const WgradConv& c = convs[i];
         if (!c.x0 || !c.g || !c.dw) return fail(RESR_ERR_ARG, "wgrad: null tensor");
+        if (x2 && (c.x_lo_off <= 0 || c.g_lo_off <= 0)) return fail(RESR_ERR_ARG, "wgrad: RESR_F16X2 needs the hi -> lo offsets of X and G");
         if (c.cin <= 0 || (c.cin & 31) || (c.cout_pad != 32 && c.cout_pad != 64) || c.cout <= 0 || c.cout > c.cout_pad ||
             c.cin_real <= 0 || c.cin_real > c.cin)
             return fail(RESR_ERR_ARG, "wgrad: cin=%d cin_real=%d cout=%d cout_pad=%d", c.cin, c.cin_real, c.cout, c.cout_pad);
         for (int ct = 0; ct < c.cout_pad / 32; ++ct)
             for (int ck = 0; ck < c.cin / 32; ++ck) {
-                if (nj >= kMaxJobs) return fail(RESR_ERR_ARG, "wgrad: more than %d jobs in one batch", kMaxJobs);
-                WgradJob& j = a.jobs[nj];
-                j.x = (const char*)c.x0 + (size_t)ck * (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * es;
-                j.g = (const char*)c.g + (size_t)ct * (c.g_chunk_stride > 0 ? c.g_chunk_stride : 32) * es;
-                j.xstride_b = (unsigned)(c.in0_stride * es);
-                j.gstride_b = (unsigned)(c.g_stride * es);
-                j.slab_off = off;
-                j.want_bias = (ck == 0 && c.db) ? 1 : 0;
-                ReduceJob& q = r.jobs[nj];
-                q.dw = c.dw; q.db = c.db; q.slab_off = off; q.co_base = ct * 32; q.ci_base = ck * 32;
-                q.cout = c.cout; q.cin_real = c.cin_real; q.scale = c.scale; q.want_bias = j.want_bias;
-                off += (unsigned)(splits * kSlab);
-                ++nj;
+                if (nj + (x2 ? 3 : 1) > kMaxJobs) return fail(RESR_ERR_ARG, "wgrad: more than %d jobs in one batch", kMaxJobs);
+                const char* xh = (const char*)c.x0 + (size_t)ck * (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * es;
+                const char* gh = (const char*)c.g + (size_t)ct * (c.g_chunk_stride > 0 ? c.g_chunk_stride : 32) * es;
+                const int want_bias = (ck == 0 && c.db) ? 1 : 0;
+                ReduceJob& q = r.jobs[nr++];
+                q.dw = c.dw; q.db = c.db; q.slab_off = off; q.slab_b = q.slab_c = ~0u;
+                q.co_base = (short)(ct * 32); q.ci_base = (short)(ck * 32);
+                q.cout = c.cout; q.cin_real = c.cin_real; q.scale = c.scale; q.want_bias = (short)want_bias; q.pad_ = 0;
+                // parts: (x_hi, g_hi); RESR_F16X2 adds (x_hi, g_lo) and (x_lo, g_hi)
+                for (int part = 0; part < (x2 ? 3 : 1); ++part) {
+                    WgradJob& j = a.jobs[nj++];
+                    j.x = xh + (part == 2 ? (size_t)c.x_lo_off * es : 0);
+                    j.g = gh + (part == 1 ? (size_t)c.g_lo_off * es : 0);
+                    j.xstride_b = (unsigned)(c.in0_stride * es);
+                    j.gstride_b = (unsigned)(c.g_stride * es);
+                    j.slab_off = off;
+                    j.want_bias = part < 2 ? want_bias : 0;
+                    if (part == 1) q.slab_b = off;
+                    if (part == 2) q.slab_c = off;
+                    off += (unsigned)(splits * kSlab);
+                }
             }
     }
     a.partial = partial; r.partial = partial; r.splits = splits;
@@ -796,23 +847,23 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
     int rc;
     bool quad_done = false;
     static const char* pair_env = getenv("RESR_WGRAD_PAIR_KERNEL");   // test knob: keep the f16 pair kernel
-    if (dtype == RESR_F16 && a.fast_addr && !pair_env) {
+    if (dtype != RESR_F32 && a.fast_addr && !pair_env) {
         rc = launch_wgrad_quad(a, nj, stream, &quad_done);
         if (rc) return rc;
     }
     if (quad_done) rc = RESR_OK;
-    else if (dtype == RESR_F16) rc = launch_wgrad<half_t, 2>(a, nj, stream);
+    else if (dtype == RESR_F16 || dtype == RESR_F16X2) rc = launch_wgrad<half_t, 2>(a, nj, stream);
     else if (dtype == RESR_F32) rc = launch_wgrad<float, 1>(a, nj, stream);
     else return fail(RESR_ERR_ARG, "wgrad: dtype=%d", dtype);
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nj, (kSlab + 63) / 64), dim3(256), 0, stream, r);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nr, (kSlab + 63) / 64), dim3(256), 0, stream, r);
     RESR_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RESR_OK;
 }
 
 // single-conv C-ABI entry (include/resr.h resr_conv3x3_wgrad)
 size_t wgrad_partial_bytes(const ResrWgradDesc* d) {
-    return (size_t)(d->cin / 32) * (d->cout_pad / 32) * d->splits * kSlab * sizeof(float);
+    return (size_t)(d->cin / 32) * (d->cout_pad / 32) * (d->dtype == RESR_F16X2 ? 3 : 1) * d->splits * kSlab * sizeof(float);
 }
 
 int wgrad_dispatch(const ResrWgradDesc* d, const void* x0, const void* x1, const void* g, float* partial, float* dw,
@@ -823,6 +874,7 @@ int wgrad_dispatch(const ResrWgradDesc* d, const void* x0, const void* x1, const
     c.x0 = x0; c.cin = d->cin; c.in0_stride = d->in0_stride; c.cin_real = d->cin_real;
     c.g = g; c.cout = d->cout; c.cout_pad = d->cout_pad; c.g_stride = d->g_stride;
     c.x_chunk_stride = c.g_chunk_stride = 0;
+    c.x_lo_off = (long)d->x_lo_offset; c.g_lo_off = (long)d->g_lo_offset;
     c.dw = dw; c.db = db; c.scale = d->scale;
     return wgrad_batch(&c, 1, d->n, d->h, d->w, d->dtype, d->flags, d->splits, partial, stream);
 }

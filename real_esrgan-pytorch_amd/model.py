@@ -28,7 +28,10 @@ def _precision_to_dtype(precision: str) -> int:
         return _lib.RESR_F16
     if precision == "strict":
         return _lib.RESR_F32
-    raise ValueError(f"precision must be 'fast' (f16 MFMA, fp32 accumulate) or 'strict' (f32 MFMA), got {precision!r}")
+    if precision == "exact16":
+        return _lib.RESR_F16X2
+    raise ValueError("precision must be 'fast' (f16 MFMA, fp32 accumulate), 'exact16' (split-operand f16 MFMA, "
+                     f"fp32-class results) or 'strict' (f32 MFMA), got {precision!r}")
 
 
 class ResidualDenseBlock(nn.Module):
@@ -110,7 +113,9 @@ class Generator(nn.Module):
     Args mirror the reference: Generator(in_channels, out_channels, upscale_factor) with
     upscale_factor in {1, 2, 4}.  Extra keyword `precision`: "fast" = f16 operands on
     v_mfma_f32_32x32x16_f16 with fp32 accumulation (the reference's CUDA-autocast numerics class),
-    "strict" = f32 operands on v_mfma_f32_32x32x2_f32 (parity gate vs the fp32 CPU oracle).
+    "exact16" = the same matrix pipe with split operands (activations and weights as hi + lo f16 pairs, three
+    MFMAs per product, fp32 accumulate: meets the 1e-3 parity tolerance vs the fp32 CPU path at about a third
+    of fast mode's throughput), "strict" = f32 operands on v_mfma_f32_32x32x2_f32 (bit-for-bit fp32 FMA chains).
     Default from $RESR_PRECISION, else "fast".
     forward(x[N,C,H,W] float in [0,1]) -> [N,out,H*s,W*s] clamped to [0,1]; differentiable.
     """

