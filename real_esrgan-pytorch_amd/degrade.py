@@ -98,16 +98,34 @@ def sample_plan(batch: int, hr_h: int, hr_w: int, crop: int, P: dict = PROC_P, w
     return plan
 
 
+def _noise_stage(out, gaussian: bool, sigma_range, scale_range, gray_prob, inj: Optional[dict]):
+    """train_realesrnet.py:291-304 / 332-345.  `inj` (parity tests): the reference's own device draws for this stage --
+    Gaussian: sigma[B], gray[B], field_gray[h,w] or None, field_color[B,3,h,w] (imgproc.py:933-936, 854, 858); Poisson:
+    scale[B], gray[B] (the Poisson samples themselves come from the device's Philox stream and cannot be injected)."""
+    if inj is None:
+        if gaussian:
+            return imgproc.random_add_gaussian_noise_torch(out, sigma_range, gray_prob, True, False)
+        return imgproc.random_add_poisson_noise_torch(out, scale_range, gray_prob, True, False)
+    if gaussian:
+        return imgproc.add_gaussian_noise_fields(out, inj["sigma"], inj["gray"], inj.get("field_gray"), inj["field_color"], True, False)
+    return imgproc.add_poisson_noise(out, inj["scale"], inj["gray"], inj.get("seed", 1), True, False)
+
+
 def run_plan(hr: torch.Tensor, plan: DegradationPlan, usm: imgproc.USMSharp, jpeg: imgproc.DiffJPEG, upscale: int,
-             crop: int, P: dict = PROC_P, trace: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Execute one plan on the current stream.  `trace` (tests) receives every intermediate."""
+             crop: int, P: dict = PROC_P, trace: Optional[dict] = None, inject: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Execute one plan on the current stream.  `trace` (tests) receives every intermediate.  `inject` (parity tests)
+    replaces device draws -- keys "noise1"/"noise2" (see _noise_stage), "q1"/"q2" (JPEG qualities [B]) -- and can
+    substitute a stage's output before the next stage runs: "replace": {stage name: tensor} (used after a Poisson
+    stage, whose samples cannot be matched draw for draw)."""
     dev = hr.device
     b, _, H, W = hr.shape
+    inject = inject or {}
+    replace = inject.get("replace", {})
 
     def rec(name, t):
         if trace is not None:
             trace[name] = t
-        return t
+        return replace.get(name, t)
 
     def dev_kernel(k):   # numpy from the plan's own sampler, or the tensors of a dataset batch (dataset.py)
         return (k if torch.is_tensor(k) else torch.from_numpy(k)).to(dev, non_blocking=True)
@@ -117,32 +135,26 @@ def run_plan(hr: torch.Tensor, plan: DegradationPlan, usm: imgproc.USMSharp, jpe
     if plan.blur1:
         out = rec("blur1", imgproc.filter2d_torch(out, k1))                                         # :276
     out = rec("resize1", imgproc.interpolate(out, scale_factor=plan.resize1_scale, mode=plan.resize1_mode))   # :288
-    if plan.noise1_gaussian:                                                                        # :291-304
-        out = imgproc.random_add_gaussian_noise_torch(out, P["noise_range1"], P["gray_noise_probability1"], True, False)
-    else:
-        out = imgproc.random_add_poisson_noise_torch(out, P["poisson_scale_range1"], P["gray_noise_probability1"], True, False)
-    rec("noise1", out)
-    q = torch.empty(b, device=dev).uniform_(*P["jpeg_range1"])                                      # :307
+    out = rec("noise1", _noise_stage(out, plan.noise1_gaussian, P["noise_range1"], P["poisson_scale_range1"],  # :291-304
+                                     P["gray_noise_probability1"], inject.get("noise1")))
+    q = inject["q1"].to(dev) if "q1" in inject else torch.empty(b, device=dev).uniform_(*P["jpeg_range1"])   # :307
     out = rec("jpeg1", jpeg(out, q, clamp_input=True))                                                    # :308-309
     if plan.blur2:
         out = rec("blur2", imgproc.filter2d_torch(out, k2))                                         # :314
     size2 = (int(H / upscale * plan.resize2_scale), int(W / upscale * plan.resize2_scale))         # :327-328
     out = rec("resize2", imgproc.interpolate(out, size=size2, mode=plan.resize2_mode))
-    if plan.noise2_gaussian:                                                                        # :332-345
-        out = imgproc.random_add_gaussian_noise_torch(out, P["noise_range2"], P["gray_noise_probability2"], True, False)
-    else:
-        out = imgproc.random_add_poisson_noise_torch(out, P["poisson_scale_range2"], P["gray_noise_probability2"], True, False)
-    rec("noise2", out)
+    out = rec("noise2", _noise_stage(out, plan.noise2_gaussian, P["noise_range2"], P["poisson_scale_range2"],  # :332-345
+                                     P["gray_noise_probability2"], inject.get("noise2")))
     size3 = (H // upscale, W // upscale)
-    q2 = torch.empty(b, device=dev).uniform_(*P["jpeg_range2"])
+    q2 = inject["q2"].to(dev) if "q2" in inject else torch.empty(b, device=dev).uniform_(*P["jpeg_range2"])
     if plan.sinc_before_jpeg:                                                                       # :347-358
-        out = imgproc.interpolate(out, size=size3, mode=plan.resize3_mode)
-        out = imgproc.filter2d_torch(out, ks)
-        out = jpeg(out, q2, clamp_input=True)
+        out = rec("resize3", imgproc.interpolate(out, size=size3, mode=plan.resize3_mode))
+        out = rec("sinc", imgproc.filter2d_torch(out, ks))
+        out = rec("jpeg2", jpeg(out, q2, clamp_input=True))
     else:                                                                                           # :359-371
-        out = jpeg(out, q2, clamp_input=True)
-        out = imgproc.interpolate(out, size=size3, mode=plan.resize3_mode)
-        out = imgproc.filter2d_torch(out, ks)
+        out = rec("jpeg2", jpeg(out, q2, clamp_input=True))
+        out = rec("resize3", imgproc.interpolate(out, size=size3, mode=plan.resize3_mode))
+        out = rec("sinc", imgproc.filter2d_torch(out, ks))
     rec("final", out)
     return imgproc.quantize_crop(out, hr, crop, upscale, plan.hr_top, plan.hr_left)                 # :374-377
 
