@@ -595,8 +595,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 int wgrad_tile_rows(int dtype) { return dtype != RESR_F32 ? 8 : 4; }
 
+// `nprod`: algorithmic products of the launch (= njobs, or njobs / 3 with RESR_F16X2) for the profiling record
 template <typename T, int RPW>
-static int launch_wgrad(WgradArgs& a, int njobs, hipStream_t stream) {
+static int launch_wgrad(WgradArgs& a, int njobs, int nprod, hipStream_t stream) {
     constexpr int PB = 32 * (int)sizeof(T);
     constexpr int TH = 4 * RPW;
     constexpr int SPP_ = PB / 16;
@@ -622,7 +623,7 @@ static int launch_wgrad(WgradArgs& a, int njobs, hipStream_t stream) {
     hipLaunchKernelGGL((wgrad_kernel<T, RPW>), dim3(njobs * splits8), dim3(256), lds, stream, a);
     // algorithmic bytes: each job's X chunk and G tile once (jobs that share a tile re-read it from L2, not counted twice
     // would need the conv list; this is the upper, per-job figure)
-    prof_after(stream, 50000 + (sizeof(T) == 2 ? 0 : 100) + RPW, 2.0 * 9 * 32 * 32 * njobs * (double)a.n * a.h * a.w_,
+    prof_after(stream, 50000 + (sizeof(T) == 2 ? 0 : 100) + RPW + (nprod != njobs ? 300 : 0), 2.0 * 9 * 32 * 32 * nprod * (double)a.n * a.h * a.w_,
                (double)njobs * 2 * 32 * sizeof(T) * (double)a.n * a.h * a.w_);
     RESR_CHECK_LAUNCH("wgrad_kernel");
     return RESR_OK;
@@ -720,7 +721,7 @@ static int build_quads(const WgradArgs& a, int nj, WgradQuadArgs& q) {
     return nq;
 }
 
-static int launch_wgrad_quad(const WgradArgs& a, int nj, hipStream_t stream, bool* done) {
+static int launch_wgrad_quad(const WgradArgs& a, int nj, int nprod, hipStream_t stream, bool* done) {
     static thread_local WgradQuadArgs q;
     *done = false;
     const int nq = build_quads(a, nj, q);
@@ -747,7 +748,7 @@ static int launch_wgrad_quad(const WgradArgs& a, int nj, hipStream_t stream, boo
     prof_before(stream);
     hipLaunchKernelGGL(wgrad_quad_kernel, dim3(nq * splits8), dim3(512), lds, stream, q);
     // algorithmic bytes: every quad's X chunks and G tiles once (quads that share an operand find it in their XCD's L2)
-    prof_after(stream, 50200, 2.0 * 9 * 32 * 32 * nj * (double)a.n * a.h * a.w_, staged * 64.0 * (double)a.n * a.h * a.w_);
+    prof_after(stream, nprod != nj ? 50500 : 50200, 2.0 * 9 * 32 * 32 * nprod * (double)a.n * a.h * a.w_, staged * 64.0 * (double)a.n * a.h * a.w_);
     RESR_CHECK_LAUNCH("wgrad_quad_kernel");
     *done = true;
     return RESR_OK;
@@ -848,12 +849,12 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
     bool quad_done = false;
     static const char* pair_env = getenv("RESR_WGRAD_PAIR_KERNEL");   // test knob: keep the f16 pair kernel
     if (dtype != RESR_F32 && a.fast_addr && !pair_env) {
-        rc = launch_wgrad_quad(a, nj, stream, &quad_done);
+        rc = launch_wgrad_quad(a, nj, nr, stream, &quad_done);
         if (rc) return rc;
     }
     if (quad_done) rc = RESR_OK;
-    else if (dtype == RESR_F16 || dtype == RESR_F16X2) rc = launch_wgrad<half_t, 2>(a, nj, stream);
-    else if (dtype == RESR_F32) rc = launch_wgrad<float, 1>(a, nj, stream);
+    else if (dtype == RESR_F16 || dtype == RESR_F16X2) rc = launch_wgrad<half_t, 2>(a, nj, nr, stream);
+    else if (dtype == RESR_F32) rc = launch_wgrad<float, 1>(a, nj, nr, stream);
     else return fail(RESR_ERR_ARG, "wgrad: dtype=%d", dtype);
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nr, (kSlab + 63) / 64), dim3(256), 0, stream, r);

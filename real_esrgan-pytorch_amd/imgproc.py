@@ -13,6 +13,7 @@ from typing import Any, Sequence, Tuple
 
 import numpy as np
 import torch
+import torch.distributed as _dist
 from torch import nn
 
 from . import _lib
@@ -27,8 +28,11 @@ _seed_counter = [0x5EED]
 
 
 def _next_seed() -> int:
+    """Philox seed of the next device-side noise draw: torch's seed, the data-parallel rank (replicas share
+    torch.manual_seed, config.py:64-66, but must not draw the same noise fields) and a per-process counter."""
     _seed_counter[0] += 1
-    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0]) & 0xFFFFFFFFFFFFFFFF
+    rank = _dist.get_rank() if _dist.is_available() and _dist.is_initialized() else 0
+    return ((torch.initial_seed() + 0x632BE59BD9B4E019 * rank) * 0x9E3779B97F4A7C15 + _seed_counter[0]) & 0xFFFFFFFFFFFFFFFF
 
 
 def _img(x: torch.Tensor, what: str) -> torch.Tensor:
