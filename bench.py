@@ -33,16 +33,27 @@ PEAK_F32_TFLOPS = 157.3
 
 
 def parse():
+    args = _parser().parse_args()
+    if args.lr_size is None:
+        args.lr_size = 64 if args.gan else 256
+    return args
+
+
+def _parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (the reference trains 16 per GPU; 8..32 measured within 5 %% of each other)")
-    ap.add_argument("--lr-size", type=int, default=256, help="LR tile edge; HR = 4x (headline: 256 -> 1024)")
+    ap.add_argument("--lr-size", type=int, default=None, help="LR tile edge; HR = 4x (default: 256 -> 1024, the headline; 64 -> 256 with --gan)")
     ap.add_argument("--precision", default="fast", choices=["fast", "exact16", "strict"])
     ap.add_argument("--no-degradation", action="store_true", help="debug only: feed pre-degraded LR tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the exact16 sub-run (parity_mode record)")
+    ap.add_argument("--gan", action="store_true",
+                    help="BASELINE config 4 instead of the headline: the RealESRGAN step (generator update with the discriminator "
+                         "frozen, USM on sr, VGG19 term, then two discriminator backwards; train_realesrgan.py:459-521), "
+                         "16 images per GPU, HR 400^2 tiles cropped to 256^2 (LR 64^2) unless --lr-size says otherwise")
     ap.add_argument("--noise-data", action="store_true",
                     help="uniform-noise HR tiles (SURVEY 8d's literal torch.rand tiles) instead of the image-like default: on those the "
                          "first Adam step saturates the output clamp, the backward pass carries zero gradients and the matrix kernels "
@@ -50,7 +61,7 @@ def parse():
     ap.add_argument("--per-tensor-adam", action="store_true", help="optimizer over the 702 per-tensor Parameters instead of the flat arena")
     ap.add_argument("--no-probe", action="store_true", help="skip the in-situ roofline step")
     ap.add_argument("--isolated-probe", action="store_true", help="also time every conv shape back-to-back in isolation")
-    return ap.parse_args()
+    return ap
 
 
 def ensure_built():
@@ -435,6 +446,107 @@ def run_mode(args, precision, steps, warmup, world, rank, probe=True):
     return res
 
 
+D_MAC_PER_HR_PX = 395_520          # discriminator forward MACs per input pixel (SURVEY.md §8 geometry)
+
+
+def run_gan(args, world, rank):
+    """BASELINE config 4, this rank's share: one RealESRGAN optimisation step per `step` on synthetic HR tiles resident in
+    HBM.  Data parallel: generator gradients from its backward hook, discriminator gradients once after the second backward."""
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd.degrade import Degrader
+    from real_esrgan_pytorch_amd.train import DataParallel, RealESRGANStep
+
+    torch.manual_seed(0)
+    g = R.Generator(3, 3, 4, precision=args.precision).cuda().train()
+    d = R.Discriminator(precision="fast" if args.precision != "strict" else "strict").cuda().train()
+    torch.cuda.manual_seed(1234 + rank)
+    dp = DataParallel()
+    dp.attach(g)
+    dp.attach_discriminator(d)
+    ema = R.EMA(g, 0.999)
+    ema.register()
+    g_opt = torch.optim.Adam(g.parameters() if args.per_tensor_adam else [g.flat_parameter()], 1e-4, (0.9, 0.99), fused=True)   # config.py:141-142
+    d_opt = torch.optim.Adam(d.parameters(), 1e-4, (0.9, 0.99), fused=True)
+    content = R.ContentLoss(["features.2", "features.7", "features.16", "features.25", "features.34"], [0.485, 0.456, 0.406],
+                            [0.229, 0.224, 0.225], precision="fast" if args.precision != "strict" else "strict").cuda()
+    B = args.batch
+    crop = args.lr_size * 4
+    tile = 400 if crop == 256 else crop              # reference tiles are 400^2, cropped to config.image_size (scripts/run.py:17)
+    hr = make_hr_tiles(args, B, tile if tile % 16 == 0 else crop, rank)
+    if hr.shape[-1] != tile:
+        hr = torch.nn.functional.interpolate(hr, size=(tile, tile), mode="bilinear").clamp(0, 1)
+        hr = torch.round(hr * 255.0) / 255.0
+    degrade = Degrader(batch=B, hr_size=tile, upscale=4, crop=crop, seed=rank)
+    scaler = torch.amp.GradScaler("cuda") if args.precision != "strict" else None
+    step = RealESRGANStep(g, d, ema, g_opt, d_opt, scaler, degrade, content_criterion=content, dp=dp)
+    for _ in range(args.warmup):
+        out = step(hr)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(hr)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    res = {"dt": dt, "losses": {k: round(float(v), 6) for k, v in out.items()}, "tile": tile, "crop": crop}
+    if not args.no_probe:
+        err = None
+        try:
+            if rank == 0:
+                res["roofline"] = roofline_in_situ(lambda: step(hr), args.precision, B)
+            else:
+                step(hr)
+                torch.cuda.synchronize()
+        except Exception as e:  # pragma: no cover
+            err = repr(e)
+        if world > 1:
+            ok = torch.tensor([0 if err is None else 1], device="cuda")
+            dist.all_reduce(ok)
+            if int(ok.item()):
+                dist.destroy_process_group()
+                raise SystemExit(f"roofline probe step failed on a rank: {err}")
+        elif err is not None:
+            res["roofline"] = {"error": err}
+    return res
+
+
+def gan_main(args, world, rank):
+    res = run_gan(args, world, rank)
+    if rank != 0:
+        return
+    B, crop = args.batch, res["crop"]
+    value = B * world * args.steps / res["dt"]
+    lr_edge = crop // 4
+    # algorithmic FLOP per image: generator train step 3 x forward; discriminator 3 fwd + 3 dgrad + 2 wgrad = 8 forward-equivalents
+    flop_g = 3 * 2 * MAC_PER_LR_PX * lr_edge * lr_edge
+    flop_d = 16 * D_MAC_PER_HR_PX * crop * crop
+    out = {
+        "metric": "x4 SR GAN train images/sec (RealESRGAN step, BASELINE config 4)", "value": round(value, 3), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(res["dt"] / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"fast": "f16", "exact16": "f16x2 generator / f16 discriminator", "strict": "f32"}[args.precision], "data": "synthetic",
+        "data_detail": "uniform-noise HR tiles" if args.noise_data else "image-like HR tiles (bicubic-upsampled noise + 10 % grain, quantised to k/255)",
+        "config": {"workload": f"RealESRGAN x4 GAN train step (G update with D frozen + USM(sr) + VGG19 term, then D(hr) / D(sr) backwards), "
+                               f"RRDBNet 23 blocks + SN U-Net discriminator, HR tiles {res['tile']}^2 cropped to {crop}^2 (LR {lr_edge}^2), "
+                               f"batch {B}/GPU, degradation=hip, 2 x Adam + EMA, shared GradScaler",
+                   "global_batch": B * world, "parallelism": f"dp{world}"},
+        "algorithmic_tflops_per_gpu": round(value / world * (flop_g + flop_d) / 1e12, 2),
+        "losses": res["losses"],
+    }
+    if "roofline" in res:
+        out["roofline"] = res["roofline"]
+    print(json.dumps(out), flush=True)
+
+
 def parity_probe(sd, edge=24):
     """Max-abs distance of every precision mode's forward to the strict (f32 MFMA) one on a seeded edge x edge probe with the
     timed model's weights; nothing from oracle/ is involved here (the CPU oracle's view of the same probe is added by the
@@ -478,6 +590,11 @@ def main():
     if world > 1:
         dist.barrier()
 
+    if args.gan:
+        gan_main(args, world, rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     B, lr_edge = args.batch, args.lr_size
     hr_edge = lr_edge * 4
     main_res = run_mode(args, args.precision, args.steps, args.warmup, world, rank)

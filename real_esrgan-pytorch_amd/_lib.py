@@ -136,9 +136,12 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
+def stream_ptr(ref=None):
+    """The HIP stream a call should be enqueued on: the current stream of the device that owns `ref` (a tensor), else of
+    the current device.  The library switches to the stream's device itself (csrc/api.hip DeviceScope)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dev = ref.device if ref is not None and getattr(ref, "is_cuda", False) else None
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def require_cuda(t, what: str):

@@ -86,7 +86,7 @@ class ContentLoss(nn.Module):
         table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(device)
         es = 2 if self._dtype == L.RESR_F16 else 4
         packed = torch.zeros(off * es + 16384, dtype=torch.uint8, device=device)
-        L.check(L.lib().resr_pack_weights(L.ptr(table), len(chunks), L.ptr(flat), L.ptr(packed), self._dtype, L.stream_ptr()),
+        L.check(L.lib().resr_pack_weights(L.ptr(table), len(chunks), L.ptr(flat), L.ptr(packed), self._dtype, L.stream_ptr(flat)),
                 "resr_pack_weights")
         self._packed = (packed, groups)
 
@@ -104,7 +104,7 @@ class ContentLoss(nn.Module):
         _lib.require_cuda(x, "ContentLoss")
         self._pack(x.device)
         packed, groups = self._packed
-        st = L.stream_ptr()
+        st = L.stream_ptr(x)
         T = torch.float16 if self._dtype == L.RESR_F16 else torch.float32
         es = 2 if self._dtype == L.RESR_F16 else 4
         xn = ((x.float() - self.mean) / self.std).contiguous()              # transforms.Normalize, model.py:317-318

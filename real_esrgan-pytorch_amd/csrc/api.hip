@@ -45,6 +45,24 @@ void prof_after(hipStream_t st, int kernel_id, double flop, double bytes) {
     g_prof_e0 = nullptr;
 }
 
+// Every entry point runs on the device that owns the caller's stream, whatever the calling thread's current device is
+// (the boundary is used from the Python main thread and from autograd worker threads, one process per GPU or not):
+// hipStreamGetDevice names it, the scope switches to it and back.  The null stream means "the current device".
+struct DeviceScope {
+    int prev = -1;
+    explicit DeviceScope(void* stream) {
+        if (!stream) return;
+        hipDevice_t dev = 0;
+        int cur = 0;
+        if (hipStreamGetDevice((hipStream_t)stream, &dev) != hipSuccess || hipGetDevice(&cur) != hipSuccess) return;
+        if ((int)dev != cur && hipSetDevice((int)dev) == hipSuccess) prev = cur;
+    }
+    ~DeviceScope() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define RESR_DEVICE_SCOPE(stream) DeviceScope resr_device_scope_(stream)
+
 void conv_trace_set(void*);
 int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*, const float*, const void*,
                      const void*, const void*, void*, void*, hipStream_t);
@@ -110,6 +128,7 @@ const char* resr_last_error(void) { return err_buf(); }
 
 int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const void* w_packed, const float* bias,
                  const void* res0, const void* res1, const void* mask, void* out, void* aux_out, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return conv3x3_dispatch(d, in0, in1, w_packed, bias, res0, res1, mask, out, aux_out, (hipStream_t)stream);
 }
 
@@ -117,26 +136,31 @@ size_t resr_wgrad_partial_bytes(const ResrWgradDesc* d) { return d ? wgrad_parti
 
 int resr_conv3x3_wgrad(const ResrWgradDesc* d, const void* x0, const void* x1, const void* g, float* partial,
                        float* dw, float* db, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return wgrad_dispatch(d, x0, x1, g, partial, dw, db, (hipStream_t)stream);
 }
 
 int resr_pack_weights(const ResrPackChunk* chunks_dev, int32_t n_chunks, const float* arena, void* packed,
                       int32_t dtype, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return pack_dispatch(chunks_dev, n_chunks, arena, packed, dtype, (hipStream_t)stream);
 }
 
 int resr_nchw_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t unshuffle,
                       int32_t c_pad, int32_t dtype, const uint8_t* mask, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return nchw_to_nhwc_dispatch(src, dst, n, c, h, w, unshuffle, c_pad, dtype, mask, (hipStream_t)stream, -1L);
 }
 
 int resr_nhwc_to_nchw(const void* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t shuffle,
                       int32_t src_stride, int32_t dtype, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return nhwc_to_nchw_dispatch(src, dst, n, c, h, w, shuffle, src_stride, dtype, (hipStream_t)stream, -1L);
 }
 
 int resr_sumpool2x2(const void* src, void* dst, const void* mask, int32_t n, int32_t h_out, int32_t w_out, int32_t c,
                     int32_t dtype, float slope, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return sumpool2x2_dispatch(src, dst, mask, n, h_out, w_out, c, dtype, slope, (hipStream_t)stream, -1L, -1L);
 }
 
@@ -153,46 +177,55 @@ int64_t resr_generator_buffer_offsets(const ResrGeneratorDesc* d, int64_t* out, 
 
 int resr_generator_forward(const ResrGeneratorDesc* d, const float* x_nchw, const float* params, const void* packed,
                            void* workspace, size_t workspace_bytes, float* y_nchw, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return generator_forward(d, x_nchw, params, packed, workspace, workspace_bytes, y_nchw, (hipStream_t)stream);
 }
 
 int resr_generator_backward(const ResrGeneratorDesc* d, const float* gy_nchw, const float* params, const void* packed,
                             void* workspace, size_t workspace_bytes, float* grad_params, float* gx_nchw, void* stream,
                             void* side_stream) {
+    RESR_DEVICE_SCOPE(stream);
     return generator_backward(d, gy_nchw, params, packed, workspace, workspace_bytes, grad_params, gx_nchw,
                               (hipStream_t)stream, (hipStream_t)side_stream);
 }
 
 int resr_ema_update(float* shadow, const float* params, int64_t count, double decay, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return ema_dispatch(shadow, params, (long)count, decay, (hipStream_t)stream);
 }
 
 int resr_filter2d(const float* src, float* dst, const float* kernel, int32_t n, int32_t c, int32_t h, int32_t w, int32_t kh,
                   int32_t kw, int32_t per_sample, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return filter2d_dispatch(src, dst, kernel, n, c, h, w, kh, kw, per_sample, (hipStream_t)stream);
 }
 
 int resr_usm_sharp(const float* src, float* dst, float* tmp3, const float* k1d, int32_t ksize, float weight, float threshold,
                    int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return usm_dispatch(src, dst, tmp3, k1d, ksize, weight, threshold, n, c, h, w, (hipStream_t)stream);
 }
 
 int resr_usm_sharp_bwd(const float* x, const float* saved_tmp3, const float* g, float* gx, float* tmp2, const float* k1d,
                        int32_t ksize, float weight, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return usm_bwd_dispatch(x, saved_tmp3, g, gx, tmp2, k1d, ksize, weight, n, c, h, w, (hipStream_t)stream);
 }
 
 int resr_resize(const float* src, float* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t oh, int32_t ow, int32_t mode,
                 double scale_h, double scale_w, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return resize_dispatch(src, dst, n, c, h, w, oh, ow, mode, scale_h, scale_w, (hipStream_t)stream);
 }
 
 int resr_randn_fill(float* dst, int64_t count, uint64_t seed, uint64_t stream_id, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return randn_dispatch(dst, (long)count, seed, stream_id, (hipStream_t)stream);
 }
 
 int resr_noise_gaussian(const float* src, float* dst, const float* sigma, const float* gray, const float* field_gray,
                         const float* field_color, int32_t n, int32_t c, int32_t h, int32_t w, int32_t clip, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return gauss_noise_dispatch(src, dst, sigma, gray, field_gray, field_color, n, c, h, w, clip, (hipStream_t)stream);
 }
 
@@ -200,51 +233,61 @@ size_t resr_noise_poisson_workspace_bytes(int32_t n) { return (size_t)n * (512 *
 
 int resr_noise_poisson(const float* src, float* dst, const float* scale, const float* gray, uint64_t seed, void* workspace,
                        int32_t n, int32_t c, int32_t h, int32_t w, int32_t clip, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return poisson_noise_dispatch(src, dst, scale, gray, seed, workspace, n, c, h, w, clip, (hipStream_t)stream);
 }
 
 int resr_jpeg(const float* src, float* dst, const float* quality, float* coeffs, int32_t n, int32_t h, int32_t w, int32_t flags,
               void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return jpeg_dispatch(src, dst, quality, coeffs, n, h, w, flags, (hipStream_t)stream);
 }
 
 int resr_quantize_crop(const float* lr, const float* hr, float* lr_out, float* hr_out, int32_t n, int32_t c, int32_t lr_h,
                        int32_t lr_w, int32_t hr_h, int32_t hr_w, int32_t hr_size, int32_t upscale, int32_t hr_top,
                        int32_t hr_left, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return quantize_crop_dispatch(lr, hr, lr_out, hr_out, n, c, lr_h, lr_w, hr_h, hr_w, hr_size, upscale, hr_top, hr_left,
                                   (hipStream_t)stream);
 }
 
 int resr_space_to_depth(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t dtype, int32_t inverse,
                         void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return s2d_dispatch(src, dst, n, h, w, c, dtype, inverse, (hipStream_t)stream);
 }
 
 int resr_bilinear_up2x(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t dtype, int32_t backward,
                        void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return bilinear_up_dispatch(src, dst, n, h, w, c, dtype, backward, (hipStream_t)stream);
 }
 
 int resr_add_mask(const void* a, const void* b, const void* mask, void* out, int64_t count, int32_t dtype, float slope,
                   void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return add_mask_dispatch(a, b, mask, out, (long)count, dtype, slope, (hipStream_t)stream);
 }
 
 int resr_spectral_norm(const float* w, float* u, float* v, int32_t rows, int32_t cols, int32_t training, float eps, float* sigma2,
                        float* tmp, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return spectral_norm_dispatch(w, u, v, rows, cols, training, eps, sigma2, tmp, (hipStream_t)stream);
 }
 
 int resr_spectral_norm_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma2, float* dst,
                            int32_t rows, int32_t cols, int32_t accumulate, float* tmp1, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return spectral_norm_bwd_dispatch(g, w, u, v, sigma2, dst, rows, cols, accumulate, tmp1, (hipStream_t)stream);
 }
 
 int resr_maxpool2x2(const void* src, void* dst, int32_t n, int32_t h_out, int32_t w_out, int32_t c, int32_t dtype, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return maxpool2x2_dispatch(src, dst, n, h_out, w_out, c, dtype, (hipStream_t)stream);
 }
 
 int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     return fold4x4_dispatch(dw3, dw4, cout, c, (hipStream_t)stream);
 }
 
@@ -283,6 +326,7 @@ int resr_debug_conv_trace(void* dev_buf) {
 }
 
 int resr_debug_tr_probe(float* out256, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
     hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out256);
     RESR_CHECK_LAUNCH("tr_probe_kernel");
     return RESR_OK;

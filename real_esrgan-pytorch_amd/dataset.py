@@ -1,5 +1,5 @@
 """Host side of the data path behind the reference's `dataset.py` surface: file reading,
-train-time augmentation, per-sample blur / sinc kernel sampling, validation LR synthesis and the prefetchers.
+train-time augmentation, per-sample blur / sinc kernel sampling, validation LR synthesis and the HBM batch stager.
 
 Same class names, constructor arguments and batch dictionaries as the reference (dataset.py:27-30); images are read
 with PIL instead of cv2 (absent from the image).  All of it is CPU work done in DataLoader workers, exactly as in the
@@ -8,8 +8,6 @@ reference -- the device side of a batch starts in `degrade.Degrader` / `train.Re
 from __future__ import annotations
 
 import os
-import queue
-import threading
 
 import numpy as np
 import torch
@@ -18,8 +16,7 @@ from torch.utils.data import DataLoader, Dataset
 from . import imgproc
 from .degrade import sample_blur_kernels
 
-__all__ = ["TrainValidImageDataset", "TestImageDataset", "PrefetchGenerator", "PrefetchDataLoader", "CPUPrefetcher",
-           "CUDAPrefetcher"]
+__all__ = ["TrainValidImageDataset", "TestImageDataset", "CUDAPrefetcher"]
 
 
 class TrainValidImageDataset(Dataset):
@@ -74,94 +71,49 @@ class TestImageDataset(Dataset):
         return len(self.lr_image_file_names)
 
 
-class PrefetchGenerator(threading.Thread):
-    """Background-thread iterator with a bounded queue (reference dataset.py:200-229)."""
-
-    def __init__(self, generator, num_data_prefetch_queue: int) -> None:
-        super().__init__(daemon=True)
-        self.queue: queue.Queue = queue.Queue(num_data_prefetch_queue)
-        self.generator = generator
-        self.start()
-
-    def run(self) -> None:
-        for item in self.generator:
-            self.queue.put(item)
-        self.queue.put(None)
-
-    def __next__(self):
-        item = self.queue.get()
-        if item is None:
-            raise StopIteration
-        return item
-
-    def __iter__(self):
-        return self
-
-
-class PrefetchDataLoader(DataLoader):
-    """Reference dataset.py:232-246."""
-
-    def __init__(self, num_data_prefetch_queue: int, **kwargs) -> None:
-        self.num_data_prefetch_queue = num_data_prefetch_queue
-        super().__init__(**kwargs)
-
-    def __iter__(self):
-        return PrefetchGenerator(super().__iter__(), self.num_data_prefetch_queue)
-
-
-class CPUPrefetcher:
-    """Reference dataset.py:249-268."""
-
-    def __init__(self, dataloader: DataLoader) -> None:
-        self.original_dataloader = dataloader
-        self.data = iter(dataloader)
-
-    def next(self):
-        try:
-            return next(self.data)
-        except StopIteration:
-            return None
-
-    def reset(self):
-        self.data = iter(self.original_dataloader)
-
-    def __len__(self) -> int:
-        return len(self.original_dataloader)
-
-
 class CUDAPrefetcher:
-    """Reference dataset.py:271-312: the next batch is copied host->device on a side HIP stream while the current one
-    trains; `next()` makes the compute stream wait for that copy.  (The degradation stage occupies the same slot one
-    step later: `degrade.Degrader`.)"""
+    """The reference's batch source for the train / validation loops (`next()` -> batch dict or None, `reset()`, `len()`;
+    reference dataset.py:271-312) as a small HBM staging pipeline: while the step of batch i runs, batch i+1 is uploaded
+    on a side HIP stream from pinned memory; `next()` orders the consumer behind that upload with an event (no stream-wide
+    wait) and tells the caching allocator which stream now uses the tensors.  The device work of a batch (degradation)
+    starts one slot later, in `degrade.Degrader` / the train step.  (The reference's CPU-side prefetch helpers --
+    PrefetchGenerator, PrefetchDataLoader, CPUPrefetcher -- are used by none of its entry points and are not provided.)"""
 
-    def __init__(self, dataloader: DataLoader, device: torch.device):
-        self.batch_data = None
+    def __init__(self, dataloader: DataLoader, device: torch.device) -> None:
         self.original_dataloader = dataloader
-        self.device = device
-        self.data = iter(dataloader)
-        self.stream = torch.cuda.Stream()
-        self.preload()
+        self.device = torch.device(device)
+        self._side = torch.cuda.Stream(device=self.device)
+        self._it = None
+        self._staged = None          # (batch dict on the device, upload-done event) or None at the end of the epoch
+        self.reset()
 
-    def preload(self):
+    def _stage(self) -> None:
         try:
-            self.batch_data = next(self.data)
+            host = next(self._it)
         except StopIteration:
-            self.batch_data = None
-            return None
-        with torch.cuda.stream(self.stream):
-            for k, v in self.batch_data.items():
-                if torch.is_tensor(v):
-                    self.batch_data[k] = v.to(self.device, non_blocking=True)
+            self._staged = None
+            return
+        with torch.cuda.stream(self._side):
+            dev = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in host.items()}
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._staged = (dev, done)
 
     def next(self):
-        torch.cuda.current_stream().wait_stream(self.stream)
-        batch_data = self.batch_data
-        self.preload()
-        return batch_data
+        if self._staged is None:
+            return None
+        batch, done = self._staged
+        consumer = torch.cuda.current_stream(self.device)
+        consumer.wait_event(done)
+        for v in batch.values():
+            if torch.is_tensor(v):
+                v.record_stream(consumer)
+        self._stage()
+        return batch
 
-    def reset(self):
-        self.data = iter(self.original_dataloader)
-        self.preload()
+    def reset(self) -> None:
+        self._it = iter(self.original_dataloader)
+        self._stage()
 
     def __len__(self) -> int:
         return len(self.original_dataloader)

@@ -180,7 +180,7 @@ class Discriminator(nn.Module):
         L, lib = _lib, _lib.lib()
         es = x.element_size()
         cout_pad_total = _r32(cout)
-        st = _lib.stream_ptr()
+        st = _lib.stream_ptr(x)
         nchw = bool(flags & L.CONV_OUT_NCHW_F32)
         for gi, (off, mt) in enumerate(groups):
             g0 = gi * 64
@@ -203,7 +203,7 @@ class Discriminator(nn.Module):
         step = 64 if chunks * 2 <= 80 else 32          # wgrad.hip kMaxJobs products per launch
         th = 8 if self._dtype == L.RESR_F16 else 4
         tiles = ((w + 31) // 32) * ((h + th - 1) // th) * n
-        st = _lib.stream_ptr()
+        st = _lib.stream_ptr(x)
         for g0 in range(0, _r32(cout), step):
             co = max(0, min(step, cout - g0))
             if co == 0:
@@ -233,7 +233,7 @@ class Discriminator(nn.Module):
         n, c, S, S2 = x.shape
         if c != 3 or (S % 8) or (S2 % 8):
             raise RuntimeError("Discriminator: expected [N,3,H,W] with H, W divisible by 8")
-        st = _lib.stream_ptr()
+        st = _lib.stream_ptr(x)
         T, dt = self._T(), self._dtype
         sn_training = self.training
         # spectral norm: power iteration (training mode), sigma per layer on the device
@@ -305,7 +305,7 @@ class Discriminator(nn.Module):
     # ---- backward ---------------------------------------------------------------------------------------------
     def _run_backward(self, s, gy: torch.Tensor, need_gx: bool, need_w: bool):
         L, lib = _lib, _lib.lib()
-        st = _lib.stream_ptr()
+        st = _lib.stream_ptr(gy)
         dt = self._dtype
         n, S, S2, packed = s["n"], s["S"], s["S2"], s["packed"]
         H1, W1, H2, W2_, H3, W3 = S // 2, S2 // 2, S // 4, S2 // 4, S // 8, S2 // 8

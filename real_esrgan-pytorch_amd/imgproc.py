@@ -54,7 +54,7 @@ def filter2d_torch(image: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
     kk = kernel.to(device=x.device, dtype=torch.float32).contiguous()
     out = torch.empty_like(x)
     _lib.check(_lib.lib().resr_filter2d(_lib.ptr(x), _lib.ptr(out), _lib.ptr(kk), b, c, h, w, k, k,
-                                        0 if kernel.size(0) == 1 else 1, _lib.stream_ptr()), "resr_filter2d")
+                                        0 if kernel.size(0) == 1 else 1, _lib.stream_ptr(x)), "resr_filter2d")
     return out
 
 
@@ -93,7 +93,7 @@ class _USMFn(torch.autograd.Function):
         out = torch.empty_like(xi)
         tmp = torch.empty(3 * xi.numel(), dtype=torch.float32, device=xi.device)
         _lib.check(_lib.lib().resr_usm_sharp(_lib.ptr(xi), _lib.ptr(out), _lib.ptr(tmp), _lib.ptr(k1d), radius, weight,
-                                             threshold, b, c, h, w, _lib.stream_ptr()), "resr_usm_sharp")
+                                             threshold, b, c, h, w, _lib.stream_ptr(x)), "resr_usm_sharp")
         if x.requires_grad:
             ctx.save_for_backward(xi, tmp, k1d)
             ctx.radius, ctx.weight = radius, weight
@@ -107,7 +107,7 @@ class _USMFn(torch.autograd.Function):
         gx = torch.empty_like(xi)
         tmp2 = torch.empty(2 * xi.numel(), dtype=torch.float32, device=xi.device)
         _lib.check(_lib.lib().resr_usm_sharp_bwd(_lib.ptr(xi), _lib.ptr(tmp), _lib.ptr(gi), _lib.ptr(gx), _lib.ptr(tmp2),
-                                                 _lib.ptr(k1d), ctx.radius, ctx.weight, b, c, h, w, _lib.stream_ptr()),
+                                                 _lib.ptr(k1d), ctx.radius, ctx.weight, b, c, h, w, _lib.stream_ptr(g)),
                    "resr_usm_sharp_bwd")
         return gx, None, None, None, None
 
@@ -127,7 +127,7 @@ def interpolate(image: torch.Tensor, size=None, scale_factor=None, mode: str = "
         oh, ow = int(math.floor(float(h) * sh)), int(math.floor(float(w) * sw))
     out = torch.empty((b, c, oh, ow), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().resr_resize(_lib.ptr(x), _lib.ptr(out), b, c, h, w, oh, ow, _MODES[mode], sh, sw,
-                                      _lib.stream_ptr()), "resr_resize")
+                                      _lib.stream_ptr(x)), "resr_resize")
     return out
 
 
@@ -145,7 +145,7 @@ def add_gaussian_noise_fields(image, sigma, gray, field_gray, field_color, clip=
                                               _lib.ptr(gray.float().contiguous()),
                                               _lib.ptr(field_gray.contiguous()) if field_gray is not None else None,
                                               _lib.ptr(field_color.contiguous()), b, c, h, w, _finish_mode(clip, rounds),
-                                              _lib.stream_ptr()), "resr_noise_gaussian")
+                                              _lib.stream_ptr(x)), "resr_noise_gaussian")
     return out
 
 
@@ -159,7 +159,7 @@ def random_add_gaussian_noise_torch(image: torch.Tensor, sigma_range: tuple = (0
     sigma = torch.rand(b, device=x.device) * (sigma_range[1] - sigma_range[0]) + sigma_range[0]
     gray = (torch.rand(b, device=x.device) < gray_prob).float()
     fields = torch.empty(h * w + x.numel(), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().resr_randn_fill(_lib.ptr(fields), fields.numel(), _next_seed(), 0, _lib.stream_ptr()), "resr_randn_fill")
+    _lib.check(_lib.lib().resr_randn_fill(_lib.ptr(fields), fields.numel(), _next_seed(), 0, _lib.stream_ptr(fields)), "resr_randn_fill")
     return add_gaussian_noise_fields(x, sigma, gray, fields[:h * w], fields[h * w:], clip, rounds)
 
 
@@ -170,7 +170,7 @@ def add_poisson_noise(image, scale, gray, seed: int, clip=True, rounds=False, re
     ws = torch.empty(_lib.lib().resr_noise_poisson_workspace_bytes(b), dtype=torch.uint8, device=x.device)
     _lib.check(_lib.lib().resr_noise_poisson(_lib.ptr(x), _lib.ptr(out), _lib.ptr(scale.float().contiguous()),
                                              _lib.ptr(gray.float().contiguous()), seed, _lib.ptr(ws), b, c, h, w,
-                                             _finish_mode(clip, rounds), _lib.stream_ptr()), "resr_noise_poisson")
+                                             _finish_mode(clip, rounds), _lib.stream_ptr(x)), "resr_noise_poisson")
     if return_vals:
         return out, ws[b * 2048:].view(torch.float32).view(b, 2)
     return out
@@ -214,7 +214,7 @@ class DiffJPEG(nn.Module):
             mb = ((h + 15) // 16) * ((w + 15) // 16)
             coeffs = torch.empty((b, mb * 6, 64), dtype=torch.float32, device=xi.device)
         _lib.check(_lib.lib().resr_jpeg(_lib.ptr(xi), _lib.ptr(out), _lib.ptr(q), _lib.ptr(coeffs), b, h, w,
-                                        1 if clamp_input else 0, _lib.stream_ptr()), "resr_jpeg")
+                                        1 if clamp_input else 0, _lib.stream_ptr(xi)), "resr_jpeg")
         if isinstance(quality, torch.Tensor):       # reference quirk: factor[i] = f(quality[i]) written into the caller's tensor
             quality.copy_(torch.where(q < 50, (5000.0 / q) / 100.0, (200.0 - q * 2) / 100.0))
         return (out, coeffs) if return_coeffs else out
@@ -230,7 +230,7 @@ def quantize_crop(lr_images, hr_images, hr_image_size, upscale_factor, hr_top, h
     phr = torch.empty((b, c, hr_image_size, hr_image_size), dtype=torch.float32, device=lr.device)
     _lib.check(_lib.lib().resr_quantize_crop(_lib.ptr(lr), _lib.ptr(hr), _lib.ptr(plr), _lib.ptr(phr), b, c, lr.shape[2],
                                              lr.shape[3], hr.shape[2], hr.shape[3], hr_image_size, upscale_factor,
-                                             hr_top, hr_left, _lib.stream_ptr()), "resr_quantize_crop")
+                                             hr_top, hr_left, _lib.stream_ptr(lr)), "resr_quantize_crop")
     return plr, phr
 
 

@@ -18,11 +18,12 @@ from .model import Generator
 
 def main(args) -> None:
     from PIL import Image
+    torch.cuda.set_device(config.device)            # one process per GPU: every launch and side stream on this device
     model = Generator(config.in_channels, config.out_channels, config.upscale_factor,
                       precision=getattr(args, "precision", None))
     model = model.to(memory_format=torch.channels_last, device=config.device)        # inference.py:28
     print("Build Real_ESRGAN model successfully.")
-    checkpoint = torch.load(args.weights_path, map_location=lambda storage, loc: storage)
+    checkpoint = torch.load(args.weights_path, map_location=lambda storage, loc: storage, weights_only=False)
     model.load_state_dict({k.replace("model.", ""): v for k, v in checkpoint["state_dict"].items()})   # inference.py:33
     print(f"Load Real_ESRGAN model weights `{args.weights_path}` successfully.")
     model.eval()
@@ -41,5 +42,5 @@ if __name__ == "__main__":
     parser.add_argument("--inputs_path", type=str, help="Low-resolution image path.")
     parser.add_argument("--output_path", type=str, help="Super-resolution image path.")
     parser.add_argument("--weights_path", type=str, help="Model weights file path.")
-    parser.add_argument("--precision", type=str, default=None, choices=["fast", "strict"])
+    parser.add_argument("--precision", type=str, default=None, choices=["fast", "exact16", "strict"])
     main(parser.parse_args())

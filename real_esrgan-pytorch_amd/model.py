@@ -55,8 +55,9 @@ class ResidualDenseBlock(nn.Module):
             m.weight.data *= 0.1
             nn.init.constant_(m.bias, 0)
 
-    def forward(self, x):  # pragma: no cover
-        raise RuntimeError("ResidualDenseBlock is fused into Generator.forward on MI355X; call the Generator")
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """model.py:87-98 on the conv kernel (forward only: training runs through `Generator`)."""
+        return _dense_blocks_forward([self], x, rrdb=False)
 
 
 class ResidualResidualDenseBlock(nn.Module):
@@ -68,16 +69,92 @@ class ResidualResidualDenseBlock(nn.Module):
         self.rdb2 = ResidualDenseBlock(channels, growth_channels)
         self.rdb3 = ResidualDenseBlock(channels, growth_channels)
 
-    def forward(self, x):  # pragma: no cover
-        raise RuntimeError("ResidualResidualDenseBlock is fused into Generator.forward on MI355X; call the Generator")
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """model.py:123-132 on the conv kernel (forward only: training runs through `Generator`)."""
+        return _dense_blocks_forward([self.rdb1, self.rdb2, self.rdb3], x, rrdb=True)
+
+
+def _pack_one(conv: nn.Conv2d, dtype: int) -> torch.Tensor:
+    """Packed forward weights of ONE conv (resr_pack_weights on a one-conv table)."""
+    w = conv.weight.detach().float().contiguous()
+    cout, cin = w.shape[:2]
+    mt, nck = (cout + 31) // 32, (cin + 31) // 32
+    chunks = (_lib.PackChunk * nck)()
+    for ck in range(nck):
+        chunks[ck] = _lib.PackChunk(0, ck * 9 * mt * 1024, cout, cin, 0, cout, ck * 32, min(32, cin - ck * 32), mt, 0, 1.0, 0, None)
+    table = torch.frombuffer(bytearray(bytes(chunks)), dtype=torch.uint8).to(w.device)
+    es = {_lib.RESR_F16: 2, _lib.RESR_F32: 4, _lib.RESR_F16X2: 6}[dtype]
+    packed = torch.zeros(nck * 9 * mt * 1024 * es + 16384, dtype=torch.uint8, device=w.device)
+    _lib.check(_lib.lib().resr_pack_weights(_lib.ptr(table), nck, _lib.ptr(w.reshape(-1)), _lib.ptr(packed), dtype,
+                                            _lib.stream_ptr(w)), "resr_pack_weights")
+    return packed
+
+
+def _dense_blocks_forward(rdbs, x: torch.Tensor, rrdb: bool, precision: Optional[str] = None) -> torch.Tensor:
+    """Standalone forward of one dense block / one RRDB (the reference exports both, model.py:22-27): five (fifteen)
+    `resr_conv3x3` passes over interleaved [N,H,W,192] workspaces -- conv_k reads the channel prefix, writes its own
+    32-channel slice, conv5 carries the `*0.2 + x` epilogue (and the RRDB's second residual).  Forward only."""
+    _lib.require_cuda(x, "ResidualDenseBlock.forward")
+    params = [p for r in rdbs for p in r.parameters()]
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        raise RuntimeError("standalone dense blocks run forward-only on the MI355X path: wrap the call in torch.no_grad() "
+                           "(training differentiates through Generator, where the blocks are fused)")
+    dtype = _precision_to_dtype(precision or os.environ.get("RESR_PRECISION", "fast"))
+    L, lib = _lib, _lib.lib()
+    n, c, h, w = x.shape
+    if c != 64:
+        raise RuntimeError("dense blocks take 64 channels")
+    x2 = dtype == L.RESR_F16X2
+    T = torch.float32 if dtype == L.RESR_F32 else torch.float16
+    pairs, px = (2 if x2 else 1), n * h * w
+    lo = px * 192 if x2 else 0
+    st = L.stream_ptr(x)
+    xc = x.detach().float().contiguous()
+    tmp = torch.empty((pairs, n, h, w, 64), dtype=T, device=x.device)
+    L.check(lib.resr_nchw_to_nhwc(L.ptr(xc), L.ptr(tmp), n, 64, h, w, 1, 64, dtype, None, st), "resr_nchw_to_nhwc")
+    bufs = [torch.zeros((pairs, n, h, w, 192), dtype=T, device=x.device) for _ in range(len(rdbs) + 1)]
+    bufs[0][..., :64] = tmp
+    es = 4 if dtype == L.RESR_F32 else 2
+    for r, rdb in enumerate(rdbs):
+        cur, nxt = bufs[r], bufs[r + 1]
+        for k in range(1, 6):
+            conv = getattr(rdb, f"conv{k}")
+            cin, cout = 64 + 32 * (k - 1), (32 if k < 5 else 64)
+            d = L.ConvDesc(n, h, w, cin, cin, 192, 0, cout, cout, 192, 192, 192, 0, dtype, L.CONV_LRELU if k < 5 else 0,
+                           0.2, 1.0, 0.2, 1.0, 0.2)
+            d.in0_lo_offset = d.out_lo_offset = d.res0_lo_offset = d.res1_lo_offset = lo
+            bias = conv.bias.detach().float().contiguous()
+            if k < 5:
+                out = C.c_void_p(cur.data_ptr() + cin * es)
+                res0 = res1 = None
+            else:
+                out, res0 = L.ptr(nxt), L.ptr(cur)
+                res1 = L.ptr(bufs[0]) if (rrdb and r == len(rdbs) - 1) else None
+            L.check(lib.resr_conv3x3(C.byref(d), L.ptr(cur), None, L.ptr(_pack_one(conv, dtype)), L.ptr(bias), res0, res1, None,
+                                     out, None, st), "resr_conv3x3")
+    y = torch.empty((n, 64, h, w), dtype=torch.float32, device=x.device)
+    L.check(lib.resr_nhwc_to_nchw(L.ptr(bufs[-1]), L.ptr(y), n, 64, h, w, 1, 192, dtype, st), "resr_nhwc_to_nchw")
+    return y
 
 
 class _Workspace:
-    """One activation workspace; `busy` while an autograd graph that saved into it is alive."""
+    """One activation workspace; `busy` while an autograd graph that saved into it is alive.  `owner` counts the
+    training-mode forwards that took it: only the graph that still owns it may release it (a stale token of an earlier
+    graph, collected late, must not free a workspace a newer graph saved its activations in)."""
 
     def __init__(self, nbytes: int, device) -> None:
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.busy = False
+        self.owner = 0
+
+    def acquire(self) -> int:
+        self.owner += 1
+        self.busy = True
+        return self.owner
+
+    def release(self, owner: int) -> None:
+        if owner == self.owner:
+            self.busy = False
 
 
 class _GeneratorFn(torch.autograd.Function):
@@ -86,25 +163,40 @@ class _GeneratorFn(torch.autograd.Function):
         y, desc, ws = module._run_forward(x, training)
         ctx.module, ctx.desc, ctx.ws = module, desc, ws
         ctx.x_needs_grad = x.requires_grad
+        ctx.owner = 0
         if training:
-            ws.busy = True
-            ctx._token = _WsToken(ws)   # frees the workspace when the graph is dropped without backward
+            ctx.owner = ws.acquire()
+            ctx._token = _WsToken(ws, ctx.owner, module)   # frees the workspace when the graph is dropped without backward
         return y
 
     @staticmethod
     def backward(ctx, gy: torch.Tensor):
         module: Generator = ctx.module
-        grads, gx = module._run_backward(ctx.desc, ctx.ws, gy.contiguous().float(), ctx.x_needs_grad)
-        ctx.ws.busy = False
+        # Another live graph of this module (two forwards before either backward: GAN-style losses, or both in one
+        # .backward()) may run its backward before autograd has consumed the views handed out here -- and that backward
+        # overwrites the arena.  Only the last live graph may hand out arena views; the others hand out copies.
+        private = module._live_graphs > 1
+        grads, gx = module._run_backward(ctx.desc, ctx.ws, gy.contiguous().float(), ctx.x_needs_grad, private)
+        ctx._token.finish()
         return (None, None, gx) + tuple(grads)
 
 
 class _WsToken:
-    def __init__(self, ws: _Workspace) -> None:
-        self.ws = ws
+    """Lifetime of one training-mode graph: counts it among the module's live graphs and gives the workspace back
+    when its backward has run or when the graph is dropped without one."""
+
+    def __init__(self, ws: _Workspace, owner: int, module: "Generator") -> None:
+        self.ws, self.owner, self.module, self.open = ws, owner, module, True
+        module._live_graphs += 1
+
+    def finish(self) -> None:
+        if self.open:
+            self.open = False
+            self.module._live_graphs -= 1
+            self.ws.release(self.owner)
 
     def __del__(self) -> None:
-        self.ws.busy = False
+        self.finish()
 
 
 class Generator(nn.Module):
@@ -153,6 +245,7 @@ class Generator(nn.Module):
         self._table_dev: Dict[int, tuple] = {}
         self._workspaces: Dict[tuple, List[_Workspace]] = {}
         self.grad_hook = None   # callable(flat_grad) run after backward wrote the arena (data-parallel all-reduce)
+        self._live_graphs = 0   # training-mode forwards whose backward has not run yet
         self.__dict__["_flat_param"] = None   # see flat_parameter(); kept out of nn.Module's parameter registry
 
     # ---- flat arena ---------------------------------------------------------------------------
@@ -240,7 +333,7 @@ class Generator(nn.Module):
             self._packed = torch.zeros(nbytes, dtype=torch.uint8, device=flat.device)
         raw, n = self._table_dev[key]
         _lib.check(L.resr_pack_weights(_lib.ptr(raw), n, _lib.ptr(flat), _lib.ptr(self._packed), self._dtype,
-                                       _lib.stream_ptr()), "resr_pack_weights")
+                                       _lib.stream_ptr(flat)), "resr_pack_weights")
 
     def _workspace(self, desc: _lib.GeneratorDesc, device) -> _Workspace:
         L = _lib.lib()
@@ -268,11 +361,11 @@ class Generator(nn.Module):
         s = self.upscale_factor
         y = torch.empty((desc.n, self.out_channels, desc.h * s, desc.w * s), dtype=torch.float32, device=xc.device)
         _lib.check(L.resr_generator_forward(C.byref(desc), _lib.ptr(xc), _lib.ptr(flat), _lib.ptr(self._packed),
-                                            _lib.ptr(ws.buf), ws.buf.numel(), _lib.ptr(y), _lib.stream_ptr()),
+                                            _lib.ptr(ws.buf), ws.buf.numel(), _lib.ptr(y), _lib.stream_ptr(xc)),
                    "resr_generator_forward")
         return y, desc, ws
 
-    def _run_backward(self, desc, ws: _Workspace, gy: torch.Tensor, need_gx: bool):
+    def _run_backward(self, desc, ws: _Workspace, gy: torch.Tensor, need_gx: bool, private: bool = False):
         L = _lib.lib()
         flat = self.flat_parameters()
         if self._flat_grad is None or self._flat_grad.device != flat.device:
@@ -280,22 +373,36 @@ class Generator(nn.Module):
         gx = None
         if need_gx:
             gx = torch.empty((desc.n, self.in_channels, desc.h, desc.w), dtype=torch.float32, device=gy.device)
+        # The native backward OVERWRITES the gradient arena.  If gradients of an earlier backward are still held (no
+        # zero_grad in between: gradient accumulation, or two losses through one generator), they may alias the arena
+        # (autograd keeps the views it was handed), so they are parked and put back, and this call's gradients are
+        # handed out as a separate tensor for autograd to add.
+        # (flat_parameter() mode keeps its documented overwrite semantics: the alias is not a module parameter, so
+        # `model.zero_grad()` never clears its .grad, and every backward simply replaces the arena.)
+        fp = self.__dict__["_flat_param"]
+        accumulate = fp is None and any(p.grad is not None for p in self._ordered_params())
+        prev = self._flat_grad.clone() if accumulate else None
         _lib.check(L.resr_generator_backward(C.byref(desc), _lib.ptr(gy), _lib.ptr(flat), _lib.ptr(self._packed),
                                              _lib.ptr(ws.buf), ws.buf.numel(), _lib.ptr(self._flat_grad),
-                                             _lib.ptr(gx), _lib.stream_ptr(), None),
+                                             _lib.ptr(gx), _lib.stream_ptr(gy), None),
                    "resr_generator_backward")
         if self.grad_hook is not None:
             self.grad_hook(self._flat_grad)
-        fp = self.__dict__["_flat_param"]
         if fp is not None:                       # flat_parameter() mode: the arena is the gradient of the alias
             if fp.data_ptr() != flat.data_ptr():
                 fp.data = flat
             fp.grad = self._flat_grad
             return [None] * len(self._ordered_params()), gx
+        src = self._flat_grad
+        if prev is not None:
+            src = self._flat_grad.clone()        # this call's gradients, for autograd to accumulate
+            self._flat_grad.copy_(prev)          # the earlier ones back where .grad may be looking
+        elif private:
+            src = self._flat_grad.clone()        # another live graph will overwrite the arena before autograd reads these
         grads, off = [], 0
         for p in self._ordered_params():
             n = p.numel()
-            grads.append(self._flat_grad[off:off + n].view(p.shape) if p.requires_grad else None)
+            grads.append(src[off:off + n].view(p.shape) if p.requires_grad else None)
             off += n
         return grads, gx
 
@@ -352,14 +459,14 @@ class EMA(nn.Module):
         if self._flat_shadow is not None and self._flat_ok():
             flat = self.model.flat_parameters()
             _lib.check(_lib.lib().resr_ema_update(_lib.ptr(self._flat_shadow), _lib.ptr(flat), flat.numel(),
-                                                  float(self.weight_decay), _lib.stream_ptr()), "resr_ema_update")
+                                                  float(self.weight_decay), _lib.stream_ptr(flat)), "resr_ema_update")
             return
         for name, param in self.model.named_parameters():
             if param.requires_grad:
                 assert name in self.shadow
                 s = self.shadow[name]
                 _lib.check(_lib.lib().resr_ema_update(_lib.ptr(s), _lib.ptr(param.data.contiguous()), s.numel(),
-                                                      float(self.weight_decay), _lib.stream_ptr()), "resr_ema_update")
+                                                      float(self.weight_decay), _lib.stream_ptr(s)), "resr_ema_update")
 
     def apply_shadow(self) -> None:
         for name, param in self.model.named_parameters():

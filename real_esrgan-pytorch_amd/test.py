@@ -25,6 +25,7 @@ def natural_sorted(names: List[str]) -> List[str]:
 
 
 def main() -> float:
+    torch.cuda.set_device(config.device)            # one process per GPU: every launch and side stream on this device
     from PIL import Image
     model = Generator(config.in_channels, config.out_channels, config.upscale_factor,
                       precision=getattr(config, "precision", "fast"))

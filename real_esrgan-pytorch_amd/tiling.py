@@ -29,8 +29,12 @@ class TiledGenerator:
         if not self.use_graph:
             with torch.no_grad():
                 return self.model(xin)
-        if self._graph is None or self._win != tuple(xin.shape):
-            self._win = tuple(xin.shape)
+        # the captured launches bake in the addresses of the parameter arena, the packed weights and the workspace: re-capture
+        # when the model re-flattened its parameters (EMA.apply_shadow/restore, .to(), load into new tensors) -- and keep
+        # references to what the graph reads so the allocator cannot hand those blocks to someone else meanwhile
+        key = (tuple(xin.shape), self.model.flat_parameters().data_ptr())
+        if self._graph is None or self._win != key:
+            self._win = key
             self._static_in = xin.clone()
             with torch.no_grad():
                 for _ in range(2):                      # warm-up: one-time init + workspace allocation outside capture
@@ -40,6 +44,7 @@ class TiledGenerator:
             with torch.cuda.graph(g), torch.no_grad():
                 self._static_out = self.model(self._static_in)
             self._graph = g
+            self._held = (self.model.flat_parameters(), self.model._packed, dict(self.model._workspaces))
         self._static_in.copy_(xin)
         self._graph.replay()
         return self._static_out

@@ -7,13 +7,48 @@ weight-gradient kernels are enqueued, before the optimiser reads the gradients.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+import os
+from typing import Callable, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
 from torch import nn
 
 from .model import EMA, Generator
+
+
+def setup_distributed(backend: Optional[str] = None) -> tuple:
+    """One process per GPU: bind this process to `cuda:LOCAL_RANK` and, when launched with WORLD_SIZE > 1
+    (`python -m torch.distributed.run --nproc-per-node N ...`), join the process group -- backend "nccl" is RCCL over xGMI.
+    Returns (rank, world, device).  Safe to call in a single-process run (world 1, no process group)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
+    torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes
+        backend = backend or os.environ.get("RESR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, device
+
+
+def _arena_of(tensors: List[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The flat fp32 tensor `tensors` are consecutive views of, if they are (same storage, back to back)."""
+    if not tensors or any(t.dtype != torch.float32 or not t.is_contiguous() for t in tensors):
+        return None
+    base = tensors[0]
+    off = base.storage_offset()
+    for t in tensors:
+        if t.untyped_storage().data_ptr() != base.untyped_storage().data_ptr() or t.storage_offset() != off:
+            return None
+        off += t.numel()
+    total = off - base.storage_offset()
+    return torch.as_strided(base, (total,), (1,), base.storage_offset())
 
 
 class DataParallel:
@@ -42,8 +77,39 @@ class DataParallel:
         flat.mul_(1.0 / self.world)
 
     def attach(self, model: Generator) -> None:
+        """Generator: identical initial weights, then one all-reduce of the flat gradient arena per backward (the generator
+        runs exactly one backward per optimiser step in both training scripts: train_realesrnet.py:388, train_realesrgan.py:484)."""
         self.broadcast_(model.flat_parameters())
         model.grad_hook = self.all_reduce_mean_
+
+    def attach_discriminator(self, discriminator: nn.Module) -> None:
+        """Discriminator: identical initial weights AND spectral-norm power-iteration vectors `weight_u` / `weight_v`
+        (they then stay identical, being deterministic functions of identical weights).  Its gradients are the sum of TWO
+        backward passes (train_realesrgan.py:503-516), so they are reduced once, explicitly, by `all_reduce_grads_` after
+        the second one -- not from a per-backward hook."""
+        self.broadcast_(discriminator.flat_parameters())
+        if self.world > 1:
+            for buf in discriminator.buffers():
+                dist.broadcast(buf, src=0)
+
+    def all_reduce_grads_(self, params: Iterable[nn.Parameter]) -> None:
+        """Mean over ranks of the `.grad` of `params`, as ONE bucketed all-reduce: in place when the gradients already
+        sit back to back in one arena (the discriminator's backward hands out views of one), else through a flat copy."""
+        if self.world == 1:
+            return
+        grads = [p.grad for p in params if p.grad is not None]
+        if not grads:
+            return
+        arena = _arena_of(grads)
+        if arena is not None:
+            self.all_reduce_mean_(arena)
+            return
+        flat = torch.cat([g.reshape(-1).float() for g in grads])
+        self.all_reduce_mean_(flat)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
 
 
 class RealESRNetStep:
@@ -86,9 +152,11 @@ class RealESRGANStep:
 
     def __init__(self, generator, discriminator, ema, g_optimizer, d_optimizer, scaler=None, degrade=None,
                  pixel_weight: float = 1.0, adversarial_weight: float = 0.1, content_criterion=None,
-                 content_weight=(0.1, 0.1, 1.0, 1.0, 1.0), return_probabilities: bool = False) -> None:
+                 content_weight=(0.1, 0.1, 1.0, 1.0, 1.0), return_probabilities: bool = False,
+                 dp: Optional[DataParallel] = None) -> None:
         from . import imgproc
         self.g, self.d, self.ema = generator, discriminator, ema
+        self.dp = dp          # data parallel: the generator reduces from its grad hook, the discriminator right before its step
         self.return_probabilities = return_probabilities
         self.g_opt, self.d_opt, self.scaler, self.degrade = g_optimizer, d_optimizer, scaler, degrade
         self.pixel_weight, self.adversarial_weight = pixel_weight, adversarial_weight
@@ -140,6 +208,8 @@ class RealESRGANStep:
         sr_out = self.d(sr.detach().clone())                                               # :507
         d_loss_sr = self.adv(sr_out, fake)
         self._backward(d_loss_sr)                                                          # :513
+        if self.dp is not None:                                                            # one exchange for both backwards
+            self.dp.all_reduce_grads_(self.d.parameters())
         self._step(self.d_opt)                                                             # :515-516
         if self.ema is not None:
             self.ema.update()                                                              # :520

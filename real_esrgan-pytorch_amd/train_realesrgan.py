@@ -27,8 +27,9 @@ from .degrade import run_plan, sample_plan
 from .discriminator import Discriminator
 from .image_quality_assessment import NIQE
 from .model import EMA, Generator
-from .train import RealESRGANStep
-from .train_realesrnet import AverageMeter, ProgressMeter, ScalarWriter, load_dataset, validate  # noqa: F401
+from . import train_realesrnet as _net
+from .train import DataParallel, RealESRGANStep, setup_distributed
+from .train_realesrnet import RunningStats, ScalarWriter, load_dataset, validate  # noqa: F401
 
 
 def build_model() -> List[nn.Module]:
@@ -75,7 +76,14 @@ def _update_state(module: nn.Module, saved: dict) -> None:
     module.load_state_dict(current)
 
 
+_DP: Optional[DataParallel] = None     # set by main(); `train()` hands it to the step
+
+
 def main() -> None:
+    global _DP
+    rank, world, device = setup_distributed()            # one process per GPU: cuda:LOCAL_RANK, RCCL group when WORLD_SIZE > 1
+    _net._RANK, _net._WORLD = rank, world
+    config.device = device
     start_epoch, best_niqe = 0, 100.0
     train_prefetcher, valid_prefetcher, test_prefetcher = load_dataset()
     discriminator, generator, ema_model = build_model()
@@ -100,14 +108,22 @@ def main() -> None:
         g_optimizer.load_state_dict(checkpoint["optimizer"])
         g_scheduler.load_state_dict(checkpoint["scheduler"])
         print("Loaded pretrained generator model weights.")
+    # data parallel (after every way of loading weights): rank 0's generator, discriminator and spectral-norm u / v everywhere;
+    # generator gradients reduced from its backward hook, discriminator gradients once after its second backward
+    _DP = DataParallel()
+    _DP.attach(generator)
+    _DP.attach_discriminator(discriminator)
     samples_dir = os.path.join("samples", config.exp_name)
     results_dir = os.path.join("results", config.exp_name)
     os.makedirs(samples_dir, exist_ok=True)
     os.makedirs(results_dir, exist_ok=True)
-    writer = ScalarWriter(os.path.join("samples", "logs", config.exp_name))
-    scaler = torch.amp.GradScaler("cuda") if getattr(config, "precision", "fast") == "fast" else None
+    writer = ScalarWriter(os.path.join("samples", "logs", config.exp_name), enabled=rank == 0)
+    scaler = torch.amp.GradScaler("cuda") if getattr(config, "precision", "fast") != "strict" else None
     niqe_model = NIQE(config.upscale_factor, config.niqe_model_path).to(device=config.device)
     for epoch in range(start_epoch, config.epochs):
+        sampler = getattr(train_prefetcher.original_dataloader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
         train(discriminator, generator, ema_model, train_prefetcher, pixel_criterion, content_criterion,
               adversarial_criterion, d_optimizer, g_optimizer, epoch, scaler, writer)
         _ = validate(generator, ema_model, valid_prefetcher, epoch, writer, niqe_model, "Valid")
@@ -117,6 +133,8 @@ def main() -> None:
         g_scheduler.step()
         is_best = niqe < best_niqe
         best_niqe = min(niqe, best_niqe)
+        if rank != 0:        # replicas are identical: one writer
+            continue
         d_path = os.path.join(samples_dir, f"d_epoch_{epoch + 1}.pth.tar")
         g_path = os.path.join(samples_dir, f"g_epoch_{epoch + 1}.pth.tar")
         torch.save({"epoch": epoch + 1, "best_niqe": best_niqe, "state_dict": discriminator.state_dict(),
@@ -140,15 +158,8 @@ def train(discriminator: nn.Module, generator: nn.Module, ema_model: nn.Module, 
     jpeg_operation = imgproc.DiffJPEG(False)
     usm_sharpener = imgproc.USMSharp(50, 0).to(device=config.device)
     batches = len(train_prefetcher)
-    batch_time = AverageMeter("Time", ":6.3f")
-    data_time = AverageMeter("Data", ":6.3f")
-    pixel_losses = AverageMeter("Pixel loss", ":6.6f")
-    content_losses = AverageMeter("Content loss", ":6.6f")
-    adversarial_losses = AverageMeter("Adversarial loss", ":6.6f")
-    d_hr_probabilities = AverageMeter("D(HR)", ":6.3f")
-    d_sr_probabilities = AverageMeter("D(SR)", ":6.3f")
-    progress = ProgressMeter(batches, [batch_time, data_time, pixel_losses, content_losses, adversarial_losses,
-                                       d_hr_probabilities, d_sr_probabilities], prefix=f"Epoch: [{epoch + 1}]")
+    names = ["pixel_loss", "content_loss", "adversarial_loss", "d_loss_hr", "d_loss_sr", "d_hr_probability", "d_sr_probability"]
+    stats = RunningStats("time", *names)
     discriminator.train()
     generator.train()
 
@@ -159,31 +170,21 @@ def train(discriminator: nn.Module, generator: nn.Module, ema_model: nn.Module, 
 
     step = RealESRGANStep(generator, discriminator, ema_model, g_optimizer, d_optimizer, scaler, degrade,
                           config.pixel_weight, config.adversarial_weight, content_criterion, config.content_weight,
-                          return_probabilities=True)
+                          return_probabilities=True, dp=_DP)
     step.pixel, step.adv = pixel_criterion, adversarial_criterion
     batch_index = 0
     train_prefetcher.reset()
     batch_data = train_prefetcher.next()
     end = time.time()
     while batch_data is not None:
-        data_time.update(time.time() - end)
         hr = batch_data["hr"].to(device=config.device, non_blocking=True)
         kernels = (batch_data["kernel1"], batch_data["kernel2"], batch_data["sinc_kernel"])
         out = step(hr)
-        # one D2H transfer for everything the meters and the log need (the reference does 5-12 `.item()` syncs)
-        names = ["pixel_loss", "content_loss", "adversarial_loss", "d_loss_hr", "d_loss_sr", "d_hr_probability",
-                 "d_sr_probability"]
-        zero = out["pixel_loss"].new_zeros(())
-        vals = dict(zip(names, torch.stack([out.get(k, zero).float() for k in names]).tolist()))
-        n = hr.size(0)
-        pixel_losses.update(vals["pixel_loss"], n)
-        content_losses.update(vals["content_loss"], n)
-        adversarial_losses.update(vals["adversarial_loss"], n)
-        d_hr_probabilities.update(vals["d_hr_probability"], n)
-        d_sr_probabilities.update(vals["d_sr_probability"], n)
-        batch_time.update(time.time() - end)
-        end = time.time()
         if batch_index % config.print_frequency == 0:
+            # one D2H transfer for everything the console line and the log need (the reference does 5-12 `.item()` syncs per step)
+            zero = out["pixel_loss"].new_zeros(())
+            vals = dict(zip(names, torch.stack([out.get(k, zero).float() for k in names]).tolist()))
+            stats.update(hr.size(0), time=time.time() - end, **vals)
             iters = batch_index + epoch * batches + 1
             writer.add_scalar("Train/D_Loss", vals["d_loss_hr"] + vals["d_loss_sr"], iters)
             writer.add_scalar("Train/G_Loss", vals["pixel_loss"] + vals["content_loss"] + vals["adversarial_loss"], iters)
@@ -192,7 +193,9 @@ def train(discriminator: nn.Module, generator: nn.Module, ema_model: nn.Module, 
             writer.add_scalar("Train/Adversarial_Loss", vals["adversarial_loss"], iters)
             writer.add_scalar("Train/D(HR)_Probability", vals["d_hr_probability"], iters)
             writer.add_scalar("Train/D(SR)_Probability", vals["d_sr_probability"], iters)
-            progress.display(batch_index)
+            if _net._RANK == 0:
+                print(stats.line(f"Epoch [{epoch + 1}] batch {batch_index}/{batches}  "))
+        end = time.time()
         batch_data = train_prefetcher.next()
         batch_index += 1
 

@@ -13,7 +13,6 @@ import json
 import os
 import shutil
 import time
-from enum import Enum
 from typing import Any, List, Optional
 
 import numpy as np
@@ -27,19 +26,48 @@ from .dataset import CUDAPrefetcher, TestImageDataset, TrainValidImageDataset
 from .degrade import run_plan, sample_plan
 from .image_quality_assessment import NIQE
 from .model import EMA, Generator
-from .train import RealESRNetStep
+from .train import DataParallel, RealESRNetStep, setup_distributed
 
 
 class ScalarWriter:
-    """`SummaryWriter.add_scalar` stand-in: one JSON line per scalar."""
+    """`SummaryWriter.add_scalar` stand-in: one JSON line per scalar (rank 0 only under data parallelism)."""
 
-    def __init__(self, log_dir: str) -> None:
-        os.makedirs(log_dir, exist_ok=True)
+    def __init__(self, log_dir: str, enabled: bool = True) -> None:
+        self.enabled = enabled
+        if enabled:
+            os.makedirs(log_dir, exist_ok=True)
         self.path = os.path.join(log_dir, "scalars.jsonl")
 
     def add_scalar(self, tag: str, value: float, step: int) -> None:
+        if not self.enabled:
+            return
         with open(self.path, "a") as f:
             f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+
+
+class RunningStats:
+    """Sample-weighted running means of a few named scalars, for the console line of the loops."""
+
+    def __init__(self, *names: str) -> None:
+        self.names = names
+        self.total = dict.fromkeys(names, 0.0)
+        self.last = dict.fromkeys(names, 0.0)
+        self.count = 0
+
+    def update(self, n: int = 1, **values: float) -> None:
+        self.count += n
+        for k, v in values.items():
+            self.last[k] = v
+            self.total[k] += v * n
+
+    def mean(self, name: str) -> float:
+        return self.total[name] / max(1, self.count)
+
+    def line(self, prefix: str) -> str:
+        return prefix + "  ".join(f"{k} {self.last[k]:.5f} (mean {self.mean(k):.5f})" for k in self.names)
+
+
+_RANK, _WORLD = 0, 1     # set by main() through train.setup_distributed()
 
 
 def load_dataset() -> List[CUDAPrefetcher]:
@@ -50,8 +78,10 @@ def load_dataset() -> List[CUDAPrefetcher]:
                                             config.degradation_model_parameters_dict)
     test_datasets = TestImageDataset(config.test_lr_image_dir, config.test_hr_image_dir)
     workers = config.num_workers
-    train_dataloader = DataLoader(train_datasets, batch_size=config.batch_size, shuffle=True, num_workers=workers,
-                                  pin_memory=True, drop_last=True, persistent_workers=workers > 0)
+    # data parallel: every rank draws its own shard of each epoch (batch_size is per GPU, as in the reference's per-process config)
+    sampler = torch.utils.data.distributed.DistributedSampler(train_datasets, _WORLD, _RANK, shuffle=True) if _WORLD > 1 else None
+    train_dataloader = DataLoader(train_datasets, batch_size=config.batch_size, shuffle=sampler is None, sampler=sampler,
+                                  num_workers=workers, pin_memory=True, drop_last=True, persistent_workers=workers > 0)
     valid_dataloader = DataLoader(valid_datasets, batch_size=1, shuffle=False, num_workers=min(1, workers),
                                   pin_memory=True, drop_last=False, persistent_workers=workers > 0)
     test_dataloader = DataLoader(test_datasets, batch_size=1, shuffle=False, num_workers=min(1, workers),
@@ -108,9 +138,14 @@ def save_checkpoint(epoch: int, best_niqe: float, is_best: bool, model, ema_mode
 
 
 def main() -> None:
+    global _RANK, _WORLD
+    _RANK, _WORLD, device = setup_distributed()          # one process per GPU: cuda:LOCAL_RANK, RCCL group when WORLD_SIZE > 1
+    config.device = device
     start_epoch, best_niqe = 0, 100.0
     train_prefetcher, valid_prefetcher, test_prefetcher = load_dataset()
     model, ema_model = build_model()
+    dp = DataParallel()
+    dp.attach(model)                                     # broadcast of the initial weights + all-reduce of the gradient arena per step
     pixel_criterion = define_loss()
     optimizer = define_optimizer(model)
     scheduler = define_scheduler(optimizer)
@@ -121,10 +156,13 @@ def main() -> None:
     results_dir = os.path.join("results", config.exp_name)
     os.makedirs(samples_dir, exist_ok=True)
     os.makedirs(results_dir, exist_ok=True)
-    writer = ScalarWriter(os.path.join("samples", "logs", config.exp_name))
-    scaler = torch.amp.GradScaler("cuda") if getattr(config, "precision", "fast") == "fast" else None
+    writer = ScalarWriter(os.path.join("samples", "logs", config.exp_name), enabled=_RANK == 0)
+    scaler = torch.amp.GradScaler("cuda") if getattr(config, "precision", "fast") != "strict" else None
     niqe_model = NIQE(config.upscale_factor, config.niqe_model_path).to(device=config.device)
     for epoch in range(start_epoch, config.epochs):
+        sampler = getattr(train_prefetcher.original_dataloader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
         train(model, ema_model, train_prefetcher, pixel_criterion, optimizer, epoch, scaler, writer)
         _ = validate(model, ema_model, valid_prefetcher, epoch, writer, niqe_model, "Valid")
         niqe = validate(model, ema_model, test_prefetcher, epoch, writer, niqe_model, "Test")
@@ -132,7 +170,8 @@ def main() -> None:
         scheduler.step()
         is_best = niqe < best_niqe
         best_niqe = min(niqe, best_niqe)
-        save_checkpoint(epoch, best_niqe, is_best, model, ema_model, optimizer, scheduler, samples_dir, results_dir)
+        if _RANK == 0:       # replicas are identical: one writer
+            save_checkpoint(epoch, best_niqe, is_best, model, ema_model, optimizer, scheduler, samples_dir, results_dir)
 
 
 def train(model: nn.Module, ema_model: nn.Module, train_prefetcher: CUDAPrefetcher, pixel_criterion: nn.L1Loss,
@@ -141,10 +180,7 @@ def train(model: nn.Module, ema_model: nn.Module, train_prefetcher: CUDAPrefetch
     jpeg_operation = imgproc.DiffJPEG(False)
     usm_sharpener = imgproc.USMSharp(50, 0).to(device=config.device)
     batches = len(train_prefetcher)
-    batch_time = AverageMeter("Time", ":6.3f")
-    data_time = AverageMeter("Data", ":6.3f")
-    losses = AverageMeter("Loss", ":6.6f")
-    progress = ProgressMeter(batches, [batch_time, data_time, losses], prefix=f"Epoch: [{epoch + 1}]")
+    stats = RunningStats("time", "data", "loss")
     model.train()
 
     def degrade(hr):   # host draws in the reference's order, kernels from the dataset batch (:262-377)
@@ -159,16 +195,17 @@ def train(model: nn.Module, ema_model: nn.Module, train_prefetcher: CUDAPrefetch
     batch_data = train_prefetcher.next()
     end = time.time()
     while batch_data is not None:
-        data_time.update(time.time() - end)
+        t_data = time.time() - end
         hr = batch_data["hr"].to(device=config.device, non_blocking=True)
         kernels = (batch_data["kernel1"], batch_data["kernel2"], batch_data["sinc_kernel"])
         loss = step(hr)
-        losses.update(loss.item(), hr.size(0))
-        batch_time.update(time.time() - end)
+        if batch_index % config.print_frequency == 0:      # the only host read-back of the loop
+            value = loss.item()
+            stats.update(hr.size(0), time=time.time() - end, data=t_data, loss=value)
+            writer.add_scalar("Train/Loss", value, batch_index + epoch * batches + 1)
+            if _RANK == 0:
+                print(stats.line(f"Epoch [{epoch + 1}] batch {batch_index}/{batches}  "))
         end = time.time()
-        if batch_index % config.print_frequency == 0:
-            writer.add_scalar("Train/Loss", loss.item(), batch_index + epoch * batches + 1)
-            progress.display(batch_index)
         batch_data = train_prefetcher.next()
         batch_index += 1
 
@@ -176,10 +213,9 @@ def train(model: nn.Module, ema_model: nn.Module, train_prefetcher: CUDAPrefetch
 def validate(model: nn.Module, ema_model: nn.Module, data_prefetcher: CUDAPrefetcher, epoch: int, writer: ScalarWriter,
              niqe_model: Any, mode: str) -> float:
     """Reference train_realesrnet.py:416-488: EMA weights applied for the evaluation, restored afterwards."""
-    batches = len(data_prefetcher)
-    batch_time = AverageMeter("Time", ":6.3f")
-    niqe_metrics = AverageMeter("NIQE", ":4.2f")
-    progress = ProgressMeter(batches, [batch_time, niqe_metrics], prefix=f"{mode}: ")
+    if mode not in ("Valid", "Test"):
+        raise ValueError("Unsupported mode, please use `Valid` or `Test`.")
+    stats = RunningStats("time", "niqe")
     ema_model.apply_shadow()
     model.eval()
     batch_index = 0
@@ -191,62 +227,15 @@ def validate(model: nn.Module, ema_model: nn.Module, data_prefetcher: CUDAPrefet
             lr = batch_data["lr"].to(device=config.device, non_blocking=True)
             sr = model(lr)
             niqe = niqe_model(sr)
-            niqe_metrics.update(niqe.item(), lr.size(0))
-            batch_time.update(time.time() - end)
+            stats.update(lr.size(0), time=time.time() - end, niqe=niqe.item())
             end = time.time()
-            if batch_index % max(1, batches // 5) == 0:
-                progress.display(batch_index)
             batch_data = data_prefetcher.next()
             batch_index += 1
     ema_model.restore()
-    progress.display_summary()
-    if mode not in ("Valid", "Test"):
-        raise ValueError("Unsupported mode, please use `Valid` or `Test`.")
-    writer.add_scalar(f"{mode}/NIQE", niqe_metrics.avg, epoch + 1)
-    return niqe_metrics.avg
-
-
-class Summary(Enum):
-    NONE = 0
-    AVERAGE = 1
-    SUM = 2
-    COUNT = 3
-
-
-class AverageMeter(object):
-    def __init__(self, name, fmt=":f", summary_type=Summary.AVERAGE):
-        self.name, self.fmt, self.summary_type = name, fmt, summary_type
-        self.reset()
-
-    def reset(self):
-        self.val = self.avg = self.sum = self.count = 0
-
-    def update(self, val, n=1):
-        self.val = val
-        self.sum += val * n
-        self.count += n
-        self.avg = self.sum / self.count
-
-    def __str__(self):
-        return ("{name} {val" + self.fmt + "} ({avg" + self.fmt + "})").format(**self.__dict__)
-
-    def summary(self):
-        fmt = {Summary.NONE: "", Summary.AVERAGE: "{name} {avg:.2f}", Summary.SUM: "{name} {sum:.2f}",
-               Summary.COUNT: "{name} {count:.2f}"}[self.summary_type]
-        return fmt.format(**self.__dict__)
-
-
-class ProgressMeter(object):
-    def __init__(self, num_batches, meters, prefix=""):
-        num_digits = len(str(num_batches // 1))
-        self.batch_fmtstr = "[{:" + str(num_digits) + "d}/" + ("{:" + str(num_digits) + "d}").format(num_batches) + "]"
-        self.meters, self.prefix = meters, prefix
-
-    def display(self, batch):
-        print("\t".join([self.prefix + self.batch_fmtstr.format(batch)] + [str(m) for m in self.meters]))
-
-    def display_summary(self):
-        print(" ".join([" *"] + [m.summary() for m in self.meters]))
+    if _RANK == 0:
+        print(f"{mode}: NIQE {stats.mean('niqe'):.4f} over {stats.count} images")
+    writer.add_scalar(f"{mode}/NIQE", stats.mean("niqe"), epoch + 1)
+    return stats.mean("niqe")
 
 
 if __name__ == "__main__":

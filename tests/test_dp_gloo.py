@@ -55,3 +55,57 @@ def test_single_process_is_identity():
     t = torch.arange(10.0)
     dp.all_reduce_mean_(t)
     assert torch.equal(t, torch.arange(10.0))
+
+
+def _grads_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from real_esrgan_pytorch_amd.train import DataParallel, _arena_of
+    dp = DataParallel(bucket_bytes=4 * 100)
+    torch.manual_seed(5)
+    # (a) gradients that are consecutive views of one arena (what the networks' backward passes hand out): reduced in place
+    arena = torch.full((60,), float(rank + 1))
+    ps = [torch.nn.Parameter(torch.zeros(4, 5)), torch.nn.Parameter(torch.zeros(10)), torch.nn.Parameter(torch.zeros(30))]
+    off = 0
+    for p in ps:
+        p.grad = arena[off:off + p.numel()].view(p.shape)
+        off += p.numel()
+    assert _arena_of([p.grad for p in ps]) is not None
+    dp.all_reduce_grads_(ps)
+    ok_a = bool(torch.allclose(arena, torch.full((60,), 1.5)))
+    # (b) scattered gradients (+ one parameter without a gradient): through a flat copy, written back
+    qs = [torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(3, 3)), torch.nn.Parameter(torch.zeros(2))]
+    qs[0].grad = torch.full((7,), float(rank))
+    qs[1].grad = torch.full((3, 3), float(10 * rank))
+    assert _arena_of([qs[0].grad, qs[1].grad]) is None
+    dp.all_reduce_grads_(qs)
+    ok_b = bool(torch.allclose(qs[0].grad, torch.full((7,), 0.5)) and torch.allclose(qs[1].grad, torch.full((3, 3), 5.0)) and qs[2].grad is None)
+    # (c) attach_discriminator: parameters and buffers (spectral-norm u / v) follow rank 0
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.full((5,), float(rank)))
+            self.register_buffer("weight_u", torch.full((3,), float(rank) + 7))
+
+        def flat_parameters(self):
+            return self.w.data
+    m = Fake()
+    dp.attach_discriminator(m)
+    ok_c = bool((m.w == 0).all() and (m.weight_u == 7).all())
+    q.put((rank, ok_a, ok_b, ok_c))
+    dist.destroy_process_group()
+
+
+def test_module_grad_exchange_and_buffer_broadcast_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grads_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] and r[2] and r[3] for r in res), res

@@ -73,6 +73,80 @@ def test_two_rank_dp_matches_single_process():
     assert rel < 1e-5, rel                    # fp32: mean of two half-batch gradients == whole-batch gradient
 
 
+def _gan_setup(precision="strict"):
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(0)
+    g = R.Generator(3, 3, 4, precision=precision, n_blocks=1).cuda()
+    d = R.Discriminator(precision=precision).cuda()
+    return R, g, d
+
+
+def _gan_step(R, g, d, lr, hr, dp):
+    from real_esrgan_pytorch_amd.train import RealESRGANStep
+    g.train(); d.train()
+    ema = R.EMA(g, 0.999)
+    ema.register()
+    # learning rate 0: the step runs end to end (both optimisers, EMA) and leaves the reduced gradients in place
+    step = RealESRGANStep(g, d, ema, torch.optim.Adam(g.parameters(), 0.0, (0.9, 0.99)),
+                          torch.optim.Adam(d.parameters(), 0.0, (0.9, 0.99)), scaler=None, dp=dp)
+    out = step(hr.cuda(), lr.cuda())
+    torch.cuda.synchronize()
+    gd = torch.cat([p.grad.reshape(-1) for p in d.parameters()]).cpu()
+    return g.flat_grad().cpu(), gd, {k: float(v) for k, v in out.items()}
+
+
+def _gan_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from real_esrgan_pytorch_amd.train import DataParallel
+    torch.cuda.set_device(0)
+    R, g, d = _gan_setup()
+    if rank == 1:                                   # replicas (weights AND spectral-norm u / v) must be made identical by attach
+        with torch.no_grad():
+            g.flat_parameters().add_(0.5)
+            d.flat_parameters().mul_(1.5)
+            for b in d.buffers():
+                b.add_(0.1)
+    dp = DataParallel(bucket_bytes=256 << 10)
+    dp.attach(g)
+    dp.attach_discriminator(d)
+    lr, hr = _data()
+    half = slice(rank * 2, rank * 2 + 2)
+    gg, gd, losses = _gan_step(R, g, d, lr[half], hr[half], dp)
+    u = torch.cat([b.reshape(-1) for b in d.buffers()]).cpu()
+    q.put((rank, gg.numpy(), gd.numpy(), u.numpy(), losses))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gan_step_matches_single_process():
+    """Config 4's data-parallel leg (reference step: train_realesrgan.py:459-521): generator AND discriminator gradients of two
+    ranks on half batches, after the exchanges, equal the single-process gradients of the whole batch; the discriminator's two
+    backwards are reduced by ONE exchange after the second; u / v stay identical across ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _port()
+    procs = [ctx.Process(target=_gan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r, gg, gd, u, losses = q.get(timeout=900)
+        res[r] = (torch.from_numpy(gg), torch.from_numpy(gd), torch.from_numpy(u), losses)
+    for p in procs:
+        p.join(timeout=120)
+    R, g, d = _gan_setup()
+    lr, hr = _data()
+    gg, gd, losses = _gan_step(R, g, d, lr, hr, None)
+    u = torch.cat([b.reshape(-1) for b in d.buffers()]).cpu()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])          # both ranks hold the same reduced gradients
+    assert torch.allclose(res[0][2], res[1][2], atol=1e-6) and torch.allclose(res[0][2], u, atol=1e-5)   # u / v: broadcast, then 3 identical power iterations
+    rel_g = ((res[0][0] - gg).norm() / gg.norm()).item()
+    rel_d = ((res[0][1] - gd).norm() / gd.norm()).item()
+    assert rel_g < 1e-5 and rel_d < 1e-5, (rel_g, rel_d)
+    for k in ("pixel_loss", "adversarial_loss", "d_loss_hr", "d_loss_sr"):                  # batch means: mean of the two halves
+        assert abs(0.5 * (res[0][3][k] + res[1][3][k]) - losses[k]) < 1e-5, k
+
+
 def test_bench_two_ranks_prints_one_line():
     """The driver's multi-GPU launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) with two
     ranks sharing the test box's one GPU (gloo): warm-up, timed steps, the in-situ roofline step (a collective step: every
@@ -93,3 +167,23 @@ def test_bench_two_ranks_prints_one_line():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and out["scaling"] == "weak" and "roofline" in out and "cpu_baseline" not in out
     assert "error" not in out["roofline"], out["roofline"]
+
+
+def test_bench_gan_two_ranks_prints_one_line():
+    """The driver's launch line with --gan (BASELINE config 4): two ranks, generator + discriminator exchanges, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RESR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--lr-size", "16", "--gan"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and "GAN" in out["metric"] and set(out["losses"]) >= {"pixel_loss", "adversarial_loss", "d_loss_hr", "d_loss_sr", "content_loss"}
+    assert "roofline" in out and "error" not in out["roofline"], out.get("roofline")

@@ -154,3 +154,56 @@ def test_tiled_inference_equals_whole_image(use_graph):
     tiled = TiledGenerator(g, tile=64, halo=24, use_graph=use_graph)(x)
     assert tiled.shape == whole.shape == (1, 3, 288, 352)
     assert torch.equal(tiled, whole)
+
+
+@pytest.mark.parametrize("precision", ["strict", "exact16", "fast"])
+def test_dense_blocks_standalone_forward(precision):
+    """ResidualDenseBlock / ResidualResidualDenseBlock are public surface of the reference (model.py:22-27): their standalone
+    forward against the reference's own outputs (tests/golden/rdb.npz, rrdb.npz)."""
+    import numpy as np
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd.model import _dense_blocks_forward
+    here = os.path.dirname(os.path.abspath(__file__))
+    tol = 2e-2 if precision == "fast" else 2e-5
+    z = np.load(os.path.join(here, "golden", "rdb.npz"))
+    rdb = R.ResidualDenseBlock(64, 32)
+    rdb.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w_")})
+    rdb = rdb.cuda()
+    with torch.no_grad():
+        y = _dense_blocks_forward([rdb], torch.from_numpy(z["x"]).cuda(), False, precision).cpu()
+    assert (y - torch.from_numpy(z["y"])).abs().max().item() < tol
+    with pytest.raises(RuntimeError):          # forward only: autograd must go through the Generator
+        rdb(torch.from_numpy(z["x"]).cuda().requires_grad_(True))
+    z = np.load(os.path.join(here, "golden", "rrdb.npz"))
+    rrdb = R.ResidualResidualDenseBlock(64, 32)
+    rrdb.load_state_dict({k[2:]: torch.from_numpy(z[k]).float() for k in z.files if k.startswith("w_")})
+    rrdb = rrdb.cuda()
+    with torch.no_grad():
+        y = _dense_blocks_forward([rrdb.rdb1, rrdb.rdb2, rrdb.rdb3], torch.from_numpy(z["x"]).cuda(), True, precision).cpu()
+        y_env = rrdb(torch.from_numpy(z["x"]).cuda()).cpu()          # module surface: precision from $RESR_PRECISION (fast)
+    assert (y - torch.from_numpy(z["y"])).abs().max().item() < tol
+    assert (y_env - torch.from_numpy(z["y"])).abs().max().item() < 2e-2
+
+
+def test_two_backwards_accumulate():
+    """Two backward passes without zero_grad in between must leave the SUM in .grad (the native backward overwrites its
+    gradient arena; model.py parks and restores earlier gradients)."""
+    g, sd, M = _setup(4, 1, 3, "strict")
+    gen = torch.Generator().manual_seed(3)
+    xa, xb = torch.rand(1, 3, 16, 16, generator=gen), torch.rand(1, 3, 16, 16, generator=gen)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    (M.generator_forward(xa, sdo, 4, 1).square().sum() + M.generator_forward(xb, sdo, 4, 1).square().sum()).backward()
+    g(xa.cuda()).square().sum().backward()
+    g(xb.cuda()).square().sum().backward()
+    torch.cuda.synchronize()
+    for name, p in g.named_parameters():
+        ref = sdo[name].grad
+        assert ((p.grad.cpu() - ref).norm() / ref.norm().clamp_min(1e-12)).item() < 1e-4, name
+    # two live graphs before either backward (GAN-style): each keeps its own workspace
+    g.zero_grad(set_to_none=True)
+    ya, yb = g(xa.cuda()), g(xb.cuda())
+    (ya.square().sum() + yb.square().sum()).backward()
+    torch.cuda.synchronize()
+    for name, p in g.named_parameters():
+        ref = sdo[name].grad
+        assert ((p.grad.cpu() - ref).norm() / ref.norm().clamp_min(1e-12)).item() < 1e-4, name
