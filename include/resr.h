@@ -210,6 +210,20 @@ int resr_quantize_crop(const float* lr, const float* hr, float* lr_out, float* h
                        int32_t lr_w, int32_t hr_h, int32_t hr_w, int32_t hr_size, int32_t upscale, int32_t hr_top,
                        int32_t hr_left, void* stream);
 
+/* ---- integer mode of blur / resize (north_star: "blur/resize/JPEG bit-exact in integer mode") ---------------------
+ * uint8 planar images [n,c,h,w], fixed-point taps, integer accumulation: the CPU restatement (oracle/imgproc_int_ref.py)
+ * and these kernels agree bit for bit.  They shadow the reference's float ops (imgproc.py:1089-1121 filter2d_torch; the
+ * F.interpolate call sites train_realesrnet.py:288,326-329,349-351,366-368), to which the distance is <= 1 LSB.
+ * resr_filter2d_u8: taps_q14 = the kernel in Q14 (int32, [kh*kw] or [n][kh*kw] with per_sample), summing to 2^14:
+ *   dst = clamp((sum q*src[reflect] + 2^13) >> 14, 0, 255).
+ * resr_resize_u8: mode 0 area (integer window means, round half up; tables unused), 1 bilinear (2 taps), 2 bicubic
+ *   (4 taps): per-axis tables idx_* [out][taps] (clamped source indices) and w_* [out][taps] (Q11, summing to 2^11),
+ *   made by the caller from ATen's coordinate map; dst = clamp((sum_y wy * (sum_x wx*src) + 2^21) >> 22, 0, 255). */
+int resr_filter2d_u8(const uint8_t* src, uint8_t* dst, const int32_t* taps_q14, int32_t n, int32_t c, int32_t h, int32_t w,
+                     int32_t kh, int32_t kw, int32_t per_sample, void* stream);
+int resr_resize_u8(const uint8_t* src, uint8_t* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t oh, int32_t ow,
+                   int32_t mode, const int32_t* idx_y, const int32_t* w_y, const int32_t* idx_x, const int32_t* w_x, void* stream);
+
 /* ---- discriminator helpers (model.py:135-203) -------------------------------------------------------- */
 /* 2x2 space-to-depth of an NHWC tensor [n,h,w,c] -> [n,h/2,w/2,4c] (inverse != 0: depth-to-space) */
 int resr_space_to_depth(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t dtype,

@@ -99,6 +99,8 @@ _PROTOS = {
     "resr_noise_poisson": (C.c_int, [_P] * 4 + [C.c_uint64, _P] + [C.c_int32] * 5 + [_P]),
     "resr_jpeg": (C.c_int, [_P] * 4 + [C.c_int32] * 4 + [_P]),
     "resr_quantize_crop": (C.c_int, [_P] * 4 + [C.c_int32] * 10 + [_P]),
+    "resr_filter2d_u8": (C.c_int, [_P, _P, _P] + [C.c_int32] * 7 + [_P]),
+    "resr_resize_u8": (C.c_int, [_P, _P] + [C.c_int32] * 7 + [_P] * 5),
 }
 
 _lib = None

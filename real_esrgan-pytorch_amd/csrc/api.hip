@@ -94,6 +94,10 @@ int poisson_noise_dispatch(const float*, float*, const float*, const float*, uin
 int jpeg_dispatch(const float*, float*, const float*, float*, int, int, int, int, hipStream_t);
 int quantize_crop_dispatch(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 
+int filter2d_u8_dispatch(const uint8_t*, uint8_t*, const int32_t*, int, int, int, int, int, int, int, hipStream_t);
+int resize_u8_dispatch(const uint8_t*, uint8_t*, int, int, int, int, int, int, int, const int32_t*, const int32_t*, const int32_t*,
+                       const int32_t*, hipStream_t);
+
 int s2d_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
 int bilinear_up_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
 int add_mask_dispatch(const void*, const void*, const void*, void*, long, int, float, hipStream_t);
@@ -249,6 +253,18 @@ int resr_quantize_crop(const float* lr, const float* hr, float* lr_out, float* h
     RESR_DEVICE_SCOPE(stream);
     return quantize_crop_dispatch(lr, hr, lr_out, hr_out, n, c, lr_h, lr_w, hr_h, hr_w, hr_size, upscale, hr_top, hr_left,
                                   (hipStream_t)stream);
+}
+
+int resr_filter2d_u8(const uint8_t* src, uint8_t* dst, const int32_t* taps_q14, int32_t n, int32_t c, int32_t h, int32_t w,
+                     int32_t kh, int32_t kw, int32_t per_sample, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return filter2d_u8_dispatch(src, dst, taps_q14, n, c, h, w, kh, kw, per_sample, (hipStream_t)stream);
+}
+
+int resr_resize_u8(const uint8_t* src, uint8_t* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t oh, int32_t ow,
+                   int32_t mode, const int32_t* idx_y, const int32_t* w_y, const int32_t* idx_x, const int32_t* w_x, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return resize_u8_dispatch(src, dst, n, c, h, w, oh, ow, mode, idx_y, w_y, idx_x, w_x, (hipStream_t)stream);
 }
 
 int resr_space_to_depth(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t dtype, int32_t inverse,

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import math
 import random
-from typing import Any, Sequence, Tuple
+from typing import Any, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -20,7 +20,7 @@ from . import _lib
 
 __all__ = ["random_add_gaussian_noise_torch", "random_add_poisson_noise_torch", "random_mixed_kernels",
            "generate_sinc_kernel", "image_to_tensor", "tensor_to_image", "random_crop", "filter2d_torch",
-           "interpolate", "DiffJPEG", "USMSharp", "image_resize", "center_crop", "random_rotate",
+           "interpolate", "filter2d_u8", "interpolate_u8", "quantize_kernel_q14", "resize_tap_tables", "DiffJPEG", "USMSharp", "image_resize", "center_crop", "random_rotate",
            "random_horizontally_flip", "random_vertically_flip", "rgb2ycbcr_torch", "read_image_rgb"]
 
 _MODES = {"area": 0, "bilinear": 1, "bicubic": 2}
@@ -128,6 +128,102 @@ def interpolate(image: torch.Tensor, size=None, scale_factor=None, mode: str = "
     out = torch.empty((b, c, oh, ow), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().resr_resize(_lib.ptr(x), _lib.ptr(out), b, c, h, w, oh, ow, _MODES[mode], sh, sw,
                                       _lib.stream_ptr(x)), "resr_resize")
+    return out
+
+
+# ---- integer mode of blur / resize (north_star "bit-exact in integer mode") ----------------
+# uint8 images, fixed-point taps, integer accumulation on the device (csrc/degrade_int.hip): bit-identical to the CPU
+# restatement whatever the summation order.  The float path above stays the training path (it is what the reference runs).
+Q_KERNEL, Q_RESIZE = 14, 11
+
+
+def quantize_kernel_q14(kernel) -> np.ndarray:
+    """Blur kernel(s) [..., kh, kw] (float) -> Q14 int32 taps whose sum per kernel is EXACTLY round(sum * 2^14): rounded to
+    nearest-even, then the rounding residue is put on the largest tap (so a normalised kernel keeps unit DC gain)."""
+    k = np.asarray(kernel.detach().cpu().numpy() if torch.is_tensor(kernel) else kernel, dtype=np.float64)
+    q = np.rint(k * (1 << Q_KERNEL)).astype(np.int64)
+    flat = q.reshape(-1, k.shape[-2] * k.shape[-1])
+    want = np.rint(k.reshape(flat.shape).sum(axis=1) * (1 << Q_KERNEL)).astype(np.int64)
+    peak = np.abs(flat).argmax(axis=1)
+    flat[np.arange(flat.shape[0]), peak] += want - flat.sum(axis=1)
+    return flat.reshape(q.shape).astype(np.int32)
+
+
+def filter2d_u8(image: torch.Tensor, kernel) -> torch.Tensor:
+    """Integer-mode `filter2d_torch` (reference imgproc.py:1089-1121): uint8 [N,C,H,W] in, uint8 out; `kernel` float
+    [1|N, k, k] (quantised here) or already-quantised int32 taps."""
+    _lib.require_cuda(image, "filter2d_u8")
+    if image.dtype != torch.uint8 or image.dim() != 4:
+        raise ValueError("filter2d_u8: expected a uint8 [N,C,H,W] image")
+    x = image.contiguous()
+    b, c, h, w = x.shape
+    taps = kernel if (torch.is_tensor(kernel) and kernel.dtype == torch.int32) else torch.from_numpy(quantize_kernel_q14(kernel))
+    if taps.dim() != 3 or taps.shape[0] not in (1, b):
+        raise ValueError("filter2d_u8: kernel must be [1 or N, kh, kw]")
+    taps = taps.to(x.device).contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().resr_filter2d_u8(_lib.ptr(x), _lib.ptr(out), _lib.ptr(taps), b, c, h, w, taps.shape[1], taps.shape[2],
+                                           0 if taps.shape[0] == 1 else 1, _lib.stream_ptr(x)), "resr_filter2d_u8")
+    return out
+
+
+def resize_tap_tables(in_size: int, out_size: int, scale: Optional[float], mode: str):
+    """Per-axis tap tables of F.interpolate(align_corners=False, antialias=False) in fixed point: (idx [out, taps] int32
+    clamped source indices, w [out, taps] int32 Q11 weights summing to 2^11).  Coordinates follow ATen
+    (area_pixel_compute_source_index): src = (dst + 0.5) * s - 0.5 with s = 1/scale_factor when the caller gave
+    scale_factor= (train_realesrnet.py:288), in/out for size=; bilinear clamps src at 0, bicubic (A = -0.75) clamps the
+    tap indices instead.  float64 on the host, one table per call."""
+    s = (1.0 / scale) if scale else in_size / out_size
+    src = (np.arange(out_size, dtype=np.float64) + 0.5) * s - 0.5
+    if mode == "bilinear":
+        src = np.maximum(src, 0.0)
+        i0 = np.minimum(np.floor(src).astype(np.int64), in_size - 1)
+        lam = src - i0
+        idx = np.stack([i0, np.minimum(i0 + 1, in_size - 1)], axis=1)
+        wts = np.stack([1.0 - lam, lam], axis=1)
+    elif mode == "bicubic":
+        A = -0.75
+        i0 = np.floor(src).astype(np.int64)
+        t = src - i0
+
+        def c1(x):
+            return ((A + 2.0) * x - (A + 3.0)) * x * x + 1.0
+
+        def c2(x):
+            return ((A * x - 5.0 * A) * x + 8.0 * A) * x - 4.0 * A
+        wts = np.stack([c2(t + 1.0), c1(t), c1(1.0 - t), c2(2.0 - t)], axis=1)
+        idx = np.clip(np.stack([i0 - 1, i0, i0 + 1, i0 + 2], axis=1), 0, in_size - 1)
+    else:
+        raise ValueError("tap tables exist for bilinear / bicubic")
+    q = np.rint(wts * (1 << Q_RESIZE)).astype(np.int64)
+    peak = np.abs(q).argmax(axis=1)
+    q[np.arange(out_size), peak] += (1 << Q_RESIZE) - q.sum(axis=1)
+    return idx.astype(np.int32), q.astype(np.int32)
+
+
+def interpolate_u8(image: torch.Tensor, size=None, scale_factor=None, mode: str = "bilinear") -> torch.Tensor:
+    """Integer-mode `interpolate` (same call forms as above): uint8 in, uint8 out."""
+    _lib.require_cuda(image, "interpolate_u8")
+    if image.dtype != torch.uint8 or image.dim() != 4:
+        raise ValueError("interpolate_u8: expected a uint8 [N,C,H,W] image")
+    x = image.contiguous()
+    b, c, h, w = x.shape
+    if (size is None) == (scale_factor is None):
+        raise ValueError("give exactly one of size / scale_factor")
+    if size is not None:
+        oh, ow = (size, size) if isinstance(size, int) else size
+        sc = None
+    else:
+        sc = float(scale_factor)
+        oh, ow = int(math.floor(float(h) * sc)), int(math.floor(float(w) * sc))
+    out = torch.empty((b, c, oh, ow), dtype=torch.uint8, device=x.device)
+    tabs = [None] * 4
+    if mode != "area":
+        iy, wy = resize_tap_tables(h, oh, sc, mode)
+        ix, wx = resize_tap_tables(w, ow, sc, mode)
+        tabs = [torch.from_numpy(t).to(x.device) for t in (iy, wy, ix, wx)]
+    _lib.check(_lib.lib().resr_resize_u8(_lib.ptr(x), _lib.ptr(out), b, c, h, w, oh, ow, _MODES[mode], *[_lib.ptr(t) for t in tabs],
+                                         _lib.stream_ptr(x)), "resr_resize_u8")
     return out
 
 
