@@ -154,6 +154,19 @@ def test_tiled_inference_equals_whole_image(use_graph):
     tiled = TiledGenerator(g, tile=64, halo=24, use_graph=use_graph)(x)
     assert tiled.shape == whole.shape == (1, 3, 288, 352)
     assert torch.equal(tiled, whole)
+    # rectangular tiles; the captured whole-frame graph replayed on a second frame; re-capture after the parameters moved
+    tg = TiledGenerator(g, tile=(48, 80), halo=24, use_graph=use_graph)
+    assert torch.equal(tg(x), whole)
+    x2 = torch.rand(1, 3, 144, 176).cuda()
+    with torch.no_grad():
+        whole2 = g(x2)
+    assert torch.equal(tg(x2), whole2)
+    with torch.no_grad():
+        for p in g.parameters():                     # what EMA.apply_shadow does: new storage behind every parameter
+            p.data = (p.data * 1.01).clone()
+        whole3 = g(x2)
+    assert not torch.equal(whole3, whole2)
+    assert torch.equal(tg(x2), whole3)
 
 
 @pytest.mark.parametrize("precision", ["strict", "exact16", "fast"])
