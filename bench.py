@@ -50,6 +50,8 @@ def _parser():
     ap.add_argument("--no-degradation", action="store_true", help="debug only: feed pre-degraded LR tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the exact16 sub-run (parity_mode record)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of the other BASELINE.json configurations (2, 3, 4, 5) reported under other_configs")
     ap.add_argument("--gan", action="store_true",
                     help="BASELINE config 4 instead of the headline: the RealESRGAN step (generator update with the discriminator "
                          "frozen, USM on sr, VGG19 term, then two discriminator backwards; train_realesrgan.py:459-521), "
@@ -547,6 +549,77 @@ def gan_main(args, world, rank):
     print(json.dumps(out), flush=True)
 
 
+def other_configs(args):
+    """Short runs of the other BASELINE.json configurations on this GPU (N = 1 only), so that every configuration has a number
+    from the same driver-run process as the headline.  They are parity-test cases (tests/), not the headline metric."""
+    import copy
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd.tiling import TiledGenerator
+    out = {}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    try:    # config 2: RRDBNet x4 f16 inference, batch 16 of 256^2 LR (generator kernels only)
+        torch.manual_seed(0)
+        g4 = R.Generator(3, 3, 4, precision="fast").cuda().eval()
+        x = torch.rand(16, 3, 256, 256, device="cuda")
+        with torch.no_grad():
+            dt = timed(lambda: g4(x), 5)
+        flop = 2 * MAC_PER_LR_PX * 256 * 256 * 16
+        out["config2_x4_f16_inference_b16_lr256"] = {"images_per_sec": round(16 / dt, 1), "ms": round(dt * 1e3, 2),
+                                                     "tflops": round(flop / dt / 1e12, 1), "frac_of_f16_peak": round(flop / dt / 1e12 / PEAK_F16_TFLOPS, 3)}
+        del g4, x
+        torch.cuda.empty_cache()
+    except Exception as e:  # pragma: no cover
+        out["config2_x4_f16_inference_b16_lr256"] = {"error": repr(e)}
+    try:    # config 3: RealESRNet x4 L1 training, batch 32 of 256^2 HR tiles (LR 64^2), degradation on the side stream
+        a3 = copy.copy(args)
+        a3.batch, a3.lr_size, a3.no_probe = 32, 64, True
+        r = run_mode(a3, "fast", 20, 5, 1, 0, probe=False)
+        v = 32 * r["steps"] / r["dt"]
+        out["config3_realesrnet_train_b32_hr256"] = {"images_per_sec": round(v, 1), "ms_per_step": round(r["dt"] / r["steps"] * 1e3, 2),
+                                                     "tflops": round(v * 3 * 2 * MAC_PER_LR_PX * 64 * 64 / 1e12, 1),
+                                                     "frac_of_f16_peak": round(v * 3 * 2 * MAC_PER_LR_PX * 64 * 64 / 1e12 / PEAK_F16_TFLOPS, 3),
+                                                     "loss": r["loss"], "unclamped_output_fraction": r.get("unclamped")}
+        del r
+        torch.cuda.empty_cache()
+    except Exception as e:  # pragma: no cover
+        out["config3_realesrnet_train_b32_hr256"] = {"error": repr(e)}
+    try:    # config 4, this GPU's share: RealESRGAN step, batch 16, HR 400^2 tiles cropped to 256^2 (full record: bench.py --gan)
+        a4 = copy.copy(args)
+        a4.batch, a4.lr_size, a4.no_probe, a4.steps, a4.warmup, a4.precision = 16, 64, True, 10, 3, "fast"
+        r = run_gan(a4, 1, 0)
+        out["config4_realesrgan_step_b16_hr256_per_gpu"] = {"images_per_sec": round(16 * a4.steps / r["dt"], 1),
+                                                            "ms_per_step": round(r["dt"] / a4.steps * 1e3, 2), "losses": r["losses"]}
+        del r
+        torch.cuda.empty_cache()
+    except Exception as e:  # pragma: no cover
+        out["config4_realesrgan_step_b16_hr256_per_gpu"] = {"error": repr(e)}
+    try:    # config 5: RRDBNet x2, 3840x2160 LR frame, tiled, whole-frame hipGraph
+        torch.manual_seed(0)
+        g2 = R.Generator(3, 3, 2, precision="fast").cuda().eval()
+        frame = torch.rand(1, 3, 2160, 3840, device="cuda")
+        tg = TiledGenerator(g2, halo=32, use_graph=True)
+        tiles, wh, ww = tg.plan(1, 2160, 3840)
+        dt = timed(lambda: tg(frame), 3)
+        flop = 2 * 17_932_032 * 1920 * 1080
+        out["config5_x2_4k_tiled_hipgraph"] = {"frames_per_sec": round(1 / dt, 3), "ms": round(dt * 1e3, 1), "tflops": round(flop / dt / 1e12, 1),
+                                               "frac_of_f16_peak": round(flop / dt / 1e12 / PEAK_F16_TFLOPS, 3),
+                                               "tiles": len(tiles), "window": [wh, ww], "halo": 32}
+        del g2, frame, tg
+        torch.cuda.empty_cache()
+    except Exception as e:  # pragma: no cover
+        out["config5_x2_4k_tiled_hipgraph"] = {"error": repr(e)}
+    return out
+
+
 def parity_probe(sd, edge=24):
     """Max-abs distance of every precision mode's forward to the strict (f32 MFMA) one on a seeded edge x edge probe with the
     timed model's weights; nothing from oracle/ is involved here (the CPU oracle's view of the same probe is added by the
@@ -651,6 +724,8 @@ def main():
                 probe_err = repr(e)
                 pm["probe"] = {"error": probe_err}
             out["parity_mode"] = pm
+        if world == 1 and not args.no_other_configs:
+            out["other_configs"] = other_configs(args)
         if args.isolated_probe:
             rows = probe_conv_kernels(B, lr_edge, args.precision)
             out["conv_probe_isolated"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "flop"}

@@ -167,9 +167,14 @@ int64_t resr_generator_buffer_offsets(const ResrGeneratorDesc* d, int64_t* out, 
 int resr_generator_forward(const ResrGeneratorDesc* d, const float* x_nchw, const float* params,
                            const void* packed, void* workspace, size_t workspace_bytes,
                            float* y_nchw, void* stream);
+/* grad_ready_events (optional, n_events = n_blocks + 2 hipEvent_t handles, else NULL / 0): recorded on `stream` as soon as a
+ * range of the gradient arena is final, in backward order -- [0] the tail (conv2, upsampling1/2, conv3, conv4: the END of the
+ * arena), [1 + j] RRDB n_blocks-1-j, [n_blocks + 1] conv1 (everything).  A data-parallel caller makes its communication
+ * stream wait on them and all-reduces each range while the rest of the backward pass still runs. */
 int resr_generator_backward(const ResrGeneratorDesc* d, const float* gy_nchw, const float* params,
                             const void* packed, void* workspace, size_t workspace_bytes,
-                            float* grad_params, float* gx_nchw, void* stream, void* side_stream);
+                            float* grad_params, float* gx_nchw, void* stream,
+                            void* const* grad_ready_events, int32_t n_events);
 
 /* ---- second-order degradation (imgproc.py device ops; call sites train_realesrnet.py:268-377) ----------
  * Images are planar fp32 [n,c,h,w] in [0,1].  No entry point synchronises or reads back. */

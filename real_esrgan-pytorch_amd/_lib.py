@@ -75,7 +75,7 @@ _PROTOS = {
     "resr_generator_pack_table": (C.c_int64, [C.POINTER(GeneratorDesc), C.c_int32, _P, C.c_int64]),
     "resr_generator_buffer_offsets": (C.c_int64, [C.POINTER(GeneratorDesc), _P, C.c_int64]),
     "resr_generator_forward": (C.c_int, [C.POINTER(GeneratorDesc), _P, _P, _P, _P, C.c_size_t, _P, _P]),
-    "resr_generator_backward": (C.c_int, [C.POINTER(GeneratorDesc), _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
+    "resr_generator_backward": (C.c_int, [C.POINTER(GeneratorDesc), _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P, C.c_int32]),
     "resr_ema_update": (C.c_int, [_P, _P, C.c_int64, C.c_double, _P]),
     "resr_debug_tr_probe": (C.c_int, [_P, _P]),
     "resr_debug_conv_trace": (C.c_int, [_P]),

@@ -81,7 +81,7 @@ int64_t generator_pack_table(const ResrGeneratorDesc*, int, ResrPackChunk*, int6
 int64_t generator_buffer_offsets(const ResrGeneratorDesc*, int64_t*, int64_t);
 int generator_forward(const ResrGeneratorDesc*, const float*, const float*, const void*, void*, size_t, float*, hipStream_t);
 int generator_backward(const ResrGeneratorDesc*, const float*, const float*, const void*, void*, size_t, float*, float*,
-                       hipStream_t, hipStream_t);
+                       hipStream_t, void* const*, int);
 
 int filter2d_dispatch(const float*, float*, const float*, int, int, int, int, int, int, int, hipStream_t);
 int usm_dispatch(const float*, float*, float*, const float*, int, float, float, int, int, int, int, hipStream_t);
@@ -187,10 +187,10 @@ int resr_generator_forward(const ResrGeneratorDesc* d, const float* x_nchw, cons
 
 int resr_generator_backward(const ResrGeneratorDesc* d, const float* gy_nchw, const float* params, const void* packed,
                             void* workspace, size_t workspace_bytes, float* grad_params, float* gx_nchw, void* stream,
-                            void* side_stream) {
+                            void* const* grad_ready_events, int32_t n_events) {
     RESR_DEVICE_SCOPE(stream);
     return generator_backward(d, gy_nchw, params, packed, workspace, workspace_bytes, grad_params, gx_nchw,
-                              (hipStream_t)stream, (hipStream_t)side_stream);
+                              (hipStream_t)stream, grad_ready_events, n_events);
 }
 
 int resr_ema_update(float* shadow, const float* params, int64_t count, double decay, void* stream) {

@@ -470,10 +470,19 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
 
 int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float* params, const void* packed,
                        void* workspace, size_t workspace_bytes, float* grad, float* gx, hipStream_t st,
-                       hipStream_t side) {
-    (void)side; (void)params;
+                       void* const* events, int n_events) {
+    (void)params;
     Plan p;
     if (!build_plan(d, p)) return fail(RESR_ERR_ARG, "generator_backward: bad descriptor");
+    if (n_events != 0 && (!events || n_events != d->n_blocks + 2))
+        return fail(RESR_ERR_ARG, "generator_backward: grad_ready_events needs n_blocks + 2 = %d events, got %d", d->n_blocks + 2, n_events);
+    // a range of the gradient arena is final once its weight-gradient reductions are enqueued: tell the caller's comm stream
+    auto ready = [&](int i) -> int {
+        if (n_events == 0) return RESR_OK;
+        if (!events[i]) return fail(RESR_ERR_ARG, "generator_backward: null event %d", i);
+        if (hipEventRecord((hipEvent_t)events[i], st) != hipSuccess) return fail(RESR_ERR_LAUNCH, "generator_backward: hipEventRecord");
+        return RESR_OK;
+    };
     if (!d->training) return fail(RESR_ERR_ARG, "generator_backward: forward was not run with training=1");
     if (!gy || !packed || !workspace || !grad) return fail(RESR_ERR_ARG, "generator_backward: null argument");
     Bufs b;
@@ -573,6 +582,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         cd.in0_chunk_stride = plane; cd.out_chunk_stride = plane;   // the gT ring (gradient wrt the RDB chain) is chunk-planar [2][N,h,w,32]
         RUN(conv3x3_dispatch(&cd, b.gF, nullptr, pk + p.pk_bwd_conv2 * wes, nullptr, nullptr, nullptr, nullptr, b.gT[0], nullptr, st));
     }
+    RUN(ready(0));   // conv4, conv3, upsampling2, upsampling1, conv2: the tail of the arena
     // trunk, mirrored dense blocks.  gT ring: e (grad wrt RRDB output) must survive its three RDBs.
     int e_idx = 0;
     for (int r = p.nrdb - 1; r >= 0; --r) {
@@ -598,6 +608,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             wc[k - 1].x_chunk_stride = plane;
         }
         RUN(wgrad_run(wc, 5, h, w, 0));   // all five weight gradients of the block in one launch pair
+        if (pos == 0) RUN(ready(1 + (d->n_blocks - 1 - r / 3)));   // rdb3, rdb2, rdb1 of this RRDB are done
         {   // g_x = convT(all) + (skip terms)
             int nxt = (cur + 1) & 3;
             if (nxt == e_idx && pos != 2) nxt = (nxt + 1) & 3;
@@ -619,6 +630,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     {   // conv1                                                            model.py:259
         const ConvSpec& c = p.convs[p.i_conv1];
         RUN(wgrad(c, h, w, b.x_in, p.ci_pad, p.ci_pad, b.gT[cur], 32, 0, 1.f, 0, plane, lo_xin, lo_t));
+        RUN(ready(d->n_blocks + 1));
         if (gx) {
             ResrConvDesc cd = dgrad(h, w, 64, 32, 64, 0, p.ci_pad, p.ci_pad, p.ci_pad, 0, lo_t, 0, lo_xin);
             cd.in0_chunk_stride = plane;

@@ -245,6 +245,10 @@ class Generator(nn.Module):
         self._table_dev: Dict[int, tuple] = {}
         self._workspaces: Dict[tuple, List[_Workspace]] = {}
         self.grad_hook = None   # callable(flat_grad) run after backward wrote the arena (data-parallel all-reduce)
+        # callable(flat_grad, ranges, events): data-parallel exchange OVERLAPPED with the backward pass -- events[i] fires on
+        # the backward stream as soon as arena range ranges[i] is final (resr_generator_backward's grad_ready_events)
+        self.grad_ready_hook = None
+        self._events: List[torch.cuda.Event] = []
         self._live_graphs = 0   # training-mode forwards whose backward has not run yet
         self.__dict__["_flat_param"] = None   # see flat_parameter(); kept out of nn.Module's parameter registry
 
@@ -289,6 +293,23 @@ class Generator(nn.Module):
 
     def flat_grad(self) -> Optional[torch.Tensor]:
         return self._flat_grad
+
+    def grad_ranges(self) -> List[tuple]:
+        """Element ranges of the gradient arena in the order the backward pass finishes them (the order of
+        resr_generator_backward's grad_ready_events): the tail convs (end of the arena), RRDB n-1 ... RRDB 0, conv1.
+        Consecutive entries are adjacent, descending."""
+        starts, off = {}, 0
+        for name, p in self.named_parameters():
+            starts.setdefault(name.split(".")[1] if name.startswith("trunk.") else name.split(".")[0], off)
+            off += p.numel()
+        total = off
+        tail = starts["conv2"]
+        blocks = [starts[str(b)] for b in range(self.n_blocks)] + [tail]
+        ranges = [(tail, total)]
+        for b in range(self.n_blocks - 1, -1, -1):
+            ranges.append((blocks[b], blocks[b + 1]))
+        ranges.append((0, blocks[0]))
+        return ranges
 
     def flat_parameter(self) -> nn.Parameter:
         """One leaf Parameter that aliases the whole fp32 arena, for an optimizer that should see a single tensor:
@@ -382,11 +403,21 @@ class Generator(nn.Module):
         fp = self.__dict__["_flat_param"]
         accumulate = fp is None and any(p.grad is not None for p in self._ordered_params())
         prev = self._flat_grad.clone() if accumulate else None
+        ev_arr, n_ev = None, 0
+        if self.grad_ready_hook is not None:
+            n_ev = self.n_blocks + 2
+            while len(self._events) < n_ev:               # torch creates the HIP event at the first record()
+                e = torch.cuda.Event()
+                e.record(torch.cuda.current_stream(gy.device))
+                self._events.append(e)
+            ev_arr = (C.c_void_p * n_ev)(*[e.cuda_event for e in self._events[:n_ev]])
         _lib.check(L.resr_generator_backward(C.byref(desc), _lib.ptr(gy), _lib.ptr(flat), _lib.ptr(self._packed),
                                              _lib.ptr(ws.buf), ws.buf.numel(), _lib.ptr(self._flat_grad),
-                                             _lib.ptr(gx), _lib.stream_ptr(gy), None),
+                                             _lib.ptr(gx), _lib.stream_ptr(gy), ev_arr, n_ev),
                    "resr_generator_backward")
-        if self.grad_hook is not None:
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(self._flat_grad, self.grad_ranges(), self._events[:n_ev])
+        elif self.grad_hook is not None:
             self.grad_hook(self._flat_grad)
         if fp is not None:                       # flat_parameter() mode: the arena is the gradient of the alias
             if fp.data_ptr() != flat.data_ptr():

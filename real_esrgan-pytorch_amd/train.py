@@ -56,7 +56,7 @@ class DataParallel:
     weights, every step all-reduces (mean) the flat gradient arena.  With backend "nccl" this is
     RCCL over xGMI; "gloo" serves the CPU tests of the host logic."""
 
-    def __init__(self, bucket_bytes: int = 32 << 20) -> None:
+    def __init__(self, bucket_bytes: int = 12 << 20) -> None:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.bucket_elems = max(1, bucket_bytes // 4)
 
@@ -76,11 +76,40 @@ class DataParallel:
             w.wait()
         flat.mul_(1.0 / self.world)
 
-    def attach(self, model: Generator) -> None:
-        """Generator: identical initial weights, then one all-reduce of the flat gradient arena per backward (the generator
-        runs exactly one backward per optimiser step in both training scripts: train_realesrnet.py:388, train_realesrgan.py:484)."""
+    def attach(self, model: Generator, overlap: bool = True) -> None:
+        """Generator: identical initial weights, then the gradient arena is all-reduced once per backward (the generator runs
+        exactly one backward per optimiser step in both training scripts: train_realesrnet.py:388, train_realesrgan.py:484).
+        overlap=True: bucket by bucket on a communication stream WHILE the rest of the backward pass runs -- the native
+        backward fires an event per finished arena range (tail convs, then RRDB 22 ... 0, then conv1)."""
         self.broadcast_(model.flat_parameters())
-        model.grad_hook = self.all_reduce_mean_
+        if overlap and self.world > 1:
+            model.grad_ready_hook = self.all_reduce_ranges_
+        else:
+            model.grad_hook = self.all_reduce_mean_
+
+    def all_reduce_ranges_(self, flat: torch.Tensor, ranges, events) -> None:
+        """`ranges` are adjacent, descending element ranges of `flat`, events[i] fires (on the producing stream) when
+        ranges[i] is final.  Neighbouring ranges are merged into buckets of >= bucket size; each bucket's all-reduce is
+        enqueued on the communication stream behind its last event, so it runs under the kernels still producing the next
+        ranges; the caller's stream rejoins at the end."""
+        if self.world == 1:
+            return
+        main = torch.cuda.current_stream(flat.device)
+        if getattr(self, "_comm", None) is None:
+            self._comm = torch.cuda.Stream(device=flat.device)
+        works, hi_open = [], None
+        for i, (lo, hi) in enumerate(ranges):
+            if hi_open is None:
+                hi_open = hi
+            if hi_open - lo >= self.bucket_elems or i == len(ranges) - 1:
+                self._comm.wait_event(events[i])
+                with torch.cuda.stream(self._comm):
+                    works.append(dist.all_reduce(flat[lo:hi_open], op=dist.ReduceOp.SUM, async_op=True))
+                hi_open = None
+        for w in works:
+            w.wait()
+        main.wait_stream(self._comm)
+        flat.mul_(1.0 / self.world)
 
     def attach_discriminator(self, discriminator: nn.Module) -> None:
         """Discriminator: identical initial weights AND spectral-norm power-iteration vectors `weight_u` / `weight_v`

@@ -73,6 +73,40 @@ def test_two_rank_dp_matches_single_process():
     assert rel < 1e-5, rel                    # fp32: mean of two half-batch gradients == whole-batch gradient
 
 
+def test_grad_ready_events_fire_after_their_range_is_final():
+    """resr_generator_backward's grad_ready_events: a side stream that waits for event i and copies arena range i must see the
+    FINAL gradients of that range (that is what lets the all-reduce of a bucket run under the rest of the backward pass), the
+    ranges tile the arena in backward order, and the gradients equal those of a backward without events."""
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(0)
+    g = R.Generator(3, 3, 4, precision="fast", n_blocks=3).cuda()
+    lr, hr = _data()
+    (g(lr.cuda()) - hr.cuda()).abs().mean().mul(1024.0).backward()
+    torch.cuda.synchronize()
+    ref = g.flat_grad().clone()
+    ranges = g.grad_ranges()
+    assert len(ranges) == 3 + 2 and ranges[0][1] == ref.numel() and ranges[-1][0] == 0
+    assert all(ranges[i][0] == ranges[i + 1][1] for i in range(len(ranges) - 1))          # adjacent, descending
+    side = torch.cuda.Stream()
+    snap = {}
+
+    def hook(flat, rngs, events):
+        assert len(events) == len(rngs) == 5
+        for i, ((lo, hi), ev) in enumerate(zip(rngs, events)):
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                snap[i] = flat[lo:hi].clone()
+        torch.cuda.current_stream().wait_stream(side)
+    g.grad_ready_hook = hook
+    g.zero_grad(set_to_none=True)
+    g.flat_grad().zero_()
+    (g(lr.cuda()) - hr.cuda()).abs().mean().mul(1024.0).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(g.flat_grad(), ref)
+    for i, (lo, hi) in enumerate(ranges):
+        assert torch.equal(snap[i], ref[lo:hi]), i
+
+
 def _gan_setup(precision="strict"):
     import real_esrgan_pytorch_amd as R
     torch.manual_seed(0)
