@@ -148,3 +148,31 @@ def realesrnet_step(params: Dict[str, torch.Tensor], lr: torch.Tensor, hr: torch
     loss = F.l1_loss(sr, hr)
     loss.backward()
     return loss.detach(), sr.detach()
+
+
+def realesrgan_step(gparams: Dict[str, torch.Tensor], dstate: Dict[str, torch.Tensor], lr: torch.Tensor, hr: torch.Tensor,
+                    pixel_weight: float = 1.0, adversarial_weight: float = 0.1, upscale: int = 4, n_blocks: int = 23):
+    """train_realesrgan.py:459-516 on the CPU, gradients only (no optimiser): generator loss with the discriminator
+    frozen -- pixel L1 on usm_sharpener(sr) + adversarial BCE(D(sr), 1), the VGG term being detached in the reference
+    (:477-478) -- then BCE(D(hr), 1) and BCE(D(sr.detach()), 0) accumulated into the discriminator's gradients.
+    `gparams` and the non-buffer entries of `dstate` must require grad; the spectral-norm u / v of `dstate` are updated in
+    place by the three training-mode discriminator calls, as torch's hook does.  Returns the four loss values and sr."""
+    usm_k = I.usm_kernel(50, 0)
+    b, _, h, w = hr.shape
+    real, fake = torch.ones(b, 1, h, w), torch.zeros(b, 1, h, w)                         # :460-461
+    trainable = [v for k, v in dstate.items() if not (k.endswith("_u") or k.endswith("_v"))]
+    for v in trainable:                                                                    # :465-466
+        v.requires_grad_(False)
+    sr = M.generator_forward(lr, gparams, upscale, n_blocks)                               # :474
+    pixel = pixel_weight * F.l1_loss(I.usm_sharp(sr, usm_k, 0.5, 10), hr)                 # :475
+    adv = adversarial_weight * F.binary_cross_entropy_with_logits(M.discriminator_forward(sr, dstate, True), real)   # :478
+    (pixel + adv).backward()                                                               # :483
+    for v in trainable:                                                                    # :491-492
+        v.requires_grad_(True)
+        v.grad = None                                                                      # :495
+    d_hr = F.binary_cross_entropy_with_logits(M.discriminator_forward(hr, dstate, True), real)            # :499-500
+    d_hr.backward()                                                                        # :503
+    d_sr = F.binary_cross_entropy_with_logits(M.discriminator_forward(sr.detach().clone(), dstate, True), fake)   # :507-508
+    d_sr.backward()                                                                        # :513
+    return {"pixel_loss": pixel.detach(), "adversarial_loss": adv.detach(), "d_loss_hr": d_hr.detach(),
+            "d_loss_sr": d_sr.detach()}, sr.detach()

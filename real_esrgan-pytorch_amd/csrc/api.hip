@@ -3,6 +3,8 @@
 // thread-local message.  Every entry point enqueues on the caller's stream and returns.
 #include <stdarg.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -23,26 +25,30 @@ int fail(int code, const char* fmt, ...) {
 }
 
 // ---- in-situ profiling -------------------------------------------------------------------------------------
+// Launches come from the Python main thread (forward) and from autograd worker threads (backward): the record list is
+// guarded by a mutex, the switch is atomic, and the "before" event of a launch lives in the launching thread.
 namespace {
 struct ProfRec { hipEvent_t e0, e1; int id; double flop, bytes; };
 std::vector<ProfRec> g_prof;
-bool g_prof_on = false;
-hipEvent_t g_prof_e0 = nullptr;
+std::mutex g_prof_mu;
+std::atomic<bool> g_prof_on{false};
+thread_local hipEvent_t t_prof_e0 = nullptr;
 }  // namespace
-bool prof_on() { return g_prof_on; }
+bool prof_on() { return g_prof_on.load(std::memory_order_relaxed); }
 void prof_before(hipStream_t st) {
-    if (!g_prof_on) return;
-    (void)hipEventCreate(&g_prof_e0);
-    (void)hipEventRecord(g_prof_e0, st);
+    if (!prof_on()) return;
+    (void)hipEventCreate(&t_prof_e0);
+    (void)hipEventRecord(t_prof_e0, st);
 }
 void prof_after(hipStream_t st, int kernel_id, double flop, double bytes) {
-    if (!g_prof_on || !g_prof_e0) return;
+    if (!prof_on() || !t_prof_e0) return;
     ProfRec r;
-    r.e0 = g_prof_e0; r.id = kernel_id; r.flop = flop; r.bytes = bytes;
+    r.e0 = t_prof_e0; r.id = kernel_id; r.flop = flop; r.bytes = bytes;
     (void)hipEventCreate(&r.e1);
     (void)hipEventRecord(r.e1, st);
+    t_prof_e0 = nullptr;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof.push_back(r);
-    g_prof_e0 = nullptr;
 }
 
 // Every entry point runs on the device that owns the caller's stream, whatever the calling thread's current device is
@@ -308,6 +314,7 @@ int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* st
 }
 
 int resr_profile_begin(void) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof.clear();
     g_prof_on = true;
@@ -316,6 +323,7 @@ int resr_profile_begin(void) {
 
 int64_t resr_profile_end(ResrProfEntry* out, int64_t capacity) {
     g_prof_on = false;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     int64_t n = 0;
     for (auto& r : g_prof) {
         (void)hipEventSynchronize(r.e1);

@@ -12,7 +12,7 @@ Run only in the build container (needs /root/reference; stand-ins of ref_shim.py
 Weights are regenerated from a seed by oracle.model_ref.init_generator_state and loaded into the reference
 Generator with load_state_dict.
 
-    python tests/golden/gen_pipeline_golden.py        # rewrites tests/golden/pipeline_*.npz
+    python tests/golden/gen_pipeline_golden.py [pipeline|gan]   # rewrites tests/golden/pipeline_*.npz / gan_step_*.npz
 """
 import os
 import random
@@ -251,6 +251,99 @@ def run_case(seed):
                        ("conv1.weight", "trunk.11.rdb2.conv3.weight", "conv4.bias")})
 
 
+def run_gan_case(seed):
+    """One batch through the reference's RealESRGAN `train()` (train_realesrgan.py:282-553) on the CPU: the LR/HR pair its
+    degradation produced, SR, the four loss values, the gradient norms of every generator and discriminator tensor, and the
+    spectral-norm vectors after the step's three discriminator calls.  The VGG19 criterion is a stand-in returning zeros
+    (torchvision and its weights are absent; in the reference the term is detached anyway, :477-478)."""
+    _load_train_module()
+    T = ref_shim.load("train_realesrgan")
+    cfg, ip = T.config, T.imgproc
+    cfg.device = torch.device("cpu")
+    cfg.image_size, cfg.upscale_factor, cfg.print_frequency = CROP, 4, 1000
+    cfg.pixel_weight, cfg.content_weight, cfg.adversarial_weight = 1.0, [0.1, 0.1, 1.0, 1.0, 1.0], 0.1     # config.py:135-138
+    gen = torch.Generator().manual_seed(2000 + seed)
+    base = torch.rand(BATCH, 3, HR_SIZE // 8, HR_SIZE // 8, generator=gen)
+    hr = torch.nn.functional.interpolate(base, size=(HR_SIZE, HR_SIZE), mode="bicubic").clamp(0, 1)
+    hr = torch.round((0.85 * hr + 0.15 * torch.rand(BATCH, 3, HR_SIZE, HR_SIZE, generator=gen)) * 255) / 255
+    random.seed(700 + seed)
+    np.random.seed(700 + seed)
+    ks = [I.sample_sample_kernels(cfg.degradation_model_parameters_dict) for _ in range(BATCH)]
+    batch = {"hr": hr.clone(), "kernel1": torch.from_numpy(np.stack([k[0] for k in ks])).float(),
+             "kernel2": torch.from_numpy(np.stack([k[1] for k in ks])).float(),
+             "sinc_kernel": torch.from_numpy(np.stack([k[2] for k in ks])).float()}
+    gsd = M.init_generator_state(60 + seed, 3, 3, 4, bias_noise=0.02)
+    gsd["conv4.bias"] = gsd["conv4.bias"] + 0.5
+    dsd = M.init_discriminator_state(80 + seed)
+    g = T.Generator(3, 3, 4)
+    g.load_state_dict(gsd)
+    d = T.Discriminator()
+    d.load_state_dict(dsd)
+    ema = T.EMA(g, 0.999)
+    ema.register()
+    g_opt = torch.optim.Adam(g.parameters(), 1e-4, (0.9, 0.99))
+    d_opt = torch.optim.Adam(d.parameters(), 1e-4, (0.9, 0.99))
+    pixel, adv = torch.nn.L1Loss(), torch.nn.BCEWithLogitsLoss()
+    rec = {"adv": []}
+
+    class ZeroContent(torch.nn.Module):
+        def forward(self, sr, hr_):
+            return (0.0, 0.0, 0.0, 0.0, 0.0)
+
+    orig_crop, orig_jpeg = ip.random_crop, ip.DiffJPEG.forward
+
+    def w_crop(lr_, hr_, size, up):
+        a, b = orig_crop(lr_, hr_, size, up)
+        rec["lr"], rec["hr_crop"] = a.detach().clone(), b.detach().clone()
+        return a, b
+
+    def w_jpeg(self, x, quality):
+        return orig_jpeg(self, x, quality).contiguous()      # see run_case
+
+    real_g = g.forward
+
+    def g_forward(x):
+        y = real_g(x)
+        rec["sr"] = y.detach().clone()
+        return y
+    g.forward = g_forward
+    real_pixel, real_adv = pixel.forward, adv.forward
+
+    def pixel_forward(a, b):
+        v = real_pixel(a, b)
+        rec["pixel"] = v.detach().clone()
+        return v
+
+    def adv_forward(a, b):
+        v = real_adv(a, b)
+        rec["adv"].append(v.detach().clone())
+        return v
+    pixel.forward, adv.forward = pixel_forward, adv_forward
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    ip.random_crop, ip.DiffJPEG.forward = w_crop, w_jpeg
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            T.train(d, g, ema, _OneBatch(batch), pixel, ZeroContent(), adv, d_opt, g_opt, 0, T.amp.GradScaler(), _Writer())
+    finally:
+        ip.random_crop, ip.DiffJPEG.forward = orig_crop, orig_jpeg
+    assert len(rec["adv"]) == 3
+    out = {"seed": seed, "lr": rec["lr"], "hr_crop": rec["hr_crop"], "sr": rec["sr"], "pixel_loss": rec["pixel"],
+           "adversarial_loss": 0.1 * rec["adv"][0], "d_loss_hr": rec["adv"][1], "d_loss_sr": rec["adv"][2],
+           "g_grad_norms": torch.stack([p.grad.norm() for p in g.parameters()]),
+           "d_grad_norms": torch.stack([p.grad.norm() for p in d.parameters()])}
+    for k, v in d.state_dict().items():
+        if k.endswith("weight_u") or k.endswith("weight_v"):
+            out["uv_" + k] = v.clone()
+    dn = dict(d.named_parameters())
+    for k in ("conv1.weight", "conv3.0.weight_orig", "conv4.bias"):
+        out["dg_" + k] = dn[k].grad.clone()
+    return out
+
+
 def describe(host):
     """The loop body's host decisions in plan form (same fields as degrade.DegradationPlan)."""
     it = iter(host)
@@ -331,5 +424,16 @@ def main():
         print("   stored:", sorted(k for k in out if k.startswith("t_")))
 
 
+def main_gan():
+    case = run_gan_case(5)
+    out = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in case.items()}
+    path = os.path.join(HERE, "gan_step_seed5.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), {k: float(out[k]) for k in ("pixel_loss", "adversarial_loss", "d_loss_hr", "d_loss_sr")})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) < 2 or sys.argv[1] == "pipeline":
+        main()
+    if len(sys.argv) < 2 or sys.argv[1] == "gan":
+        main_gan()

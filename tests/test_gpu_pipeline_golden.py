@@ -136,3 +136,46 @@ def test_realesrnet_step_matches_reference(precision):
         gref = torch.from_numpy(z["g_" + k])
         got = dict(g.named_parameters())[k].grad.cpu() / scale
         assert ((got - gref).norm() / gref.norm()).item() < 1e-3, k
+
+
+@pytest.mark.parametrize("precision", ["strict", "exact16"])
+def test_realesrgan_step_matches_reference(precision):
+    """train.RealESRGANStep (generator update with the discriminator frozen, USM on sr, three discriminator calls;
+    train_realesrgan.py:459-521) on the LR/HR pair of tests/golden/gan_step_seed5.npz against the values the reference's own
+    train() produced: the four losses, SR, every gradient norm of both networks and the spectral-norm vectors afterwards."""
+    import real_esrgan_pytorch_amd as R
+    from oracle import model_ref as M
+    from real_esrgan_pytorch_amd.train import RealESRGANStep
+    z = np.load(os.path.join(HERE, "golden", "gan_step_seed5.npz"))
+    seed = int(z["seed"])
+    gsd = M.init_generator_state(60 + seed, 3, 3, 4, bias_noise=0.02)
+    gsd["conv4.bias"] = gsd["conv4.bias"] + 0.5
+    g = R.Generator(3, 3, 4, precision=precision)
+    g.load_state_dict(gsd)
+    g = g.cuda().train()
+    d = R.Discriminator(precision="strict")          # the discriminator has the f16 and f32 modes
+    d.load_state_dict(M.init_discriminator_state(80 + seed))
+    d = d.cuda().train()
+    ema = R.EMA(g, 0.999)
+    ema.register()
+    scaler = None
+    if precision != "strict":                        # exact16 keeps gradients as f16 pairs: a fixed loss scale like GradScaler's
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=10 ** 9)
+    step = RealESRGANStep(g, d, ema, torch.optim.SGD(g.parameters(), 0.0), torch.optim.SGD(d.parameters(), 0.0), scaler=scaler)
+    out = step(torch.from_numpy(z["hr_crop"]).cuda(), torch.from_numpy(z["lr"]).cuda())
+    torch.cuda.synchronize()
+    for k in ("pixel_loss", "adversarial_loss", "d_loss_hr", "d_loss_sr"):
+        assert abs(out[k].item() - float(z[k])) < 1e-5, (k, out[k].item(), float(z[k]))
+    gn = torch.stack([p.grad.norm() for p in g.parameters()]).cpu()
+    dn = torch.stack([p.grad.norm() for p in d.parameters()]).cpu()
+    rg, rd = torch.from_numpy(z["g_grad_norms"]), torch.from_numpy(z["d_grad_norms"])
+    assert ((gn - rg).abs() / rg.clamp_min(1e-12)).max().item() < 5e-3
+    assert ((dn - rd).abs() / rd.clamp_min(1e-12)).max().item() < 5e-3
+    sd = d.state_dict()
+    for k in z.files:
+        if k.startswith("uv_"):
+            assert torch.allclose(sd[k[3:]].cpu(), torch.from_numpy(z[k]), atol=1e-5), k
+        if k.startswith("dg_"):
+            ref = torch.from_numpy(z[k])
+            got = dict(d.named_parameters())[k[3:]].grad.cpu()
+            assert ((got - ref).norm() / ref.norm()).item() < 2e-3, k

@@ -96,3 +96,46 @@ def test_oracle_realesrnet_step_matches_reference(path):
     for k in ("conv1.weight", "trunk.11.rdb2.conv3.weight", "conv4.bias"):
         g = torch.from_numpy(z["g_" + k])
         assert ((params[k].grad - g).norm() / g.norm()).item() < 1e-4, k
+
+
+def test_oracle_gan_step_matches_reference():
+    """The oracle's RealESRGAN step (oracle/degrade_ref.py:realesrgan_step) against the reference's own `train()` of
+    train_realesrgan.py executed for one batch (tests/golden/gan_step_seed5.npz): the four losses, SR, the gradient norm of
+    every generator / discriminator tensor and the spectral-norm vectors after the step's three discriminator calls."""
+    z = np.load(os.path.join(HERE, "golden", "gan_step_seed5.npz"))
+    seed = int(z["seed"])
+    gsd = M.init_generator_state(60 + seed, 3, 3, 4, bias_noise=0.02)
+    gsd["conv4.bias"] = gsd["conv4.bias"] + 0.5
+    dsd = M.init_discriminator_state(80 + seed)
+    gp = {k: v.clone().requires_grad_(True) for k, v in gsd.items()}
+    dp = {k: v.clone() for k, v in dsd.items()}
+    for k in dp:
+        if not (k.endswith("_u") or k.endswith("_v")):
+            dp[k].requires_grad_(True)
+    losses, sr = D.realesrgan_step(gp, dp, torch.from_numpy(z["lr"]), torch.from_numpy(z["hr_crop"]))
+    for k, v in losses.items():
+        assert abs(v.item() - float(z[k])) < 2e-6, (k, v.item(), float(z[k]))
+    assert (sr - torch.from_numpy(z["sr"])).abs().max().item() < 1e-5
+    gn = torch.stack([gp[k].grad.norm() for k in gsd])
+    ref = torch.from_numpy(z["g_grad_norms"])
+    assert ((gn - ref).abs() / ref.clamp_min(1e-12)).max().item() < 2e-3
+    dkeys = [k for k in dsd if not (k.endswith("_u") or k.endswith("_v"))]
+    dn = torch.stack([dp[k].grad.norm() for k in _ref_param_order(dkeys)])
+    ref = torch.from_numpy(z["d_grad_norms"])
+    assert dn.shape == ref.shape and ((dn - ref).abs() / ref.clamp_min(1e-12)).max().item() < 2e-3
+    for k in z.files:
+        if k.startswith("uv_"):
+            assert torch.allclose(dp[k[3:]], torch.from_numpy(z[k]), atol=2e-6), k
+        if k.startswith("dg_"):
+            g = torch.from_numpy(z[k])
+            assert ((dp[k[3:]].grad - g).norm() / g.norm()).item() < 1e-4, k
+
+
+def _ref_param_order(keys):
+    """named_parameters() order of the reference Discriminator (model.py:136-175): a spectral-norm conv registers its
+    `weight_orig` where `weight` stood, biases follow weights."""
+    order = ["conv1.weight", "conv1.bias", "down_block1.0.weight_orig", "down_block2.0.weight_orig", "down_block3.0.weight_orig",
+             "up_block1.0.weight_orig", "up_block2.0.weight_orig", "up_block3.0.weight_orig", "conv2.0.weight_orig",
+             "conv3.0.weight_orig", "conv4.weight", "conv4.bias"]
+    assert sorted(order) == sorted(keys), (order, keys)
+    return order
