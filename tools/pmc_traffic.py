@@ -12,9 +12,10 @@ import sys
 
 
 def short(name):
-    m = re.search(r"conv3x3_ws_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)E", name)  # epilogue kinds are summed
+    m = re.search(r"conv3x3_ws_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)ELi\d+E(Lb[01]E)?", name)  # epilogue kinds are summed
     if m:
-        return f"conv3x3_ws_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'},{m.group(2)},{m.group(3)},{m.group(4)}>"
+        t = "f32" if m.group(1) != "DF16_" else ("f16x2" if m.group(5) == "Lb1E" else "f16")
+        return f"conv3x3_ws_kernel<{t},{m.group(2)},{m.group(3)},{m.group(4)}>"
     m = re.search(r"conv3x3_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)E", name)
     if m:
         return f"conv3x3_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'},{m.group(2)},{m.group(3)},{m.group(4)}>"
@@ -34,14 +35,19 @@ def load(path, counter):
     return agg
 
 
-fetch = load(sys.argv[1], "FETCH_SIZE")
-write = load(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in fetch:
-    if k not in write:
-        continue
-    f = sum(fetch[k]) / len(fetch[k]) * 1024 * 2      # KiB -> B, x2 gfx950 correction for wide reads
-    w = sum(write[k]) / len(write[k]) * 1024
-    out[k] = {"launches": len(fetch[k]), "read_bytes_per_launch": round(f), "write_bytes_per_launch": round(w),
-              "hbm_bytes_per_launch": round(f + w)}
-print(json.dumps(out, indent=1))
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in fetch:
+        if k not in write:
+            continue
+        f = sum(fetch[k]) / len(fetch[k]) * 1024 * 2      # KiB -> B, x2 gfx950 correction for wide reads
+        w = sum(write[k]) / len(write[k]) * 1024
+        out[k] = {"launches": len(fetch[k]), "read_bytes_per_launch": round(f), "write_bytes_per_launch": round(w),
+                  "hbm_bytes_per_launch": round(f + w)}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
