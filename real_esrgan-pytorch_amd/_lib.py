@@ -28,7 +28,9 @@ class ConvDesc(C.Structure):
                 ("in0_chunk_stride", C.c_int32), ("in1_chunk_stride", C.c_int32), ("out_chunk_stride", C.c_int32),
                 ("res0_chunk_stride", C.c_int32), ("res1_chunk_stride", C.c_int32), ("mask_chunk_stride", C.c_int32),
                 ("in0_lo_offset", C.c_int64), ("in1_lo_offset", C.c_int64), ("out_lo_offset", C.c_int64),
-                ("res0_lo_offset", C.c_int64), ("res1_lo_offset", C.c_int64)]
+                ("res0_lo_offset", C.c_int64), ("res1_lo_offset", C.c_int64),
+                ("s2d_in_channels", C.c_int32), ("s2d_out_channels", C.c_int32), ("cout_groups", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 class WgradDesc(C.Structure):

@@ -28,6 +28,13 @@ struct ConvArgs {
     // RESR_F16X2: byte offsets hi -> lo of the two input segments, element offsets hi -> lo of out / residuals
     size_t in0_lo_b, in1_lo_b;
     long out_lo, res0_lo, res1_lo;
+    // sparse taps of a 4x4 / stride-2 convolution run over the space-to-depth image (conv3x3_ws.h, SP): channels per
+    // sub-position of the input (forward), sub-position of this launch's output group (backward-data)
+    int s2d_c, tap_c;
+    // output groups per launch (cout 64 shape): group g reads its packed weights at w + g * w_group_b and writes / reads
+    // its epilogue operands 64 channels further inside the pixel; no bias, no sign-bit tensors, NHWC output
+    int ngroups;
+    size_t w_group_b;
     const char* zero;  // 16 zero bytes in device memory (source of out-of-image LDS-DMA lanes)
     unsigned long long* trace;  // debug: per-workgroup s_memrealtime stamps (resr_debug_conv_trace), else null
 };

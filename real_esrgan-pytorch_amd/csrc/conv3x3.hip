@@ -336,6 +336,25 @@ int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, co
     a.out_chunk = chunk(d->out_chunk_stride); a.res0_chunk = chunk(d->res0_chunk_stride);
     a.res1_chunk = chunk(d->res1_chunk_stride); a.mask_chunk = chunk(d->mask_chunk_stride);
     a.flags = d->flags; a.s0 = d->s0; a.t0 = d->t0; a.s1 = d->s1; a.t1 = d->t1; a.slope = d->slope;
+    a.s2d_c = 0; a.tap_c = 0; a.ngroups = 1; a.w_group_b = 0;
+    const int groups = d->cout_groups > 1 ? d->cout_groups : 1;
+    if (groups > 1) {
+        if (d->dtype != RESR_F16 || d->cout != 64 || d->cout_pad != 64 || bias || in1 ||
+            (d->flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_WRITE_SIGNBITS | RESR_CONV_MASK_BITS | RESR_CONV_CLAMP01)) || !(d->flags & RESR_CONV_NO_BIAS))
+            return fail(RESR_ERR_ARG, "conv3x3: cout_groups > 1 needs f16, cout = cout_pad = 64 per group, no bias, NHWC output, no sign-bit tensors");
+        a.ngroups = groups;
+        a.w_group_b = (size_t)(d->cin / 32) * 9 * 2 * 1024 * es;
+    }
+    if (d->s2d_in_channels > 0) {
+        if ((d->s2d_in_channels & 31) || d->cin != 4 * d->s2d_in_channels)
+            return fail(RESR_ERR_ARG, "conv3x3: s2d_in_channels=%d must be a multiple of 32 with cin = 4 * s2d_in_channels", d->s2d_in_channels);
+        a.s2d_c = d->s2d_in_channels;
+    }
+    if (d->s2d_out_channels > 0) {
+        if ((d->s2d_out_channels & 63) || d->s2d_in_channels > 0 || groups * 64 != 4 * d->s2d_out_channels)
+            return fail(RESR_ERR_ARG, "conv3x3: s2d_out_channels=%d needs cout_groups * 64 = 4 * s2d_out_channels", d->s2d_out_channels);
+        a.tap_c = d->s2d_out_channels;
+    }
     const int mt = d->cout_pad / 32;
     if (d->dtype == RESR_F16X2) {
         // hi/lo pairs: only the producer/consumer kernel has the mode
@@ -357,6 +376,7 @@ int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, co
     if (d->dtype == RESR_F16) {
         static const char* old_env = getenv("RESR_CONV_ONE_ROLE");  // test knob: fast mode on the one-role kernel below
         if (!old_env && conv3x3_ws_supported(a)) return conv3x3_ws_f16(a, mt, false, stream);
+        if (groups > 1) return fail(RESR_ERR_ARG, "conv3x3: cout_groups > 1 needs the producer/consumer kernel's preconditions");
         // measured on MI355X (B=8, 256^2): cout 32 -> 8 waves x 2 rows (4 waves/SIMD, 2 workgroups/CU) beats
         // 4 waves x 4 rows by 5-16 %; cout 64 -> 4 waves x 2 rows (2 waves/SIMD) beats every 8-wave shape
         if (mt == 1) return big ? launch_conv<half_t, 1, 2, 8>(a, stream) : launch_conv<half_t, 1, 2, 4>(a, stream);

@@ -105,7 +105,14 @@ __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
 // (x_hi, W1 = remainder of W0), (x_lo, W2 = f16(w)) with x_lo stored times 2^12 -- accumulated into the same fp32
 // registers; the packed weights are laid out in that stage order, so only the producers' chunk -> address map and the
 // epilogue (descale, hi/lo split of the result, hi + lo residuals) know about the mode.
-template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false>
+//
+// SP (sparse taps): the discriminator's 4x4 / stride-2 convolutions (model.py:140-152) run as 3x3 convolutions over the
+// 2x2 space-to-depth image with a "virtual" kernel (pack.hip); of the 9 taps of a 32-channel chunk only 2 x 2 are
+// non-zero -- which ones depends on the chunk's sub-position (i, j) in the 2x2 cell.  SP = 1 (forward: the INPUT is the
+// space-to-depth image, sub-position per input chunk = chunk*32 / a.s2d_c) and SP = 2 (backward-data: the OUTPUT group
+// of this launch lies in sub-position a.tap_sub, taps flipped) skip the other 5 taps: 16 instead of 36 tap-products, the
+// FLOPs of the dense 4x4 kernel.  Same tiles, buffers and barrier protocol as the dense loop.
+template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0>
 __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCfg<T, MT, NT, NWC>::NP) / 4) void conv3x3_ws_kernel(const ConvArgs a) {
     using C = WsCfg<T, MT, NT, NWC>;
     constexpr int SPP = C::SPP, KS = C::KS, PB = C::PB, TH = C::TH, TW = C::TW, HW = C::HW, BUF = C::BUF;
@@ -115,7 +122,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntiles = a.tiles_x * a.tiles_y * a.n;
+    // Output groups: a launch may cover a.ngroups consecutive 64-channel output groups of one convolution (the
+    // discriminator's 128..512-channel layers at 32^2..128^2 pixels would otherwise be one under-filled launch per group);
+    // tile index = group * spatial tiles + spatial tile, each group with its own packed weights (cout 64 shape only).
+    const int ntiles_sp = a.tiles_x * a.tiles_y * a.n;
+    const int ntiles = ntiles_sp * (MT == 2 ? a.ngroups : 1);
     const int G = gridDim.x;
     const int first = xcd_remap(blockIdx.x, G);
     const int nchunks = X2 ? 3 * (a.cin >> 5) : a.cin >> 5;   // stages per tile
@@ -288,8 +299,9 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         // every launch: the memory latency runs under the rest of the math instead of after it).
         unsigned cst[NIP], pix[NIP], pixn[NIP];
         {
-            const int tx = first % a.tiles_x;
-            const int t2 = first / a.tiles_x;
+            const int fsp = first % ntiles_sp;
+            const int tx = fsp % a.tiles_x;
+            const int t2 = fsp / a.tiles_x;
             const int ty = t2 % a.tiles_y;
             const int n = t2 / a.tiles_y;
             const int x0 = tx * TW - 1, y0 = ty * TH - 1;
@@ -313,19 +325,20 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             }
         }
         const unsigned wdst0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + C::WOFF);
-        auto stage_weights = [&](int ck, int par) {   // chunk ck's packed weights, lane-linear = fragment order
-            const char* wbase = a.w + (size_t)ck * C::WBUF;
+        auto stage_weights = [&](int tile, int ck, int par) {   // chunk ck's packed weights of the tile's output group, lane-linear = fragment order
+            const char* wbase = a.w + (size_t)(tile / ntiles_sp) * a.w_group_b + (size_t)ck * C::WBUF;
 #pragma unroll
             for (int i = 0; i < C::NWIP; ++i) {
                 const int idx = i * NP + pw;
                 if (idx < C::NWI) conv_glds16_s(wbase, (unsigned)(idx * 1024) + ((unsigned)lane << 4), wdst0 + par * C::WBUF + idx * 1024);
             }
         };
-        if (first < ntiles) stage_weights(0, 0);
+        if (first < ntiles) stage_weights(first, 0, 0);
         // source pixel index per slot (< 2^24, host-checked); ~0u = zero (padding / outside the image)
         auto tile_pix = [&](int tile, unsigned (&pix)[NIP]) {
-            const int tx = tile % a.tiles_x;
-            const int t2 = tile / a.tiles_x;
+            const int tsp = tile % ntiles_sp;
+            const int tx = tsp % a.tiles_x;
+            const int t2 = tsp / a.tiles_x;
             const int ty = t2 % a.tiles_y;
             const int n = t2 / a.tiles_y;
             const int x0 = tx * TW - 1, y0 = ty * TH - 1;
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         };
         int par = 0;
         int nstage = 0;   // index of the stage this iteration requests
-        const bool wres2 = nchunks <= C::NWB;
+        const bool wres2 = nchunks <= C::NWB && ntiles == ntiles_sp;   // resident weights need one output group per launch
         for (int tile = first; tile < ntiles; tile += G) {
             stamp(0);
             for (int ck = 0; ck < nchunks; ++ck) {
@@ -362,8 +375,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             conv_glds16_s(a.zero, 0u, ldst);
                         }
                     }
-                    if (!wres2) stage_weights(ck, par);                    // ring of two by stage parity
-                    else if (nstage < nchunks) stage_weights(ck, ck);    // resident: buffer = chunk, first tile only
+                    if (!wres2) stage_weights(tile, ck, par);                    // ring of two by stage parity
+                    else if (nstage < nchunks) stage_weights(tile, ck, ck);    // resident: buffer = chunk, first tile only
                 }
                 par ^= 1;
                 ++nstage;
@@ -433,7 +446,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             asm volatile("s_barrier" ::: "memory");
             if (wave == 0) stamp(1);
             const char* lbuf = smem + hbc * BUF;
-            const int wsel = nchunks <= C::NWB ? ck : par;   // resident weights: buffer = chunk; else the ring of two
+            const int wsel = (nchunks <= C::NWB && ntiles == ntiles_sp) ? ck : par;   // resident weights: buffer = chunk; else the ring of two
             // halo rows of group gi+1 are read from LDS while the MFMAs of group gi run (ping-pong registers; NG is even)
             // when the register budget allows (PP); otherwise each group reads its own rows first
             constexpr int PP = (NWC == 4 || MT * NT * 16 + (NT + 2) * 8 <= 112) ? 1 : 0;   // 4-consumer shapes have a 256-register budget
@@ -443,6 +456,60 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                 for (int r = 0; r < NT + 2; ++r) rowf[slot][r] = *reinterpret_cast<const uint4*>(bp + r * (HW * PB));
             };
+            if constexpr (SP != 0) {
+                // ---- sparse taps: valid dy in {dy0, dy0+1}, valid dx in {dx0, dx0+1}; rows dy0 .. dy0+NT; 2*KS groups ----
+                const int sub = SP == 1 ? ((X2 ? ck / 3 : ck) * 32) / a.s2d_c : ((tile / ntiles_sp) * 64) / a.tap_c;   // wave-uniform
+                auto sparse_stage = [&](auto si_c, auto sj_c) {
+                    constexpr int SI = decltype(si_c)::value, SJ = decltype(sj_c)::value;
+                    // forward: ky = 2*ty + i - 1 in [0,4)  ->  i = 0: ty in {1,2}, i = 1: ty in {0,1}; backward-data uses the
+                    // flipped taps (pack.hip: t = 8 - tap)  ->  i = 0: {0,1}, i = 1: {1,2}
+                    constexpr int dy0 = SP == 1 ? (SI == 0 ? 1 : 0) : (SI == 0 ? 0 : 1);
+                    constexpr int dx0 = SP == 1 ? (SJ == 0 ? 1 : 0) : (SJ == 0 ? 0 : 1);
+                    constexpr int NGS = 2 * KS;
+                    uint4 rows[2][NT + 1], wq[2][MT];
+                    auto rl = [&](int slot, int g) {          // g = ks * 2 + dxi
+                        const char* bp = lbuf + boff[dx0 + (g & 1)][g >> 1] + dy0 * (HW * PB);
+#pragma unroll
+                        for (int r = 0; r < NT + 1; ++r) rows[slot][r] = *reinterpret_cast<const uint4*>(bp + r * (HW * PB));
+                    };
+                    auto wl = [&](int slot, int g, int dyi) {
+                        const int ks = g >> 1, dx = dx0 + (g & 1), dy = dy0 + dyi;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            wq[slot][m] = *reinterpret_cast<const uint4*>(wlds + wsel * C::WBUF + (((dy * 3 + dx) * KS + ks) * MT + m) * 1024);
+                    };
+                    rl(0, 0);
+                    wl(0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NGS; ++g) {
+                        if (g + 1 < NGS) rl((g + 1) & 1, g + 1);
+#pragma unroll
+                        for (int dyi = 0; dyi < 2; ++dyi) {
+                            const int u = g * 2 + dyi;
+                            if (u + 1 < NGS * 2) wl((u + 1) & 1, (u + 1) >> 1, (u + 1) & 1);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                for (int m = 0; m < MT; ++m)
+                                    acc[m][t] = Frag<T>::mma(wq[u & 1][m], rows[g & 1][t + dyi], acc[m][t]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                };
+                using I0 = std::integral_constant<int, 0>;
+                using I1 = std::integral_constant<int, 1>;
+                switch (sub) {
+                    case 0: sparse_stage(I0{}, I0{}); break;
+                    case 1: sparse_stage(I0{}, I1{}); break;
+                    case 2: sparse_stage(I1{}, I0{}); break;
+                    default: sparse_stage(I1{}, I1{}); break;
+                }
+                par ^= 1;
+                hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;
+                if (wave == 0) stamp(1);
+                continue;
+            }
             // the stage's weights are in LDS once the barrier is passed: no prefetch across stages
 #pragma unroll
             for (int u = 0; u < RING - 1; ++u) wload(u, wsel, u);
@@ -470,9 +537,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         }
 
         // ---- epilogue: lane owns pixel (row0+t, lx) and 4 consecutive couts per accumulator quad ----
-        const int x0 = (tile % a.tiles_x) * TW;
-        const int y0 = ((tile / a.tiles_x) % a.tiles_y) * TH;
-        const int n = tile / (a.tiles_x * a.tiles_y);
+        const int tsp = tile % ntiles_sp;
+        const size_t goff = (size_t)(tile / ntiles_sp) * 64;   // element offset of the tile's output group inside a pixel
+        const int x0 = (tsp % a.tiles_x) * TW;
+        const int y0 = ((tsp / a.tiles_x) % a.tiles_y) * TH;
+        const int n = tsp / (a.tiles_x * a.tiles_y);
         // The epilogue's arguments and per-lane indices are re-read / re-derived per tile through opaque copies:
         // hoisted out of the tile loop they would sit in registers across the MFMA loop.
         typedef const ConvArgs __attribute__((address_space(4))) * KernargPtr;
@@ -533,7 +602,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         };
         // element offset of piece (m, j) inside a pixel of an operand with chunk stride cs (clamped when beyond cout)
         auto poff = [&](int m, int j, int cs) {
-            return m * 32 + (2 * j + kh_e) * 8 < e.cout ? (size_t)m * cs + (2 * j + kh_e) * 8 : (size_t)0;
+            return goff + (m * 32 + (2 * j + kh_e) * 8 < e.cout ? (size_t)m * cs + (2 * j + kh_e) * 8 : (size_t)0);
         };
         auto request = [&](int b, size_t p, int m, int j0) {
             if (EMB) {
@@ -684,7 +753,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     }
 }
 
-template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false>
+template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0>
 static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     using C = WsCfg<T, MT, NT, NWC>;
     ConvArgs args = a;
@@ -700,12 +769,12 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     int& resident = resident_dev[cur_dev];
     const char*& zero = zero_dev[cur_dev];
     if (!resident) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2, SP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int per_cu = 0;
         hipDeviceProp_t prop;
         void* zp = nullptr;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2>, C::NTHR, lds) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2, SP>, C::NTHR, lds) != hipSuccess ||
             hipGetDeviceProperties(&prop, cur_dev) != hipSuccess || per_cu <= 0 ||
             hipGetSymbolAddress(&zp, HIP_SYMBOL(g_conv_zero16)) != hipSuccess || !zp)
             return fail(RESR_ERR_LAUNCH, "conv3x3: occupancy / zero-page query failed");
@@ -715,11 +784,13 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     }
     args.zero = zero;
     args.trace = g_conv_trace;
-    const int ntiles = args.tiles_x * args.tiles_y * a.n;
+    const int ntiles = args.tiles_x * args.tiles_y * a.n * (MT == 2 && a.ngroups > 1 ? a.ngroups : 1);
     const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
     prof_before(stream);
-    hipLaunchKernelGGL((conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2>), dim3(grid), dim3(C::NTHR), lds, stream, args);
-    prof_after(stream, (X2 ? 25000 : 20000) + MT * 100 + NT * 10 + NWC, 2.0 * 9 * a.cin * a.cout * (double)a.n * a.h * a.w_,
+    hipLaunchKernelGGL((conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2, SP>), dim3(grid), dim3(C::NTHR), lds, stream, args);
+    // sparse-tap launches count the 16 real tap-products of the 4x4 kernel (4 of 9 taps per chunk)
+    prof_after(stream, (X2 ? 25000 : 20000) + (SP ? 2000 : 0) + MT * 100 + NT * 10 + NWC,
+               2.0 * (SP ? 4 : 9) * a.cin * a.cout * (a.ngroups > 1 ? a.ngroups : 1) * (double)a.n * a.h * a.w_,
                conv_algorithmic_bytes(a, sizeof(T) * (X2 ? 2 : 1)));
     RESR_CHECK_LAUNCH("conv3x3_ws_kernel");
     return RESR_OK;

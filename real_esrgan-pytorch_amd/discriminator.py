@@ -175,13 +175,28 @@ class Discriminator(nn.Module):
     def _new(self, n, h, w, c):
         return torch.empty((n, h, w, c), dtype=self._T(), device=self._flat.device)
 
-    def _conv(self, packed, groups, x, cin_pad, n, h, w, cout, out, flags=0, bias=None, res0=None, mask=None, aux=None):
-        """3x3 conv of NHWC `x` (first cin_pad channels) into NHWC `out` ([..., C_out_total]) in 64-channel groups."""
+    def _conv(self, packed, groups, x, cin_pad, n, h, w, cout, out, flags=0, bias=None, res0=None, mask=None, aux=None,
+              s2d_in=0, s2d_out=0):
+        """3x3 conv of NHWC `x` (first cin_pad channels) into NHWC `out` ([..., C_out_total]) in 64-channel groups.
+        s2d_in = C: `x` is a space-to-depth image with C channels per sub-position (a 4x4 / stride-2 conv, forward);
+        s2d_out = C: `out` is the gradient of one (backward-data of such a conv) -- the kernel then skips the virtual
+        kernel's zero taps (16 tap-products instead of 36)."""
         L, lib = _lib, _lib.lib()
         es = x.element_size()
         cout_pad_total = _r32(cout)
         st = _lib.stream_ptr(x)
         nchw = bool(flags & L.CONV_OUT_NCHW_F32)
+        if (len(groups) > 1 and self._dtype == L.RESR_F16 and cout == 64 * len(groups) and bias is None and not nchw
+                and (flags & L.CONV_NO_BIAS)):
+            # all 64-channel output groups of the layer in ONE launch (they would each under-fill the GPU at 32^2..128^2 pixels)
+            d = L.ConvDesc(n, h, w, cin_pad, cin_pad, x.shape[-1], 0, 64, 64, out.shape[-1],
+                           res0.shape[-1] if res0 is not None else 0, 0, mask.shape[-1] if mask is not None else 0,
+                           self._dtype, flags, 1.0, 1.0, 1.0, 1.0, SLOPE)
+            d.cout_groups = len(groups)
+            d.s2d_in_channels, d.s2d_out_channels = s2d_in, s2d_out
+            L.check(lib.resr_conv3x3(C.byref(d), L.ptr(x), None, C.c_void_p(packed.data_ptr() + groups[0][0] * es), None,
+                                     L.ptr(res0), None, L.ptr(mask), L.ptr(out), L.ptr(aux), st), "resr_conv3x3")
+            return
         for gi, (off, mt) in enumerate(groups):
             g0 = gi * 64
             co = max(0, min(mt * 32, cout - g0))
@@ -190,6 +205,7 @@ class Discriminator(nn.Module):
             d = L.ConvDesc(n, h, w, cin_pad, cin_pad, x.shape[-1], 0, co, mt * 32, 0 if nchw else out.shape[-1],
                            res0.shape[-1] if res0 is not None else 0, 0, mask.shape[-1] if mask is not None else 0,
                            self._dtype, flags, 1.0, 1.0, 1.0, 1.0, SLOPE)
+            d.s2d_in_channels = s2d_in
             sh = lambda t: None if t is None else C.c_void_p(t.data_ptr() + g0 * t.element_size())
             L.check(lib.resr_conv3x3(C.byref(d), L.ptr(x), None, C.c_void_p(packed.data_ptr() + off * es),
                                      None if bias is None else C.c_void_p(bias.data_ptr() + g0 * 4),
@@ -271,13 +287,13 @@ class Discriminator(nn.Module):
         NB = L.CONV_NO_BIAS
         s1 = s2d(out1, S, S2, 64)
         d1 = self._new(n, H1, W1, 128)
-        self._conv(packed, P["down_block1.0"], s1, 256, n, H1, W1, 128, d1, L.CONV_LRELU | NB)
+        self._conv(packed, P["down_block1.0"], s1, 256, n, H1, W1, 128, d1, L.CONV_LRELU | NB, s2d_in=64)
         s2 = s2d(d1, H1, W1, 128)
         d2 = self._new(n, H2, W2_, 256)
-        self._conv(packed, P["down_block2.0"], s2, 512, n, H2, W2_, 256, d2, L.CONV_LRELU | NB)
+        self._conv(packed, P["down_block2.0"], s2, 512, n, H2, W2_, 256, d2, L.CONV_LRELU | NB, s2d_in=128)
         s3 = s2d(d2, H2, W2_, 256)
         d3 = self._new(n, H3, W3, 512)
-        self._conv(packed, P["down_block3.0"], s3, 1024, n, H3, W3, 512, d3, L.CONV_LRELU | NB)
+        self._conv(packed, P["down_block3.0"], s3, 1024, n, H3, W3, 512, d3, L.CONV_LRELU | NB, s2d_in=256)
         FL = L.CONV_LRELU | NB | (L.CONV_AUX_BEFORE_RES if training else 0)
         b1 = up(d3, H3, W3, 512)
         u1, a1 = self._new(n, H2, W2_, 256), (self._new(n, H2, W2_, 256) if training else None)
@@ -383,15 +399,15 @@ class Discriminator(nn.Module):
         G3 = add_mask(g_d3, None, s["d3"])
         wgrad_layer("down_block3.0", s["s3"], 1024, 1024, G3, 512, H3, W3, LI["down_block3.0"], virt_c=256)
         g_s3 = self._new(n, H3, W3, 1024)
-        self._conv(packed, B["down_block3.0"], G3, 512, n, H3, W3, 1024, g_s3, NB)
+        self._conv(packed, B["down_block3.0"], G3, 512, n, H3, W3, 1024, g_s3, NB, s2d_out=256)
         G2 = add_mask(d2s(g_s3, H2, W2_, 256), g_u1, s["d2"])
         wgrad_layer("down_block2.0", s["s2"], 512, 512, G2, 256, H2, W2_, LI["down_block2.0"], virt_c=128)
         g_s2 = self._new(n, H2, W2_, 512)
-        self._conv(packed, B["down_block2.0"], G2, 256, n, H2, W2_, 512, g_s2, NB)
+        self._conv(packed, B["down_block2.0"], G2, 256, n, H2, W2_, 512, g_s2, NB, s2d_out=128)
         G1 = add_mask(d2s(g_s2, H1, W1, 128), g_u2, s["d1"])
         wgrad_layer("down_block1.0", s["s1"], 256, 256, G1, 128, H1, W1, LI["down_block1.0"], virt_c=64)
         g_s1 = self._new(n, H1, W1, 256)
-        self._conv(packed, B["down_block1.0"], G1, 128, n, H1, W1, 256, g_s1, NB)
+        self._conv(packed, B["down_block1.0"], G1, 128, n, H1, W1, 256, g_s1, NB, s2d_out=64)
         G0 = add_mask(d2s(g_s1, S, S2, 64), g_u3, None)
         wgrad_layer("conv1", s["x_in"], 32, 3, G0, 64, S, S2, None, bias=True)
         gx = None
