@@ -253,7 +253,8 @@ int resr_bilinear_up2x(const void* src, void* dst, int32_t n, int32_t h, int32_t
 int resr_add_mask(const void* a, const void* b, const void* mask, void* out, int64_t count, int32_t dtype, float slope,
                   void* stream);
 /* torch.nn.utils.spectral_norm forward (model.py:140-168): W [rows][cols] fp32; training: one power iteration
- * updating u[rows], v[cols] in place; sigma2[0] = sigma, sigma2[1] = 1/sigma; tmp = rows+cols floats */
+ * updating u[rows], v[cols] in place; sigma2[0] = sigma, sigma2[1] = 1/sigma; tmp = rows + ceil(rows/32) * cols floats
+ * (W^T u is summed in 32-row groups, in a fixed order: bit-identical on every data-parallel rank) */
 int resr_spectral_norm(const float* w, float* u, float* v, int32_t rows, int32_t cols, int32_t training, float eps,
                        float* sigma2, float* tmp, void* stream);
 /* gradient wrt W_orig from the gradient wrt W = W_orig/sigma; tmp1 = 1 float */

@@ -218,13 +218,25 @@ int maxpool2x2_dispatch(const void* src, void* dst, int n, int ho, int wo, int c
 
 // ---- spectral norm -----------------------------------------------------------------------------------------------
 // W is [rows = cout][cols = cin*k*k] row-major fp32 (the OIHW parameter viewed as a matrix).
-__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ vraw,
+// W^T u in row groups of kSnRows: part[g][k] = sum over the group's rows of W[r][k] * u[r].  (cols / 256) x (rows / 32)
+// workgroups instead of cols / 256 (a 512 x 4608 matrix was 18 workgroups of 512 dependent loads each: 71 us); the groups
+// are summed in a fixed order by the normalisation kernel -- no atomics, so every rank computes bit-identical v.
+constexpr int kSnRows = 32;
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ part,
                                                       int rows, int cols) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= cols) return;
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += W[(size_t)r * cols + k] * u[r];
-    vraw[k] = s;
+    const int r0 = blockIdx.y * kSnRows, r1 = min(rows, r0 + kSnRows);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        s0 += W[(size_t)r * cols + k] * u[r];
+        s1 += W[(size_t)(r + 1) * cols + k] * u[r + 1];
+        s2 += W[(size_t)(r + 2) * cols + k] * u[r + 2];
+        s3 += W[(size_t)(r + 3) * cols + k] * u[r + 3];
+    }
+    for (; r < r1; ++r) s0 += W[(size_t)r * cols + k] * u[r];
+    part[(size_t)blockIdx.y * cols + k] = (s0 + s1) + (s2 + s3);
 }
 
 __device__ float block_sum(float v, float* red) {
@@ -237,12 +249,18 @@ __device__ float block_sum(float v, float* red) {
     return t;
 }
 
-// dst = src / max(||src||, eps); optionally out2[0] = dot(dst, src), out2[1] = 1 / out2[0]
-__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, float eps,
-                                                           float* __restrict__ sigma2) {
+// src = sum of `parts` consecutive [n] vectors (fixed order); dst = src / max(||src||, eps); optionally out2[0] = dot(dst, src),
+// out2[1] = 1 / out2[0].  The summed vector is written back to the first part.
+__global__ __launch_bounds__(256) void sn_normalize_kernel(float* __restrict__ src, float* __restrict__ dst, int n, float eps,
+                                                           float* __restrict__ sigma2, int parts) {
     __shared__ float red[4];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += src[i] * src[i];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float t = src[i];
+        for (int g = 1; g < parts; ++g) t += src[(size_t)g * n + i];
+        src[i] = t;
+        s += t * t;
+    }
     const float nrm = sqrtf(block_sum(s, red));
     const float inv = 1.f / fmaxf(nrm, eps);
     float d = 0.f;
@@ -280,13 +298,14 @@ __global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ u
 int spectral_norm_dispatch(const float* W, float* u, float* v, int rows, int cols, int training, float eps, float* sigma2,
                            float* tmp, hipStream_t st) {
     if (!W || !u || !v || !sigma2 || !tmp || rows <= 0 || cols <= 0) return fail(RESR_ERR_ARG, "spectral_norm: bad argument");
-    float* vraw = tmp;            // [cols]
-    float* wv = tmp + cols;       // [rows]
+    const int groups = (rows + kSnRows - 1) / kSnRows;
+    float* wv = tmp;              // [rows]
+    float* vraw = tmp + rows;     // [groups][cols] partial sums of W^T u (spectral_norm_tmp_floats)
     if (training) {               // one power iteration, u and v updated in place (torch spectral_norm, training forward)
-        hipLaunchKernelGGL(sn_wt_u_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, W, u, vraw, rows, cols);
-        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, vraw, v, cols, eps, (float*)nullptr);
+        hipLaunchKernelGGL(sn_wt_u_kernel, dim3((cols + 255) / 256, groups), dim3(256), 0, st, W, u, vraw, rows, cols);
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, vraw, v, cols, eps, (float*)nullptr, groups);
         hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, st, W, v, wv, cols);
-        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, wv, u, rows, eps, sigma2);   // sigma = u_new . (W v_new)
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, wv, u, rows, eps, sigma2, 1);   // sigma = u_new . (W v_new)
     } else {
         hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, st, W, v, wv, cols);
         hipLaunchKernelGGL(sn_dot_kernel, dim3(1), dim3(256), 0, st, u, wv, rows, sigma2);

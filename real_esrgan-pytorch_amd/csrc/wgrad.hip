@@ -556,31 +556,33 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
     }
 }
 
-// deterministic slab reduction -> OIHW fp32 gradient (+ bias gradient).  64 slab elements per workgroup, the splits dealt to
-// four thread groups (more loads in flight: the slabs of a dense block are 69 MB) and summed in a fixed order.
+// deterministic slab reduction -> OIHW fp32 gradient (+ bias gradient).  32 slab elements per workgroup, the splits dealt
+// to eight thread groups (a thread sums splits/8 slabs: the launch is latency-bound at small images -- 19 us with four
+// groups of 64 elements -- and the slabs of a full-size dense block are 69 MB) and combined in a fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
-    __shared__ float red[4][64];
+    __shared__ float red[8][32];
     const ReduceJob job = a.jobs[blockIdx.x];
-    const int e = blockIdx.y * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int e = blockIdx.y * 32 + lane;
     float s = 0.f;
     if (e < kSlab) {
         const float* p = a.partial + job.slab_off + e;
-        for (int k = g; k < a.splits; k += 4) s += p[(size_t)k * kSlab];
+        for (int k = g; k < a.splits; k += 8) s += p[(size_t)k * kSlab];
         if (job.slab_b != ~0u) {   // RESR_F16X2: the two cross products (bias sums: only the g_lo one)
             float s2 = 0.f;
             const float* pb = a.partial + job.slab_b + e;
-            for (int k = g; k < a.splits; k += 4) s2 += pb[(size_t)k * kSlab];
+            for (int k = g; k < a.splits; k += 8) s2 += pb[(size_t)k * kSlab];
             if (e < 9 * 1024) {
                 const float* pc = a.partial + job.slab_c + e;
-                for (int k = g; k < a.splits; k += 4) s2 += pc[(size_t)k * kSlab];
+                for (int k = g; k < a.splits; k += 8) s2 += pc[(size_t)k * kSlab];
             }
             s = __builtin_fmaf(s2, kLoInv, s);
         }
     }
-    red[g][threadIdx.x & 63] = s;
+    red[g][lane] = s;
     __syncthreads();
     if (g != 0 || e >= kSlab) return;
-    s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * job.scale;
+    s = (((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) + ((red[4][lane] + red[5][lane]) + (red[6][lane] + red[7][lane]))) * job.scale;
     if (e < 9 * 1024) {
         const int tap = e >> 10, co = job.co_base + ((e >> 5) & 31), ci = job.ci_base + (e & 31);
         if (co < job.cout && ci < job.cin_real) job.dw[((size_t)co * job.cin_real + ci) * 9 + tap] = s;
@@ -857,7 +859,7 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
     else if (dtype == RESR_F32) rc = launch_wgrad<float, 1>(a, nj, nr, stream);
     else return fail(RESR_ERR_ARG, "wgrad: dtype=%d", dtype);
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nr, (kSlab + 63) / 64), dim3(256), 0, stream, r);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nr, (kSlab + 31) / 32), dim3(256), 0, stream, r);
     RESR_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RESR_OK;
 }

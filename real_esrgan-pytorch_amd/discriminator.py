@@ -253,7 +253,7 @@ class Discriminator(nn.Module):
         T, dt = self._T(), self._dtype
         sn_training = self.training
         # spectral norm: power iteration (training mode), sigma per layer on the device
-        tmp = torch.empty(4608 + 512 + 8, dtype=torch.float32, device=flat.device)
+        tmp = torch.empty(512 + 16 * 4608 + 8, dtype=torch.float32, device=flat.device)   # rows + ceil(rows/32) * cols of the largest layer
         for li, (name, cin, cout, virt, sn, _b) in enumerate(_LAYERS):
             if not sn:
                 continue
