@@ -27,6 +27,8 @@ bool conv3x3_ws_supported(const ConvArgs& a) {
 // Tile height: the tallest tile (least halo, most weight reuse) that still gives every CU a workgroup; small images
 // (GAN crops, the discriminator's coarse levels) fall back to shorter tiles instead of leaving CUs idle.
 static int pick_rows(const ConvArgs& a, const int* rows, int nrows) {
+    static const char* force = getenv("RESR_CONV_TILE_ROWS");   // experiment knob: force the tile height (16 or 8)
+    if (force) return atoi(force);
     static int cus_dev[kMaxDevices] = {0};   // per device; idempotent
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;

@@ -36,6 +36,7 @@ int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*,
 size_t wgrad_batch_partial_bytes(const WgradConv*, int, int, int);
 int wgrad_batch(const WgradConv*, int, int, int, int, int, int, int, float*, hipStream_t);
 int wgrad_tile_rows(int dtype);
+int wgrad_x2_products();
 int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long);
 int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t, long);
 int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int, float, hipStream_t, long, long);
@@ -173,7 +174,7 @@ int splits_for(const Plan& p, int npairs, int h, int w) {
 
 void carve(const Plan& p, char* base, Bufs& b) {
     const size_t es = elem_size(p.d.dtype) * act_tensors(p.d.dtype);   // bytes per activation element (hi + lo)
-    const int wm = p.d.dtype == RESR_F16X2 ? 3 : 1;                     // weight-gradient jobs per product
+    const int wm = p.d.dtype == RESR_F16X2 ? 3 : 1;                     // weight-gradient jobs per product (upper bound: sizes the slab buffer)
     const size_t px = (size_t)p.d.n * p.h * p.w;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -209,12 +210,16 @@ void carve(const Plan& p, char* base, Bufs& b) {
         b.gxin = take(px * p.ci_pad * es);
         // wgrad slabs: largest batch (a dense block = 26 jobs at LR; single 64->64 convs = 4 jobs at 1x/2x/4x)
         const size_t slab = (9 * 1024 + 32) * sizeof(float);
-        size_t pb = (size_t)26 * wm * splits_for(p, 26 * wm, p.h, p.w) * slab;
-        for (int m = 1; m <= 4; m *= 2) {
-            const size_t q = (size_t)4 * wm * splits_for(p, 4 * wm, p.h * m, p.w * m) * slab;
-            if (q > pb) pb = q;
-            const size_t q2 = (size_t)2 * wm * splits_for(p, 2 * wm, p.h * m, p.w * m) * slab;
-            if (q2 > pb) pb = q2;
+        size_t pb = 0;
+        for (int k = 1; k <= wm; k += 2) {          // both weight-gradient settings of RESR_F16X2 (1 or 3 jobs per product)
+            const size_t q0 = (size_t)26 * k * splits_for(p, 26 * k, p.h, p.w) * slab;
+            if (q0 > pb) pb = q0;
+            for (int m = 1; m <= 4; m *= 2) {
+                const size_t q = (size_t)4 * k * splits_for(p, 4 * k, p.h * m, p.w * m) * slab;
+                if (q > pb) pb = q;
+                const size_t q2 = (size_t)2 * k * splits_for(p, 2 * k, p.h * m, p.w * m) * slab;
+                if (q2 > pb) pb = q2;
+            }
         }
         b.partial_bytes = pb;
         b.partial = (float*)take(b.partial_bytes);
@@ -491,7 +496,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     const size_t es = elem_size(d->dtype);
     const bool x2 = d->dtype == RESR_F16X2;
     const size_t wes = es * (x2 ? 3 : 1);
-    const int wm = x2 ? 3 : 1;
+    const int wm = x2 ? wgrad_x2_products() : 1;
     const char* pk = (const char*)packed;
     const int N = d->n, h = p.h, w = p.w;
     const int H4 = 4 * h, W4 = 4 * w, H2 = 2 * h, W2 = 2 * w;

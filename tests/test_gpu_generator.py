@@ -220,3 +220,17 @@ def test_two_backwards_accumulate():
     for name, p in g.named_parameters():
         ref = sdo[name].grad
         assert ((p.grad.cpu() - ref).norm() / ref.norm().clamp_min(1e-12)).item() < 1e-4, name
+
+
+def test_exact16_hi_only_weight_gradients_knob():
+    """RESR_X2_WGRAD_PRODUCTS=1 (weight gradients of exact16 from the hi tensors only, a third of the matrix work): the lo parts are
+    2^-12-relative rounding residues that average out over the pixels a weight gradient sums -- even on these tiny images
+    (a few hundred to ~1500 pixels per weight) every tensor stays within 1e-3 of the float64 evaluation (measured 3-4e-4; the
+    three-product default: 6e-6).  The knob is read once per process, hence the subprocess."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RESR_X2_WGRAD_PRODUCTS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_generator.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "forward_backward and exact16"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
