@@ -246,6 +246,9 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 else __builtin_amdgcn_s_waitcnt((K0 & 15) | 0x0F70 | ((K0 >> 4) << 14));
             };
             if (first >= ntiles) return;
+            // X2: stage (chunk, part 1) multiplies the SAME x_hi halo as (chunk, part 0) with the second weight block: no new
+            // halo is requested for it and the consumers stay on the buffer (one LDS-DMA halo less per three stages)
+            auto needs_h = [&](int ck) { return !X2 || (ck % 3) != 1; };
             const bool wres = nchunks <= C::NWB;
             int it = first, ick = 0;   // the stage whose halo was requested last
             int hb = 0;                // ... and its buffer
@@ -258,10 +261,14 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             have_next = it < ntiles;
             if (have_next) {
                 if (ick == 0) tile_pix(it);
-                hb = 1;
-                issue_h(ick, hb);
                 ck_next = ick;
-                wait_all_but_h();
+                if (needs_h(ick)) {
+                    hb = 1;
+                    issue_h(ick, hb);
+                    wait_all_but_h();
+                } else {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
             } else {
                 __builtin_amdgcn_s_waitcnt(0x0F70);
             }
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 else if (s + 1 < nchunks) issue_w(ck_next, ck_next);
                 if (++ick == nchunks) { ick = 0; it += G; }
                 const bool have_next2 = it < ntiles;
-                if (have_next2) {
+                if (have_next2 && needs_h(ick)) {
                     if (ick == 0) tile_pix(it);
                     hb = hb == 2 ? 0 : hb + 1;
                     issue_h(ick, hb);                    // buffer of stage s-1 as well
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 pix[i] = ok ? nbase + (unsigned)(iy >> ups) * a.ws + (unsigned)(ix >> ups) : ~0u;
             }
         };
-        int par = 0;
+        int par = 0, hpar = 0;   // weight-ring / halo-buffer parity (they differ in X2, where a halo serves two stages)
         int nstage = 0;   // index of the stage this iteration requests
         const bool wres2 = nchunks <= C::NWB && ntiles == ntiles_sp;   // resident weights need one output group per launch
         for (int tile = first; tile < ntiles; tile += G) {
@@ -363,10 +370,12 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
                 if (X2 && ck - ckr * 3 == 2) base += seg1 ? a.in1_lo_b : a.in0_lo_b;
                 const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
-                const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + par * BUF);
+                const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + hpar * BUF);
+                const bool new_halo = !X2 || (ck % 3) != 1;   // X2 part 1: the x_hi halo of part 0 again, second weight block
                 if (tile != first || ck != 0) {  // the first stage was requested above
 #pragma unroll
                     for (int i = 0; i < NIP; ++i) {
+                        if (!new_halo) break;
                         // uniform base + 32-bit lane offset (tensor < 4 GB, host-checked); padding lanes copy the zero page
                         const unsigned ldst = dst + (i * NP + pw) * 1024;
                         if (pix[i] != ~0u) {
@@ -379,6 +388,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     else if (nstage < nchunks) stage_weights(tile, ck, ck);    // resident: buffer = chunk, first tile only
                 }
                 par ^= 1;
+                if (!X2 || (ck % 3) != 0) hpar ^= 1;   // X2 part 0: the next stage stays on this buffer
                 ++nstage;
                 stamp(0);
                 // the next tile's index math runs while this tile's last chunk is in flight
@@ -532,7 +542,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 }
             }
             par ^= 1;
-            hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;
+            if (!X2 || (ck % 3) != 0) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
             if (wave == 0) stamp(1);
         }
 
