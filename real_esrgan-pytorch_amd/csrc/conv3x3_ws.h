@@ -581,8 +581,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         const bool f_lrelu = e.flags & RESR_CONV_LRELU, f_clamp = EX && (e.flags & RESR_CONV_CLAMP01);
         const bool f_nchw = EX && (e.flags & RESR_CONV_OUT_NCHW_F32);
         const bool f_mask = EX ? (e.flags & RESR_CONV_MASK) != 0 : EM;
-        const bool f_aux_mask = EX && (e.flags & RESR_CONV_AUX_BEFORE_MASK) && e.aux && !f_nchw;
-        const bool f_aux_res = EX && (e.flags & RESR_CONV_AUX_BEFORE_RES) && e.aux && !f_nchw;
+        // EPI bit 6: the aux tensor is stored (compile-time forms of the discriminator's two uses: before the residual of
+        // an up block -- EPI 66 --, before the mask of a backward-data pass -- EPI 65)
+        constexpr bool EA = (EPI & 64) != 0;
+        const bool f_aux_mask = EX ? ((e.flags & RESR_CONV_AUX_BEFORE_MASK) && e.aux && !f_nchw) : (EA && EM && !ER);
+        const bool f_aux_res = EX ? ((e.flags & RESR_CONV_AUX_BEFORE_RES) && e.aux && !f_nchw) : (EA && ER);
         const bool f_res0 = EX ? e.res0 != nullptr : (EPI & 2) != 0, f_res1 = EX ? e.res1 != nullptr : (EPI & 4) != 0;
         const int x = x0 + lx_e;
         // MFMA results -> first non-MFMA reader: the swaps below are asm, so the compiler cannot count this hazard
@@ -813,6 +816,14 @@ static int launch_ws(const ConvArgs& a, hipStream_t stream) {
         return launch_ws_epi<T, MT, NT, NWC, 16, X2>(a, stream);
     }
     if (a.flags & RESR_CONV_MASK_BITS) return launch_ws_epi<T, MT, NT, NWC, 33, X2>(a, stream);
+    if constexpr (MT == 2 && !X2) {   // the discriminator's aux-storing passes (cout 64 groups), specialised like the plain ones
+        if (a.aux && !(a.flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_CLAMP01))) {
+            if (combo == 2 && (a.flags & RESR_CONV_AUX_BEFORE_RES) && !(a.flags & RESR_CONV_AUX_BEFORE_MASK))
+                return launch_ws_epi<T, MT, NT, NWC, 66, X2>(a, stream);
+            if (combo == 1 && (a.flags & RESR_CONV_AUX_BEFORE_MASK) && !(a.flags & RESR_CONV_AUX_BEFORE_RES))
+                return launch_ws_epi<T, MT, NT, NWC, 65, X2>(a, stream);
+        }
+    }
     const bool extras = a.aux || (a.flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_CLAMP01));
     if (!extras) switch (combo) {
         case 0: return launch_ws_epi<T, MT, NT, NWC, 0, X2>(a, stream);  // forward convs 1-4, upsampling, D forward
