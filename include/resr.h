@@ -266,6 +266,30 @@ int resr_maxpool2x2(const void* src, void* dst, int32_t n, int32_t h_out, int32_
 /* virtual [cout][4C][3][3] weight gradient of a space-to-depth conv -> real [cout][C][4][4] */
 int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* stream);
 
+/* Whole-discriminator passes (model.py:135-203, torch.nn.utils.spectral_norm included, and the autograd backward), enqueued
+ * natively like the generator's: see real_esrgan-pytorch_amd/csrc/disc_native.hip for the parameter / spectral-norm arena
+ * layouts (the reference's named_parameters() / named_buffers() orders) and the workspace plan.  The workspace holds the
+ * activations kept for backward, THIS call's spectral-norm vectors, sigmas and packed weights (the module is called three
+ * times per GAN step, train_realesrgan.py:479,500,508) and all scratch: nothing is allocated per tensor. */
+typedef struct {
+    int32_t n, h, w;       /* input [n,3,h,w], h and w multiples of 8                                  */
+    int32_t dtype;         /* RESR_F16 or RESR_F32                                                     */
+    int32_t training;      /* keep activations for resr_discriminator_backward                         */
+    int32_t sn_training;   /* module in training mode: one power iteration, u / v updated in place     */
+} ResrDiscriminatorDesc;
+size_t resr_discriminator_param_count(void);
+size_t resr_discriminator_uv_count(void);
+size_t resr_discriminator_workspace_bytes(const ResrDiscriminatorDesc* d);
+/* chunk table for the pack launch inside resr_discriminator_forward (host memory; returns the count, `chunks` may be NULL to
+ * query it).  1/sigma of the normalised layers is read on the device from the head of `workspace`: one table per workspace. */
+int64_t resr_discriminator_pack_table(const ResrDiscriminatorDesc* d, const void* workspace, ResrPackChunk* chunks, int64_t capacity);
+int resr_discriminator_forward(const ResrDiscriminatorDesc* d, const float* x_nchw, const float* params, float* uv,
+                               const ResrPackChunk* table_dev, int32_t n_chunks, void* workspace, size_t workspace_bytes,
+                               float* y_nchw, void* stream);
+/* grad_params = NULL: gradient wrt the input only (the generator's adversarial term, discriminator frozen); gx_nchw optional */
+int resr_discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy_nchw, const float* params, void* workspace,
+                                size_t workspace_bytes, float* grad_params, float* gx_nchw, void* stream);
+
 /* EMA.update (model.py:43-48) over the flat parameter arena, one launch. */
 int resr_ema_update(float* shadow, const float* params, int64_t count, double decay, void* stream);
 

@@ -58,8 +58,19 @@ class GeneratorDesc(C.Structure):
                 ("n_blocks", C.c_int32), ("dtype", C.c_int32), ("training", C.c_int32), ("wgrad_splits", C.c_int32)]
 
 
+class DiscriminatorDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("dtype", C.c_int32), ("training", C.c_int32),
+                ("sn_training", C.c_int32)]
+
+
 _P = C.c_void_p
 _PROTOS = {
+    "resr_discriminator_param_count": (C.c_size_t, []),
+    "resr_discriminator_uv_count": (C.c_size_t, []),
+    "resr_discriminator_workspace_bytes": (C.c_size_t, [C.POINTER(DiscriminatorDesc)]),
+    "resr_discriminator_pack_table": (C.c_int64, [C.POINTER(DiscriminatorDesc), _P, _P, C.c_int64]),
+    "resr_discriminator_forward": (C.c_int, [C.POINTER(DiscriminatorDesc), _P, _P, _P, _P, C.c_int32, _P, C.c_size_t, _P, _P]),
+    "resr_discriminator_backward": (C.c_int, [C.POINTER(DiscriminatorDesc), _P, _P, _P, C.c_size_t, _P, _P, _P]),
     "resr_version": (C.c_int, []),
     "resr_last_error": (C.c_char_p, []),
     "resr_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

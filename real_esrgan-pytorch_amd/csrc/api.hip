@@ -89,6 +89,14 @@ int generator_forward(const ResrGeneratorDesc*, const float*, const float*, cons
 int generator_backward(const ResrGeneratorDesc*, const float*, const float*, const void*, void*, size_t, float*, float*,
                        hipStream_t, void* const*, int);
 
+size_t discriminator_param_count();
+size_t discriminator_uv_count();
+size_t discriminator_workspace_bytes(const ResrDiscriminatorDesc*);
+int64_t discriminator_pack_table(const ResrDiscriminatorDesc*, const void*, ResrPackChunk*, int64_t);
+int discriminator_forward(const ResrDiscriminatorDesc*, const float*, const float*, float*, const ResrPackChunk*, int, void*, size_t, float*,
+                          hipStream_t);
+int discriminator_backward(const ResrDiscriminatorDesc*, const float*, const float*, void*, size_t, float*, float*, hipStream_t);
+
 int filter2d_dispatch(const float*, float*, const float*, int, int, int, int, int, int, int, hipStream_t);
 int usm_dispatch(const float*, float*, float*, const float*, int, float, float, int, int, int, int, hipStream_t);
 int resize_dispatch(const float*, float*, int, int, int, int, int, int, int, double, double, hipStream_t);
@@ -197,6 +205,26 @@ int resr_generator_backward(const ResrGeneratorDesc* d, const float* gy_nchw, co
     RESR_DEVICE_SCOPE(stream);
     return generator_backward(d, gy_nchw, params, packed, workspace, workspace_bytes, grad_params, gx_nchw,
                               (hipStream_t)stream, grad_ready_events, n_events);
+}
+
+size_t resr_discriminator_param_count(void) { return discriminator_param_count(); }
+size_t resr_discriminator_uv_count(void) { return discriminator_uv_count(); }
+size_t resr_discriminator_workspace_bytes(const ResrDiscriminatorDesc* d) { return discriminator_workspace_bytes(d); }
+int64_t resr_discriminator_pack_table(const ResrDiscriminatorDesc* d, const void* workspace, ResrPackChunk* chunks, int64_t capacity) {
+    return discriminator_pack_table(d, workspace, chunks, capacity);
+}
+
+int resr_discriminator_forward(const ResrDiscriminatorDesc* d, const float* x_nchw, const float* params, float* uv,
+                               const ResrPackChunk* table_dev, int32_t n_chunks, void* workspace, size_t workspace_bytes,
+                               float* y_nchw, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return discriminator_forward(d, x_nchw, params, uv, table_dev, n_chunks, workspace, workspace_bytes, y_nchw, (hipStream_t)stream);
+}
+
+int resr_discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy_nchw, const float* params, void* workspace,
+                                size_t workspace_bytes, float* grad_params, float* gx_nchw, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return discriminator_backward(d, gy_nchw, params, workspace, workspace_bytes, grad_params, gx_nchw, (hipStream_t)stream);
 }
 
 int resr_ema_update(float* shadow, const float* params, int64_t count, double decay, void* stream) {

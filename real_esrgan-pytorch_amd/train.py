@@ -118,8 +118,11 @@ class DataParallel:
         the second one -- not from a per-backward hook."""
         self.broadcast_(discriminator.flat_parameters())
         if self.world > 1:
-            for buf in discriminator.buffers():
-                dist.broadcast(buf, src=0)
+            if hasattr(discriminator, "flat_uv"):          # the eight (u, v) pairs as one message
+                dist.broadcast(discriminator.flat_uv(), src=0)
+            else:
+                for buf in discriminator.buffers():
+                    dist.broadcast(buf, src=0)
 
     def all_reduce_grads_(self, params: Iterable[nn.Parameter]) -> None:
         """Mean over ranks of the `.grad` of `params`, as ONE bucketed all-reduce: in place when the gradients already
