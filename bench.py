@@ -358,7 +358,7 @@ def make_hr_tiles(args, B, hr_edge, rank):
     return hr
 
 
-def run_mode(args, precision, steps, warmup, world, rank, probe=True):
+def run_mode(args, precision, steps, warmup, world, rank, probe=True, centre_output=False):
     """Build the training state in `precision`, run `warmup` untimed + `steps` timed steps (barrier + synchronize on both
     sides, max over ranks) and, optionally, one more step with per-launch events for the roofline record."""
     import real_esrgan_pytorch_amd as R
@@ -367,6 +367,9 @@ def run_mode(args, precision, steps, warmup, world, rank, probe=True):
     torch.manual_seed(0)                                  # reference config.py:64-66: same init on every rank
     model = R.Generator(3, 3, 4, precision=precision).cuda()
     model.train()
+    if centre_output:   # start the output in the middle of the training-time clamp (model.py:270) instead of around 0
+        with torch.no_grad():
+            model.conv4.bias.add_(0.5)
     torch.cuda.manual_seed(1234 + rank)                   # device-side draws of the degradation (sigma, quality, ...) differ per rank
     dp = DataParallel()
     dp.attach(model)
@@ -582,12 +585,15 @@ def other_configs(args):
     try:    # config 3: RealESRNet x4 L1 training, batch 32 of 256^2 HR tiles (LR 64^2), degradation on the side stream
         a3 = copy.copy(args)
         a3.batch, a3.lr_size, a3.no_probe = 32, 64, True
-        r = run_mode(a3, "fast", 20, 5, 1, 0, probe=False)
+        # random init puts the output around 0; at this size a first Adam step that overshoots the clamp leaves the step with
+        # zero gradients for good (loss 0.4998, 8 % "faster"): centre the output bias so the timed regime carries real gradients
+        r = run_mode(a3, "fast", 20, 5, 1, 0, probe=False, centre_output=True)
         v = 32 * r["steps"] / r["dt"]
         out["config3_realesrnet_train_b32_hr256"] = {"images_per_sec": round(v, 1), "ms_per_step": round(r["dt"] / r["steps"] * 1e3, 2),
                                                      "tflops": round(v * 3 * 2 * MAC_PER_LR_PX * 64 * 64 / 1e12, 1),
                                                      "frac_of_f16_peak": round(v * 3 * 2 * MAC_PER_LR_PX * 64 * 64 / 1e12 / PEAK_F16_TFLOPS, 3),
-                                                     "loss": r["loss"], "unclamped_output_fraction": r.get("unclamped")}
+                                                     "loss": r["loss"], "unclamped_output_fraction": r.get("unclamped"),
+                                                     "init": "reference init, conv4.bias + 0.5 (output starts inside the training-time clamp)"}
         del r
         torch.cuda.empty_cache()
     except Exception as e:  # pragma: no cover
