@@ -31,6 +31,52 @@ __global__ __launch_bounds__(256) void s2d_kernel(const T* __restrict__ src, T* 
     else *reinterpret_cast<uint4*>(dst + full) = *reinterpret_cast<const uint4*>(src + packed);
 }
 
+// depth-to-space fused with the skip-gradient merge and the LeakyReLU backward that follow it in the discriminator's backward
+// pass: out[full] = (src[packed] + add[full]) * (mask[full] > 0 ? 1 : slope)   (add, mask optional) -- the same roundings as
+// s2d(inverse) followed by add_mask, one pass instead of two
+template <typename T>
+__global__ __launch_bounds__(256) void d2s_add_mask_kernel(const T* __restrict__ src, const T* __restrict__ add, const T* __restrict__ mask,
+                                                           T* __restrict__ out, int n, int h, int w, int c, float slope) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const int groups = c / E;
+    const long total = (long)n * h * w * groups;      // h, w = full-resolution dims
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int g = (int)(t % groups);
+    const long p = t / groups;
+    const int x = (int)(p % w), y = (int)((p / w) % h), b = (int)(p / ((long)w * h));
+    const size_t full = (((size_t)b * h + y) * w + x) * c + g * E;
+    const size_t packed = ((((size_t)b * (h / 2) + y / 2) * (w / 2) + x / 2) * 4 + (y & 1) * 2 + (x & 1)) * c + g * E;
+    const uint4 rs = *reinterpret_cast<const uint4*>(src + packed);
+    uint4 ra = make_uint4(0, 0, 0, 0), rm = make_uint4(0, 0, 0, 0);
+    if (add) ra = *reinterpret_cast<const uint4*>(add + full);
+    if (mask) rm = *reinterpret_cast<const uint4*>(mask + full);
+    const T *ps = reinterpret_cast<const T*>(&rs), *pa = reinterpret_cast<const T*>(&ra), *pm = reinterpret_cast<const T*>(&rm);
+    uint4 o;
+    T* po = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        float v = (float)ps[e] + (add ? (float)pa[e] : 0.f);
+        if (mask) v *= ((float)pm[e] > 0.f ? 1.f : slope);
+        po[e] = (T)v;
+    }
+    *reinterpret_cast<uint4*>(out + full) = o;
+}
+
+int d2s_add_mask_dispatch(const void* src, const void* add, const void* mask, void* out, int n, int h, int w, int c, int dtype, float slope,
+                          hipStream_t st) {
+    const int E = dtype == RESR_F16 ? 8 : 4;
+    if (!src || !out || n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || c <= 0 || (c % E)) return fail(RESR_ERR_ARG, "d2s_add_mask: bad argument");
+    const long total = (long)n * h * w * (c / E);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == RESR_F16)
+        hipLaunchKernelGGL(d2s_add_mask_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (const half_t*)add, (const half_t*)mask, (half_t*)out, n, h, w, c, slope);
+    else
+        hipLaunchKernelGGL(d2s_add_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (const float*)add, (const float*)mask, (float*)out, n, h, w, c, slope);
+    RESR_CHECK_LAUNCH("d2s_add_mask_kernel");
+    return RESR_OK;
+}
+
 int s2d_dispatch(const void* src, void* dst, int n, int h, int w, int c, int dtype, int inverse, hipStream_t st) {
     const int E = dtype == RESR_F16 ? 8 : 4;
     if (!src || !dst || n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || c <= 0 || (c % E))
@@ -84,9 +130,12 @@ __global__ __launch_bounds__(256) void bilinear_up_kernel(const T* __restrict__ 
 }
 
 // backward as a gather: input pixel (y,x) collects from the <= 4x4 outputs whose stencil touches it
+// optional second output: gmasked = gin * (mask > 0 ? 1 : slope) (the LeakyReLU backward that follows in the discriminator; gin
+// itself is kept, it is a skip gradient later) -- computed from the rounded gin, like a separate add_mask pass would
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const T* __restrict__ g, T* __restrict__ gin, int n, int h, int w,
-                                                              int c) {
+                                                              int c, const T* __restrict__ mask = nullptr, T* __restrict__ gmasked = nullptr,
+                                                              float slope = 0.f) {
     constexpr int E = 16 / (int)sizeof(T);
     const int groups = c / E, oh = 2 * h, ow = 2 * w;
     const long total = (long)n * h * w * groups;
@@ -122,6 +171,29 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < E; ++e) ov[e] = (T)acc[e];
     *reinterpret_cast<uint4*>(gin + p * c + gi * E) = o;
+    if (gmasked) {
+        const uint4 rm = *reinterpret_cast<const uint4*>(mask + p * c + gi * E);
+        const T* pm = reinterpret_cast<const T*>(&rm);
+        uint4 om;
+        T* omv = reinterpret_cast<T*>(&om);
+#pragma unroll
+        for (int e = 0; e < E; ++e) omv[e] = (T)((float)ov[e] * ((float)pm[e] > 0.f ? 1.f : slope));
+        *reinterpret_cast<uint4*>(gmasked + p * c + gi * E) = om;
+    }
+}
+
+int bilinear_up_bwd_mask_dispatch(const void* g, void* gin, const void* mask, void* gmasked, int n, int h, int w, int c, int dtype, float slope,
+                                  hipStream_t st) {
+    const int E = dtype == RESR_F16 ? 8 : 4;
+    if (!g || !gin || !mask || !gmasked || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c % E)) return fail(RESR_ERR_ARG, "bilinear_up_bwd_mask: bad argument");
+    const long total = (long)n * h * w * (c / E);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == RESR_F16)
+        hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)g, (half_t*)gin, n, h, w, c, (const half_t*)mask, (half_t*)gmasked, slope);
+    else
+        hipLaunchKernelGGL(bilinear_up_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)g, (float*)gin, n, h, w, c, (const float*)mask, (float*)gmasked, slope);
+    RESR_CHECK_LAUNCH("bilinear_up_bwd_kernel");
+    return RESR_OK;
 }
 
 int bilinear_up_dispatch(const void* src, void* dst, int n, int h, int w, int c, int dtype, int backward, hipStream_t st) {
@@ -131,10 +203,10 @@ int bilinear_up_dispatch(const void* src, void* dst, int n, int h, int w, int c,
     const unsigned blocks = (unsigned)((total + 255) / 256);
     if (dtype == RESR_F16) {
         if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c);
-        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c);
+        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, (const half_t*)nullptr, (half_t*)nullptr, 0.f);
     } else {
         if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c);
-        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c);
+        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, (const float*)nullptr, (float*)nullptr, 0.f);
     }
     RESR_CHECK_LAUNCH("bilinear_up_kernel");
     return RESR_OK;

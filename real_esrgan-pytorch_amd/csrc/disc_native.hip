@@ -34,6 +34,8 @@ int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int
 int s2d_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
 int bilinear_up_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
 int add_mask_dispatch(const void*, const void*, const void*, void*, long, int, float, hipStream_t);
+int d2s_add_mask_dispatch(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t);
+int bilinear_up_bwd_mask_dispatch(const void*, void*, const void*, void*, int, int, int, int, int, float, hipStream_t);
 int spectral_norm_dispatch(const float*, float*, float*, int, int, int, float, float*, float*, hipStream_t);
 int spectral_norm_bwd_dispatch(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, float*,
                                hipStream_t);
@@ -101,7 +103,7 @@ struct DBufs {
     // activations (T)
     char *x_in, *out1, *s1, *d1, *s2, *d2, *s3, *d3, *b1, *u1, *a1, *b2, *u2, *a2, *b3, *u3, *a3, *c2, *c3;
     // backward scratch (T)
-    char *g4, *G8, *G7, *G6, *g_u3, *g_b3, *g_u2, *G5, *g_b2, *g_u1, *G4, *g_b1, *g_d3, *G3, *g_s3, *t3, *G2, *g_s2, *t2, *G1, *g_s1, *t1,
+    char *g4, *G8, *G7, *G6, *g_u3, *g_b3, *g_u2, *G5, *g_b2, *g_u1, *G4, *g_b1, *g_d3, *G3, *g_s3, *G2, *g_s2, *G1, *g_s1,
         *G0, *gxin;
     float *raw, *folded, *tmp1, *partial;
     size_t partial_bytes, total;
@@ -143,9 +145,9 @@ void carve(const DPlan& p, char* base, DBufs& b) {
         b.g_u2 = take(px / 4 * 128 * es); b.G5 = take(px / 4 * 128 * es); b.g_b2 = take(px / 4 * 256 * es);
         b.g_u1 = take(px / 16 * 256 * es); b.G4 = take(px / 16 * 256 * es); b.g_b1 = take(px / 16 * 512 * es);
         b.g_d3 = take(px / 64 * 512 * es); b.G3 = take(px / 64 * 512 * es); b.g_s3 = take(px / 64 * 1024 * es);
-        b.t3 = take(px / 16 * 256 * es); b.G2 = take(px / 16 * 256 * es); b.g_s2 = take(px / 16 * 512 * es);
-        b.t2 = take(px / 4 * 128 * es); b.G1 = take(px / 4 * 128 * es); b.g_s1 = take(px / 4 * 256 * es);
-        b.t1 = take(px * 64 * es); b.G0 = take(px * 64 * es); b.gxin = take(px * 32 * es);
+        b.G2 = take(px / 16 * 256 * es); b.g_s2 = take(px / 16 * 512 * es);
+        b.G1 = take(px / 4 * 128 * es); b.g_s1 = take(px / 4 * 256 * es);
+        b.G0 = take(px * 64 * es); b.gxin = take(px * 32 * es);
         b.raw = (float*)take((size_t)512 * 1024 * 9 * sizeof(float));
         b.folded = (float*)take((size_t)512 * 256 * 16 * sizeof(float));
         b.tmp1 = (float*)take(256);
@@ -338,6 +340,7 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
             c.x0 = x; c.cin = cin_pad; c.in0_stride = xs; c.cin_real = cin_v;
             c.g = g + (size_t)g0 * es; c.cout = co; c.cout_pad = r32(co); c.g_stride = gs;
             c.x_chunk_stride = c.g_chunk_stride = 0; c.x_lo_off = c.g_lo_off = 0;
+            c.x_s2d_c = l.k4 ? l.cin : 0;      // 4x4 / stride-2 layers: X is the space-to-depth image, skip the virtual kernel's zero taps
             c.dw = raw + (size_t)g0 * cin_v * 9; c.db = (l.bias ? grad + p.b_off[li] + g0 : nullptr); c.scale = 1.f;
             const int jobs = chunks * (c.cout_pad / 32);
             const int splits = wsplits(dt, jobs, N, h, w);
@@ -357,10 +360,6 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
                      char* aux, int s2d_out) {
         return conv_layer(p, b, li, true, g, gs, N, h, w, out, out_stride, flags | NB, nullptr, nullptr, 0, mask, mask_stride, aux, 0, s2d_out, st);
     };
-    auto addmask = [&](const char* a, const char* bb, const char* m, char* out, size_t count) {
-        return add_mask_dispatch(a, bb, m, out, (long)count, dt, kSlope, st);
-    };
-    const size_t px = (size_t)N * S * W;
 
     DRUN(nchw_to_nhwc_dispatch(gy, b.g4, N, 1, S, W, 1, 32, dt, nullptr, st, 0));
     DRUN(wgrad_layer(CONV4, b.c3, 64, b.g4, 32, S, W));
@@ -371,28 +370,22 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
     DRUN(dconv(CONV2, b.G7, 64, S, W, b.G6, 64, MK | RESR_CONV_AUX_BEFORE_MASK, b.a3, 64, b.g_u3, 0));
     DRUN(wgrad_layer(UP3, b.b3, 128, b.G6, 64, S, W));
     DRUN(dconv(UP3, b.G6, 64, S, W, b.g_b3, 128, 0, nullptr, 0, nullptr, 0));
-    DRUN(bilinear_up_dispatch(b.g_b3, b.g_u2, N, H1, W1, 128, dt, 1, st));
-    DRUN(addmask(b.g_u2, nullptr, b.a2, b.G5, px / 4 * 128));
+    DRUN(bilinear_up_bwd_mask_dispatch(b.g_b3, b.g_u2, b.a2, b.G5, N, H1, W1, 128, dt, kSlope, st));   // g_u2 (skip gradient) and G5 = masked
     DRUN(wgrad_layer(UP2, b.b2, 256, b.G5, 128, H1, W1));
     DRUN(dconv(UP2, b.G5, 128, H1, W1, b.g_b2, 256, 0, nullptr, 0, nullptr, 0));
-    DRUN(bilinear_up_dispatch(b.g_b2, b.g_u1, N, H2, W2, 256, dt, 1, st));
-    DRUN(addmask(b.g_u1, nullptr, b.a1, b.G4, px / 16 * 256));
+    DRUN(bilinear_up_bwd_mask_dispatch(b.g_b2, b.g_u1, b.a1, b.G4, N, H2, W2, 256, dt, kSlope, st));
     DRUN(wgrad_layer(UP1, b.b1, 512, b.G4, 256, H2, W2));
     DRUN(dconv(UP1, b.G4, 256, H2, W2, b.g_b1, 512, 0, nullptr, 0, nullptr, 0));
-    DRUN(bilinear_up_dispatch(b.g_b1, b.g_d3, N, H3, W3, 512, dt, 1, st));
-    DRUN(addmask(b.g_d3, nullptr, b.d3, b.G3, px / 64 * 512));
+    DRUN(bilinear_up_bwd_mask_dispatch(b.g_b1, b.g_d3, b.d3, b.G3, N, H3, W3, 512, dt, kSlope, st));
     DRUN(wgrad_layer(DOWN3, b.s3, 1024, b.G3, 512, H3, W3));
     DRUN(dconv(DOWN3, b.G3, 512, H3, W3, b.g_s3, 1024, 0, nullptr, 0, nullptr, 256));
-    DRUN(s2d_dispatch(b.g_s3, b.t3, N, H2, W2, 256, dt, 1, st));
-    DRUN(addmask(b.t3, b.g_u1, b.d2, b.G2, px / 16 * 256));
+    DRUN(d2s_add_mask_dispatch(b.g_s3, b.g_u1, b.d2, b.G2, N, H2, W2, 256, dt, kSlope, st));   // depth-to-space + skip gradient + LeakyReLU backward
     DRUN(wgrad_layer(DOWN2, b.s2, 512, b.G2, 256, H2, W2));
     DRUN(dconv(DOWN2, b.G2, 256, H2, W2, b.g_s2, 512, 0, nullptr, 0, nullptr, 128));
-    DRUN(s2d_dispatch(b.g_s2, b.t2, N, H1, W1, 128, dt, 1, st));
-    DRUN(addmask(b.t2, b.g_u2, b.d1, b.G1, px / 4 * 128));
+    DRUN(d2s_add_mask_dispatch(b.g_s2, b.g_u2, b.d1, b.G1, N, H1, W1, 128, dt, kSlope, st));
     DRUN(wgrad_layer(DOWN1, b.s1, 256, b.G1, 128, H1, W1));
     DRUN(dconv(DOWN1, b.G1, 128, H1, W1, b.g_s1, 256, 0, nullptr, 0, nullptr, 64));
-    DRUN(s2d_dispatch(b.g_s1, b.t1, N, S, W, 64, dt, 1, st));
-    DRUN(addmask(b.t1, b.g_u3, nullptr, b.G0, px * 64));
+    DRUN(d2s_add_mask_dispatch(b.g_s1, b.g_u3, nullptr, b.G0, N, S, W, 64, dt, kSlope, st));
     DRUN(wgrad_layer(CONV1, b.x_in, 32, b.G0, 64, S, W));
     if (gx) {
         DRUN(dconv(CONV1, b.G0, 64, S, W, b.gxin, 32, 0, nullptr, 0, nullptr, 0));

@@ -514,7 +514,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         wc.x0 = x0; wc.cin = cin; wc.in0_stride = s0; wc.cin_real = c.cin;
         wc.g = g; wc.cout = c.cout; wc.cout_pad = c.cout_pad; wc.g_stride = gstride;
         wc.x_chunk_stride = wc.g_chunk_stride = 0;
-        wc.x_lo_off = x_lo; wc.g_lo_off = g_lo;
+        wc.x_lo_off = x_lo; wc.g_lo_off = g_lo; wc.x_s2d_c = 0;
         wc.dw = grad + c.w_off; wc.db = grad + c.b_off; wc.scale = scale;
         return wc;
     };

@@ -45,6 +45,8 @@ struct WgradJob {
     unsigned xstride_b, gstride_b;
     unsigned slab_off;    // float offset of this job's [splits][kSlab] slabs in `partial`
     unsigned want_bias;   // 1: also produce sum_p G[p][co] (one job per co tile does)
+    unsigned xsub;        // 0..3: X chunk lies in sub-position (i*2+j) of a space-to-depth image -- only 2x2 of the 9 taps of the
+                          // virtual kernel of a 4x4 / stride-2 conv are non-zero there; 4: all taps
 };
 
 struct WgradArgs {
@@ -351,7 +353,7 @@ struct WgradQuad {
     unsigned xstride_b[2], gstride_b[2];
     unsigned slab_off[4];   // float offset of product p's [splits][kSlab] slabs, ~0u = product not wanted
     unsigned bias_mask;     // bit p: product p also yields sum_p G (one product per G tile does)
-    unsigned pad_;
+    unsigned xsub;          // byte xi: tap pattern of X chunk xi (WgradJob::xsub)
 };
 
 struct WgradQuadArgs {
@@ -475,57 +477,83 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the asm LDS-DMA is not counted by the compiler
     __syncthreads();
-    int it = 0;
-    for (; tile < a.ntiles; tile += a.splits, ++it) {
-        const int next = tile + a.splits;
-        const bool has_next = next < a.ntiles;
-        const TileAt tn = tile_at(has_next ? next : tile);
-        const int nb = (it + 1) & 1;
-        const char* gbase = smem + (it & 1) * kQBUF + goff;
-        const char* xbase = smem + (it & 1) * kQBUF + xoff;
-        // X-row-major walk: halo row j of the wave's 6 serves output rows j (dy 0), j-1 (dy 1), j-2 (dy 2), so every
-        // X fragment is read from LDS once (88 transpose reads per tile instead of 160 -- the LDS pipe, not the
-        // matrix pipe, was the limit); the G fragments of the last three output rows stay in registers.
-        // Software pipeline: the transpose reads of step st+1 are issued before the MFMAs of step st (a step = one
-        // halo row j of one 16-pixel half kbh), so the matrix pipe never waits for an LDS round trip inside a tile.
-        uint4 fg[2][4], fb[2][3];
-        auto fload = [&](int st) {
-            const int kbh = st / 6, j = st % 6;
-            if (j < 4) {
-                const char* ga = gbase + (j * 32 + kbh * 16) * PB;
-                const uint2 alo = tr_read(ga), ahi = tr_read(ga + 4 * PB);
-                fg[kbh][j] = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
+    // The tile loop, instantiated per tap pattern of this wave's X chunk (MODE 0..3: sub-position (i, j) = (MODE >> 1, MODE & 1)
+    // of a space-to-depth image: valid dy in {1,2} for i = 0, {0,1} for i = 1, same for dx / j -- 4 of the 9 accumulators, 4/9
+    // of the MFMAs and 2/3 of the X fragment reads; MODE 4: all taps).  Waves of one workgroup may run different
+    // instantiations: every one executes the same staging instructions and one barrier per tile.
+    auto tile_loop = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        auto vdy = [](int dy) { return MODE == 4 || (MODE >> 1 == 0 ? dy >= 1 : dy <= 1); };
+        auto vdx = [](int dx) { return MODE == 4 || ((MODE & 1) == 0 ? dx >= 1 : dx <= 1); };
+        int it = 0;
+        for (; tile < a.ntiles; tile += a.splits, ++it) {
+            const int next = tile + a.splits;
+            const bool has_next = next < a.ntiles;
+            const TileAt tn = tile_at(has_next ? next : tile);
+            const int nb = (it + 1) & 1;
+            const char* gbase = smem + (it & 1) * kQBUF + goff;
+            const char* xbase = smem + (it & 1) * kQBUF + xoff;
+            // X-row-major walk: halo row j of the wave's 6 serves output rows j (dy 0), j-1 (dy 1), j-2 (dy 2), so every
+            // X fragment is read from LDS once (88 transpose reads per tile instead of 160 -- the LDS pipe, not the
+            // matrix pipe, was the limit); the G fragments of the last three output rows stay in registers.
+            // Software pipeline: the transpose reads of step st+1 are issued before the MFMAs of step st (a step = one
+            // halo row j of one 16-pixel half kbh), so the matrix pipe never waits for an LDS round trip inside a tile.
+            uint4 fg[2][4], fb[2][3];
+            auto fload = [&](int st) {
+                const int kbh = st / 6, j = st % 6;
+                if (j < 4) {
+                    const char* ga = gbase + (j * 32 + kbh * 16) * PB;
+                    const uint2 alo = tr_read(ga), ahi = tr_read(ga + 4 * PB);
+                    fg[kbh][j] = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    if (!vdx(dx)) continue;
+                    const char* xa = xbase + (j * HW + kbh * 16 + dx) * PB;
+                    const uint2 lo = tr_read(xa), hi = tr_read(xa + 4 * PB);
+                    fb[st & 1][dx] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            };
+            fload(0);
+#pragma unroll
+            for (int st = 0; st < 12; ++st) {
+                const int kbh = st / 6, j = st % 6;
+                if (st + 1 < 12) fload(st + 1);
+                if (j < 4) bsum += sum8_f16(fg[kbh][j]);     // 4 dot instructions; only written where a bias is wanted
+                // the next tile's ten requests go out during the first five steps, two per step, each behind a group of MFMAs:
+                // the last one then has seven steps (~2.5 us) to land before the tile barrier
+                int slot = 2 * st;
+#pragma unroll
+                for (int dy = 2; dy >= 0; --dy) {    // descending: the accumulators the previous step touched last come last
+                    const int r = j - dy;
+                    if (r < 0 || r > 3 || !vdy(dy)) continue;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        if (!vdx(dx)) continue;
+                        acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fg[kbh][r]),
+                                                                                  __builtin_bit_cast(half8, fb[st & 1][dx]), acc[dy * 3 + dx], 0, 0, 0);
+                    }
+                    if (slot < 2 * st + 2 && slot < NSX + NSG) { stage_slot(slot, tn, nb, has_next); ++slot; }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)   // steps with fewer than two MFMA groups still issue their two requests
+                    if (slot < 2 * st + 2 && slot < NSX + NSG) { stage_slot(slot, tn, nb, has_next); ++slot; }
             }
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const char* xa = xbase + (j * HW + kbh * 16 + dx) * PB;
-                const uint2 lo = tr_read(xa), hi = tr_read(xa + 4 * PB);
-                fb[st & 1][dx] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            }
-        };
-        fload(0);
-#pragma unroll
-        for (int st = 0; st < 12; ++st) {
-            const int kbh = st / 6, j = st % 6;
-            if (st + 1 < 12) fload(st + 1);
-            if (j < 4) bsum += sum8_f16(fg[kbh][j]);     // 4 dot instructions; only written where a bias is wanted
-            // the next tile's ten requests go out during the first five steps, two per step, each behind a group of MFMAs:
-            // the last one then has seven steps (~2.5 us) to land before the tile barrier
-            int slot = 2 * st;
-#pragma unroll
-            for (int dy = 2; dy >= 0; --dy) {    // descending: the accumulators the previous step touched last come last
-                const int r = j - dy;
-                if (r < 0 || r > 3) continue;
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-                    acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fg[kbh][r]),
-                                                                              __builtin_bit_cast(half8, fb[st & 1][dx]), acc[dy * 3 + dx], 0, 0, 0);
-                if (slot < 2 * st + 2 && slot < NSX + NSG) { stage_slot(slot, tn, nb, has_next); ++slot; }
-            }
-            if (slot < 2 * st + 2 && slot < NSX + NSG) { stage_slot(slot, tn, nb, has_next); ++slot; }   // one-group steps
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's asm LDS-DMA has landed
+            __syncthreads();
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's asm LDS-DMA has landed
-        __syncthreads();
+    };
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+    using M3 = std::integral_constant<int, 3>;
+    using M4 = std::integral_constant<int, 4>;
+    switch ((job.xsub >> (8 * xi)) & 0xffu) {   // wave-uniform
+        case 0: tile_loop(M0{}); break;
+        case 1: tile_loop(M1{}); break;
+        case 2: tile_loop(M2{}); break;
+        case 3: tile_loop(M3{}); break;
+        default: tile_loop(M4{}); break;
     }
 
     // ---- sum the two row-halves of every product through LDS, write the slabs ---------------------------------
@@ -691,13 +719,13 @@ static const std::vector<QuadIdx>* plan_quads(const int* jx, const int* jg, int 
 
 static int build_quads(const WgradArgs& a, int nj, WgradQuadArgs& q) {
     const char* xs[kMaxJobs]; const char* gs[kMaxJobs];
-    unsigned xstr[kMaxJobs], gstr[kMaxJobs];
+    unsigned xstr[kMaxJobs], gstr[kMaxJobs], xsub[kMaxJobs];
     int nx = 0, ng = 0;
     int jx[kMaxJobs], jg[kMaxJobs];
     for (int i = 0; i < nj; ++i) {
         int xi = 0, gi = 0;
         while (xi < nx && xs[xi] != a.jobs[i].x) ++xi;
-        if (xi == nx) { xs[nx] = a.jobs[i].x; xstr[nx] = a.jobs[i].xstride_b; ++nx; }
+        if (xi == nx) { xs[nx] = a.jobs[i].x; xstr[nx] = a.jobs[i].xstride_b; xsub[nx] = a.jobs[i].xsub; ++nx; }
         while (gi < ng && gs[gi] != a.jobs[i].g) ++gi;
         if (gi == ng) { gs[ng] = a.jobs[i].g; gstr[ng] = a.jobs[i].gstride_b; ++ng; }
         jx[i] = xi; jg[i] = gi;
@@ -709,7 +737,8 @@ static int build_quads(const WgradArgs& a, int nj, WgradQuadArgs& q) {
         WgradQuad& w = q.jobs[nq++];
         memset(&w, 0, sizeof(w));
         w.x[0] = xs[qi.xa]; w.xstride_b[0] = xstr[qi.xa];
-        if (qi.xb != qi.xa) { w.x[1] = xs[qi.xb]; w.xstride_b[1] = xstr[qi.xb]; }
+        w.xsub = xsub[qi.xa] | (4u << 8);
+        if (qi.xb != qi.xa) { w.x[1] = xs[qi.xb]; w.xstride_b[1] = xstr[qi.xb]; w.xsub = xsub[qi.xa] | (xsub[qi.xb] << 8); }
         w.g[0] = gs[qi.ga]; w.gstride_b[0] = gstr[qi.ga];
         if (qi.gb != qi.ga) { w.g[1] = gs[qi.gb]; w.gstride_b[1] = gstr[qi.gb]; }
         for (int p = 0; p < 4; ++p) {
@@ -773,6 +802,7 @@ int wgrad_debug_plan(const int* cin, const int* cout_pad, int nconv, int* out, i
                 a.jobs[nj].x = xbase + ck * 64;
                 a.jobs[nj].g = gbase + gt * 64;
                 a.jobs[nj].slab_off = (unsigned)nj;     // product index
+                a.jobs[nj].xsub = 4;
                 ++nj;
             }
     }
@@ -845,6 +875,7 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
                     j.gstride_b = (unsigned)(c.g_stride * es);
                     j.slab_off = off;
                     j.want_bias = part < 2 ? want_bias : 0;
+                    j.xsub = (c.x_s2d_c > 0 && dtype == RESR_F16) ? (unsigned)((ck * 32) / c.x_s2d_c) : 4u;
                     if (part == 1) q.slab_b = off;
                     if (part == 2) q.slab_c = off;
                     off += (unsigned)(splits * kSlab);
@@ -891,7 +922,7 @@ int wgrad_dispatch(const ResrWgradDesc* d, const void* x0, const void* x1, const
     c.x0 = x0; c.cin = d->cin; c.in0_stride = d->in0_stride; c.cin_real = d->cin_real;
     c.g = g; c.cout = d->cout; c.cout_pad = d->cout_pad; c.g_stride = d->g_stride;
     c.x_chunk_stride = c.g_chunk_stride = 0;
-    c.x_lo_off = (long)d->x_lo_offset; c.g_lo_off = (long)d->g_lo_offset;
+    c.x_lo_off = (long)d->x_lo_offset; c.g_lo_off = (long)d->g_lo_offset; c.x_s2d_c = 0;
     c.dw = dw; c.db = db; c.scale = d->scale;
     return wgrad_batch(&c, 1, d->n, d->h, d->w, d->dtype, d->flags, d->splits, partial, stream);
 }
