@@ -1,9 +1,12 @@
-"""Train steps of the hot path (reference train_realesrnet.py:258-413 loop body), data-parallel ready.
+"""Train steps of the hot path (reference train_realesrnet.py:258-413 and train_realesrgan.py:338-556 loop bodies),
+data-parallel ready.
 
-One process per GPU.  The generator's backward writes every weight gradient into one flat fp32
-arena, so the data-parallel exchange is a single bucketed RCCL all-reduce over contiguous HBM
-(`DataParallel.attach`), issued from the generator's `grad_hook` -- i.e. after backward-data and
-weight-gradient kernels are enqueued, before the optimiser reads the gradients.
+One process per GPU (`setup_distributed`).  Exchanges per optimiser step (`DataParallel`):
+  * generator: its backward writes every weight gradient into one flat fp32 arena and fires an event per finished range
+    (tail convs, RRDB 22 ... 0, conv1); the ranges are all-reduced bucket by bucket on a communication stream WHILE the
+    rest of the backward pass runs (`attach` / `all_reduce_ranges_`);
+  * discriminator (GAN step): its gradients are the sum of two backward passes, reduced once after the second
+    (`attach_discriminator` / `all_reduce_grads_`); weights and spectral-norm u / v are broadcast at attach time.
 """
 from __future__ import annotations
 
