@@ -113,3 +113,40 @@ def test_flat_parameter_adam_matches_per_tensor_adam():
     w_flat, l_flat = run(True)
     assert l_ref == l_flat
     assert torch.equal(w_ref, w_flat), (w_ref - w_flat).abs().max().item()
+
+
+def test_exact16_at_full_geometry():
+    """exact16 at BASELINE's full geometry (hi / lo tensors of 2.1 GB each at the HR end, offsets beyond 2^31 bytes), where the
+    CPU oracle is out of reach: (a) inference at the bench batch (16 x 256^2) stays within fast mode's error class of the f16
+    path on the same weights -- an addressing slip in the hi / lo pairs would be O(1); (b) a training step at 2 x 256^2 is
+    deterministic, and its gradients agree with fast mode's to fast mode's accuracy while exact16's own linearity in the loss
+    scale is fp32-class (the f16 path's is not)."""
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(3)
+    gf = R.Generator(3, 3, 4, precision="fast").cuda()
+    with torch.no_grad():
+        gf.conv4.bias.add_(0.5)
+    ge = R.Generator(3, 3, 4, precision="exact16")
+    ge.load_state_dict(gf.state_dict())
+    ge = ge.cuda()
+    rng = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.rand(16, 3, 256, 256, device="cuda", generator=rng)
+    with torch.no_grad():
+        yf, ye = gf(x), ge(x)
+    d = (yf - ye).abs()
+    assert ye.shape == (16, 3, 1024, 1024) and torch.isfinite(ye).all()
+    assert d.max().item() < 1e-2 and d.mean().item() < 5e-4, (d.max().item(), d.mean().item())
+    del yf, ye, d
+    torch.cuda.empty_cache()
+    x2 = x[:2].contiguous()
+    gy = torch.randn(2, 3, 1024, 1024, device="cuda", generator=rng) / 1024.0
+    ge.train(); gf.train()
+    y1, g1 = _grads(ge, x2, gy, 1024.0)
+    y2, g2 = _grads(ge, x2, gy, 1024.0)
+    assert torch.equal(y1, y2) and torch.equal(g1, g2)                       # deterministic
+    _, g4 = _grads(ge, x2, gy, 4096.0)
+    lin = ((g4 / 4.0 - g1).norm() / g1.norm()).item()
+    assert lin < 1e-5, lin                                                    # linear in the loss scale to fp32 rounding
+    _, gfast = _grads(gf, x2, gy, 1024.0)
+    rel = ((gfast - g1).norm() / g1.norm()).item()
+    assert rel < 0.1, rel                                                     # fast mode's distance (4-8 % per tensor at 23 blocks)
