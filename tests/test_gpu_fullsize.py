@@ -150,3 +150,23 @@ def test_exact16_at_full_geometry():
     _, gfast = _grads(gf, x2, gy, 1024.0)
     rel = ((gfast - g1).norm() / g1.norm()).item()
     assert rel < 0.1, rel                                                     # fast mode's distance (4-8 % per tensor at 23 blocks)
+
+
+def test_tiled_4k_frame_two_tilings_agree():
+    """BASELINE config 5 geometry (x2 model, 3840x2160 LR frame): the automatic plan (three 2160x1344 windows, one hipGraph for
+    the whole frame) and an explicit 3 x 3 grid of 720x1280 tiles stitch the SAME 7680x4320 image bit for bit when the halo covers
+    the receptive field (1-block trunk: ~21 LR pixels < halo 32) -- the whole-image pass itself is beyond the conv kernels'
+    per-tensor pixel limit, which is why the tiler exists."""
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd.tiling import TiledGenerator
+    torch.manual_seed(5)
+    g = R.Generator(3, 3, 2, precision="fast", n_blocks=1).cuda().eval()
+    frame = torch.rand(1, 3, 2160, 3840, device="cuda")
+    auto = TiledGenerator(g, halo=32, use_graph=True)
+    tiles, wh, ww = auto.plan(1, 2160, 3840)
+    assert len(tiles) == 3 and (wh, ww) == (2160, 1344)
+    a = auto(frame).clone()
+    assert torch.equal(auto(frame), a)                       # graph replay
+    b = TiledGenerator(g, tile=(720, 1280), halo=32, use_graph=False)(frame)
+    assert a.shape == b.shape == (1, 3, 4320, 7680) and torch.isfinite(a).all()
+    assert torch.equal(a, b)
