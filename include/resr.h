@@ -227,7 +227,7 @@ int resr_quantize_crop(const float* lr, const float* hr, float* lr_out, float* h
                        int32_t lr_w, int32_t hr_h, int32_t hr_w, int32_t hr_size, int32_t upscale, int32_t hr_top,
                        int32_t hr_left, void* stream);
 
-/* ---- integer mode of blur / resize (north_star: "blur/resize/JPEG bit-exact in integer mode") ---------------------
+/* ---- integer mode of blur / resize / JPEG (north_star: "blur/resize/JPEG bit-exact in integer mode") --------------
  * uint8 planar images [n,c,h,w], fixed-point taps, integer accumulation: the CPU restatement (oracle/imgproc_int_ref.py)
  * and these kernels agree bit for bit.  They shadow the reference's float ops (imgproc.py:1089-1121 filter2d_torch; the
  * F.interpolate call sites train_realesrnet.py:288,326-329,349-351,366-368), to which the distance is <= 1 LSB.
@@ -240,6 +240,15 @@ int resr_filter2d_u8(const uint8_t* src, uint8_t* dst, const int32_t* taps_q14, 
                      int32_t kh, int32_t kw, int32_t per_sample, void* stream);
 int resr_resize_u8(const uint8_t* src, uint8_t* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t oh, int32_t ow,
                    int32_t mode, const int32_t* idx_y, const int32_t* w_y, const int32_t* idx_x, const int32_t* w_x, void* stream);
+/* resr_jpeg_u8: DiffJPEG(differentiable=False).forward (imgproc.py:1462-1494) as an integer round trip on uint8 RGB
+ *   [n,3,h,w]: zero padding to multiples of 16, RGB -> YCbCr and the 8x8 DCT with Q20 constants and int64 accumulation,
+ *   quantiser steps rint(table * factor * 2^20) (the reference's transposed tables, imgproc.py:40-49; factor from the
+ *   float32 quality[n] as imgproc.py:1134-1139, evaluated in float64 on the device), round-half-even division (torch.round),
+ *   inverse DCT, nearest chroma upsampling, YCbCr -> RGB, clamp.  `coeffs` (nullable): the quantised coefficients, int32,
+ *   per image [Y blocks row-major | Cb blocks | Cr blocks] x 64 over the padded size -- the same layout as resr_jpeg's.
+ *   `quality` is read, never written (the reference mutates its argument in place; the Python mirror does that). */
+int resr_jpeg_u8(const uint8_t* src, uint8_t* dst, const float* quality, int32_t* coeffs, int32_t n, int32_t h, int32_t w,
+                 void* stream);
 
 /* ---- discriminator helpers (model.py:135-203) -------------------------------------------------------- */
 /* 2x2 space-to-depth of an NHWC tensor [n,h,w,c] -> [n,h/2,w/2,4c] (inverse != 0: depth-to-space) */

@@ -1,4 +1,4 @@
-"""Oracle restatement of the INTEGER mode of blur / resize (north_star: "blur/resize/JPEG bit-exact in integer mode";
+"""Oracle restatement of the INTEGER mode of blur / resize / JPEG (north_star: "blur/resize/JPEG bit-exact in integer mode";
 SURVEY.md §7 defines the mode: uint8-quantised inputs, fixed-point taps, integer accumulation).
 
 TEST INFRASTRUCTURE ONLY (imported by tests/ and nothing else).  Pure numpy integer arithmetic, written independently of
@@ -91,3 +91,87 @@ def resize_u8(img: np.ndarray, out_hw, scale, mode: str) -> np.ndarray:
     rows = (x[:, :, :, ix] * wx[None, None, None, :, :]).sum(axis=4)               # [N,C,H,ow]   horizontal pass
     acc = (rows[:, :, iy, :] * wy[None, None, :, :, None]).sum(axis=3)             # [N,C,oh,ow]  vertical pass
     return np.clip((acc + (1 << (2 * QR - 1))) >> (2 * QR), 0, 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# JPEG round trip in integer mode: DiffJPEG(differentiable=False) (imgproc.py:1462-1494; colour :1195-1262, DCT :1296-1316,
+# quantisation :1319-1353, inverse :1356-1459, tables :40-49, quality -> factor :1124-1141) on uint8 images with fixed-point
+# constants and int64 accumulation.  Fixed-point formats (the HIP kernel csrc/degrade_int.hip:jpeg_u8_kernel must agree bit
+# for bit; every ">>" is an arithmetic shift, i.e. floor; nothing exceeds 2^55):
+#   colour matrices  rint(M * 2^20), samples level-shifted; luma x 4 and the 2x2 chroma SUM -> Q22
+#   DCT matrix       C[u][x] = rint(0.5 * alpha(u) * cos((2x+1) u pi / 16) * 2^20); pass 1 descaled by 20 -> Q22, pass 2 -> Q42
+#   quantiser step   S = max(1, rint(table * factor * 2^20)), factor in float64 from the float32 quality;
+#                    q = round-half-even(F / (S * 2^22)), dequantised q * S (Q20)
+#   inverse          the same matrix transposed, pass 1 descaled by 24 -> Q16, pass 2 by 20 -> Q16; colour back with
+#                    rint(M^-1 * 2^20): out = clamp((v + 2^35) >> 36, 0, 255)
+# ---------------------------------------------------------------------------------------------------------------------
+_Y_STD = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51,
+                   87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120,
+                   101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float64).reshape(8, 8).T          # imgproc.py:40-44 (transposed)
+_C_STD = np.full((8, 8), 99.0)
+_C_STD[:4, :4] = np.array([17, 18, 24, 47, 18, 21, 26, 66, 24, 26, 56, 99, 47, 66, 99, 99], dtype=np.float64).reshape(4, 4).T  # :45-48
+JQ = 20
+_TO_YCC = np.rint(np.array([[0.299, 0.587, 0.114], [-0.168736, -0.331264, 0.5], [0.5, -0.418688, -0.081312]]) * (1 << JQ)).astype(np.int64)  # :1217-1222
+_R_CR, _G_CB, _G_CR, _B_CB = (int(np.rint(v * (1 << JQ))) for v in (1.402, -0.344136, -0.714136, 1.772))                         # :1435-1440
+
+
+def jpeg_dct_matrix() -> np.ndarray:
+    u = np.arange(8, dtype=np.float64)[:, None]
+    x = np.arange(8, dtype=np.float64)[None, :]
+    alpha = np.where(u == 0, 1.0 / np.sqrt(2.0), 1.0)
+    return np.rint(0.5 * alpha * np.cos((2 * x + 1) * u * np.pi / 16) * (1 << JQ)).astype(np.int64)
+
+
+def jpeg_steps(quality: np.ndarray) -> np.ndarray:
+    """float32 quality [N] -> int64 [N,2,8,8] quantiser steps in Q20 (luma, chroma)."""
+    q = np.asarray(quality, dtype=np.float32).astype(np.float64)
+    factor = np.where(q < 50, 50.0 / q, 2.0 - q / 50.0)                       # imgproc.py:1134-1139: (5000/q)/100, (200-2q)/100
+    tabs = np.stack([_Y_STD, _C_STD])[None] * factor[:, None, None, None]
+    return np.maximum(np.rint(tabs * float(1 << JQ)), 1).astype(np.int64)
+
+
+def _blocks(p: np.ndarray) -> np.ndarray:
+    n, h, w = p.shape
+    return p.reshape(n, h // 8, 8, w // 8, 8).transpose(0, 1, 3, 2, 4)           # [N, by, bx, 8, 8]
+
+
+def _unblocks(b: np.ndarray) -> np.ndarray:
+    n, by, bx = b.shape[:3]
+    return b.transpose(0, 1, 3, 2, 4).reshape(n, by * 8, bx * 8)
+
+
+def _div_half_even(a: np.ndarray, d: np.ndarray) -> np.ndarray:
+    q, r = np.divmod(2 * a + d, 2 * d)                                            # floor((a + d/2) / d), exact
+    return q - ((r == 0) & (q % 2 != 0))                                          # a tie went up: back to the even neighbour
+
+
+def jpeg_u8(img: np.ndarray, quality: np.ndarray, return_coefficients: bool = False):
+    """uint8 [N,3,H,W], float32 quality [N] -> uint8 [N,3,H,W] (and the quantised coefficients [N, by, bx, 8, 8] of Y, Cb, Cr)."""
+    n, _, h, w = img.shape
+    hp, wp = -h % 16, -w % 16
+    x = np.pad(img.astype(np.int64), ((0, 0), (0, 0), (0, hp), (0, wp)))          # zero padding of the RGB image, imgproc.py:1486-1488
+    ycc = np.einsum("kc,nchw->nkhw", _TO_YCC, x)                                  # Q20; Cb, Cr without their +128 (= level-shifted)
+    ycc[:, 0] -= 128 << JQ
+    planes = [ycc[:, 0] << 2]                                                     # Q22
+    for k in (1, 2):                                                              # 2x2 chroma SUM = 4 x the average, :1240-1262
+        c = ycc[:, k]
+        planes.append(c[:, 0::2, 0::2] + c[:, 0::2, 1::2] + c[:, 1::2, 0::2] + c[:, 1::2, 1::2])
+    C = jpeg_dct_matrix()
+    steps = jpeg_steps(quality)
+    out, coefs = [], []
+    for k, p in enumerate(planes):
+        b = _blocks(p)                                                            # [..., x, y]
+        t = (np.einsum("ux,nabxy->nabuy", C, b) + (1 << 19)) >> 20                # Q22
+        f = np.einsum("vy,nabuy->nabuv", C, t)                                    # Q42
+        st = steps[:, min(k, 1)][:, None, None]
+        q = _div_half_even(f, st << 22)
+        coefs.append(q)
+        s = (np.einsum("ux,nabuv->nabxv", C, q * st) + (1 << 23)) >> 24           # Q20 * Q20 -> Q16
+        r = (np.einsum("vy,nabxv->nabxy", C, s) + (1 << 19)) >> 20                # Q16
+        out.append(_unblocks(r))
+    Y = (out[0] + (128 << 16)) << JQ                                              # Q36
+    cb = np.repeat(np.repeat(out[1], 2, axis=1), 2, axis=2)                       # nearest x2, imgproc.py:1412-1432
+    cr = np.repeat(np.repeat(out[2], 2, axis=1), 2, axis=2)
+    rgb = np.stack([Y + _R_CR * cr, Y + _G_CB * cb + _G_CR * cr, Y + _B_CB * cb], axis=1)
+    res = np.clip((rgb + (1 << 35)) >> 36, 0, 255).astype(np.uint8)[:, :, :h, :w]
+    return (res, coefs) if return_coefficients else res

@@ -114,6 +114,7 @@ _PROTOS = {
     "resr_quantize_crop": (C.c_int, [_P] * 4 + [C.c_int32] * 10 + [_P]),
     "resr_filter2d_u8": (C.c_int, [_P, _P, _P] + [C.c_int32] * 7 + [_P]),
     "resr_resize_u8": (C.c_int, [_P, _P] + [C.c_int32] * 7 + [_P] * 5),
+    "resr_jpeg_u8": (C.c_int, [_P, _P, _P, _P] + [C.c_int32] * 3 + [_P]),
 }
 
 _lib = None

@@ -109,6 +109,7 @@ int jpeg_dispatch(const float*, float*, const float*, float*, int, int, int, int
 int quantize_crop_dispatch(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 
 int filter2d_u8_dispatch(const uint8_t*, uint8_t*, const int32_t*, int, int, int, int, int, int, int, hipStream_t);
+int jpeg_u8_dispatch(const uint8_t*, uint8_t*, const float*, int32_t*, int, int, int, hipStream_t);
 int resize_u8_dispatch(const uint8_t*, uint8_t*, int, int, int, int, int, int, int, const int32_t*, const int32_t*, const int32_t*,
                        const int32_t*, hipStream_t);
 
@@ -299,6 +300,12 @@ int resr_resize_u8(const uint8_t* src, uint8_t* dst, int32_t n, int32_t c, int32
                    int32_t mode, const int32_t* idx_y, const int32_t* w_y, const int32_t* idx_x, const int32_t* w_x, void* stream) {
     RESR_DEVICE_SCOPE(stream);
     return resize_u8_dispatch(src, dst, n, c, h, w, oh, ow, mode, idx_y, w_y, idx_x, w_x, (hipStream_t)stream);
+}
+
+int resr_jpeg_u8(const uint8_t* src, uint8_t* dst, const float* quality, int32_t* coeffs, int32_t n, int32_t h, int32_t w,
+                 void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return jpeg_u8_dispatch(src, dst, quality, coeffs, n, h, w, (hipStream_t)stream);
 }
 
 int resr_space_to_depth(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t dtype, int32_t inverse,

@@ -11,7 +11,14 @@
 //                float64 from ATen's coordinate map), horizontal pass in int32, vertical pass in int64,
 //                dst = clamp((acc + 2^21) >> 22, 0, 255);  area (adaptive average): integer window sums,
 //                dst = (2 * sum + count) / (2 * count)  (round half up).
+//   jpeg_u8      DiffJPEG(differentiable=False) (imgproc.py:1462-1494) as an integer round trip: colour matrices and the
+//                DCT matrix in Q20, int64 accumulation, quantiser steps rint(table * factor * 2^20) (factor in float64 from
+//                the float32 quality), round-half-even division, the inverse transform and colour matrix likewise; formats
+//                stage by stage in oracle/imgproc_int_ref.py (jpeg_u8), which this kernel reproduces bit for bit.
 // All shifts are arithmetic (floor), so negative accumulators round the same way on both sides.
+#include <cmath>
+#include <mutex>
+
 #include "common.h"
 
 namespace resr {
@@ -132,6 +139,146 @@ int resize_u8_dispatch(const uint8_t* src, uint8_t* dst, int n, int c, int h, in
     hipLaunchKernelGGL(resize_u8_kernel, dim3(blocks), dim3(256), 0, st, src, dst, n * c, h, w, oh, ow, mode == 1 ? 2 : 4, idx_y, w_y,
                        idx_x, w_x);
     RESR_CHECK_LAUNCH("resize_u8_kernel");
+    return RESR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// JPEG round trip, integer mode
+// ---------------------------------------------------------------------------------------------------------
+struct JpegIntTables {
+    long long dct[64];            // C[u][x] = rint(0.5 alpha(u) cos((2x+1) u pi / 16) 2^20)
+    double ytab[64], ctab[64];    // the reference's (transposed) tables, imgproc.py:40-49, indexed [u*8+v]
+};
+__device__ JpegIntTables g_jpeg_int;
+
+static void jpeg_int_tables_host(JpegIntTables& t) {
+    static const double ystd[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
+                                    14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+                                    49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+    static const double cstd[16] = {17, 18, 24, 47, 18, 21, 26, 66, 24, 26, 56, 99, 47, 66, 99, 99};
+    for (int u = 0; u < 8; ++u)
+        for (int x = 0; x < 8; ++x) {
+            const double a = u == 0 ? 1.0 / std::sqrt(2.0) : 1.0;
+            t.dct[u * 8 + x] = (long long)std::nearbyint(0.5 * a * std::cos((2 * x + 1) * u * M_PI / 16) * 1048576.0);
+        }
+    for (int u = 0; u < 8; ++u)
+        for (int v = 0; v < 8; ++v) {
+            t.ytab[u * 8 + v] = ystd[v * 8 + u];
+            t.ctab[u * 8 + v] = (u < 4 && v < 4) ? cstd[v * 4 + u] : 99.0;
+        }
+}
+
+// one workgroup per 16x16 macroblock: 6 blocks of 8x8 (4 Y, Cb, Cr); everything between the uint8 load and the uint8 store
+// is int64 in LDS (4 arrays of 3 KB)
+__global__ __launch_bounds__(256) void jpeg_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                      const float* __restrict__ quality, int32_t* __restrict__ coeffs, int h,
+                                                      int w, int mbx, int mby) {
+    typedef long long i64;
+    __shared__ i64 ycc[3][256];      // Q20, level-shifted
+    __shared__ i64 a0[6][64], a1[6][64];
+    __shared__ i64 dct[64];
+    const int b = blockIdx.z, my = blockIdx.y, mx = blockIdx.x;
+    const int t = threadIdx.x, ly = t >> 4, lx = t & 15;
+    const int y = my * 16 + ly, x = mx * 16 + lx;
+    const size_t hw = (size_t)h * w;
+    const uint8_t* sp = src + (size_t)b * 3 * hw;
+    i64 r = 0, g = 0, bl = 0;                            // zero padding up to a multiple of 16 (imgproc.py:1486-1488)
+    if (y < h && x < w) {
+        r = sp[(size_t)y * w + x]; g = sp[hw + (size_t)y * w + x]; bl = sp[2 * hw + (size_t)y * w + x];
+    }
+    ycc[0][t] = 313524 * r + 615514 * g + 119538 * bl - (128LL << 20);
+    ycc[1][t] = -176933 * r - 347355 * g + 524288 * bl;
+    ycc[2][t] = 524288 * r - 439026 * g - 85262 * bl;
+    if (t < 64) dct[t] = g_jpeg_int.dct[t];
+    __syncthreads();
+    // block split, Q22: luma x 4, chroma = 2x2 sum
+    a0[(ly >> 3) * 2 + (lx >> 3)][(ly & 7) * 8 + (lx & 7)] = ycc[0][t] << 2;
+    if (t < 128) {
+        const int cidx = t >> 6, e = t & 63, cy = e >> 3, cx = e & 7;
+        const i64* pc = ycc[1 + cidx];
+        a0[4 + cidx][e] = pc[(2 * cy) * 16 + 2 * cx] + pc[(2 * cy) * 16 + 2 * cx + 1] + pc[(2 * cy + 1) * 16 + 2 * cx] +
+                          pc[(2 * cy + 1) * 16 + 2 * cx + 1];
+    }
+    __syncthreads();
+    for (int i = t; i < 384; i += 256) {                 // pass 1: T[u][y] = sum_x C[u][x] blk[x][y]  -> Q22
+        const int bi = i >> 6, u = (i >> 3) & 7, yy = i & 7;
+        i64 s = 0;
+#pragma unroll
+        for (int xx = 0; xx < 8; ++xx) s += dct[u * 8 + xx] * a0[bi][xx * 8 + yy];
+        a1[bi][u * 8 + yy] = (s + (1LL << 19)) >> 20;
+    }
+    __syncthreads();
+    const double qd = (double)quality[b];
+    const double factor = qd < 50.0 ? 50.0 / qd : 2.0 - qd / 50.0;        // imgproc.py:1134-1139
+    for (int i = t; i < 384; i += 256) {                 // pass 2 (Q42), quantise (half to even), dequantise (Q20)
+        const int bi = i >> 6, uv = i & 63, u = uv >> 3, v = uv & 7;
+        i64 f = 0;
+#pragma unroll
+        for (int yy = 0; yy < 8; ++yy) f += dct[v * 8 + yy] * a1[bi][u * 8 + yy];
+        const double tab = (bi < 4 ? g_jpeg_int.ytab[uv] : g_jpeg_int.ctab[uv]) * factor;
+        i64 step = (i64)rint(tab * 1048576.0);
+        if (step < 1) step = 1;
+        const i64 d = step << 22, num = 2 * f + d, den = 2 * d;
+        i64 q = num / den, rem = num - q * den;
+        if (rem < 0) { q -= 1; rem += den; }             // floor division
+        if (rem == 0 && (q & 1)) q -= 1;                 // a tie went up: back to the even neighbour
+        if (coeffs) {
+            // layout: per image [Y blocks (H/8 * W/8) | Cb blocks | Cr blocks] x 64, block order row-major
+            const int nyb = mbx * 2 * mby * 2, ncb = mbx * mby;
+            size_t off;
+            if (bi < 4) off = (size_t)((my * 2 + (bi >> 1)) * (mbx * 2) + mx * 2 + (bi & 1));
+            else off = (size_t)nyb + (size_t)(bi - 4) * ncb + (size_t)my * mbx + mx;
+            coeffs[((size_t)b * (nyb + 2 * ncb) + off) * 64 + uv] = (int32_t)q;
+        }
+        a0[bi][uv] = q * step;
+    }
+    __syncthreads();
+    for (int i = t; i < 384; i += 256) {                 // inverse pass 1: S[x][v] = sum_u C[u][x] D[u][v]  -> Q16
+        const int bi = i >> 6, xx = (i >> 3) & 7, v = i & 7;
+        i64 s = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += dct[u * 8 + xx] * a0[bi][u * 8 + v];
+        a1[bi][xx * 8 + v] = (s + (1LL << 23)) >> 24;
+    }
+    __syncthreads();
+    for (int i = t; i < 384; i += 256) {                 // inverse pass 2: rec[x][y] = sum_v C[v][y] S[x][v]  -> Q16
+        const int bi = i >> 6, xx = (i >> 3) & 7, yy = i & 7;
+        i64 s = 0;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) s += dct[v * 8 + yy] * a1[bi][xx * 8 + v];
+        a0[bi][xx * 8 + yy] = (s + (1LL << 19)) >> 20;
+    }
+    __syncthreads();
+    if (y < h && x < w) {
+        const i64 Y = (a0[(ly >> 3) * 2 + (lx >> 3)][(ly & 7) * 8 + (lx & 7)] + (128LL << 16)) << 20;      // Q36
+        const i64 cb = a0[4][(ly >> 1) * 8 + (lx >> 1)], cr = a0[5][(ly >> 1) * 8 + (lx >> 1)];             // nearest x2
+        const i64 R = (Y + 1470104 * cr + (1LL << 35)) >> 36;
+        const i64 G = (Y - 360853 * cb - 748826 * cr + (1LL << 35)) >> 36;
+        const i64 B = (Y + 1858077 * cb + (1LL << 35)) >> 36;
+        uint8_t* dp = dst + (size_t)b * 3 * hw + (size_t)y * w + x;
+        dp[0] = (uint8_t)(R < 0 ? 0 : (R > 255 ? 255 : R));
+        dp[hw] = (uint8_t)(G < 0 ? 0 : (G > 255 ? 255 : G));
+        dp[2 * hw] = (uint8_t)(B < 0 ? 0 : (B > 255 ? 255 : B));
+    }
+}
+
+int jpeg_u8_dispatch(const uint8_t* src, uint8_t* dst, const float* quality, int32_t* coeffs, int n, int h, int w, hipStream_t st) {
+    if (!src || !dst || !quality || n <= 0 || h <= 0 || w <= 0) return fail(RESR_ERR_ARG, "jpeg_u8: bad argument");
+    if (n > 65535 || (h + 15) / 16 > 65535) return fail(RESR_ERR_ARG, "jpeg_u8: batch or height beyond the launch grid");
+    static std::once_flag once[kMaxDevices];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) return fail(RESR_ERR_ARG, "jpeg_u8: device index beyond %d", kMaxDevices);
+    hipError_t err = hipSuccess;
+    std::call_once(once[dev], [&]() {
+        static JpegIntTables host;
+        jpeg_int_tables_host(host);
+        err = hipMemcpyToSymbol(HIP_SYMBOL(g_jpeg_int), &host, sizeof(JpegIntTables));
+    });
+    if (err != hipSuccess) return fail(RESR_ERR_LAUNCH, "jpeg_u8: table upload failed: %s", hipGetErrorString(err));
+    const int mbx = (w + 15) / 16, mby = (h + 15) / 16;
+    hipLaunchKernelGGL(jpeg_u8_kernel, dim3(mbx, mby, n), dim3(256), 0, st, src, dst, quality, coeffs, h, w, mbx, mby);
+    RESR_CHECK_LAUNCH("jpeg_u8_kernel");
     return RESR_OK;
 }
 

@@ -20,7 +20,7 @@ from . import _lib
 
 __all__ = ["random_add_gaussian_noise_torch", "random_add_poisson_noise_torch", "random_mixed_kernels",
            "generate_sinc_kernel", "image_to_tensor", "tensor_to_image", "random_crop", "filter2d_torch",
-           "interpolate", "filter2d_u8", "interpolate_u8", "quantize_kernel_q14", "resize_tap_tables", "DiffJPEG", "USMSharp", "image_resize", "center_crop", "random_rotate",
+           "interpolate", "filter2d_u8", "interpolate_u8", "jpeg_u8", "quantize_kernel_q14", "resize_tap_tables", "DiffJPEG", "USMSharp", "image_resize", "center_crop", "random_rotate",
            "random_horizontally_flip", "random_vertically_flip", "rgb2ycbcr_torch", "read_image_rgb"]
 
 _MODES = {"area": 0, "bilinear": 1, "bicubic": 2}
@@ -314,6 +314,34 @@ class DiffJPEG(nn.Module):
         if isinstance(quality, torch.Tensor):       # reference quirk: factor[i] = f(quality[i]) written into the caller's tensor
             quality.copy_(torch.where(q < 50, (5000.0 / q) / 100.0, (200.0 - q * 2) / 100.0))
         return (out, coeffs) if return_coeffs else out
+
+
+def jpeg_u8(image: torch.Tensor, quality, return_coeffs: bool = False):
+    """Integer-mode `DiffJPEG(False).forward` (reference imgproc.py:1462-1494): uint8 RGB [N,3,H,W] in, uint8 out, fixed-point
+    constants and integer accumulation throughout (include/resr.h: resr_jpeg_u8).  `quality`: a number or a [N] tensor, which
+    -- as in the reference -- is overwritten in place with the quantisation factors.  With `return_coeffs` also the quantised
+    coefficients, int32 [N, blocks, 64] in DiffJPEG.forward(return_coeffs=True)'s block order."""
+    _lib.require_cuda(image, "jpeg_u8")
+    if image.dtype != torch.uint8 or image.dim() != 4 or image.shape[1] != 3:
+        raise ValueError("jpeg_u8: expected a uint8 [N,3,H,W] image")
+    x = image.contiguous()
+    b, _, h, w = x.shape
+    if isinstance(quality, (int, float)):
+        q = torch.full((b,), float(quality), dtype=torch.float32, device=x.device)
+    else:
+        q = quality.to(device=x.device, dtype=torch.float32).contiguous().clone()
+    if q.numel() != b:
+        raise ValueError("jpeg_u8: quality must be a number or one value per image")
+    out = torch.empty_like(x)
+    coeffs = None
+    if return_coeffs:
+        mb = ((h + 15) // 16) * ((w + 15) // 16)
+        coeffs = torch.empty((b, mb * 6, 64), dtype=torch.int32, device=x.device)
+    _lib.check(_lib.lib().resr_jpeg_u8(_lib.ptr(x), _lib.ptr(out), _lib.ptr(q), _lib.ptr(coeffs), b, h, w, _lib.stream_ptr(x)),
+               "resr_jpeg_u8")
+    if isinstance(quality, torch.Tensor):
+        quality.copy_(torch.where(q < 50, (5000.0 / q) / 100.0, (200.0 - q * 2) / 100.0))
+    return (out, coeffs) if return_coeffs else out
 
 
 # ---- crop / conversions --------------------------------------------------------------------------------
