@@ -155,6 +155,32 @@ def pmc_traffic(kernel, batch):
     return None, None
 
 
+def sustained_frontier():
+    """(matrix PFLOP/s alone, stream TB/s, matrix PFLOP/s next to that stream, file) from the committed run of
+    tools/micro/sustained.hip (profiles/r*_micro_sustained.txt: each arm held for 1.5 s), or None."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_micro_sustained.txt")), reverse=True):
+        try:
+            alone = both_s = both_m = None
+            for line in open(path):
+                if "sustained" not in line:
+                    continue
+                m = re.search(r"stream\s+([0-9.]+) TB/s\s+matrix\s+([0-9.]+) PFLOP/s", line)
+                if not m:
+                    continue
+                st, mx = float(m.group(1)), float(m.group(2))
+                if st == 0.0:
+                    alone = mx
+                elif mx > 0.0:
+                    both_s, both_m = st, mx
+            if alone and both_s:
+                return alone, both_s, both_m, os.path.basename(path)
+        except Exception:
+            pass
+    return None
+
+
 def kernel_name(kid):
     if kid >= 50000:
         k = kid - 50000
@@ -212,6 +238,18 @@ def roofline_in_situ(step_fn, precision, batch):
                               "algorithmic_gbs": round(v["b"] / v["t"] / 1e6, 1)} for k, v in by.items()}}
     if src:
         r["traffic_source"] = "profiles/" + src
+    fr = sustained_frontier()
+    if fr and precision != "strict":
+        # the matrix pipe and the HBM stream share one power budget: what the pipe sustains on real f16 operands next to a
+        # stream of this kernel's measured (else algorithmic) HBM rate, by linear interpolation between the two measured arms
+        alone, st, mx, fsrc = fr
+        tbs = (traffic if traffic else b["b"] / b["n"]) / (b["t"] / b["n"]) / 1e9
+        frontier = (alone - (alone - mx) / st * tbs) * 1e3
+        executed = achieved * (3.0 if precision == "exact16" else 1.0)
+        r["vs_sustained"] = {"matrix_alone_tflops": round(alone * 1e3, 1), "matrix_next_to_stream_tflops": round(mx * 1e3, 1),
+                             "stream_tbs": st, "kernel_hbm_tbs": round(tbs, 2), "frontier_tflops": round(frontier, 1),
+                             "executed_tflops": round(executed, 2), "frac": round(executed / frontier, 4),
+                             "source": "profiles/" + fsrc + " (tools/micro/sustained.hip, each arm held 1.5 s; an earlier box)"}
     return r
 
 
