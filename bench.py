@@ -754,7 +754,7 @@ def main():
                   "generator_tflops_per_gpu": round(pv / world * flop_per_image / 1e12, 2), "loss": parity_res["loss"]}
             if "roofline" in parity_res:
                 r = parity_res["roofline"]
-                pm["roofline"] = {k: r[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "per_instance") if k in r}
+                pm["roofline"] = {k: r[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "per_instance", "vs_sustained") if k in r}
                 pm["roofline"]["note"] = "achieved = algorithmic FLOP (2*9*cin*cout*px) per second; the matrix pipe executes 3x that"
             try:
                 x, ys = parity_probe(main_res["state_dict"])
