@@ -8,7 +8,8 @@ Weights: torchvision's pretrained VGG19 cannot be downloaded here, so the convs 
 *initialisation* (kaiming_normal fan_out / zero bias); `load_state_dict` accepts a torchvision `vgg19()` state
 dict (`features.N.weight|bias`) when one is available.  Numerics vs the real torchvision graph are therefore
 unpinned; in particular torchvision's ReLU(inplace=True) makes every tapped conv output except the
-last one alias its ReLU-ed value -- reproduced here under `inplace_relu_aliasing=True` (default), unverified.
+last one alias its ReLU-ed value -- reproduced here under `inplace_relu_aliasing=True` (default); checked against a torch.fx
+extractor over a plain-torch clone of the module structure (tests/test_oracle_vgg_extractor.py), not against torchvision itself.
 """
 from __future__ import annotations
 
