@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libresr_hip.so")
+# RESR_LIB_PATH: experiment knob -- load a variant build (tools/build_variant.py) for same-box A/B timing
+LIB_PATH = os.environ.get("RESR_LIB_PATH") or os.path.join(_HERE, "csrc", "libresr_hip.so")
 
 RESR_F16, RESR_F32, RESR_F16X2 = 0, 1, 2
 CONV_LRELU, CONV_UPSAMPLE_IN, CONV_CLAMP01, CONV_OUT_NCHW_F32, CONV_MASK, CONV_NO_BIAS = 1, 2, 4, 8, 16, 32

@@ -72,6 +72,9 @@ struct WsCfg {
     // keeps them resident (buffer = chunk, loaded during the first tile only); otherwise the two-buffer ring by stage parity.
     static constexpr int NWB = (160 * 1024 - WOFF) / WBUF < 2 ? 2 : (160 * 1024 - WOFF) / WBUF;
     static constexpr int LDS_BYTES = WOFF + NWB * WBUF;
+    // LeakyReLU-backward multipliers by 4 mask bits (16 x float4), behind the weight buffers (EPI 33 of the lean epilogue)
+    static constexpr int LUT_OFF = LDS_BYTES, LUT_BYTES = 256;
+    static_assert(LDS_BYTES + LUT_BYTES <= 160 * 1024, "LDS");
 };
 
 __device__ __forceinline__ void conv_glds16(const char* gsrc, char* lds_wave_base) {
@@ -94,6 +97,49 @@ __device__ __forceinline__ void conv_glds16_s(const char* sbase, unsigned voff, 
 // otherwise insert itself.
 __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
     asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
+
+// ---- pieces of the lean epilogue (FAST instantiations of conv3x3_ws_kernel) ----
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+
+// v_max_f32 without the canonicalising self-max the compiler puts in front of fmaxf under IEEE mode
+__device__ __forceinline__ float vmax_f32(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// t * (float)half of a packed f16 pair, one VALU instruction (v_fma_mix_f32 reads the f16 operand directly; + 0 keeps
+// the product's single rounding)
+__device__ __forceinline__ float mixmul_lo(unsigned h2, float t) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(t));
+    return d;
+}
+__device__ __forceinline__ float mixmul_hi(unsigned h2, float t) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(t));
+    return d;
+}
+// four lane-half exchanges in one block: (a_r, b_r) of lanes lx / lx+32 -> 8 consecutive output channels per lane.
+// One pair of wait-state nops for the block (the swaps touch disjoint registers); volatile: stays behind the
+// MFMA-result wait states the epilogue issues first.
+__device__ __forceinline__ void permlane32_swap4(float& a0, float& a1, float& a2, float& a3, float& b0, float& b1, float& b2, float& b3) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\t"
+        "v_permlane32_swap_b32 %3, %7\n\ts_nop 1"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+}
+// bit r of the result (times 128) <-> f16 half r of (d0, d1) is > 0, r = 0..3, weights = one byte per half.
+// A half is positive iff it is positive as a 16-bit integer; 0 - h (saturating) then carries that in its sign bit.
+__device__ __forceinline__ unsigned signs4_x128(unsigned d0, unsigned d1, unsigned weights, unsigned acc) {
+    const short2v z = {0, 0};
+    const unsigned s0 = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(z, __builtin_bit_cast(short2v, d0)));
+    const unsigned s1 = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(z, __builtin_bit_cast(short2v, d1)));
+    const unsigned p = __builtin_amdgcn_perm(s1, s0, 0x07050301u);   // the four high bytes
+    return __builtin_amdgcn_udot4(p & 0x80808080u, weights, acc, false);
 }
 
 // EPI: epilogue features of the instantiation -- bit 0 LeakyReLU-mask multiply, bit 1 residual 0, bit 2 residual 1 (each
@@ -145,6 +191,21 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     if (wave == 0) {
         const bool f_bias = !(a.flags & RESR_CONV_NO_BIAS) && a.bias != nullptr;
         bias_lds[lane] = (f_bias && lane < a.cout) ? a.bias[lane] * (X2 ? kLoScale : 1.f) : 0.f;
+    }
+    // FAST: instantiations with the lean epilogue (the generator's hot forms: plain / LeakyReLU, residuals, sign-bit
+    // output, sign-bit mask); everything else keeps the general one
+#ifdef RESR_GENERAL_EPILOGUE   // A/B builds (tools/build_variant.py): every instantiation on the general epilogue
+    constexpr bool FAST = false;
+#else
+    constexpr bool FAST = !X2 && (EPI == 0 || EPI == 2 || EPI == 6 || EPI == 16 || EPI == 33);
+#endif
+    if constexpr (FAST && EPI == 33) {
+        if (wave == 1 && lane < 16) {
+            float4v m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = ((lane >> r) & 1) ? 1.f : a.slope;
+            *reinterpret_cast<float4v*>(smem + C::LUT_OFF + lane * 16) = m;
+        }
     }
     __syncthreads();
     if (wave >= NWC) {
@@ -450,6 +511,25 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 
     int par = 0, hbc = 0;   // weight-buffer parity / halo buffer of the current stage
     for (int tile = first; tile < ntiles; tile += G) {
+        // lean epilogue, sign-bit mask (EPI 33): the mask words of this wave's rows are requested HERE and land under the
+        // tile's MFMAs (requested in the epilogue they cost one exposed memory round trip per row)
+        unsigned mword[(FAST && EPI == 33) ? NT : 1][MT];
+        if constexpr (FAST && EPI == 33) {
+            const int tsp = tile % ntiles_sp;
+            const int x = (tsp % a.tiles_x) * TW + (lane & 31);
+            const int y0 = ((tsp / a.tiles_x) % a.tiles_y) * TH + row0;
+            const int n = tsp / (a.tiles_x * a.tiles_y);
+            const unsigned xc = (unsigned)(x < a.w_ ? x : a.w_ - 1);
+            const unsigned wpp = (unsigned)((a.cout + 31) >> 5);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int y = y0 + t;
+                const unsigned p = ((unsigned)n * a.h + (unsigned)(y < a.h ? y : a.h - 1)) * a.w_ + xc;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    mword[t][m] = reinterpret_cast<const unsigned*>(a.mask)[(size_t)p * wpp + (m < (int)wpp ? m : 0)];
+            }
+        }
         for (int ck = 0; ck < nchunks; ++ck) {
             // consumers only read LDS: a bare barrier (no vmcnt drain of the weight ring) is enough
             if (wave == 0) stamp(1);
@@ -546,6 +626,157 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             if (wave == 0) stamp(1);
         }
 
+        if constexpr (FAST) {
+            // ---- lean epilogue (same results as the general one below; about a third of its vector instructions) ----
+            // MFMA leaves lane (lx, kh) with couts g*8 + kh*4 + 0..3 of each quad g; one permlane32_swap block per quad pair
+            // regroups them IN PLACE into 8 consecutive couts ((2j + kh)*8 + 0..7) in 8 consecutive registers, so every
+            // later step is a packed instruction on register pairs: LeakyReLU = max(v, slope*v) (v_pk_mul_f32 + v_max_f32),
+            // residuals = v_fma_mix_f32 (reads the f16 directly) + v_pk_fma_f32, v_cvt_pk_f16_f32, the sign byte from the
+            // converted halves (v_pk_sub_i16 clamp / v_perm_b32 / v_dot4_u32_u8), the sign-bit mask through a 16-entry
+            // float4 table in LDS (one ds_read_b128 + two v_pk_mul_f32 per four values).
+            const int tsp = tile % ntiles_sp;
+            const size_t goff = MT == 2 ? (size_t)(tile / ntiles_sp) * 64 : 0;
+            const int x0 = (tsp % a.tiles_x) * TW;
+            const int y0 = ((tsp / a.tiles_x) % a.tiles_y) * TH;
+            const int n = tsp / (a.tiles_x * a.tiles_y);
+            typedef const ConvArgs __attribute__((address_space(4))) * KernargPtr;
+            KernargPtr ep = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ep));
+            struct {
+                const char *res0, *res1;
+                char* out;
+                uint8_t* aux;
+                int h, w_, cout, out_stride, res0_stride, res1_stride, flags;
+                int out_chunk, res0_chunk, res1_chunk;
+                float s0, t0, s1, t1, slope;
+            } e;
+            e.out = ep->out; e.h = ep->h; e.w_ = ep->w_; e.cout = ep->cout; e.out_stride = ep->out_stride;
+            e.out_chunk = ep->out_chunk; e.flags = ep->flags; e.slope = ep->slope;
+            constexpr bool R0 = (EPI & 2) != 0, R1 = (EPI & 4) != 0, ESB = EPI == 16, EMB = EPI == 33;
+            if constexpr (R0) { e.res0 = ep->res0; e.res0_stride = ep->res0_stride; e.res0_chunk = ep->res0_chunk; e.s0 = ep->s0; e.t0 = ep->t0; }
+            if constexpr (R1) { e.res1 = ep->res1; e.res1_stride = ep->res1_stride; e.res1_chunk = ep->res1_chunk; e.s1 = ep->s1; e.t1 = ep->t1; }
+            if constexpr (ESB) e.aux = ep->aux;
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int lx_e = lane_e & 31, kh_e = lane_e >> 5;
+            const int x = x0 + lx_e;
+            const unsigned xc = (unsigned)(x < e.w_ ? x : e.w_ - 1);
+            const bool f_lrelu = e.flags & RESR_CONV_LRELU;
+            const float2v sl2 = {e.slope, e.slope};
+            const unsigned kh16 = (unsigned)kh_e * 16u;   // byte offset of this lane half's 8 channels inside a 16-channel piece pair
+            // row double buffer of the residual pieces (cout 64): row t+1 is requested before row t is processed
+            constexpr bool RES = R0 || R1;
+            constexpr int NB = (RES && MT == 2) ? 2 : 1;
+            uint4v rr0[NB][MT][2], rr1[NB][MT][2];
+            auto row_pix = [&](int t) {
+                const int y = y0 + row0 + t;
+                return ((unsigned)n * e.h + (unsigned)(y < e.h ? y : e.h - 1)) * e.w_ + xc;
+            };
+            // pieces beyond cout (cout = 8, 16, 24 ... of a 32-channel tile) are neither read nor stored
+            auto piece_ok = [&](int m, int j) { return m * 32 + (2 * j + kh_e) * 8 < e.cout; };
+            // Residual loads are unconditional (a load under a divergent branch makes the compiler wait with vmcnt(0), which
+            // also waits for the NEXT row's prefetch): a piece pair beyond cout reads the pixel's first pair instead
+            // (wave-uniform select; cout is a multiple of 16 for these instantiations, host-checked) and is dropped at the store.
+            auto request = [&](int b, int t) {
+                const unsigned p = row_pix(t);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bool pair_ok = m * 32 + j * 16 < e.cout;   // wave-uniform
+                        if constexpr (R0)
+                            rr0[b][m][j] = *reinterpret_cast<const uint4v*>(e.res0 + ((size_t)p * e.res0_stride + goff + (pair_ok ? (size_t)m * e.res0_chunk + j * 16 : (size_t)0)) * 2 + kh16);
+                        if constexpr (R1)
+                            rr1[b][m][j] = *reinterpret_cast<const uint4v*>(e.res1 + ((size_t)p * e.res1_stride + goff + (pair_ok ? (size_t)m * e.res1_chunk + j * 16 : (size_t)0)) * 2 + kh16);
+                    }
+            };
+            // MFMA results -> first non-MFMA reader: the swaps are asm, so the compiler cannot count this hazard
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");
+            if constexpr (RES) request(0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int y = y0 + row0 + t;
+                const bool in_img = y < e.h && x < e.w_;
+                const unsigned p = row_pix(t);
+                const int b = NB == 2 ? (t & 1) : 0;
+                if constexpr (RES && NB == 2) {
+                    if (t + 1 < NT) request((t + 1) & 1, t + 1);
+                }
+                if constexpr (RES && NB == 1) {
+                    if (t > 0) request(0, t);
+                }
+                char* const orow = e.out + ((size_t)p * e.out_stride + goff) * 2 + kh16;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    unsigned sacc[2] = {0u, 0u};   // ESB: 128 x the sign byte of piece j
+                    unsigned wk = 0;
+                    if constexpr (EMB) wk = mword[t][m] >> (kh_e * 8);   // this lane half's bytes: j = 0 at bit 0, j = 1 at bit 16
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float16v& A = acc[m][t];
+                        float v0 = A[8 * j + 0], v1 = A[8 * j + 1], v2 = A[8 * j + 2], v3 = A[8 * j + 3];
+                        float v4 = A[8 * j + 4], v5 = A[8 * j + 5], v6 = A[8 * j + 6], v7 = A[8 * j + 7];
+                        permlane32_swap4(v0, v1, v2, v3, v4, v5, v6, v7);
+                        float2v q[4] = {{v0, v1}, {v2, v3}, {v4, v5}, {v6, v7}};
+                        if constexpr (EMB) {
+                            const char* lut = smem + C::LUT_OFF;
+                            const float4v ma = *reinterpret_cast<const float4v*>(lut + ((wk >> (16 * j)) & 15u) * 16);
+                            const float4v mb = *reinterpret_cast<const float4v*>(lut + ((wk >> (16 * j + 4)) & 15u) * 16);
+                            q[0] *= float2v{ma[0], ma[1]};
+                            q[1] *= float2v{ma[2], ma[3]};
+                            q[2] *= float2v{mb[0], mb[1]};
+                            q[3] *= float2v{mb[2], mb[3]};
+                        }
+                        if (f_lrelu) {   // 0 <= slope <= 1 (host-checked): LeakyReLU(v) = max(v, slope * v)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float2v sq = q[k] * sl2;
+                                q[k][0] = vmax_f32(q[k][0], sq[0]);
+                                q[k][1] = vmax_f32(q[k][1], sq[1]);
+                            }
+                        }
+                        if constexpr (R0) {
+                            const float2v s02 = {e.s0, e.s0};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float2v tr = {mixmul_lo(rr0[b][m][j][k], e.t0), mixmul_hi(rr0[b][m][j][k], e.t0)};
+                                q[k] = __builtin_elementwise_fma(q[k], s02, tr);
+                            }
+                        }
+                        if constexpr (R1) {
+                            const float2v s12 = {e.s1, e.s1};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float2v tr = {mixmul_lo(rr1[b][m][j][k], e.t1), mixmul_hi(rr1[b][m][j][k], e.t1)};
+                                q[k] = __builtin_elementwise_fma(q[k], s12, tr);
+                            }
+                        }
+                        uint4v d;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) d[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(q[k], half2v));
+                        if (in_img && piece_ok(m, j))
+                            *reinterpret_cast<uint4v*>(orow + ((size_t)m * e.out_chunk + j * 16) * 2) = d;
+                        if constexpr (ESB) {
+                            sacc[j] = signs4_x128(d[0], d[1], 0x08040201u, 0u);
+                            sacc[j] = signs4_x128(d[2], d[3], 0x80402010u, sacc[j]);
+                        }
+                    }
+                    if constexpr (ESB) {
+                        // bytes 2j + kh of the pixel's word: (byte_0 | byte_1 << 16) << 8 kh, all of it times 128 so far
+                        const unsigned both = sacc[0] | (sacc[1] << 16);
+                        const unsigned mine = __builtin_amdgcn_alignbit(both, both, kh_e ? 31u : 7u);   // rotate: >> 7 or << 1
+                        float sa = __builtin_bit_cast(float, mine), sb = sa;
+                        permlane32_swap(sa, sb);
+                        const unsigned word = __builtin_bit_cast(unsigned, sa) | __builtin_bit_cast(unsigned, sb);
+                        if (in_img && kh_e == 0 && m * 32 < e.cout)
+                            reinterpret_cast<unsigned*>(e.aux)[(size_t)p * (size_t)((e.cout + 31) >> 5) + m] = word;
+                    }
+                }
+            }
+            init_acc();
+            if (wave == 0) stamp(1);  // tile done
+            continue;
+        }
         // ---- epilogue: lane owns pixel (row0+t, lx) and 4 consecutive couts per accumulator quad ----
         const int tsp = tile % ntiles_sp;
         const size_t goff = (size_t)(tile / ntiles_sp) * 64;   // element offset of the tile's output group inside a pixel
@@ -772,7 +1003,7 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     ConvArgs args = a;
     args.tiles_x = (a.w_ + 31) / 32;
     args.tiles_y = (a.h + C::TH - 1) / C::TH;
-    const size_t lds = C::LDS_BYTES;  // two halo buffers + the bias (+ two weight buffers for cout 64)
+    const size_t lds = C::LDS_BYTES + ((!X2 && EPI == 33) ? C::LUT_BYTES : 0);  // halo buffers, bias, weight buffers (+ the mask-multiplier table)
     // per device (the boundary is callable with any current device): workgroups the device holds at once and the
     // address of this translation unit's zero page there; idempotent, so a race between two first calls is benign
     static int resident_dev[kMaxDevices] = {0};
@@ -813,6 +1044,7 @@ template <typename T, int MT, int NT, int NWC, bool X2 = false>
 static int launch_ws(const ConvArgs& a, hipStream_t stream) {
     const int combo = ((a.flags & RESR_CONV_MASK) ? 1 : 0) | (a.res0 ? 2 : 0) | (a.res1 ? 4 : 0);
     if (a.flags & RESR_CONV_WRITE_SIGNBITS) {   // forward conv + LeakyReLU that also emits its 1-bit mask (checked by the caller)
+        if (!X2 && (a.flags & RESR_CONV_LRELU) && !(a.slope >= 0.f && a.slope <= 1.f)) return fail(RESR_ERR_ARG, "conv3x3: sign-bit output needs 0 <= slope <= 1");
         return launch_ws_epi<T, MT, NT, NWC, 16, X2>(a, stream);
     }
     if (a.flags & RESR_CONV_MASK_BITS) return launch_ws_epi<T, MT, NT, NWC, 33, X2>(a, stream);
@@ -824,7 +1056,10 @@ static int launch_ws(const ConvArgs& a, hipStream_t stream) {
                 return launch_ws_epi<T, MT, NT, NWC, 65, X2>(a, stream);
         }
     }
-    const bool extras = a.aux || (a.flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_CLAMP01));
+    // the lean epilogue computes LeakyReLU as max(v, slope * v): slopes outside [0, 1] take the general one
+    const bool odd_slope = (a.flags & RESR_CONV_LRELU) && !(a.slope >= 0.f && a.slope <= 1.f);
+    const bool odd_cout = (a.res0 || a.res1) && (a.cout & 15);   // its residual loads select whole 16-channel piece pairs
+    const bool extras = odd_slope || odd_cout || a.aux || (a.flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_CLAMP01));
     if (!extras) switch (combo) {
         case 0: return launch_ws_epi<T, MT, NT, NWC, 0, X2>(a, stream);  // forward convs 1-4, upsampling, D forward
         case 1: return launch_ws_epi<T, MT, NT, NWC, 1, X2>(a, stream);  // backward-data through a LeakyReLU
