@@ -304,6 +304,11 @@ int resr_ema_update(float* shadow, const float* params, int64_t count, double de
 
 /* Debug: per-workgroup timeline of the fast-mode conv kernel (32 workgroups x 2 roles x 64 uint64 stamps, 100 MHz). */
 int resr_debug_conv_trace(void* dev_buf);
+/* Debug: health of the chained dense-block launches on the current device (the four cout-32 passes of a dense block,
+ * model.py:90-93, run as one persistent launch whose jobs wait for each other through per-tile flags): low 32 bits =
+ * flag polls that timed out, high 32 bits = workgroups found on another XCD than the tile ownership assumes.  Both must
+ * be 0; synchronises the device.  RESR_CONV_NO_CHAIN=1 in the environment disables chaining. */
+int64_t resr_debug_chain_errors(void);
 /* Host logic of the f16 weight-gradient launch, no GPU needed: how the (X chunk, G tile) products of `nconv` convolutions
  * that read one channel-prefix workspace (conv i: the first cin[i] channels; its own cout_pad[i] gradient channels) are
  * grouped into 2x2 jobs of the quad kernel.  out[q*4 + p] = index of the product computed by slot p of job q (products are

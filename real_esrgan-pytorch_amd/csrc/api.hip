@@ -70,6 +70,7 @@ struct DeviceScope {
 #define RESR_DEVICE_SCOPE(stream) DeviceScope resr_device_scope_(stream)
 
 void conv_trace_set(void*);
+long long conv3x3_chain_errors();
 int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*, const float*, const void*,
                      const void*, const void*, void*, void*, hipStream_t);
 int wgrad_dispatch(const ResrWgradDesc*, const void*, const void*, const void*, float*, float*, float*, hipStream_t);
@@ -383,6 +384,8 @@ int resr_debug_conv_trace(void* dev_buf) {
     resr::conv_trace_set(dev_buf);
     return RESR_OK;
 }
+
+int64_t resr_debug_chain_errors(void) { return (int64_t)resr::conv3x3_chain_errors(); }
 
 int resr_debug_tr_probe(float* out256, void* stream) {
     RESR_DEVICE_SCOPE(stream);

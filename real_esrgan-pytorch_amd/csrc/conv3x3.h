@@ -39,6 +39,27 @@ struct ConvArgs {
     unsigned long long* trace;  // debug: per-workgroup s_memrealtime stamps (resr_debug_conv_trace), else null
 };
 
+// A chain of dependent cout-32 convolutions of one dense block in ONE persistent launch (conv3x3_ws.h, CH): job j reads
+// the plane prefix of the shared operands and writes its own plane, which is the LAST 32-channel chunk of job j+1's input.
+// Everything a job does not share with the others:
+struct ChainJob {
+    const char* w;        // packed weights
+    const float* bias;    // or null
+    char* out;            // the job's output plane
+    void* aux;            // sign words written (forward) / read as the mask (backward-data)
+    int cin;              // input channels: a prefix of the shared in0 [+ in1] planes
+    int pad_;
+};
+constexpr int kMaxChain = 4;
+struct ChainArgs {
+    int njobs;
+    unsigned epoch;        // flag value of "job j of this launch done" = epoch + j + 1 (flags only ever grow: no reset between launches)
+    unsigned* flags;       // [tiles] per-tile progress, device memory
+    unsigned* errors;      // [2]: poll time-outs, workgroups found on an unexpected XCD
+    ChainJob job[kMaxChain];
+};
+struct ChainNone {};
+
 // Algorithmic HBM bytes of one pass: input channels + output (+ mask, residuals, aux) once per pixel.
 inline double conv_algorithmic_bytes(const ConvArgs& a, size_t es) {
     const double px_out = (double)a.n * a.h * a.w_, px_in = (double)a.n * a.hs * a.ws;

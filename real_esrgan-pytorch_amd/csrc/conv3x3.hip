@@ -293,9 +293,13 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
 int conv3x3_ws_f16(const ConvArgs& a, int mt, bool x2, hipStream_t stream);  // conv3x3_ws.hip
 bool conv3x3_ws_supported(const ConvArgs& a);
 
-int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, const void* w,
-                     const float* bias, const void* res0, const void* res1, const void* mask,
-                     void* out, void* aux, hipStream_t stream) {
+int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, const double* flop, const double* bytes, hipStream_t stream);   // conv3x3_ws.hip
+static int conv3x3_route(const ResrConvDesc* d, ConvArgs& a, bool have_bias, bool have_in1, hipStream_t stream);
+
+// descriptor + pointers -> kernel arguments (validation included)
+static int conv3x3_args(const ResrConvDesc* d, const void* in0, const void* in1, const void* w,
+                        const float* bias, const void* res0, const void* res1, const void* mask,
+                        void* out, void* aux, ConvArgs& a) {
     if (!d || !in0 || !w || !out) return fail(RESR_ERR_ARG, "conv3x3: null argument");
     if (d->cin <= 0 || (d->cin & 31) || (d->cin0 & 31) || d->cin0 <= 0 || d->cin0 > d->cin)
         return fail(RESR_ERR_ARG, "conv3x3: cin=%d cin0=%d must be positive multiples of 32", d->cin, d->cin0);
@@ -319,7 +323,6 @@ int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, co
             return fail(RESR_ERR_ARG, "conv3x3: MASK_BITS goes with MASK, cout %% 8 == 0, no residuals / aux");
     }
     const size_t es = elem_size(d->dtype);
-    ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in0 = (const char*)in0; a.in1 = (const char*)in1; a.w = (const char*)w; a.bias = bias;
     a.res0 = (const char*)res0; a.res1 = (const char*)res1; a.mask = (const char*)mask;
@@ -355,6 +358,25 @@ int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, co
             return fail(RESR_ERR_ARG, "conv3x3: s2d_out_channels=%d needs cout_groups * 64 = 4 * s2d_out_channels", d->s2d_out_channels);
         a.tap_c = d->s2d_out_channels;
     }
+    return RESR_OK;
+}
+
+int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, const void* w,
+                     const float* bias, const void* res0, const void* res1, const void* mask,
+                     void* out, void* aux, hipStream_t stream) {
+    ConvArgs a;
+    const int rc = conv3x3_args(d, in0, in1, w, bias, res0, res1, mask, out, aux, a);
+    if (rc) return rc;
+    return conv3x3_route(d, a, bias != nullptr, in1 != nullptr, stream);
+}
+
+static int conv3x3_route(const ResrConvDesc* d, ConvArgs& a, bool have_bias, bool have_in1, hipStream_t stream) {
+    const size_t es = elem_size(d->dtype);
+    const void* in1 = have_in1 ? (const void*)a.in1 : nullptr;
+    const void* res0 = a.res0;
+    const void* res1 = a.res1;
+    const int groups = d->cout_groups > 1 ? d->cout_groups : 1;
+    (void)have_bias;
     const int mt = d->cout_pad / 32;
     if (d->dtype == RESR_F16X2) {
         // hi/lo pairs: only the producer/consumer kernel has the mode
@@ -386,6 +408,67 @@ int conv3x3_dispatch(const ResrConvDesc* d, const void* in0, const void* in1, co
         return launch_conv<float, 2, 2>(a, stream);
     }
     return fail(RESR_ERR_ARG, "conv3x3: dtype=%d", d->dtype);
+}
+
+// The four cout-32 passes of one dense block (forward conv1..conv4, model.py:90-93, or the mirrored backward-data passes)
+// as ONE persistent launch when the fast-mode kernel can chain them (conv3x3_ws.h, CH); otherwise one launch each.
+// Job j: descriptor d[j], weights w[j], bias[j] (or null), mask[j] (or null), output out[j], aux[j] (or null); the
+// shared inputs in0 / in1 hold the plane prefix every job reads.
+int conv3x3_chain_dispatch(int njobs, const ResrConvDesc* d, const void* in0, const void* in1, const void* const* w,
+                           const float* const* bias, const void* const* mask, void* const* out, void* const* aux,
+                           hipStream_t stream) {
+    if (njobs <= 0 || njobs > kMaxChain || !d) return fail(RESR_ERR_ARG, "conv3x3_chain: njobs=%d", njobs);
+    ConvArgs a[kMaxChain];
+    for (int j = 0; j < njobs; ++j) {
+        const int rc = conv3x3_args(&d[j], in0, in1, w[j], bias ? bias[j] : nullptr, nullptr, nullptr, mask ? mask[j] : nullptr,
+                                    out[j], aux ? aux[j] : nullptr, a[j]);
+        if (rc) return rc;
+    }
+    const char* no_chain = getenv("RESR_CONV_NO_CHAIN");   // test / A-B knob: one launch per job (read per call, so a test can flip it)
+    bool ok = !no_chain && njobs >= 2 && d[0].dtype == RESR_F16;
+    const int fwd_flags = RESR_CONV_LRELU | RESR_CONV_WRITE_SIGNBITS;
+    const int bwd_flags = RESR_CONV_MASK | RESR_CONV_MASK_BITS | RESR_CONV_NO_BIAS;
+    const ConvArgs& b = a[njobs - 1];   // the widest job: its in0 / in1 split describes every prefix
+    for (int j = 0; ok && j < njobs; ++j) {
+        const ConvArgs& c = a[j];
+        ok = d[j].dtype == RESR_F16 && d[j].cout_pad == 32 && c.cout == 32 && (c.flags == fwd_flags || c.flags == bwd_flags) &&
+             c.flags == b.flags && c.n == b.n && c.h == b.h && c.w_ == b.w_ && c.hs == c.h && c.ws == c.w_ &&
+             (c.n % 8) == 0 && (c.w_ % 2) == 0 && c.slope == b.slope &&
+             c.in0_stride_b == 64 && c.in0_chunk_b == b.in0_chunk_b && c.out_stride == 32 &&
+             (c.cin0 == c.cin || (c.cin0 == b.cin0 && c.in1_stride_b == 64 && c.in1_chunk_b == b.in1_chunk_b)) &&
+             c.cin >= (j == 0 ? 64 : 96) && c.ngroups == 1 && !c.s2d_c && !c.tap_c &&
+             ((c.flags == fwd_flags) ? c.aux != nullptr : c.mask != nullptr) && conv3x3_ws_supported(c);
+        if (ok && j + 1 < njobs) {   // this job's output plane is the next job's last input chunk
+            const ConvArgs& nx = a[j + 1];
+            const int c0 = nx.cin - 32;
+            const bool seg1 = c0 >= nx.cin0;
+            const char* plane = seg1 ? nx.in1 + (size_t)((c0 - nx.cin0) >> 5) * nx.in1_chunk_b : nx.in0 + (size_t)(c0 >> 5) * nx.in0_chunk_b;
+            ok = nx.cin == c.cin + 32 && plane == c.out;
+        }
+    }
+    if (ok) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) ok = false;   // the flag epoch is a launch argument
+    }
+    if (!ok) {
+        for (int j = 0; j < njobs; ++j) {
+            const int rc = conv3x3_route(&d[j], a[j], a[j].bias != nullptr, a[j].in1 != nullptr, stream);
+            if (rc) return rc;
+        }
+        return RESR_OK;
+    }
+    ChainJob jobs[kMaxChain];
+    double flop[kMaxChain], bytes[kMaxChain];
+    for (int j = 0; j < njobs; ++j) {
+        jobs[j].w = a[j].w; jobs[j].bias = a[j].bias; jobs[j].out = a[j].out;
+        jobs[j].aux = (a[j].flags == fwd_flags) ? (void*)a[j].aux : (void*)a[j].mask;
+        jobs[j].cin = a[j].cin; jobs[j].pad_ = 0;
+        flop[j] = 2.0 * 9 * a[j].cin * a[j].cout * (double)a[j].n * a[j].h * a[j].w_;
+        bytes[j] = conv_algorithmic_bytes(a[j], 2);
+    }
+    ConvArgs base = b;
+    if (base.cin0 == base.cin) base.cin0 = base.cin;   // single-segment prefix: every chunk of every job lies in in0
+    return conv3x3_ws_chain_f16(base, jobs, njobs, flop, bytes, stream);
 }
 
 }  // namespace resr

@@ -74,7 +74,9 @@ struct WsCfg {
     static constexpr int LDS_BYTES = WOFF + NWB * WBUF;
     // LeakyReLU-backward multipliers by 4 mask bits (16 x float4), behind the weight buffers (EPI 33 of the lean epilogue)
     static constexpr int LUT_OFF = LDS_BYTES, LUT_BYTES = 256;
-    static_assert(LDS_BYTES + LUT_BYTES <= 160 * 1024, "LDS");
+    // chain launches: the biases of kMaxChain jobs + the consumers' arrival counter, behind the table
+    static constexpr int CHAIN_OFF = LUT_OFF + LUT_BYTES, CHAIN_BYTES = 4 * 128 + 64;
+    static_assert(LDS_BYTES + LUT_BYTES + CHAIN_BYTES <= 160 * 1024, "LDS");
 };
 
 __device__ __forceinline__ void conv_glds16(const char* gsrc, char* lds_wave_base) {
@@ -158,8 +160,19 @@ __device__ __forceinline__ unsigned signs4_x128(unsigned d0, unsigned d1, unsign
 // space-to-depth image, sub-position per input chunk = chunk*32 / a.s2d_c) and SP = 2 (backward-data: the OUTPUT group
 // of this launch lies in sub-position a.tap_sub, taps flipped) skip the other 5 taps: 16 instead of 36 tap-products, the
 // FLOPs of the dense 4x4 kernel.  Same tiles, buffers and barrier protocol as the dense loop.
-template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0>
-__global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCfg<T, MT, NT, NWC>::NP) / 4) void conv3x3_ws_kernel(const ConvArgs a) {
+//
+// CH (chain): the launch runs cj.njobs dependent convolutions of one dense block back to back (ChainJob, conv3x3.h) --
+// job j+1's last input chunk is job j's output plane -- without kernel boundaries: every workgroup walks its tiles of job
+// 0, then of job 1, ...; the producers run ahead ACROSS jobs (the prefix chunks of job j+1 do not depend on job j), and
+// only the halo of the dependent chunk waits, per tile, for the (up to) nine neighbouring tiles of job j (flags[] in
+// device memory, published by the consumers once their stores are acknowledged).  Each XCD owns whole images (tiles
+// xcd * T/8 ... of the image-major numbering, n % 8 == 0 host-checked), so writer and reader of a plane always share one
+// L2: plain stores and loads are coherent there, and the flags only order them.  Deadlock-free with all workgroups
+// resident: a tile of job j never waits for anything of job j+1, consumers publish a tile one stage after its epilogue
+// without waiting for their producers, and producers only poll (for stage s+2) after barrier s.
+template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0, bool CH = false>
+__global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCfg<T, MT, NT, NWC>::NP) / 4) void conv3x3_ws_kernel(const ConvArgs a, const std::conditional_t<CH, ChainArgs, ChainNone> cj) {
+    static_assert(!CH || (MT == 1 && !X2 && SP == 0 && (EPI == 16 || EPI == 33) && WsCfg<T, MT, NT, NWC>::NHB == 3), "chain: cout-32 dense-block passes only");
     using C = WsCfg<T, MT, NT, NWC>;
     constexpr int SPP = C::SPP, KS = C::KS, PB = C::PB, TH = C::TH, TW = C::TW, HW = C::HW, BUF = C::BUF;
     constexpr int NI = C::NI, NG = C::NG, NP = C::NP, NIP = C::NIP;
@@ -174,8 +187,21 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     const int ntiles_sp = a.tiles_x * a.tiles_y * a.n;
     const int ntiles = ntiles_sp * (MT == 2 ? a.ngroups : 1);
     const int G = gridDim.x;
-    const int first = xcd_remap(blockIdx.x, G);
-    const int nchunks = X2 ? 3 * (a.cin >> 5) : a.cin >> 5;   // stages per tile
+    // CH: XCD x = blockIdx & 7 walks tiles [x * T/8, (x+1) * T/8) with its G/8 workgroups (whole images per XCD)
+    int first = xcd_remap(blockIdx.x, G);
+    int tile_end = ntiles, tile_step = G;
+    if constexpr (CH) {
+        const int t8 = ntiles >> 3, xcd = blockIdx.x & 7;
+        first = xcd * t8 + (blockIdx.x >> 3);
+        tile_end = (xcd + 1) * t8;
+        tile_step = G >> 3;
+        if (threadIdx.x == 0) {   // the ownership argument rests on the dispatcher's round-robin placement: check it
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]
+            if (xcc != (unsigned)xcd) atomicAdd(cj.errors + 1, 1u);
+        }
+    }
+    int nchunks = X2 ? 3 * (a.cin >> 5) : a.cin >> 5;   // stages per tile (CH: of the current job)
+    if constexpr (CH) nchunks = cj.job[0].cin >> 5;
     int tk = 0;
     auto stamp = [&](int role) {
         // traced workgroups: blockIdx 16k .. 16k+0 for k < 32 (a sample across the whole grid)
@@ -192,6 +218,14 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         const bool f_bias = !(a.flags & RESR_CONV_NO_BIAS) && a.bias != nullptr;
         bias_lds[lane] = (f_bias && lane < a.cout) ? a.bias[lane] * (X2 ? kLoScale : 1.f) : 0.f;
     }
+    if constexpr (CH) {   // the biases of all jobs (kMaxChain x 32 floats) and the consumers' arrival counter
+        float* cb = reinterpret_cast<float*>(smem + C::CHAIN_OFF);
+        if (wave < kMaxChain && lane < 32) {
+            const float* bp = wave < cj.njobs ? cj.job[wave].bias : nullptr;
+            cb[wave * 32 + lane] = (bp && !(a.flags & RESR_CONV_NO_BIAS) && lane < a.cout) ? bp[lane] : 0.f;
+        }
+        if (wave == 0 && lane == 0) *reinterpret_cast<unsigned*>(smem + C::CHAIN_OFF + kMaxChain * 128) = 0u;
+    }
     // FAST: instantiations with the lean epilogue (the generator's hot forms: plain / LeakyReLU, residuals, sign-bit
     // output, sign-bit mask); everything else keeps the general one
 #ifdef RESR_GENERAL_EPILOGUE   // A/B builds (tools/build_variant.py): every instantiation on the general epilogue
@@ -207,7 +241,9 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             *reinterpret_cast<float4v*>(smem + C::LUT_OFF + lane * 16) = m;
         }
     }
-    __syncthreads();
+    // The set-up barrier (bias / table visible to the consumers) is passed by the producers AFTER they have requested the
+    // first stage: the bias load's round trip runs under the first halo's instead of in front of it (a launch of one tile
+    // per CU -- the 64^2 training crops -- spends a quarter of its time waiting for that first stage).
     if (wave >= NWC) {
         const int pw = wave - NWC;  // producer index: this wave issues DMA instructions pw, pw + NP, ...
         // =============================== producer ===============================
@@ -306,16 +342,95 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 if (pw < REM) __builtin_amdgcn_s_waitcnt((K1 & 15) | 0x0F70 | ((K1 >> 4) << 14));
                 else __builtin_amdgcn_s_waitcnt((K0 & 15) | 0x0F70 | ((K0 >> 4) << 14));
             };
-            if (first >= ntiles) return;
+            if constexpr (CH) {
+                // ---- chain: the same pipeline over the stages of ALL jobs; ring weights; the dependent chunk polls first ----
+                const int njobs = cj.njobs;
+                int job = 0, nch = nchunks;   // job / chunk count of the stage whose halo was requested last
+                int it = first, ick = 0, hb = 0;
+                auto issue_wj = [&](const char* wjob, int ck, int par) {
+                    const char* wbase = wjob + (size_t)ck * C::WBUF;
+#pragma unroll
+                    for (int i = 0; i < C::NWIP; ++i) {
+                        const int idx = i * NP + pw;
+                        if (idx < C::NWI) conv_glds16_s(wbase, (unsigned)(idx * 1024) + ((unsigned)lane << 4), lds_base + C::WOFF + par * C::WBUF + idx * 1024);
+                    }
+                };
+                // lanes 0..8 watch the tile's 3 x 3 neighbourhood inside its image; `need` = flag value of "previous job done"
+                auto poll = [&](int tile, unsigned need) {
+                    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y;
+                    const int dx = lane % 3 - 1, dy = lane / 3 - 1;
+                    const bool watch = lane < 9 && (unsigned)(tx + dx) < (unsigned)a.tiles_x && (unsigned)(ty + dy) < (unsigned)a.tiles_y;
+                    const unsigned* fp = cj.flags + (watch ? tile + dy * a.tiles_x + dx : tile);
+                    for (int spin = 0;; ++spin) {
+                        const unsigned v = watch ? __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                        if (__ballot((int)(v - need) < 0) == 0ull) break;
+                        if (spin > (1 << 22)) {   // ~ seconds: never hang the device; the host reads the counter
+                            if (lane == 0) atomicAdd(cj.errors, 1u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                };
+                auto advance = [&]() -> bool {
+                    if (++ick == nch) {
+                        ick = 0;
+                        it += tile_step;
+                        if (it >= tile_end) {
+                            it = first;
+                            if (++job < njobs) nch = cj.job[job].cin >> 5;
+                        }
+                    }
+                    return job < njobs;
+                };
+                tile_pix(it);
+                issue_wj(cj.job[0].w, 0, 0);
+                issue_h(0, 0);
+                __syncthreads();           // the set-up barrier
+                bool have_next = advance();   // chunk 1 of the same tile (every job has >= 2 chunks, host-checked)
+                int ck_next = ick, job_next = job;
+                if (have_next) {
+                    if (ick == 0) tile_pix(it);
+                    hb = 1;
+                    issue_h(ick, hb);
+                    wait_all_but_h();
+                } else {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
+                __syncthreads();           // barrier 0
+                for (int s = 0; have_next; ++s) {   // stage s is being multiplied; H(s+1) is in flight
+                    issue_wj(cj.job[job_next].w, ck_next, (s + 1) & 1);
+                    const bool have_next2 = advance();
+                    if (have_next2) {
+                        if (ick == 0) tile_pix(it);
+                        // the last chunk of a job > 0 is the previous job's output plane
+                        if (job > 0 && ick == nch - 1) poll(it, cj.epoch + (unsigned)job);
+                        hb = hb == 2 ? 0 : hb + 1;
+                        issue_h(ick, hb);
+                        wait_all_but_h();
+                    } else {
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                    }
+                    __syncthreads();       // barrier s+1
+                    ck_next = ick; job_next = job;
+                    have_next = have_next2;
+                }
+                return;
+            }
+            if (first >= ntiles) { __syncthreads(); return; }
             // X2: stage (chunk, part 1) multiplies the SAME x_hi halo as (chunk, part 0) with the second weight block: no new
             // halo is requested for it and the consumers stay on the buffer (one LDS-DMA halo less per three stages)
             auto needs_h = [&](int ck) { return !X2 || (ck % 3) != 1; };
             const bool wres = nchunks <= C::NWB;
             int it = first, ick = 0;   // the stage whose halo was requested last
             int hb = 0;                // ... and its buffer
+            stamp(0);
             tile_pix(it);
+            stamp(0);
             issue_w(0, 0);
+            stamp(0);
             issue_h(0, 0);
+            stamp(0);
+            __syncthreads();           // the set-up barrier
             int ck_next = 0;           // chunk of stage s+1 (valid when have_next)
             bool have_next;            // stage s+1 exists (its halo is in flight)
             if (++ick == nchunks) { ick = 0; it += G; }
@@ -402,6 +517,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             }
         };
         if (first < ntiles) stage_weights(first, 0, 0);
+        __syncthreads();   // the set-up barrier
         // source pixel index per slot (< 2^24, host-checked); ~0u = zero (padding / outside the image)
         auto tile_pix = [&](int tile, unsigned (&pix)[NIP]) {
             const int tsp = tile % ntiles_sp;
@@ -466,6 +582,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     }
 
     // =============================== consumers ===============================
+    __syncthreads();   // the set-up barrier
     const int lx = lane & 31, kh = lane >> 5;
     const int row0 = wave * NT;
     const unsigned lane16 = (unsigned)lane << 4;
@@ -479,6 +596,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 
     // Accumulators start from the bias: register g*4+r of tile m holds cout m*32 + g*8 + kh*4 + r.
     float16v acc[MT][NT];
+    const float* bias_cur = bias_lds;   // CH: the current job's 32 values
     auto init_acc = [&]() {
         int kh_l = lane >> 5;
         asm volatile("" : "+v"(kh_l));  // opaque: keeps the 16*MT bias values out of registers across the tile loop
@@ -486,13 +604,14 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4v b = *reinterpret_cast<const float4v*>(bias_lds + m * 32 + g * 8 + kh_l * 4);
+                const float4v b = *reinterpret_cast<const float4v*>(bias_cur + m * 32 + g * 8 + kh_l * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) acc[m][t][g * 4 + r] = b[r];
             }
     };
+    if constexpr (CH) bias_cur = reinterpret_cast<const float*>(smem + C::CHAIN_OFF);
     init_acc();
 
     // Weight fragments: ring of (k-step, dx, dy) units -- one tap's MT fragments each -- in consumption order, fetched
@@ -510,7 +629,15 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     };
 
     int par = 0, hbc = 0;   // weight-buffer parity / halo buffer of the current stage
-    for (int tile = first; tile < ntiles; tile += G) {
+    // CH: a finished tile is published (flags[tile] = pend_tag) at the end of the NEXT stage's multiply: by then its stores
+    // have long been acknowledged, and the consumers never wait for their producers between epilogue and publication
+    bool pend = false;
+    int pend_tile = 0;
+    unsigned pend_tag = 0;
+    const int njobs_c = [&] { if constexpr (CH) return cj.njobs; else return 1; }();
+    for (int job = 0; job < njobs_c; ++job) {
+    if constexpr (CH) nchunks = cj.job[job].cin >> 5;
+    for (int tile = first; tile < tile_end; tile += tile_step) {
         // lean epilogue, sign-bit mask (EPI 33): the mask words of this wave's rows are requested HERE and land under the
         // tile's MFMAs (requested in the epilogue they cost one exposed memory round trip per row)
         unsigned mword[(FAST && EPI == 33) ? NT : 1][MT];
@@ -526,8 +653,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 const int y = y0 + t;
                 const unsigned p = ((unsigned)n * a.h + (unsigned)(y < a.h ? y : a.h - 1)) * a.w_ + xc;
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    mword[t][m] = reinterpret_cast<const unsigned*>(a.mask)[(size_t)p * wpp + (m < (int)wpp ? m : 0)];
+                for (int m = 0; m < MT; ++m) {
+                    const unsigned* mk = reinterpret_cast<const unsigned*>(a.mask);
+                    if constexpr (CH) mk = reinterpret_cast<const unsigned*>(cj.job[job].aux);
+                    mword[t][m] = mk[(size_t)p * wpp + (m < (int)wpp ? m : 0)];
+                }
             }
         }
         for (int ck = 0; ck < nchunks; ++ck) {
@@ -536,7 +666,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             asm volatile("s_barrier" ::: "memory");
             if (wave == 0) stamp(1);
             const char* lbuf = smem + hbc * BUF;
-            const int wsel = (nchunks <= C::NWB && ntiles == ntiles_sp) ? ck : par;   // resident weights: buffer = chunk; else the ring of two
+            const int wsel = (!CH && nchunks <= C::NWB && ntiles == ntiles_sp) ? ck : par;   // resident weights: buffer = chunk; else the ring of two
             // halo rows of group gi+1 are read from LDS while the MFMAs of group gi run (ping-pong registers; NG is even)
             // when the register budget allows (PP); otherwise each group reads its own rows first
             constexpr int PP = (NWC == 4 || MT * NT * 16 + (NT + 2) * 8 <= 112) ? 1 : 0;   // 4-consumer shapes have a 256-register budget
@@ -624,6 +754,18 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             par ^= 1;
             if (!X2 || (ck % 3) != 0) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
             if (wave == 0) stamp(1);
+            if constexpr (CH) {
+                if (pend) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's stores of the finished tile are acknowledged (in L2)
+                    if (lane == 0) {
+                        unsigned* cnt = reinterpret_cast<unsigned*>(smem + C::CHAIN_OFF + kMaxChain * 128);
+                        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if ((old % NWC) == NWC - 1)   // the last of the NWC consumer waves: everyone's stores are in
+                            __hip_atomic_store(cj.flags + pend_tile, pend_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    pend = false;
+                }
+            }
         }
 
         if constexpr (FAST) {
@@ -652,10 +794,12 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             } e;
             e.out = ep->out; e.h = ep->h; e.w_ = ep->w_; e.cout = ep->cout; e.out_stride = ep->out_stride;
             e.out_chunk = ep->out_chunk; e.flags = ep->flags; e.slope = ep->slope;
+            if constexpr (CH) e.out = cj.job[job].out;
             constexpr bool R0 = (EPI & 2) != 0, R1 = (EPI & 4) != 0, ESB = EPI == 16, EMB = EPI == 33;
             if constexpr (R0) { e.res0 = ep->res0; e.res0_stride = ep->res0_stride; e.res0_chunk = ep->res0_chunk; e.s0 = ep->s0; e.t0 = ep->t0; }
             if constexpr (R1) { e.res1 = ep->res1; e.res1_stride = ep->res1_stride; e.res1_chunk = ep->res1_chunk; e.s1 = ep->s1; e.t1 = ep->t1; }
             if constexpr (ESB) e.aux = ep->aux;
+            if constexpr (ESB && CH) e.aux = reinterpret_cast<uint8_t*>(cj.job[job].aux);
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
             const int lx_e = lane_e & 31, kh_e = lane_e >> 5;
@@ -771,6 +915,15 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         if (in_img && kh_e == 0 && m * 32 < e.cout)
                             reinterpret_cast<unsigned*>(e.aux)[(size_t)p * (size_t)((e.cout + 31) >> 5) + m] = word;
                     }
+                }
+            }
+            if constexpr (CH) {
+                if (job + 1 < njobs_c) {   // the last job's tiles have no reader inside the launch
+                    pend = true;
+                    pend_tile = tile;
+                    pend_tag = cj.epoch + (unsigned)job + 1u;
+                    if (tile + tile_step >= tile_end)   // the next tile belongs to the next job
+                        bias_cur = reinterpret_cast<const float*>(smem + C::CHAIN_OFF) + (job + 1) * 32;
                 }
             }
             init_acc();
@@ -995,6 +1148,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         init_acc();
         if (wave == 0) stamp(1);  // tile done
     }
+    }   // jobs
 }
 
 template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0>
@@ -1027,11 +1181,12 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
         if (getenv("RESR_DEBUG_OCC")) fprintf(stderr, "conv3x3_ws<%d,%d,%d,%d,%d>: %d workgroups/CU, lds %zu\n", (int)sizeof(T), MT, NT, NWC, EPI, per_cu, lds);
     }
     args.zero = zero;
-    args.trace = g_conv_trace;
+    static const char* trace_chain_only = getenv("RESR_TRACE_CHAIN_ONLY");   // debug: keep the timeline buffer for the chained launches
+    args.trace = trace_chain_only ? nullptr : g_conv_trace;
     const int ntiles = args.tiles_x * args.tiles_y * a.n * (MT == 2 && a.ngroups > 1 ? a.ngroups : 1);
     const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
     prof_before(stream);
-    hipLaunchKernelGGL((conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2, SP>), dim3(grid), dim3(C::NTHR), lds, stream, args);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2, SP>), dim3(grid), dim3(C::NTHR), lds, stream, args, ChainNone{});
     // sparse-tap launches count the 16 real tap-products of the 4x4 kernel (4 of 9 taps per chunk)
     prof_after(stream, (X2 ? 25000 : 20000) + (SP ? 2000 : 0) + MT * 100 + NT * 10 + NWC,
                2.0 * (SP ? 4 : 9) * a.cin * a.cout * (a.ngroups > 1 ? a.ngroups : 1) * (double)a.n * a.h * a.w_,

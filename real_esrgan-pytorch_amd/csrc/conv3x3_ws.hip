@@ -2,6 +2,9 @@
 // conv3x3_ws_mt1.hip for cout <= 32, conv3x3_ws_mt2.hip for cout 64 -- two translation units so they build in parallel).
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "conv3x3.h"
 
 namespace resr {
@@ -45,6 +48,78 @@ static int pick_rows(const ConvArgs& a, const int* rows, int nrows) {
 }
 
 int conv3x3_ws_sparse(const ConvArgs& a, int tile_rows, int sp, hipStream_t stream);   // conv3x3_ws_sp.hip
+int conv3x3_ws_chain_launch(const ConvArgs& a, const ChainArgs& cj, int tile_rows, bool backward, double flop, double bytes, hipStream_t stream);   // conv3x3_ws_chain.hip
+
+// ---- chained dense-block passes (conv3x3_ws.h, CH): per-(device, stream) progress flags ----
+// flags[tile] only ever grows: a launch's jobs publish epoch + 1 ... epoch + njobs, and the next launch on the stream
+// starts 8 higher, so nothing is reset between launches.  One buffer per stream: two streams would read each other's epochs.
+namespace {
+struct ChainState {
+    int dev;
+    hipStream_t stream;
+    unsigned* buf;      // [cap] flags + [2] error counters
+    size_t cap;
+    unsigned epoch;
+};
+std::mutex g_chain_mu;
+std::vector<ChainState> g_chain;
+}  // namespace
+
+// sum over all streams of (poll time-outs, misplaced workgroups); synchronises the device (debug / test entry)
+long long conv3x3_chain_errors() {
+    std::lock_guard<std::mutex> lk(g_chain_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    long long polls = 0, xcd = 0;
+    for (const ChainState& c : g_chain) {
+        if (c.dev != dev) continue;
+        unsigned e[2] = {0, 0};
+        if (hipMemcpy(e, c.buf + c.cap, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        polls += e[0];
+        xcd += e[1];
+    }
+    return polls + (xcd << 32);
+}
+
+int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, const double* flop, const double* bytes, hipStream_t stream) {
+    static const int rows1[] = {16, 8};
+    const int rows = pick_rows(a, rows1, 2);
+    const size_t ntiles = (size_t)((a.w_ + 31) / 32) * ((a.h + rows - 1) / rows) * a.n;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipGetDevice");
+    ChainArgs cj;
+    memset(&cj, 0, sizeof(cj));
+    {
+        std::lock_guard<std::mutex> lk(g_chain_mu);
+        ChainState* st = nullptr;
+        for (ChainState& c : g_chain)
+            if (c.dev == dev && c.stream == stream) st = &c;
+        if (!st) {
+            g_chain.push_back(ChainState{dev, stream, nullptr, 0, 8u});
+            st = &g_chain.back();
+        }
+        if (st->cap < ntiles) {   // first use / larger geometry: a fresh zeroed buffer (the old one may still be read by queued launches: kept)
+            const size_t cap = ntiles < 4096 ? 4096 : ntiles * 2;
+            unsigned* nb = nullptr;
+            if (hipMalloc((void**)&nb, (cap + 2) * sizeof(unsigned)) != hipSuccess || hipMemset(nb, 0, (cap + 2) * sizeof(unsigned)) != hipSuccess)
+                return fail(RESR_ERR_LAUNCH, "conv3x3_chain: flag buffer");
+            st->buf = nb; st->cap = cap; st->epoch = 8u;
+        }
+        if (st->epoch > 0x70000000u) {   // far from wrapping the signed comparison: start over behind everything queued
+            if (hipMemsetAsync(st->buf, 0, st->cap * sizeof(unsigned), stream) != hipSuccess) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: flag reset");
+            st->epoch = 8u;
+        }
+        cj.flags = st->buf;
+        cj.errors = st->buf + st->cap;
+        cj.epoch = st->epoch;
+        st->epoch += 8u;
+    }
+    cj.njobs = njobs;
+    double f = 0, b = 0;
+    for (int j = 0; j < njobs; ++j) { cj.job[j] = jobs[j]; f += flop[j]; b += bytes[j]; }
+    for (int j = njobs; j < kMaxChain; ++j) cj.job[j] = jobs[njobs - 1];
+    return conv3x3_ws_chain_launch(a, cj, rows, (a.flags & RESR_CONV_MASK_BITS) != 0, f, b, stream);
+}
 
 int conv3x3_ws_f16(const ConvArgs& a, int mt, bool x2, hipStream_t stream) {
     static const int rows1[] = {16, 8}, rows2[] = {16, 8};

@@ -1,0 +1,52 @@
+// Chained dense-block passes: the four cout-32 convolutions of a dense block (forward: LeakyReLU + sign words, EPI 16;
+// mirrored backward-data: sign-word mask, EPI 33) as one persistent launch of the producer/consumer kernel (conv3x3_ws.h, CH).
+#include "conv3x3_ws.h"
+
+namespace resr {
+
+template <int NT, int EPI>
+static int launch_chain(const ConvArgs& a, const ChainArgs& cj, double flop, double bytes, hipStream_t stream) {
+    using C = WsCfg<half_t, 1, NT, 8>;
+    auto kern = conv3x3_ws_kernel<half_t, 1, NT, 8, EPI, false, 0, true>;
+    ConvArgs args = a;
+    args.tiles_x = (a.w_ + 31) / 32;
+    args.tiles_y = (a.h + C::TH - 1) / C::TH;
+    const size_t lds = C::LDS_BYTES + C::LUT_BYTES + C::CHAIN_BYTES;
+    static int resident_dev[kMaxDevices] = {0};
+    static const char* zero_dev[kMaxDevices] = {nullptr};
+    int cur_dev = 0;
+    if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= kMaxDevices) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipGetDevice");
+    int& resident = resident_dev[cur_dev];
+    const char*& zero = zero_dev[cur_dev];
+    if (!resident) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        void* zp = nullptr;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, C::NTHR, lds) != hipSuccess ||
+            hipGetDeviceProperties(&prop, cur_dev) != hipSuccess || per_cu <= 0 ||
+            hipGetSymbolAddress(&zp, HIP_SYMBOL(g_conv_zero16)) != hipSuccess || !zp)
+            return fail(RESR_ERR_LAUNCH, "conv3x3_chain: occupancy / zero-page query failed");
+        zero = (const char*)zp;
+        resident = per_cu * prop.multiProcessorCount;
+    }
+    args.zero = zero;
+    args.trace = g_conv_trace;
+    const int ntiles = args.tiles_x * args.tiles_y * a.n;   // a multiple of 8 (n is)
+    // every workgroup must be resident (the flags are waited for inside the launch): the grid never exceeds what the device
+    // holds at once, and is a multiple of 8 so that each XCD gets the same number of workgroups
+    const unsigned grid = (unsigned)((ntiles < resident ? ntiles : resident) & ~7);
+    if (grid == 0) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: empty grid");
+    prof_before(stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), lds, stream, args, cj);
+    prof_after(stream, 20000 + 100 + NT * 10 + 8, flop, bytes);
+    RESR_CHECK_LAUNCH("conv3x3_ws_kernel (chain)");
+    return RESR_OK;
+}
+
+int conv3x3_ws_chain_launch(const ConvArgs& a, const ChainArgs& cj, int tile_rows, bool backward, double flop, double bytes, hipStream_t stream) {
+    if (tile_rows >= 16) return backward ? launch_chain<2, 33>(a, cj, flop, bytes, stream) : launch_chain<2, 16>(a, cj, flop, bytes, stream);
+    return backward ? launch_chain<1, 33>(a, cj, flop, bytes, stream) : launch_chain<1, 16>(a, cj, flop, bytes, stream);
+}
+
+}  // namespace resr

@@ -34,6 +34,8 @@ namespace resr {
 int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*, const float*, const void*,
                      const void*, const void*, void*, void*, hipStream_t);
 size_t wgrad_batch_partial_bytes(const WgradConv*, int, int, int);
+int conv3x3_chain_dispatch(int njobs, const ResrConvDesc* d, const void* in0, const void* in1, const void* const* w,
+                           const float* const* bias, const void* const* mask, void* const* out, void* const* aux, hipStream_t stream);
 int wgrad_batch(const WgradConv*, int, int, int, int, int, int, int, float*, hipStream_t);
 int wgrad_tile_rows(int dtype);
 int wgrad_x2_products();
@@ -401,18 +403,26 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
     }
     for (int r = 0; r < p.nrdb; ++r) {
         char* cur = b.ws[r % nws];
-        for (int k = 1; k <= 4; ++k) {  // model.py:90-93
-            const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
-            ResrConvDesc cd = conv_desc(p, N, h, w, c.cin, c.cin, 32, 0, 32, 32, 32, RESR_CONV_LRELU);
-            cd.in0_chunk_stride = plane;
-            cd.in0_lo_offset = lo_ws; cd.out_lo_offset = lo_ws;
-            char* signs = nullptr;
-            if (d->training) {   // the backward pass reads the 1-bit mask, not the activation
-                cd.flags |= RESR_CONV_WRITE_SIGNBITS;
-                signs = b.bits[r] + (size_t)(k - 1) * N * h * w * sizeof(uint32_t);
+        {   // conv1..conv4 (model.py:90-93): one chained launch where the kernel supports it, else four
+            ResrConvDesc cds[4];
+            const void* ws4[4];
+            const float* bs4[4];
+            void* outs4[4];
+            void* signs4[4];
+            for (int k = 1; k <= 4; ++k) {
+                const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
+                ResrConvDesc cd = conv_desc(p, N, h, w, c.cin, c.cin, 32, 0, 32, 32, 32, RESR_CONV_LRELU);
+                cd.in0_chunk_stride = plane;
+                cd.in0_lo_offset = lo_ws; cd.out_lo_offset = lo_ws;
+                char* signs = nullptr;
+                if (d->training) {   // the backward pass reads the 1-bit mask, not the activation
+                    cd.flags |= RESR_CONV_WRITE_SIGNBITS;
+                    signs = b.bits[r] + (size_t)(k - 1) * N * h * w * sizeof(uint32_t);
+                }
+                cds[k - 1] = cd; ws4[k - 1] = W(c); bs4[k - 1] = Bias(c);
+                outs4[k - 1] = cur + (size_t)(2 + (k - 1)) * plane * es; signs4[k - 1] = signs;
             }
-            RUN(conv3x3_dispatch(&cd, cur, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr,
-                                 cur + (size_t)(2 + (k - 1)) * plane * es, signs, st));
+            RUN(conv3x3_chain_dispatch(4, cds, cur, nullptr, ws4, bs4, nullptr, outs4, signs4, st));
         }
         const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + 4];
         const bool last = r == p.nrdb - 1;
@@ -599,6 +609,10 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         WgradConv wc[5];
         wc[4] = wconv(p.convs[p.i_trunk0 + r * 5 + 4], act, 192, 32, gin, 32, fold, lo_ws, lo_t);   // conv5: G = fold * gin
         wc[4].x_chunk_stride = plane; wc[4].g_chunk_stride = plane;
+        ResrConvDesc cds[4];
+        const void* ws4[4];
+        const void* masks4[4];
+        void* outs4[4];
         for (int ps = 0; ps < 4; ++ps) {   // g_o4, g_o3, g_o2, g_o1
             const int k = 4 - ps;           // conv index whose pre-activation gradient this pass yields
             const int cin = 64 + 32 * ps;
@@ -606,12 +620,13 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             cd.in0_chunk_stride = plane; cd.in1_chunk_stride = plane;
             char* out = b.gS + (size_t)ps * plane * es;
             const char* mask = b.bits[r] + (size_t)(k - 1) * N * h * w * sizeof(uint32_t);   // sign plane of o_k
-            RUN(conv3x3_dispatch(&cd, gin, b.gS, pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * wes, nullptr, nullptr, nullptr,
-                                 mask, out, nullptr, st));
+            cds[ps] = cd; ws4[ps] = pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * wes; masks4[ps] = mask; outs4[ps] = out;
             const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
             wc[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f, lo_ws, lo_gs);
             wc[k - 1].x_chunk_stride = plane;
         }
+        // the four mirrored cout-32 passes: one chained launch where the kernel supports it, else four
+        RUN(conv3x3_chain_dispatch(4, cds, gin, b.gS, ws4, nullptr, masks4, outs4, nullptr, st));
         RUN(wgrad_run(wc, 5, h, w, 0));   // all five weight gradients of the block in one launch pair
         if (pos == 0) RUN(ready(1 + (d->n_blocks - 1 - r / 3)));   // rdb3, rdb2, rdb1 of this RRDB are done
         {   // g_x = convT(all) + (skip terms)

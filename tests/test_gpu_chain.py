@@ -1,0 +1,82 @@
+"""-m gpu: the chained dense-block launches (the four cout-32 passes of a dense block as ONE persistent launch whose jobs
+wait for each other through per-tile flags, conv3x3_ws.h CH) against the same passes as four launches.
+
+The arithmetic is identical, only the scheduling differs, so forward output and every gradient must be BIT-equal; the
+device-side health counters (flag polls that timed out, workgroups on an unexpected XCD) must stay 0.  Reference
+semantics of the block: /root/reference/model.py:87-98."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(g, x, gw, no_chain):
+    if no_chain:
+        os.environ["RESR_CONV_NO_CHAIN"] = "1"
+    else:
+        os.environ.pop("RESR_CONV_NO_CHAIN", None)
+    try:
+        for p in g.parameters():
+            p.grad = None
+        xd = x.clone().requires_grad_(True)
+        y = g(xd)
+        (y * gw).sum().mul(256.0).backward()
+        torch.cuda.synchronize()
+        return y.detach().clone(), [p.grad.detach().clone() for p in g.parameters()], xd.grad.detach().clone()
+    finally:
+        os.environ.pop("RESR_CONV_NO_CHAIN", None)
+
+
+# n (a multiple of 8: every XCD owns whole images), h, w (even), dense blocks: one tile per workgroup (16- and 8-row tiles),
+# ragged last tiles, and several tiles per workgroup
+CASES = [(8, 24, 40, 2), (8, 64, 64, 1), (16, 36, 70, 1), (16, 128, 128, 1), (32, 64, 64, 1)]
+
+
+@pytest.mark.parametrize("n,h,w,n_blocks", CASES)
+def test_chain_equals_separate_launches(n, h, w, n_blocks):
+    import real_esrgan_pytorch_amd as R
+    L = R._lib
+    torch.manual_seed(3)
+    g = R.Generator(3, 3, 4, precision="fast", n_blocks=n_blocks).cuda().train()
+    with torch.no_grad():
+        g.conv4.bias.add_(0.5)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.rand(n, 3, h, w, device="cuda", generator=gen)
+    gw = torch.randn(n, 3, 4 * h, 4 * w, device="cuda", generator=gen)
+    y0, g0, gx0 = _run(g, x, gw, no_chain=True)
+    for rep in range(3):   # scheduling differs from run to run: repeat
+        y1, g1, gx1 = _run(g, x, gw, no_chain=False)
+        assert torch.equal(y0, y1), f"forward differs (rep {rep}): {(y0 - y1).abs().max().item()}"
+        assert torch.equal(gx0, gx1), f"input gradient differs (rep {rep})"
+        for i, (a, b) in enumerate(zip(g0, g1)):
+            assert torch.equal(a, b), f"gradient tensor {i} differs (rep {rep}): {(a - b).abs().max().item()}"
+    err = int(L.lib().resr_debug_chain_errors())
+    assert err == 0, f"chain health counters: polls timed out {err & 0xffffffff}, misplaced workgroups {err >> 32}"
+
+
+def test_chain_is_taken():
+    """The profiling records show ONE conv launch for the four cout-32 passes of a block when chaining is on."""
+    import ctypes as C
+    import real_esrgan_pytorch_amd as R
+    L = R._lib
+    lib = L.lib()
+    g = R.Generator(3, 3, 4, precision="fast", n_blocks=1).cuda().train()
+    x = torch.rand(8, 3, 32, 32, device="cuda")
+
+    def launches(no_chain):
+        if no_chain:
+            os.environ["RESR_CONV_NO_CHAIN"] = "1"
+        else:
+            os.environ.pop("RESR_CONV_NO_CHAIN", None)
+        try:
+            lib.resr_profile_begin()
+            g(x)
+            torch.cuda.synchronize()
+            buf = (L.ProfEntry * 4096)()
+            return int(lib.resr_profile_end(C.cast(buf, C.c_void_p), 4096))
+        finally:
+            os.environ.pop("RESR_CONV_NO_CHAIN", None)
+    a, b = launches(True), launches(False)
+    assert a - b == 3 * 3, (a, b)   # three dense blocks per RRDB, three launches saved in each
