@@ -306,7 +306,8 @@ int resr_ema_update(float* shadow, const float* params, int64_t count, double de
 int resr_debug_conv_trace(void* dev_buf);
 /* Debug: health of the chained dense-block launches on the current device (the four cout-32 passes of a dense block,
  * model.py:90-93, run as one persistent launch whose jobs wait for each other through per-tile flags): low 32 bits =
- * flag polls that timed out, high 32 bits = workgroups found on another XCD than the tile ownership assumes.  Both must
+ * flag polls that timed out, high 32 bits = workgroups an XCD received beyond its share of the grid (tile ownership follows
+ * the XCD a workgroup really runs on and assumes the dispatcher deals every XCD grid / 8 workgroups).  Both must
  * be 0; synchronises the device.  RESR_CONV_NO_CHAIN=1 in the environment disables chaining. */
 int64_t resr_debug_chain_errors(void);
 /* Host logic of the f16 weight-gradient launch, no GPU needed: how the (X chunk, G tile) products of `nconv` convolutions

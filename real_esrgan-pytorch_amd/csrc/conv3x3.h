@@ -55,7 +55,10 @@ struct ChainArgs {
     int njobs;
     unsigned epoch;        // flag value of "job j of this launch done" = epoch + j + 1 (flags only ever grow: no reset between launches)
     unsigned* flags;       // [tiles] per-tile progress, device memory
-    unsigned* errors;      // [2]: poll time-outs, workgroups found on an unexpected XCD
+    unsigned* errors;      // [2]: poll time-outs, workgroups beyond their XCD's share of the grid
+    unsigned* tickets;     // [8] per-XCD workgroup tickets (only ever grow)
+    unsigned ticket_base;  // value of every ticket counter when this launch starts (each launch adds grid / 8 to each)
+    unsigned pad_;
     ChainJob job[kMaxChain];
 };
 struct ChainNone {};

@@ -426,18 +426,19 @@ int conv3x3_chain_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
     }
     const char* no_chain = getenv("RESR_CONV_NO_CHAIN");   // test / A-B knob: one launch per job (read per call, so a test can flip it)
     bool ok = !no_chain && njobs >= 2 && d[0].dtype == RESR_F16;
-    const int fwd_flags = RESR_CONV_LRELU | RESR_CONV_WRITE_SIGNBITS;
+    const int fwd_flags = RESR_CONV_LRELU | RESR_CONV_WRITE_SIGNBITS, inf_flags = RESR_CONV_LRELU;
     const int bwd_flags = RESR_CONV_MASK | RESR_CONV_MASK_BITS | RESR_CONV_NO_BIAS;
     const ConvArgs& b = a[njobs - 1];   // the widest job: its in0 / in1 split describes every prefix
     for (int j = 0; ok && j < njobs; ++j) {
         const ConvArgs& c = a[j];
-        ok = d[j].dtype == RESR_F16 && d[j].cout_pad == 32 && c.cout == 32 && (c.flags == fwd_flags || c.flags == bwd_flags) &&
+        ok = d[j].dtype == RESR_F16 && d[j].cout_pad == 32 && c.cout == 32 && (c.flags == fwd_flags || c.flags == bwd_flags || c.flags == inf_flags) &&
              c.flags == b.flags && c.n == b.n && c.h == b.h && c.w_ == b.w_ && c.hs == c.h && c.ws == c.w_ &&
              (c.n % 8) == 0 && (c.w_ % 2) == 0 && c.slope == b.slope &&
              c.in0_stride_b == 64 && c.in0_chunk_b == b.in0_chunk_b && c.out_stride == 32 &&
              (c.cin0 == c.cin || (c.cin0 == b.cin0 && c.in1_stride_b == 64 && c.in1_chunk_b == b.in1_chunk_b)) &&
              c.cin >= (j == 0 ? 64 : 96) && c.ngroups == 1 && !c.s2d_c && !c.tap_c &&
-             ((c.flags == fwd_flags) ? c.aux != nullptr : c.mask != nullptr) && conv3x3_ws_supported(c);
+             (c.flags == fwd_flags ? c.aux != nullptr : c.flags == bwd_flags ? c.mask != nullptr : (!c.aux && !c.mask)) &&
+             (c.slope >= 0.f && c.slope <= 1.f) && !c.res0 && !c.res1 && conv3x3_ws_supported(c);
         if (ok && j + 1 < njobs) {   // this job's output plane is the next job's last input chunk
             const ConvArgs& nx = a[j + 1];
             const int c0 = nx.cin - 32;
@@ -461,7 +462,7 @@ int conv3x3_chain_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
     double flop[kMaxChain], bytes[kMaxChain];
     for (int j = 0; j < njobs; ++j) {
         jobs[j].w = a[j].w; jobs[j].bias = a[j].bias; jobs[j].out = a[j].out;
-        jobs[j].aux = (a[j].flags == fwd_flags) ? (void*)a[j].aux : (void*)a[j].mask;
+        jobs[j].aux = (a[j].flags == bwd_flags) ? (void*)a[j].mask : (void*)a[j].aux;
         jobs[j].cin = a[j].cin; jobs[j].pad_ = 0;
         flop[j] = 2.0 * 9 * a[j].cin * a[j].cout * (double)a[j].n * a[j].h * a[j].w_;
         bytes[j] = conv_algorithmic_bytes(a[j], 2);

@@ -172,7 +172,7 @@ __device__ __forceinline__ unsigned signs4_x128(unsigned d0, unsigned d1, unsign
 // without waiting for their producers, and producers only poll (for stage s+2) after barrier s.
 template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0, bool CH = false>
 __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCfg<T, MT, NT, NWC>::NP) / 4) void conv3x3_ws_kernel(const ConvArgs a, const std::conditional_t<CH, ChainArgs, ChainNone> cj) {
-    static_assert(!CH || (MT == 1 && !X2 && SP == 0 && (EPI == 16 || EPI == 33) && WsCfg<T, MT, NT, NWC>::NHB == 3), "chain: cout-32 dense-block passes only");
+    static_assert(!CH || (MT == 1 && !X2 && SP == 0 && (EPI == 0 || EPI == 16 || EPI == 33) && WsCfg<T, MT, NT, NWC>::NHB == 3), "chain: cout-32 dense-block passes only");
     using C = WsCfg<T, MT, NT, NWC>;
     constexpr int SPP = C::SPP, KS = C::KS, PB = C::PB, TH = C::TH, TW = C::TW, HW = C::HW, BUF = C::BUF;
     constexpr int NI = C::NI, NG = C::NG, NP = C::NP, NIP = C::NIP;
@@ -191,14 +191,27 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     int first = xcd_remap(blockIdx.x, G);
     int tile_end = ntiles, tile_step = G;
     if constexpr (CH) {
-        const int t8 = ntiles >> 3, xcd = blockIdx.x & 7;
-        first = xcd * t8 + (blockIdx.x >> 3);
+        // Ownership follows the XCD the workgroup REALLY runs on (XCC_ID), not blockIdx: the dispatcher deals workgroups
+        // to the XCDs round-robin, but where a dispatch starts is not fixed (measured: launches from a second stream
+        // start elsewhere).  Index inside the XCD = a ticket (the counters only grow; the host knows where this launch's
+        // tickets start as long as every launch gives each XCD grid / 8 workgroups, which is checked here).
+        unsigned* tk = reinterpret_cast<unsigned*>(smem + C::CHAIN_OFF + kMaxChain * 128 + 16);
+        if (threadIdx.x == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]
+            const unsigned per = (unsigned)G >> 3;
+            unsigned idx = atomicAdd(cj.tickets + (xcc & 7u), 1u) - cj.ticket_base;
+            if (xcc >= 8u || idx >= per) {   // an XCD with more than its share: counted (the host fails loudly), kept in range
+                atomicAdd(cj.errors + 1, 1u);
+                idx %= per;
+            }
+            tk[0] = xcc & 7u;
+            tk[1] = idx;
+        }
+        __syncthreads();
+        const int t8 = ntiles >> 3, xcd = (int)tk[0];
+        first = xcd * t8 + (int)tk[1];
         tile_end = (xcd + 1) * t8;
         tile_step = G >> 3;
-        if (threadIdx.x == 0) {   // the ownership argument rests on the dispatcher's round-robin placement: check it
-            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]
-            if (xcc != (unsigned)xcd) atomicAdd(cj.errors + 1, 1u);
-        }
     }
     int nchunks = X2 ? 3 * (a.cin >> 5) : a.cin >> 5;   // stages per tile (CH: of the current job)
     if constexpr (CH) nchunks = cj.job[0].cin >> 5;

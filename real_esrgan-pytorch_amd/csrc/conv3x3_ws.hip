@@ -48,7 +48,7 @@ static int pick_rows(const ConvArgs& a, const int* rows, int nrows) {
 }
 
 int conv3x3_ws_sparse(const ConvArgs& a, int tile_rows, int sp, hipStream_t stream);   // conv3x3_ws_sp.hip
-int conv3x3_ws_chain_launch(const ConvArgs& a, const ChainArgs& cj, int tile_rows, bool backward, double flop, double bytes, hipStream_t stream);   // conv3x3_ws_chain.hip
+int conv3x3_ws_chain_launch(const ConvArgs& a, const ChainArgs& cj, int tile_rows, int kind, unsigned* ticket_base, double flop, double bytes, hipStream_t stream);   // conv3x3_ws_chain.hip
 
 // ---- chained dense-block passes (conv3x3_ws.h, CH): per-(device, stream) progress flags ----
 // flags[tile] only ever grows: a launch's jobs publish epoch + 1 ... epoch + njobs, and the next launch on the stream
@@ -57,9 +57,10 @@ namespace {
 struct ChainState {
     int dev;
     hipStream_t stream;
-    unsigned* buf;      // [cap] flags + [2] error counters
+    unsigned* buf;      // [cap] flags + [2] error counters + [8] per-XCD workgroup tickets
     size_t cap;
     unsigned epoch;
+    unsigned ticket_base;   // value of the ticket counters before the next launch
 };
 std::mutex g_chain_mu;
 std::vector<ChainState> g_chain;
@@ -73,10 +74,13 @@ long long conv3x3_chain_errors() {
     long long polls = 0, xcd = 0;
     for (const ChainState& c : g_chain) {
         if (c.dev != dev) continue;
-        unsigned e[2] = {0, 0};
+        unsigned e[16] = {0};
         if (hipMemcpy(e, c.buf + c.cap, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         polls += e[0];
         xcd += e[1];
+        if (getenv("RESR_DEBUG_CHAIN"))
+            fprintf(stderr, "chain state: stream %p cap %zu epoch %u ticket_base %u | time-outs %u beyond-share %u | tickets %u %u %u %u %u %u %u %u\n",
+                    (void*)c.stream, c.cap, c.epoch, c.ticket_base, e[0], e[1], e[8], e[9], e[10], e[11], e[12], e[13], e[14], e[15]);
     }
     return polls + (xcd << 32);
 }
@@ -91,19 +95,31 @@ int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, con
     memset(&cj, 0, sizeof(cj));
     {
         std::lock_guard<std::mutex> lk(g_chain_mu);
+        // A chained launch waits for its own workgroups from inside: two of them running side by side on different streams
+        // could each hold CUs the other's missing workgroups need.  One stream per device owns chaining at a time; a
+        // launch from another stream first drains the device (once per change of owner, not per launch).
+        static hipStream_t owner[kMaxDevices] = {nullptr};
+        static bool owned[kMaxDevices] = {false};
+        if (dev >= 0 && dev < kMaxDevices) {
+            if (owned[dev] && owner[dev] != stream && hipDeviceSynchronize() != hipSuccess)   // (the old owner may be gone: drain the device)
+                return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipDeviceSynchronize");
+            owner[dev] = stream;
+            owned[dev] = true;
+        }
         ChainState* st = nullptr;
         for (ChainState& c : g_chain)
             if (c.dev == dev && c.stream == stream) st = &c;
         if (!st) {
-            g_chain.push_back(ChainState{dev, stream, nullptr, 0, 8u});
+            g_chain.push_back(ChainState{dev, stream, nullptr, 0, 8u, 0u});
             st = &g_chain.back();
         }
         if (st->cap < ntiles) {   // first use / larger geometry: a fresh zeroed buffer (the old one may still be read by queued launches: kept)
             const size_t cap = ntiles < 4096 ? 4096 : ntiles * 2;
             unsigned* nb = nullptr;
-            if (hipMalloc((void**)&nb, (cap + 2) * sizeof(unsigned)) != hipSuccess || hipMemset(nb, 0, (cap + 2) * sizeof(unsigned)) != hipSuccess)
+            // zeroed ON THE LAUNCHING STREAM: hipMemset runs on the null stream, which a non-blocking stream does not wait for
+            if (hipMalloc((void**)&nb, (cap + 16) * sizeof(unsigned)) != hipSuccess || hipMemsetAsync(nb, 0, (cap + 16) * sizeof(unsigned), stream) != hipSuccess)
                 return fail(RESR_ERR_LAUNCH, "conv3x3_chain: flag buffer");
-            st->buf = nb; st->cap = cap; st->epoch = 8u;
+            st->buf = nb; st->cap = cap; st->epoch = 8u; st->ticket_base = 0u;
         }
         if (st->epoch > 0x70000000u) {   // far from wrapping the signed comparison: start over behind everything queued
             if (hipMemsetAsync(st->buf, 0, st->cap * sizeof(unsigned), stream) != hipSuccess) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: flag reset");
@@ -111,14 +127,16 @@ int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, con
         }
         cj.flags = st->buf;
         cj.errors = st->buf + st->cap;
+        cj.tickets = st->buf + st->cap + 8;
         cj.epoch = st->epoch;
         st->epoch += 8u;
+        cj.njobs = njobs;
+        double f = 0, b = 0;
+        for (int j = 0; j < njobs; ++j) { cj.job[j] = jobs[j]; f += flop[j]; b += bytes[j]; }
+        for (int j = njobs; j < kMaxChain; ++j) cj.job[j] = jobs[njobs - 1];
+        const int kind = (a.flags & RESR_CONV_MASK_BITS) ? 2 : (a.flags & RESR_CONV_WRITE_SIGNBITS) ? 1 : 0;
+        return conv3x3_ws_chain_launch(a, cj, rows, kind, &st->ticket_base, f, b, stream);   // under the lock: the ticket base follows launch order
     }
-    cj.njobs = njobs;
-    double f = 0, b = 0;
-    for (int j = 0; j < njobs; ++j) { cj.job[j] = jobs[j]; f += flop[j]; b += bytes[j]; }
-    for (int j = njobs; j < kMaxChain; ++j) cj.job[j] = jobs[njobs - 1];
-    return conv3x3_ws_chain_launch(a, cj, rows, (a.flags & RESR_CONV_MASK_BITS) != 0, f, b, stream);
 }
 
 int conv3x3_ws_f16(const ConvArgs& a, int mt, bool x2, hipStream_t stream) {

@@ -1,11 +1,11 @@
-// Chained dense-block passes: the four cout-32 convolutions of a dense block (forward: LeakyReLU + sign words, EPI 16;
-// mirrored backward-data: sign-word mask, EPI 33) as one persistent launch of the producer/consumer kernel (conv3x3_ws.h, CH).
+// Chained dense-block passes: the four cout-32 convolutions of a dense block (forward: LeakyReLU, EPI 0, + sign words in
+// training, EPI 16; mirrored backward-data: sign-word mask, EPI 33) as one persistent launch of the producer/consumer kernel (conv3x3_ws.h, CH).
 #include "conv3x3_ws.h"
 
 namespace resr {
 
 template <int NT, int EPI>
-static int launch_chain(const ConvArgs& a, const ChainArgs& cj, double flop, double bytes, hipStream_t stream) {
+static int launch_chain(const ConvArgs& a, ChainArgs cj, unsigned* ticket_base, double flop, double bytes, hipStream_t stream) {
     using C = WsCfg<half_t, 1, NT, 8>;
     auto kern = conv3x3_ws_kernel<half_t, 1, NT, 8, EPI, false, 0, true>;
     ConvArgs args = a;
@@ -37,6 +37,8 @@ static int launch_chain(const ConvArgs& a, const ChainArgs& cj, double flop, dou
     // holds at once, and is a multiple of 8 so that each XCD gets the same number of workgroups
     const unsigned grid = (unsigned)((ntiles < resident ? ntiles : resident) & ~7);
     if (grid == 0) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: empty grid");
+    cj.ticket_base = *ticket_base;
+    *ticket_base += grid / 8;
     prof_before(stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), lds, stream, args, cj);
     prof_after(stream, 20000 + 100 + NT * 10 + 8, flop, bytes);
@@ -44,9 +46,15 @@ static int launch_chain(const ConvArgs& a, const ChainArgs& cj, double flop, dou
     return RESR_OK;
 }
 
-int conv3x3_ws_chain_launch(const ConvArgs& a, const ChainArgs& cj, int tile_rows, bool backward, double flop, double bytes, hipStream_t stream) {
-    if (tile_rows >= 16) return backward ? launch_chain<2, 33>(a, cj, flop, bytes, stream) : launch_chain<2, 16>(a, cj, flop, bytes, stream);
-    return backward ? launch_chain<1, 33>(a, cj, flop, bytes, stream) : launch_chain<1, 16>(a, cj, flop, bytes, stream);
+// kind: 0 = forward at inference (LeakyReLU), 1 = forward in training (LeakyReLU + sign words), 2 = mirrored backward-data
+// *ticket_base: the stream's running ticket value (conv3x3_ws.hip), advanced by this launch's workgroups per XCD
+int conv3x3_ws_chain_launch(const ConvArgs& a, const ChainArgs& cj, int tile_rows, int kind, unsigned* ticket_base, double flop, double bytes, hipStream_t stream) {
+    if (tile_rows >= 16) {
+        if (kind == 2) return launch_chain<2, 33>(a, cj, ticket_base, flop, bytes, stream);
+        return kind == 1 ? launch_chain<2, 16>(a, cj, ticket_base, flop, bytes, stream) : launch_chain<2, 0>(a, cj, ticket_base, flop, bytes, stream);
+    }
+    if (kind == 2) return launch_chain<1, 33>(a, cj, ticket_base, flop, bytes, stream);
+    return kind == 1 ? launch_chain<1, 16>(a, cj, ticket_base, flop, bytes, stream) : launch_chain<1, 0>(a, cj, ticket_base, flop, bytes, stream);
 }
 
 }  // namespace resr

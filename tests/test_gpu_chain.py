@@ -80,3 +80,47 @@ def test_chain_is_taken():
             os.environ.pop("RESR_CONV_NO_CHAIN", None)
     a, b = launches(True), launches(False)
     assert a - b == 3 * 3, (a, b)   # three dense blocks per RRDB, three launches saved in each
+
+
+def test_chain_from_two_streams():
+    """Chained launches issued from two streams take turns (a change of the owning stream drains the device first): two
+    generators stepping on their own streams give what they give alone."""
+    import real_esrgan_pytorch_amd as R
+    L = R._lib
+    torch.manual_seed(5)
+    gs = [R.Generator(3, 3, 4, precision="fast", n_blocks=1).cuda().train() for _ in range(2)]
+    xs = [torch.rand(8, 3, 32, 48, device="cuda") for _ in range(2)]
+    with torch.no_grad():
+        ref = [g(x).clone() for g, x in zip(gs, xs)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = [None, None]
+    for rep in range(3):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]), torch.no_grad():
+                outs[i] = gs[i](xs[i]).clone()
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        assert torch.equal(outs[i], ref[i])
+    assert int(L.lib().resr_debug_chain_errors()) == 0
+
+
+@pytest.mark.parametrize("n,h,w", [(8, 40, 48), (16, 128, 96)])
+def test_chain_inference(n, h, w):
+    """eval() forward (plain LeakyReLU epilogue, rotating workspaces): chained == four launches, bit for bit."""
+    import real_esrgan_pytorch_amd as R
+    L = R._lib
+    torch.manual_seed(9)
+    g = R.Generator(3, 3, 4, precision="fast", n_blocks=2).cuda().eval()
+    x = torch.rand(n, 3, h, w, device="cuda")
+    os.environ["RESR_CONV_NO_CHAIN"] = "1"
+    try:
+        with torch.no_grad():
+            y0 = g(x).clone()
+    finally:
+        os.environ.pop("RESR_CONV_NO_CHAIN", None)
+    for _ in range(3):
+        with torch.no_grad():
+            y1 = g(x).clone()
+        assert torch.equal(y0, y1)
+    assert int(L.lib().resr_debug_chain_errors()) == 0
