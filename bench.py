@@ -194,6 +194,9 @@ def kernel_name(kid):
     if kid >= 25000:  # exact16: the same kernel on hi/lo f16 pairs, three stages per chunk
         k = kid - 25000
         return f"conv3x3_ws_kernel<f16x2,{k // 100},{(k // 10) % 10},{k % 10}>"
+    if kid >= 24000:  # the same kernel running the four cout-32 passes of a dense block as one chained launch
+        k = kid - 24000
+        return f"conv3x3_ws_kernel<f16,{k // 100},{(k // 10) % 10},{k % 10},chain>"
     if kid >= 20000:  # fast-mode producer/consumer kernel: <f16, MT, NT, consumer waves>
         k = kid - 20000
         return f"conv3x3_ws_kernel<f16,{k // 100},{(k // 10) % 10},{k % 10}>"

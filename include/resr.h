@@ -106,6 +106,18 @@ int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const 
                  const float* bias, const void* res0, const void* res1, const void* mask,
                  void* out, void* aux_out, void* stream);
 
+/* The growth convolutions of one dense block in ONE call (model.py:90-93: out_k = leaky_relu(conv_k(cat(x, out_1 ..
+ * out_{k-1})))), or their mirrored backward-data passes: njobs (2..4) descriptors as for resr_conv3x3, all reading the
+ * SAME in0 [/ in1] tensors -- job j the first descs[j].cin channels of them -- each with its own packed weights, bias (or
+ * NULL), sign-word mask (or NULL), output and aux_out (or NULL); job j's output must be the tensor that job j+1 reads as
+ * its last 32 channels.  Same results as njobs calls of resr_conv3x3 (to which it falls back); where the fast-mode kernel
+ * supports it (f16, cout 32, chunk-planar operands, batch a multiple of 8, even width, LeakyReLU [+ sign words] or the
+ * sign-word mask) the jobs run as one persistent launch that orders them through per-tile flags instead of kernel
+ * boundaries.  bias / mask / aux_out may be NULL pointers to mean "no job has one". */
+int resr_conv3x3_chain(int32_t njobs, const ResrConvDesc* descs, const void* in0, const void* in1,
+                       const void* const* packed_w, const float* const* bias, const void* const* mask,
+                       void* const* out, void* const* aux_out, void* stream);
+
 /* Weight-gradient of the same convolution: dW[co][ci][tap] = sum_p G[p][co] * X[p + tap][ci]
  * (autograd backward of F.conv2d wrt weight, all conv call sites of model.py) and
  * db[co] = sum_p G[p][co].  Two launches: partial sums over pixel splits into `partial`

@@ -75,6 +75,7 @@ _PROTOS = {
     "resr_version": (C.c_int, []),
     "resr_last_error": (C.c_char_p, []),
     "resr_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "resr_conv3x3_chain": (C.c_int, [C.c_int32, C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "resr_wgrad_partial_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "resr_conv3x3_wgrad": (C.c_int, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _P, _P]),
     "resr_pack_weights": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P]),

@@ -73,6 +73,8 @@ void conv_trace_set(void*);
 long long conv3x3_chain_errors();
 int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*, const float*, const void*,
                      const void*, const void*, void*, void*, hipStream_t);
+int conv3x3_chain_dispatch(int, const ResrConvDesc*, const void*, const void*, const void* const*, const float* const*,
+                           const void* const*, void* const*, void* const*, hipStream_t);
 int wgrad_dispatch(const ResrWgradDesc*, const void*, const void*, const void*, float*, float*, float*, hipStream_t);
 size_t wgrad_partial_bytes(const ResrWgradDesc*);
 int wgrad_debug_plan(const int*, const int*, int, int*, int);
@@ -150,6 +152,14 @@ int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const 
                  const void* res0, const void* res1, const void* mask, void* out, void* aux_out, void* stream) {
     RESR_DEVICE_SCOPE(stream);
     return conv3x3_dispatch(d, in0, in1, w_packed, bias, res0, res1, mask, out, aux_out, (hipStream_t)stream);
+}
+
+int resr_conv3x3_chain(int32_t njobs, const ResrConvDesc* descs, const void* in0, const void* in1,
+                       const void* const* packed_w, const float* const* bias, const void* const* mask,
+                       void* const* out, void* const* aux_out, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    if (!descs || !in0 || !packed_w || !out) return fail(RESR_ERR_ARG, "conv3x3_chain: null argument");
+    return conv3x3_chain_dispatch(njobs, descs, in0, in1, packed_w, bias, mask, out, aux_out, (hipStream_t)stream);
 }
 
 size_t resr_wgrad_partial_bytes(const ResrWgradDesc* d) { return d ? wgrad_partial_bytes(d) : 0; }

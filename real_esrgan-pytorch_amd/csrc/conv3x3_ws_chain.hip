@@ -41,7 +41,7 @@ static int launch_chain(const ConvArgs& a, ChainArgs cj, unsigned* ticket_base, 
     *ticket_base += grid / 8;
     prof_before(stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), lds, stream, args, cj);
-    prof_after(stream, 20000 + 100 + NT * 10 + 8, flop, bytes);
+    prof_after(stream, 24000 + 100 + NT * 10 + 8, flop, bytes);   // 24xxx: a chain of the <f16,1,NT,8> kernel; FLOP / bytes = the sum over its jobs
     RESR_CHECK_LAUNCH("conv3x3_ws_kernel (chain)");
     return RESR_OK;
 }

@@ -124,3 +124,48 @@ def test_chain_inference(n, h, w):
             y1 = g(x).clone()
         assert torch.equal(y0, y1)
     assert int(L.lib().resr_debug_chain_errors()) == 0
+
+
+@pytest.mark.parametrize("n,h,w", [(8, 24, 32), (16, 70, 36), (3, 20, 24)])
+def test_conv3x3_chain_entry_vs_torch(n, h, w):
+    """resr_conv3x3_chain on a chunk-planar dense-block workspace against torch (model.py:90-93: out_k =
+    leaky_relu(conv_k(cat(x, out_1 .. out_{k-1})))), sign words included; n = 3 takes the one-launch-per-job fallback."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from tests import gpu_util as U
+    L = U.L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(n * 100 + h)
+    x = U.quant(torch.randn(n, 64, h, w, generator=g), L.RESR_F16)
+    ws = torch.zeros(6, n, h, w, 32, dtype=torch.float16, device="cuda")   # planes [x0 x1 | o1 | o2 | o3 | o4]
+    ws[:2] = x.reshape(n, 2, 32, h, w).permute(1, 0, 3, 4, 2).half().cuda()
+    plane = n * h * w * 32
+    descs = (L.ConvDesc * 4)()
+    wts, biases, packed, bias_d, signs = [], [], [], [], []
+    for k in range(4):
+        cin = 64 + 32 * k
+        wt = torch.randn(32, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        b = torch.randn(32, generator=g) * 0.1
+        wts.append(wt); biases.append(b)
+        packed.append(U.pack_conv(wt, L.RESR_F16)); bias_d.append(b.cuda())
+        signs.append(torch.zeros((n, h, w, 1), dtype=torch.int32, device="cuda"))
+        d = L.ConvDesc(n, h, w, cin, cin, 32, 0, 32, 32, 32, 0, 0, 0, L.RESR_F16, L.CONV_LRELU | L.CONV_WRITE_SIGNBITS,
+                       1.0, 1.0, 1.0, 1.0, 0.2)
+        d.in0_chunk_stride = plane
+        descs[k] = d
+    arr = lambda ptrs: (C.c_void_p * 4)(*ptrs)
+    outs = [ws.data_ptr() + (2 + k) * plane * 2 for k in range(4)]
+    L.check(lib.resr_conv3x3_chain(4, descs, L.ptr(ws), None, arr([p.data_ptr() for p in packed]),
+                                   arr([b.data_ptr() for b in bias_d]), None, arr(outs),
+                                   arr([s.data_ptr() for s in signs]), L.stream_ptr()), "resr_conv3x3_chain")
+    torch.cuda.synchronize()
+    feats = [x]
+    for k in range(4):   # the reference recursion on the values the kernel stored (f16 activations)
+        ref = F.leaky_relu(F.conv2d(torch.cat(feats, 1), U.quant(wts[k], L.RESR_F16), biases[k], padding=1), 0.2)
+        got = ws[2 + k].float().cpu().permute(0, 3, 1, 2)
+        err = (got - ref).abs().max().item()
+        assert err < 2e-2 * max(1.0, ref.abs().max().item()), (k, err)
+        bits = ((signs[k].cpu().to(torch.int64) & 0xFFFFFFFF).unsqueeze(-1) >> torch.arange(32)) & 1
+        assert torch.equal(bits.reshape(n, h, w, 32).permute(0, 3, 1, 2).bool(), got > 0), f"sign words of job {k}"
+        feats.append(got)
+    assert int(lib.resr_debug_chain_errors()) == 0
