@@ -593,17 +593,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int e = blockIdx.y * 32 + lane;
     float s = 0.f;
-    if (e < kSlab) {
-        const float* p = a.partial + job.slab_off + e;
-        for (int k = g; k < a.splits; k += 8) s += p[(size_t)k * kSlab];
-        if (job.slab_b != ~0u) {   // RESR_F16X2: the two cross products (bias sums: only the g_lo one)
-            float s2 = 0.f;
-            const float* pb = a.partial + job.slab_b + e;
-            for (int k = g; k < a.splits; k += 8) s2 += pb[(size_t)k * kSlab];
-            if (e < 9 * 1024) {
-                const float* pc = a.partial + job.slab_c + e;
-                for (int k = g; k < a.splits; k += 8) s2 += pc[(size_t)k * kSlab];
+    // a thread's slabs k = g, g + 8, ... are requested eight at a time and then added in that order: the plain loop waited
+    // for every load before issuing the next (4-9 dependent memory round trips at the 36-72 splits of a training launch)
+    auto sum_splits = [&](const float* p, float acc) {
+        constexpr int U = 8;
+        for (int k0 = g; k0 < a.splits; k0 += 8 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 8 * u;
+                v[u] = k < a.splits ? p[(size_t)k * kSlab] : 0.f;
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + 8 * u < a.splits) acc += v[u];
+        }
+        return acc;
+    };
+    if (e < kSlab) {
+        s = sum_splits(a.partial + job.slab_off + e, 0.f);
+        if (job.slab_b != ~0u) {   // RESR_F16X2: the two cross products (bias sums: only the g_lo one)
+            float s2 = sum_splits(a.partial + job.slab_b + e, 0.f);
+            if (e < 9 * 1024) s2 = sum_splits(a.partial + job.slab_c + e, s2);
             s = __builtin_fmaf(s2, kLoInv, s);
         }
     }
