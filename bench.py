@@ -743,6 +743,8 @@ def main():
             # health of the timed regime: the share of output values strictly inside the training-time clamp (model.py:270).
             # Near 0 the backward pass multiplies (almost) only zeros and runs faster than on real gradients (see --noise-data)
             "unclamped_output_fraction": main_res.get("unclamped"),
+            # chained dense-block launches: polls that timed out + workgroups beyond an XCD's share (resr_debug_chain_errors); must be 0
+            "chain_errors": int(__import__("real_esrgan_pytorch_amd")._lib.lib().resr_debug_chain_errors()),
         }
         if "roofline" in main_res:
             out["roofline"] = main_res["roofline"]

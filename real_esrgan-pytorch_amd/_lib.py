@@ -150,6 +150,16 @@ def check(rc: int, what: str = "resr") -> None:
         raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
 
+def chain_health() -> None:
+    """Raise if a chained dense-block launch (conv3x3_ws.h, CH) ever gave up waiting for a neighbouring tile or found
+    an XCD with more than its share of workgroups: results after that are not trustworthy.  Synchronises the device, so it
+    is called at epoch / benchmark ends, not per step."""
+    e = int(lib().resr_debug_chain_errors())
+    if e != 0:
+        raise RuntimeError(f"chained conv launches reported errors: {e & 0xffffffff} polls timed out, {e >> 32} workgroups beyond "
+                           "their XCD's share (set RESR_CONV_NO_CHAIN=1 to run one launch per pass)")
+
+
 def ptr(t):
     """Raw device pointer of a torch tensor (or None)."""
     return None if t is None else C.c_void_p(t.data_ptr())

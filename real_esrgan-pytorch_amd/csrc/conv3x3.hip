@@ -292,6 +292,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
 
 int conv3x3_ws_f16(const ConvArgs& a, int mt, bool x2, hipStream_t stream);  // conv3x3_ws.hip
 bool conv3x3_ws_supported(const ConvArgs& a);
+bool conv3x3_chain_device_ok();
 
 int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, const double* flop, const double* bytes, hipStream_t stream);   // conv3x3_ws.hip
 static int conv3x3_route(const ResrConvDesc* d, ConvArgs& a, bool have_bias, bool have_in1, hipStream_t stream);
@@ -425,7 +426,7 @@ int conv3x3_chain_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
         if (rc) return rc;
     }
     const char* no_chain = getenv("RESR_CONV_NO_CHAIN");   // test / A-B knob: one launch per job (read per call, so a test can flip it)
-    bool ok = !no_chain && njobs >= 2 && d[0].dtype == RESR_F16;
+    bool ok = !no_chain && njobs >= 2 && d[0].dtype == RESR_F16 && conv3x3_chain_device_ok();
     const int fwd_flags = RESR_CONV_LRELU | RESR_CONV_WRITE_SIGNBITS, inf_flags = RESR_CONV_LRELU;
     const int bwd_flags = RESR_CONV_MASK | RESR_CONV_MASK_BITS | RESR_CONV_NO_BIAS;
     const ConvArgs& b = a[njobs - 1];   // the widest job: its in0 / in1 split describes every prefix

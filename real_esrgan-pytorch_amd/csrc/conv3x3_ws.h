@@ -377,7 +377,9 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     for (int spin = 0;; ++spin) {
                         const unsigned v = watch ? __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
                         if (__ballot((int)(v - need) < 0) == 0ull) break;
-                        if (spin > (1 << 22)) {   // ~ seconds: never hang the device; the host reads the counter
+                        // never hang the device: give up after ~0.5 s (the host reads the counter), and once any poll of the
+                        // process has given up every later one does so within a millisecond
+                        if (spin > (1 << 18) || ((spin & 1023) == 1023 && __hip_atomic_load(cj.errors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                             if (lane == 0) atomicAdd(cj.errors, 1u);
                             break;
                         }

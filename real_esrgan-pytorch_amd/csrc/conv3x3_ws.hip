@@ -19,6 +19,19 @@ int conv3x3_ws_x2_mt2(const ConvArgs& a, int tile_rows, hipStream_t stream);
 
 // Preconditions of the producer's 24 x 24-bit offsets and of the 8-channel epilogue; otherwise the caller uses the
 // one-role kernel.
+// The chained launches split the image range over 8 XCDs of 32 CUs (conv3x3_ws.h, CH): only on the full device (an
+// MI355X in SPX mode reports 256 CUs; a partitioned device has one XCD per agent).
+bool conv3x3_chain_device_ok() {
+    static int ok_dev[kMaxDevices] = {0};   // 0 unknown, 1 yes, -1 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
+    if (!ok_dev[dev]) {
+        hipDeviceProp_t prop;
+        ok_dev[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount == 256) ? 1 : -1;
+    }
+    return ok_dev[dev] > 0;
+}
+
 bool conv3x3_ws_supported(const ConvArgs& a) {
     const size_t px = (size_t)a.n * a.hs * a.ws;
     const size_t stride = (size_t)(a.in0_stride_b > a.in1_stride_b ? a.in0_stride_b : a.in1_stride_b);

@@ -21,6 +21,7 @@ from torch import nn, optim
 from torch.optim import lr_scheduler
 
 from . import config, imgproc
+from . import _lib
 from .content_loss import ContentLoss
 from .dataset import CUDAPrefetcher
 from .degrade import run_plan, sample_plan
@@ -126,6 +127,7 @@ def main() -> None:
             sampler.set_epoch(epoch)
         train(discriminator, generator, ema_model, train_prefetcher, pixel_criterion, content_criterion,
               adversarial_criterion, d_optimizer, g_optimizer, epoch, scaler, writer)
+        _lib.chain_health()   # fail loudly if a chained conv launch ever gave up on a neighbouring tile
         _ = validate(generator, ema_model, valid_prefetcher, epoch, writer, niqe_model, "Valid")
         niqe = validate(generator, ema_model, test_prefetcher, epoch, writer, niqe_model, "Test")
         print("\n")

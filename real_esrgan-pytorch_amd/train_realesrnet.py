@@ -22,6 +22,7 @@ from torch.optim import lr_scheduler
 from torch.utils.data import DataLoader
 
 from . import config, imgproc
+from . import _lib
 from .dataset import CUDAPrefetcher, TestImageDataset, TrainValidImageDataset
 from .degrade import run_plan, sample_plan
 from .image_quality_assessment import NIQE
@@ -164,6 +165,7 @@ def main() -> None:
         if hasattr(sampler, "set_epoch"):
             sampler.set_epoch(epoch)
         train(model, ema_model, train_prefetcher, pixel_criterion, optimizer, epoch, scaler, writer)
+        _lib.chain_health()   # fail loudly if a chained conv launch ever gave up on a neighbouring tile
         _ = validate(model, ema_model, valid_prefetcher, epoch, writer, niqe_model, "Valid")
         niqe = validate(model, ema_model, test_prefetcher, epoch, writer, niqe_model, "Test")
         print("\n")
