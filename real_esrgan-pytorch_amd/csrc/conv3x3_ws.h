@@ -650,17 +650,39 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     int pend_tile = 0;
     unsigned pend_tag = 0;
     const int njobs_c = [&] { if constexpr (CH) return cj.njobs; else return 1; }();
+    // Lean epilogue: the tile's coordinates (column tile, row tile, image; output group) are carried from tile to tile --
+    // derived by division they are ~65 dependent scalar instructions per tile (twice with the mask prefetch), paid
+    // between two tiles where nothing overlaps them.  One division chain per job (the first tile), additions with carry after.
+    int c_tx = 0, c_ty = 0, c_n = 0, c_grp = 0;
+    const int s_tx = tile_step % a.tiles_x, s_t2 = tile_step / a.tiles_x;
+    const int s_ty = s_t2 % a.tiles_y, s_n = s_t2 / a.tiles_y;   // s_n counts images of ALL groups (group = image / a.n)
     for (int job = 0; job < njobs_c; ++job) {
     if constexpr (CH) nchunks = cj.job[job].cin >> 5;
     for (int tile = first; tile < tile_end; tile += tile_step) {
+        if constexpr (FAST) {
+            if (tile == first) {
+                const int t2 = first / a.tiles_x;
+                c_tx = first % a.tiles_x;
+                c_ty = t2 % a.tiles_y;
+                c_n = t2 / a.tiles_y;
+            } else {
+                c_tx += s_tx;
+                if (c_tx >= a.tiles_x) { c_tx -= a.tiles_x; ++c_ty; }
+                c_ty += s_ty;
+                if (c_ty >= a.tiles_y) { c_ty -= a.tiles_y; ++c_n; }
+                c_n += s_n;
+            }
+            // output groups (cout 64 shape): tile index = group * spatial tiles + spatial tile, image-major inside a group
+            c_grp = 0;
+            if (MT == 2 && a.ngroups > 1) c_grp = c_n / a.n;
+        }
         // lean epilogue, sign-bit mask (EPI 33): the mask words of this wave's rows are requested HERE and land under the
         // tile's MFMAs (requested in the epilogue they cost one exposed memory round trip per row)
         unsigned mword[(FAST && EPI == 33) ? NT : 1][MT];
         if constexpr (FAST && EPI == 33) {
-            const int tsp = tile % ntiles_sp;
-            const int x = (tsp % a.tiles_x) * TW + (lane & 31);
-            const int y0 = ((tsp / a.tiles_x) % a.tiles_y) * TH + row0;
-            const int n = tsp / (a.tiles_x * a.tiles_y);
+            const int x = c_tx * TW + (lane & 31);
+            const int y0 = c_ty * TH + row0;
+            const int n = c_n - c_grp * a.n;
             const unsigned xc = (unsigned)(x < a.w_ ? x : a.w_ - 1);
             const unsigned wpp = (unsigned)((a.cout + 31) >> 5);
 #pragma unroll
@@ -791,11 +813,10 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             // residuals = v_fma_mix_f32 (reads the f16 directly) + v_pk_fma_f32, v_cvt_pk_f16_f32, the sign byte from the
             // converted halves (v_pk_sub_i16 clamp / v_perm_b32 / v_dot4_u32_u8), the sign-bit mask through a 16-entry
             // float4 table in LDS (one ds_read_b128 + two v_pk_mul_f32 per four values).
-            const int tsp = tile % ntiles_sp;
-            const size_t goff = MT == 2 ? (size_t)(tile / ntiles_sp) * 64 : 0;
-            const int x0 = (tsp % a.tiles_x) * TW;
-            const int y0 = ((tsp / a.tiles_x) % a.tiles_y) * TH;
-            const int n = tsp / (a.tiles_x * a.tiles_y);
+            const size_t goff = MT == 2 ? (size_t)c_grp * 64 : 0;
+            const int x0 = c_tx * TW;
+            const int y0 = c_ty * TH;
+            const int n = c_n - c_grp * a.n;
             typedef const ConvArgs __attribute__((address_space(4))) * KernargPtr;
             KernargPtr ep = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ep));
