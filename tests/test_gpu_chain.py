@@ -29,10 +29,11 @@ def _run(g, x, gw, no_chain):
         os.environ.pop("RESR_CONV_NO_CHAIN", None)
 
 
-# n (a multiple of 8: every XCD owns whole images), h, w (even), dense blocks: one tile per workgroup (16- and 8-row tiles),
+# n (a multiple of 8: every XCD owns whole images), h, w (even), dense blocks: one workgroup per XCD, three images per XCD
+# with ragged tiles, one tile per workgroup (16- and 8-row tiles),
 # ragged last tiles, and several tiles per workgroup
 # ... and BASELINE's headline geometry (16 x 256^2: eight tiles per workgroup and job)
-CASES = [(8, 24, 40, 2), (8, 64, 64, 1), (16, 36, 70, 1), (16, 128, 128, 1), (32, 64, 64, 1), (16, 256, 256, 1)]
+CASES = [(8, 16, 16, 1), (24, 18, 34, 1), (8, 24, 40, 2), (8, 64, 64, 1), (16, 36, 70, 1), (16, 128, 128, 1), (32, 64, 64, 1), (16, 256, 256, 1)]
 
 
 @pytest.mark.parametrize("n,h,w,n_blocks", CASES)
