@@ -171,3 +171,36 @@ def test_conv3x3_chain_entry_vs_torch(n, h, w):
         assert torch.equal(bits.reshape(n, h, w, 32).permute(0, 3, 1, 2).bool(), got > 0), f"sign words of job {k}"
         feats.append(got)
     assert int(lib.resr_debug_chain_errors()) == 0
+
+
+def test_chain_training_trajectory():
+    """Ten optimiser steps (GradScaler, fused Adam over the flat arena, EMA) with chaining on and off from the same seeds: every
+    loss and the final weights are bit-equal (tools/chain_soak.py runs the same comparison for hundreds of steps at BASELINE's
+    geometries)."""
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd.train import RealESRNetStep
+
+    def run(no_chain):
+        if no_chain:
+            os.environ["RESR_CONV_NO_CHAIN"] = "1"
+        else:
+            os.environ.pop("RESR_CONV_NO_CHAIN", None)
+        try:
+            torch.manual_seed(0)
+            g = R.Generator(3, 3, 4, precision="fast", n_blocks=2).cuda().train()
+            ema = R.EMA(g, 0.999)
+            ema.register()
+            opt = torch.optim.Adam([g.flat_parameter()], 2e-4, (0.9, 0.99), fused=True)
+            gen = torch.Generator(device="cuda").manual_seed(1)
+            hr = torch.rand(8, 3, 128, 128, device="cuda", generator=gen)
+            lr = torch.nn.functional.interpolate(hr, scale_factor=0.25, mode="area")
+            step = RealESRNetStep(g, ema, opt, torch.amp.GradScaler("cuda"), None)
+            losses = [float(step(hr, lr)) for _ in range(10)]
+            return losses, g.flat_parameter().detach().clone()
+        finally:
+            os.environ.pop("RESR_CONV_NO_CHAIN", None)
+    l0, p0 = run(True)
+    l1, p1 = run(False)
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(p0, p1)
+    assert int(R._lib.lib().resr_debug_chain_errors()) == 0
