@@ -58,6 +58,13 @@ CONV_CASES = [
     ("rows16_ragged32", 96, 96, 32, "lrelu,signbits", 8, 200, 200),
     ("rows16_ragged64", 64, 64, 64, "res0", 8, 200, 200),
     ("rows16_maskbits_2seg", 160, 64, 32, "mask,nobias,maskbits", 6, 184, 216),
+    # partial output tiles of the lean epilogue: 8-channel pieces beyond cout are neither read nor stored
+    ("cout8", 64, 64, 8, "lrelu", 1, 20, 40),
+    ("cout16", 96, 96, 16, "lrelu", 2, 18, 34),
+    ("cout24", 64, 64, 24, "lrelu", 1, 33, 32),
+    ("cout48", 64, 64, 48, "lrelu", 1, 20, 36),
+    ("cout24_res", 64, 64, 24, "res0", 1, 17, 40),      # residual with cout % 16 != 0: the general epilogue
+    ("cout48_res", 64, 64, 48, "res0,res1", 1, 17, 40),
 ]
 
 
