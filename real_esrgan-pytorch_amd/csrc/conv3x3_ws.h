@@ -241,11 +241,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     }
     // FAST: instantiations with the lean epilogue (the generator's hot forms: plain / LeakyReLU, residuals, sign-bit
     // output, sign-bit mask); everything else keeps the general one
-#ifdef RESR_GENERAL_EPILOGUE   // A/B builds (tools/build_variant.py): every instantiation on the general epilogue
-    constexpr bool FAST = false;
-#else
     constexpr bool FAST = !X2 && (EPI == 0 || EPI == 2 || EPI == 6 || EPI == 16 || EPI == 33);
-#endif
     if constexpr (FAST && EPI == 33) {
         if (wave == 1 && lane < 16) {
             float4v m;

@@ -1,7 +1,8 @@
 """Build a variant of libresr_hip.so with extra compiler flags into tools/ab/<name>.so (same-box A/B timing:
 RESR_LIB_PATH=tools/ab/<name>.so python bench.py ...).
 
-    python tools/build_variant.py old_epilogue -DRESR_GENERAL_EPILOGUE
+    git stash; python tools/build_variant.py prev; git stash pop        # the committed build next to the working tree's
+    python tools/build_variant.py exp -DSOME_EXPERIMENT=1               # or the tree with an experiment's define
 """
 import os
 import subprocess
