@@ -48,9 +48,17 @@ struct ChainJob {
     char* out;            // the job's output plane
     void* aux;            // sign words written (forward) / read as the mask (backward-data)
     int cin;              // input channels: a prefix of the shared in0 [+ in1] planes
+    int dep;              // the job whose output plane is this job's LAST input chunk (-1: none)
+    // kind 3: one 32-channel half of the block's closing convolution (conv5, model.py:94-96, or its mirrored backward-data
+    // pass) instead of a growth convolution: no LeakyReLU / sign words / mask, v = v * s0 + t0 * res0 [, v * s1 + t1 * res1]
+    int kind;             // 0: the launch's own epilogue kind (EPI 0 / 16 / 33), 3: residual half
+    int w_mt, w_m;        // packed weights are laid out for w_mt (1 or 2) output tiles; this job multiplies tile w_m
     int pad_;
+    const char* res0;     // kind 3: residual planes (pixel stride 32 elements) and their scales
+    const char* res1;     // or null
+    float s0, t0, s1, t1;
 };
-constexpr int kMaxChain = 4;
+constexpr int kMaxChain = 6;
 struct ChainArgs {
     int njobs;
     unsigned epoch;        // flag value of "job j of this launch done" = epoch + j + 1 (flags only ever grow: no reset between launches)

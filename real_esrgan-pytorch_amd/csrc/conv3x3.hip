@@ -411,25 +411,33 @@ static int conv3x3_route(const ResrConvDesc* d, ConvArgs& a, bool have_bias, boo
     return fail(RESR_ERR_ARG, "conv3x3: dtype=%d", d->dtype);
 }
 
-// The four cout-32 passes of one dense block (forward conv1..conv4, model.py:90-93, or the mirrored backward-data passes)
-// as ONE persistent launch when the fast-mode kernel can chain them (conv3x3_ws.h, CH); otherwise one launch each.
-// Job j: descriptor d[j], weights w[j], bias[j] (or null), mask[j] (or null), output out[j], aux[j] (or null); the
-// shared inputs in0 / in1 hold the plane prefix every job reads.
-int conv3x3_chain_dispatch(int njobs, const ResrConvDesc* d, const void* in0, const void* in1, const void* const* w,
+// The passes of one dense block (forward conv1..conv4 [+ conv5], model.py:90-96, or the mirrored backward-data passes) as
+// ONE persistent launch when the fast-mode kernel can chain them (conv3x3_ws.h, CH); otherwise one launch each.
+// Job j < njobs: descriptor d[j], weights w[j], bias[j] (or null), mask[j] (or null), output out[j], aux[j] (or null); the
+// shared inputs in0 / in1 hold the plane prefix every job reads.  d5 (optional): the block's closing cout-64 convolution
+// over the same inputs with its residuals; on launches of at most two tiles per CU (the 64^2 training crops) it joins the
+// chain as two cout-32 jobs that read the cout-64 weight packing in place -- there a launch's fill / drain costs more than
+// the cout-64 shape's better register tile gains; at full size it stays its own launch.
+int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, const void* in1, const void* const* w,
                            const float* const* bias, const void* const* mask, void* const* out, void* const* aux,
-                           hipStream_t stream) {
-    if (njobs <= 0 || njobs > kMaxChain || !d) return fail(RESR_ERR_ARG, "conv3x3_chain: njobs=%d", njobs);
-    ConvArgs a[kMaxChain];
+                           const ResrConvDesc* d5, const void* w5, const float* bias5, const void* res0_5, const void* res1_5,
+                           void* out5, hipStream_t stream) {
+    if (njobs <= 0 || njobs > 4 || !d) return fail(RESR_ERR_ARG, "conv3x3_chain: njobs=%d", njobs);
+    ConvArgs a[4], a5;
     for (int j = 0; j < njobs; ++j) {
         const int rc = conv3x3_args(&d[j], in0, in1, w[j], bias ? bias[j] : nullptr, nullptr, nullptr, mask ? mask[j] : nullptr,
                                     out[j], aux ? aux[j] : nullptr, a[j]);
+        if (rc) return rc;
+    }
+    if (d5) {
+        const int rc = conv3x3_args(d5, in0, in1, w5, bias5, res0_5, res1_5, nullptr, out5, nullptr, a5);
         if (rc) return rc;
     }
     const char* no_chain = getenv("RESR_CONV_NO_CHAIN");   // test / A-B knob: one launch per job (read per call, so a test can flip it)
     bool ok = !no_chain && njobs >= 2 && d[0].dtype == RESR_F16 && conv3x3_chain_device_ok();
     const int fwd_flags = RESR_CONV_LRELU | RESR_CONV_WRITE_SIGNBITS, inf_flags = RESR_CONV_LRELU;
     const int bwd_flags = RESR_CONV_MASK | RESR_CONV_MASK_BITS | RESR_CONV_NO_BIAS;
-    const ConvArgs& b = a[njobs - 1];   // the widest job: its in0 / in1 split describes every prefix
+    const ConvArgs& b = a[njobs - 1];   // the widest growth job: its in0 / in1 split describes every prefix
     for (int j = 0; ok && j < njobs; ++j) {
         const ConvArgs& c = a[j];
         ok = d[j].dtype == RESR_F16 && d[j].cout_pad == 32 && c.cout == 32 && (c.flags == fwd_flags || c.flags == bwd_flags || c.flags == inf_flags) &&
@@ -452,25 +460,70 @@ int conv3x3_chain_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) ok = false;   // the flag epoch is a launch argument
     }
+    // the closing convolution as jobs 4 and 5 of the chain
+    bool with5 = ok && d5 && njobs == 4;
+    if (with5) {
+        const char* knob = getenv("RESR_CHAIN_CONV5");   // A/B knob: 0 never, 1 whenever possible; default by launch size
+        const long tiles16 = (long)((b.w_ + 31) / 32) * ((b.h + 15) / 16) * b.n;
+        with5 = knob ? knob[0] == '1' : tiles16 <= 512;
+        const ConvArgs& c = a5;
+        const int c0 = c.cin - 32;
+        const bool seg1 = c0 >= c.cin0;
+        const char* last = seg1 ? c.in1 + (size_t)((c0 - c.cin0) >> 5) * c.in1_chunk_b : c.in0 + (size_t)(c0 >> 5) * c.in0_chunk_b;
+        with5 = with5 && d5->dtype == RESR_F16 && d5->cout_pad == 64 && c.cout == 64 && c.cin == b.cin + 32 && last == b.out &&
+                (c.flags & ~RESR_CONV_NO_BIAS) == 0 && ((c.flags & RESR_CONV_NO_BIAS) != 0) == ((b.flags & RESR_CONV_NO_BIAS) != 0) &&
+                c.n == b.n && c.h == b.h && c.w_ == b.w_ && c.hs == c.h && c.ws == c.w_ &&
+                c.in0_stride_b == 64 && c.in0_chunk_b == b.in0_chunk_b &&
+                (c.cin0 == c.cin || (c.cin0 == b.cin0 && c.in1_stride_b == 64 && c.in1_chunk_b == b.in1_chunk_b)) &&
+                c.out_stride == 32 && c.out_chunk > 32 && c.res0 && c.res0_stride == 32 && c.res0_chunk > 32 &&
+                (!c.res1 || (c.res1_stride == 32 && c.res1_chunk > 32)) && !c.mask && !c.aux && c.ngroups == 1 && !c.s2d_c && !c.tap_c &&
+                conv3x3_ws_supported(c);
+    }
     if (!ok) {
         for (int j = 0; j < njobs; ++j) {
             const int rc = conv3x3_route(&d[j], a[j], a[j].bias != nullptr, a[j].in1 != nullptr, stream);
             if (rc) return rc;
         }
-        return RESR_OK;
+        return d5 ? conv3x3_route(d5, a5, a5.bias != nullptr, a5.in1 != nullptr, stream) : RESR_OK;
     }
     ChainJob jobs[kMaxChain];
     double flop[kMaxChain], bytes[kMaxChain];
+    memset(jobs, 0, sizeof(jobs));
     for (int j = 0; j < njobs; ++j) {
         jobs[j].w = a[j].w; jobs[j].bias = a[j].bias; jobs[j].out = a[j].out;
         jobs[j].aux = (a[j].flags == bwd_flags) ? (void*)a[j].mask : (void*)a[j].aux;
-        jobs[j].cin = a[j].cin; jobs[j].pad_ = 0;
+        jobs[j].cin = a[j].cin; jobs[j].dep = j - 1; jobs[j].kind = 0; jobs[j].w_mt = 1; jobs[j].w_m = 0;
         flop[j] = 2.0 * 9 * a[j].cin * a[j].cout * (double)a[j].n * a[j].h * a[j].w_;
         bytes[j] = conv_algorithmic_bytes(a[j], 2);
     }
     ConvArgs base = b;
     if (base.cin0 == base.cin) base.cin0 = base.cin;   // single-segment prefix: every chunk of every job lies in in0
-    return conv3x3_ws_chain_f16(base, jobs, njobs, flop, bytes, stream);
+    int total = njobs;
+    if (with5) {
+        for (int m = 0; m < 2; ++m) {
+            ChainJob& q = jobs[4 + m];
+            q.w = a5.w; q.w_mt = 2; q.w_m = m;
+            q.bias = a5.bias ? a5.bias + 32 * m : nullptr;
+            q.out = a5.out + (size_t)m * a5.out_chunk * 2;
+            q.aux = nullptr; q.cin = a5.cin; q.dep = 3; q.kind = 3;
+            q.res0 = a5.res0 + (size_t)m * a5.res0_chunk * 2;
+            q.res1 = a5.res1 ? a5.res1 + (size_t)m * a5.res1_chunk * 2 : nullptr;
+            q.s0 = a5.s0; q.t0 = a5.t0; q.s1 = a5.s1; q.t1 = a5.t1;
+            flop[4 + m] = 2.0 * 9 * a5.cin * 32 * (double)a5.n * a5.h * a5.w_;
+            bytes[4 + m] = conv_algorithmic_bytes(a5, 2) * 0.5;
+        }
+        if (a5.cin0 == a5.cin) base.cin0 = a5.cin;   // the single segment now reaches the closing convolution's last chunk
+        total = 6;
+    }
+    const int rc = conv3x3_ws_chain_f16(base, jobs, total, flop, bytes, stream);
+    if (rc || !d5 || with5) return rc;
+    return conv3x3_route(d5, a5, a5.bias != nullptr, a5.in1 != nullptr, stream);
+}
+
+int conv3x3_chain_dispatch(int njobs, const ResrConvDesc* d, const void* in0, const void* in1, const void* const* w,
+                           const float* const* bias, const void* const* mask, void* const* out, void* const* aux,
+                           hipStream_t stream) {
+    return conv3x3_block_dispatch(njobs, d, in0, in1, w, bias, mask, out, aux, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 }  // namespace resr

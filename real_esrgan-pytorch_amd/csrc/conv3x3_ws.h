@@ -75,7 +75,7 @@ struct WsCfg {
     // LeakyReLU-backward multipliers by 4 mask bits (16 x float4), behind the weight buffers (EPI 33 of the lean epilogue)
     static constexpr int LUT_OFF = LDS_BYTES, LUT_BYTES = 256;
     // chain launches: the biases of kMaxChain jobs + the consumers' arrival counter, behind the table
-    static constexpr int CHAIN_OFF = LUT_OFF + LUT_BYTES, CHAIN_BYTES = 4 * 128 + 64;
+    static constexpr int CHAIN_OFF = LUT_OFF + LUT_BYTES, CHAIN_BYTES = kMaxChain * 128 + 64;
     static_assert(LDS_BYTES + LUT_BYTES + CHAIN_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -356,12 +356,15 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 const int njobs = cj.njobs;
                 int job = 0, nch = nchunks;   // job / chunk count of the stage whose halo was requested last
                 int it = first, ick = 0, hb = 0;
-                auto issue_wj = [&](const char* wjob, int ck, int par) {
-                    const char* wbase = wjob + (size_t)ck * C::WBUF;
+                // job jb's weights of chunk ck: fragment idx of this kernel's 32-channel output tile is fragment idx * w_mt + w_m of
+                // a buffer packed for w_mt tiles (the closing convolution's halves read the cout-64 packing in place)
+                auto issue_wj = [&](int jb, int ck, int par) {
+                    const int wmt = cj.job[jb].w_mt, wm = cj.job[jb].w_m;
+                    const char* wbase = cj.job[jb].w + (size_t)ck * C::WBUF * wmt + (size_t)wm * 1024;
 #pragma unroll
                     for (int i = 0; i < C::NWIP; ++i) {
                         const int idx = i * NP + pw;
-                        if (idx < C::NWI) conv_glds16_s(wbase, (unsigned)(idx * 1024) + ((unsigned)lane << 4), lds_base + C::WOFF + par * C::WBUF + idx * 1024);
+                        if (idx < C::NWI) conv_glds16_s(wbase, (unsigned)(idx * wmt * 1024) + ((unsigned)lane << 4), lds_base + C::WOFF + par * C::WBUF + idx * 1024);
                     }
                 };
                 // lanes 0..8 watch the tile's 3 x 3 neighbourhood inside its image; `need` = flag value of "previous job done"
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     return job < njobs;
                 };
                 tile_pix(it);
-                issue_wj(cj.job[0].w, 0, 0);
+                issue_wj(0, 0, 0);
                 issue_h(0, 0);
                 __syncthreads();           // the set-up barrier
                 bool have_next = advance();   // chunk 1 of the same tile (every job has >= 2 chunks, host-checked)
@@ -409,12 +412,12 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 }
                 __syncthreads();           // barrier 0
                 for (int s = 0; have_next; ++s) {   // stage s is being multiplied; H(s+1) is in flight
-                    issue_wj(cj.job[job_next].w, ck_next, (s + 1) & 1);
+                    issue_wj(job_next, ck_next, (s + 1) & 1);
                     const bool have_next2 = advance();
                     if (have_next2) {
                         if (ick == 0) tile_pix(it);
-                        // the last chunk of a job > 0 is the previous job's output plane
-                        if (job > 0 && ick == nch - 1) poll(it, cj.epoch + (unsigned)job);
+                        // the last chunk of a dependent job is the output plane of job `dep`
+                        if (ick == nch - 1 && cj.job[job].dep >= 0) poll(it, cj.epoch + (unsigned)cj.job[job].dep + 1u);
                         hb = hb == 2 ? 0 : hb + 1;
                         issue_h(ick, hb);
                         wait_all_but_h();
@@ -675,7 +678,9 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         // lean epilogue, sign-bit mask (EPI 33): the mask words of this wave's rows are requested HERE and land under the
         // tile's MFMAs (requested in the epilogue they cost one exposed memory round trip per row)
         unsigned mword[(FAST && EPI == 33) ? NT : 1][MT];
-        if constexpr (FAST && EPI == 33) {
+        bool own_top = true;   // CH: not for the closing convolution's halves (kind 3: no mask)
+        if constexpr (CH) own_top = cj.job[job].kind != 3;
+        if constexpr (FAST && EPI == 33) if (own_top) {
             const int x = c_tx * TW + (lane & 31);
             const int y0 = c_ty * TH + row0;
             const int n = c_n - c_grp * a.n;
@@ -827,22 +832,35 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             e.out = ep->out; e.h = ep->h; e.w_ = ep->w_; e.cout = ep->cout; e.out_stride = ep->out_stride;
             e.out_chunk = ep->out_chunk; e.flags = ep->flags; e.slope = ep->slope;
             if constexpr (CH) e.out = cj.job[job].out;
-            constexpr bool R0 = (EPI & 2) != 0, R1 = (EPI & 4) != 0, ESB = EPI == 16, EMB = EPI == 33;
-            if constexpr (R0) { e.res0 = ep->res0; e.res0_stride = ep->res0_stride; e.res0_chunk = ep->res0_chunk; e.s0 = ep->s0; e.t0 = ep->t0; }
-            if constexpr (R1) { e.res1 = ep->res1; e.res1_stride = ep->res1_stride; e.res1_chunk = ep->res1_chunk; e.s1 = ep->s1; e.t1 = ep->t1; }
+            constexpr bool R0c = (EPI & 2) != 0, R1c = (EPI & 4) != 0, ESB = EPI == 16, EMB = EPI == 33;
+            // What the instantiation fixes at compile time a chained launch may replace per job at run time: a job of kind 3 (one
+            // half of the block's closing convolution) has residuals instead of LeakyReLU / sign words / mask.  Outside chained
+            // launches r0 / r1 / own are constants and the code below is what it was.
+            bool r0 = R0c, r1 = R1c, own = true;
+            if constexpr (R0c) { e.res0 = ep->res0; e.res0_stride = ep->res0_stride; e.res0_chunk = ep->res0_chunk; e.s0 = ep->s0; e.t0 = ep->t0; }
+            if constexpr (R1c) { e.res1 = ep->res1; e.res1_stride = ep->res1_stride; e.res1_chunk = ep->res1_chunk; e.s1 = ep->s1; e.t1 = ep->t1; }
             if constexpr (ESB) e.aux = ep->aux;
             if constexpr (ESB && CH) e.aux = reinterpret_cast<uint8_t*>(cj.job[job].aux);
+            if constexpr (CH) {
+                if (cj.job[job].kind == 3) {
+                    own = false;
+                    r0 = true;
+                    e.res0 = cj.job[job].res0; e.res0_stride = 32; e.res0_chunk = 0; e.s0 = cj.job[job].s0; e.t0 = cj.job[job].t0;
+                    r1 = cj.job[job].res1 != nullptr;
+                    e.res1 = cj.job[job].res1; e.res1_stride = 32; e.res1_chunk = 0; e.s1 = cj.job[job].s1; e.t1 = cj.job[job].t1;
+                }
+            }
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
             const int lx_e = lane_e & 31, kh_e = lane_e >> 5;
             const int x = x0 + lx_e;
             const unsigned xc = (unsigned)(x < e.w_ ? x : e.w_ - 1);
-            const bool f_lrelu = e.flags & RESR_CONV_LRELU;
+            const bool f_lrelu = own && (e.flags & RESR_CONV_LRELU);
             const float2v sl2 = {e.slope, e.slope};
             const unsigned kh16 = (unsigned)kh_e * 16u;   // byte offset of this lane half's 8 channels inside a 16-channel piece pair
             // row double buffer of the residual pieces (cout 64): row t+1 is requested before row t is processed
-            constexpr bool RES = R0 || R1;
-            constexpr int NB = (RES && MT == 2) ? 2 : 1;
+            constexpr bool RESc = R0c || R1c;
+            constexpr int NB = (RESc && MT == 2) ? 2 : 1;
             uint4v rr0[NB][MT][2], rr1[NB][MT][2];
             auto row_pix = [&](int t) {
                 const int y = y0 + row0 + t;
@@ -860,33 +878,34 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const bool pair_ok = m * 32 + j * 16 < e.cout;   // wave-uniform
-                        if constexpr (R0)
+                        if (r0)
                             rr0[b][m][j] = *reinterpret_cast<const uint4v*>(e.res0 + ((size_t)p * e.res0_stride + goff + (pair_ok ? (size_t)m * e.res0_chunk + j * 16 : (size_t)0)) * 2 + kh16);
-                        if constexpr (R1)
+                        if (r1)
                             rr1[b][m][j] = *reinterpret_cast<const uint4v*>(e.res1 + ((size_t)p * e.res1_stride + goff + (pair_ok ? (size_t)m * e.res1_chunk + j * 16 : (size_t)0)) * 2 + kh16);
                     }
             };
             // MFMA results -> first non-MFMA reader: the swaps are asm, so the compiler cannot count this hazard
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");
-            if constexpr (RES) request(0, 0);
+            if (r0 || r1) request(0, 0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int y = y0 + row0 + t;
                 const bool in_img = y < e.h && x < e.w_;
                 const unsigned p = row_pix(t);
                 const int b = NB == 2 ? (t & 1) : 0;
-                if constexpr (RES && NB == 2) {
+                if constexpr (NB == 2) {
                     if (t + 1 < NT) request((t + 1) & 1, t + 1);
-                }
-                if constexpr (RES && NB == 1) {
-                    if (t > 0) request(0, t);
+                } else {
+                    if ((r0 || r1) && t > 0) request(0, t);
                 }
                 char* const orow = e.out + ((size_t)p * e.out_stride + goff) * 2 + kh16;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     unsigned sacc[2] = {0u, 0u};   // ESB: 128 x the sign byte of piece j
                     unsigned wk = 0;
-                    if constexpr (EMB) wk = mword[t][m] >> (kh_e * 8);   // this lane half's bytes: j = 0 at bit 0, j = 1 at bit 16
+                    if constexpr (EMB) {
+                        if (own) wk = mword[t][m] >> (kh_e * 8);   // this lane half's bytes: j = 0 at bit 0, j = 1 at bit 16
+                    }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         float16v& A = acc[m][t];
@@ -894,7 +913,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         float v4 = A[8 * j + 4], v5 = A[8 * j + 5], v6 = A[8 * j + 6], v7 = A[8 * j + 7];
                         permlane32_swap4(v0, v1, v2, v3, v4, v5, v6, v7);
                         float2v q[4] = {{v0, v1}, {v2, v3}, {v4, v5}, {v6, v7}};
-                        if constexpr (EMB) {
+                        if (EMB && own) {
                             const char* lut = smem + C::LUT_OFF;
                             const float4v ma = *reinterpret_cast<const float4v*>(lut + ((wk >> (16 * j)) & 15u) * 16);
                             const float4v mb = *reinterpret_cast<const float4v*>(lut + ((wk >> (16 * j + 4)) & 15u) * 16);
@@ -911,7 +930,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                                 q[k][1] = vmax_f32(q[k][1], sq[1]);
                             }
                         }
-                        if constexpr (R0) {
+                        if (r0) {
                             const float2v s02 = {e.s0, e.s0};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
@@ -919,7 +938,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                                 q[k] = __builtin_elementwise_fma(q[k], s02, tr);
                             }
                         }
-                        if constexpr (R1) {
+                        if (r1) {
                             const float2v s12 = {e.s1, e.s1};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
@@ -932,12 +951,12 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         for (int k = 0; k < 4; ++k) d[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(q[k], half2v));
                         if (in_img && piece_ok(m, j))
                             *reinterpret_cast<uint4v*>(orow + ((size_t)m * e.out_chunk + j * 16) * 2) = d;
-                        if constexpr (ESB) {
+                        if (ESB && own) {
                             sacc[j] = signs4_x128(d[0], d[1], 0x08040201u, 0u);
                             sacc[j] = signs4_x128(d[2], d[3], 0x80402010u, sacc[j]);
                         }
                     }
-                    if constexpr (ESB) {
+                    if (ESB && own) {
                         // bytes 2j + kh of the pixel's word: (byte_0 | byte_1 << 16) << 8 kh, all of it times 128 so far
                         const unsigned both = sacc[0] | (sacc[1] << 16);
                         const unsigned mine = __builtin_amdgcn_alignbit(both, both, kh_e ? 31u : 7u);   // rotate: >> 7 or << 1

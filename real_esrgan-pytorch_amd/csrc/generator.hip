@@ -34,8 +34,10 @@ namespace resr {
 int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*, const float*, const void*,
                      const void*, const void*, void*, void*, hipStream_t);
 size_t wgrad_batch_partial_bytes(const WgradConv*, int, int, int);
-int conv3x3_chain_dispatch(int njobs, const ResrConvDesc* d, const void* in0, const void* in1, const void* const* w,
-                           const float* const* bias, const void* const* mask, void* const* out, void* const* aux, hipStream_t stream);
+int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, const void* in1, const void* const* w,
+                           const float* const* bias, const void* const* mask, void* const* out, void* const* aux,
+                           const ResrConvDesc* d5, const void* w5, const float* bias5, const void* res0_5, const void* res1_5,
+                           void* out5, hipStream_t stream);
 int wgrad_batch(const WgradConv*, int, int, int, int, int, int, int, float*, hipStream_t);
 int wgrad_tile_rows(int dtype);
 int wgrad_x2_products();
@@ -422,22 +424,22 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
                 cds[k - 1] = cd; ws4[k - 1] = W(c); bs4[k - 1] = Bias(c);
                 outs4[k - 1] = cur + (size_t)(2 + (k - 1)) * plane * es; signs4[k - 1] = signs;
             }
-            RUN(conv3x3_chain_dispatch(4, cds, cur, nullptr, ws4, bs4, nullptr, outs4, signs4, st));
+            // conv5 (model.py:94-96) goes with them: one chained launch of six jobs on small launches, else its own launch
+            const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + 4];
+            const bool last = r == p.nrdb - 1;
+            char* dst = last ? b.trunk_out : b.ws[(r + 1) % nws];
+            ResrConvDesc cd = conv_desc(p, N, h, w, 192, 192, 32, 0, 64, 64, 32, 0);
+            cd.in0_chunk_stride = plane;
+            cd.out_chunk_stride = plane;
+            cd.in0_lo_offset = lo_ws; cd.out_lo_offset = last ? lo_t : lo_ws;
+            cd.s0 = 0.2f; cd.t0 = 1.f; cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.res0_lo_offset = lo_ws;  // model.py:95-96
+            const char* res1 = nullptr;
+            if (r % 3 == 2) {  // model.py:129-130
+                res1 = b.ws[(r - 2) % nws];
+                cd.s1 = 0.2f; cd.t1 = 1.f; cd.res1_stride = 32; cd.res1_chunk_stride = plane; cd.res1_lo_offset = lo_ws;
+            }
+            RUN(conv3x3_block_dispatch(4, cds, cur, nullptr, ws4, bs4, nullptr, outs4, signs4, &cd, W(c), Bias(c), cur, res1, dst, st));
         }
-        const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + 4];
-        const bool last = r == p.nrdb - 1;
-        char* dst = last ? b.trunk_out : b.ws[(r + 1) % nws];
-        ResrConvDesc cd = conv_desc(p, N, h, w, 192, 192, 32, 0, 64, 64, 32, 0);
-        cd.in0_chunk_stride = plane;
-        cd.out_chunk_stride = plane;
-        cd.in0_lo_offset = lo_ws; cd.out_lo_offset = last ? lo_t : lo_ws;
-        cd.s0 = 0.2f; cd.t0 = 1.f; cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.res0_lo_offset = lo_ws;  // model.py:95-96
-        const char* res1 = nullptr;
-        if (r % 3 == 2) {  // model.py:129-130
-            res1 = b.ws[(r - 2) % nws];
-            cd.s1 = 0.2f; cd.t1 = 1.f; cd.res1_stride = 32; cd.res1_chunk_stride = plane; cd.res1_lo_offset = lo_ws;
-        }
-        RUN(conv3x3_dispatch(&cd, cur, nullptr, W(c), Bias(c), cur, res1, nullptr, dst, nullptr, st));
     }
     {   // conv2 + skip                                                   model.py:261-262
         const ConvSpec& c = p.convs[p.i_conv2];
@@ -625,11 +627,8 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             wc[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f, lo_ws, lo_gs);
             wc[k - 1].x_chunk_stride = plane;
         }
-        // the four mirrored cout-32 passes: one chained launch where the kernel supports it, else four
-        RUN(conv3x3_chain_dispatch(4, cds, gin, b.gS, ws4, nullptr, masks4, outs4, nullptr, st));
-        RUN(wgrad_run(wc, 5, h, w, 0));   // all five weight gradients of the block in one launch pair
-        if (pos == 0) RUN(ready(1 + (d->n_blocks - 1 - r / 3)));   // rdb3, rdb2, rdb1 of this RRDB are done
-        {   // g_x = convT(all) + (skip terms)
+        {   // the four mirrored cout-32 passes, then g_x = convT(all) + (skip terms): one chained launch where the kernel supports
+            // it (g_x joins on small launches), else one launch per pass
             int nxt = (cur + 1) & 3;
             if (nxt == e_idx && pos != 2) nxt = (nxt + 1) & 3;
             ResrConvDesc cd = dgrad(h, w, 64, 32, 192, 32, 64, 64, 32, 0, lo_t, lo_gs, lo_t);
@@ -639,10 +638,12 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.s0 = 1.f; cd.res0_lo_offset = lo_t;
             cd.t0 = pos == 2 ? 0.2f : 1.f;       // d(rdb3_out*0.2 + x)/d(rdb3_out) reaches x3 scaled
             if (pos == 0) { res1 = b.gT[e_idx]; cd.res1_stride = 32; cd.res1_chunk_stride = plane; cd.s1 = 1.f; cd.t1 = 1.f; cd.res1_lo_offset = lo_t; }
-            RUN(conv3x3_dispatch(&cd, gin, b.gS, pk + p.pk_bwd_trunk[(size_t)r * 5 + 4] * wes, nullptr, res0, res1, nullptr,
-                                 b.gT[nxt], nullptr, st));
+            RUN(conv3x3_block_dispatch(4, cds, gin, b.gS, ws4, nullptr, masks4, outs4, nullptr, &cd,
+                                       pk + p.pk_bwd_trunk[(size_t)r * 5 + 4] * wes, nullptr, res0, res1, b.gT[nxt], st));
             cur = nxt;
         }
+        RUN(wgrad_run(wc, 5, h, w, 0));   // all five weight gradients of the block in one launch pair (they read gin and gS, not g_x)
+        if (pos == 0) RUN(ready(1 + (d->n_blocks - 1 - r / 3)));   // rdb3, rdb2, rdb1 of this RRDB are done
     }
     if (debug_stop() == 4) return RESR_OK;
     // gradient wrt out1 = trunk path + skip (model.py:262)

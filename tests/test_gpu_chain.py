@@ -59,7 +59,7 @@ def test_chain_equals_separate_launches(n, h, w, n_blocks):
 
 
 def test_chain_is_taken():
-    """The profiling records show ONE conv launch for the four cout-32 passes of a block when chaining is on."""
+    """The profiling records show ONE conv launch for the passes of a block when chaining is on."""
     import ctypes as C
     import real_esrgan_pytorch_amd as R
     L = R._lib
@@ -81,7 +81,14 @@ def test_chain_is_taken():
         finally:
             os.environ.pop("RESR_CONV_NO_CHAIN", None)
     a, b = launches(True), launches(False)
-    assert a - b == 3 * 3, (a, b)   # three dense blocks per RRDB, three launches saved in each
+    # three dense blocks per RRDB; on a launch this small conv5 joins the chain as two more jobs: five launches become one
+    assert a - b == 3 * 4, (a, b)
+    os.environ["RESR_CHAIN_CONV5"] = "0"   # ... and without it, four become one
+    try:
+        c = launches(False)
+    finally:
+        os.environ.pop("RESR_CHAIN_CONV5", None)
+    assert a - c == 3 * 3, (a, c)
 
 
 def test_chain_from_two_streams():
