@@ -161,7 +161,8 @@ __device__ __forceinline__ unsigned signs4_x128(unsigned d0, unsigned d1, unsign
 // of this launch lies in sub-position a.tap_sub, taps flipped) skip the other 5 taps: 16 instead of 36 tap-products, the
 // FLOPs of the dense 4x4 kernel.  Same tiles, buffers and barrier protocol as the dense loop.
 //
-// CH (chain): the launch runs cj.njobs dependent convolutions of one dense block back to back (ChainJob, conv3x3.h) --
+// CH (chain; 2 = some jobs are residual halves of the closing convolution, switched per job at run time -- its own
+// instantiation so that the homogeneous chains of the full-size batch do not pay for the switches): the launch runs cj.njobs dependent convolutions of one dense block back to back (ChainJob, conv3x3.h) --
 // job j+1's last input chunk is job j's output plane -- without kernel boundaries: every workgroup walks its tiles of job
 // 0, then of job 1, ...; the producers run ahead ACROSS jobs (the prefix chunks of job j+1 do not depend on job j), and
 // only the halo of the dependent chunk waits, per tile, for the (up to) nine neighbouring tiles of job j (flags[] in
@@ -170,8 +171,8 @@ __device__ __forceinline__ unsigned signs4_x128(unsigned d0, unsigned d1, unsign
 // L2: plain stores and loads are coherent there, and the flags only order them.  Deadlock-free with all workgroups
 // resident: a tile of job j never waits for anything of job j+1, consumers publish a tile one stage after its epilogue
 // without waiting for their producers, and producers only poll (for stage s+2) after barrier s.
-template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0, bool CH = false>
-__global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCfg<T, MT, NT, NWC>::NP) / 4) void conv3x3_ws_kernel(const ConvArgs a, const std::conditional_t<CH, ChainArgs, ChainNone> cj) {
+template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0, int CH = 0>
+__global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCfg<T, MT, NT, NWC>::NP) / 4) void conv3x3_ws_kernel(const ConvArgs a, const std::conditional_t<CH != 0, ChainArgs, ChainNone> cj) {
     static_assert(!CH || (MT == 1 && !X2 && SP == 0 && (EPI == 0 || EPI == 16 || EPI == 33) && WsCfg<T, MT, NT, NWC>::NHB == 3), "chain: cout-32 dense-block passes only");
     using C = WsCfg<T, MT, NT, NWC>;
     constexpr int SPP = C::SPP, KS = C::KS, PB = C::PB, TH = C::TH, TW = C::TW, HW = C::HW, BUF = C::BUF;
@@ -359,7 +360,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 // job jb's weights of chunk ck: fragment idx of this kernel's 32-channel output tile is fragment idx * w_mt + w_m of
                 // a buffer packed for w_mt tiles (the closing convolution's halves read the cout-64 packing in place)
                 auto issue_wj = [&](int jb, int ck, int par) {
-                    const int wmt = cj.job[jb].w_mt, wm = cj.job[jb].w_m;
+                    int wmt = 1, wm = 0;
+                    if constexpr (CH == 2) { wmt = cj.job[jb].w_mt; wm = cj.job[jb].w_m; }
                     const char* wbase = cj.job[jb].w + (size_t)ck * C::WBUF * wmt + (size_t)wm * 1024;
 #pragma unroll
                     for (int i = 0; i < C::NWIP; ++i) {
@@ -417,7 +419,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     if (have_next2) {
                         if (ick == 0) tile_pix(it);
                         // the last chunk of a dependent job is the output plane of job `dep`
-                        if (ick == nch - 1 && cj.job[job].dep >= 0) poll(it, cj.epoch + (unsigned)cj.job[job].dep + 1u);
+                        if (ick == nch - 1) {
+                            int dep = job - 1;   // homogeneous chains: the previous job
+                            if constexpr (CH == 2) dep = cj.job[job].dep;
+                            if (dep >= 0) poll(it, cj.epoch + (unsigned)dep + 1u);
+                        }
                         hb = hb == 2 ? 0 : hb + 1;
                         issue_h(ick, hb);
                         wait_all_but_h();
@@ -678,8 +684,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         // lean epilogue, sign-bit mask (EPI 33): the mask words of this wave's rows are requested HERE and land under the
         // tile's MFMAs (requested in the epilogue they cost one exposed memory round trip per row)
         unsigned mword[(FAST && EPI == 33) ? NT : 1][MT];
-        bool own_top = true;   // CH: not for the closing convolution's halves (kind 3: no mask)
-        if constexpr (CH) own_top = cj.job[job].kind != 3;
+        bool own_top = true;   // CH 2: not for the closing convolution's halves (kind 3: no mask)
+        if constexpr (CH == 2) own_top = cj.job[job].kind != 3;
         if constexpr (FAST && EPI == 33) if (own_top) {
             const int x = c_tx * TW + (lane & 31);
             const int y0 = c_ty * TH + row0;
@@ -841,7 +847,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             if constexpr (R1c) { e.res1 = ep->res1; e.res1_stride = ep->res1_stride; e.res1_chunk = ep->res1_chunk; e.s1 = ep->s1; e.t1 = ep->t1; }
             if constexpr (ESB) e.aux = ep->aux;
             if constexpr (ESB && CH) e.aux = reinterpret_cast<uint8_t*>(cj.job[job].aux);
-            if constexpr (CH) {
+            if constexpr (CH == 2) {
                 if (cj.job[job].kind == 3) {
                     own = false;
                     r0 = true;

@@ -4,10 +4,10 @@
 
 namespace resr {
 
-template <int NT, int EPI>
+template <int NT, int EPI, int CH>
 static int launch_chain(const ConvArgs& a, ChainArgs cj, unsigned* ticket_base, double flop, double bytes, hipStream_t stream) {
     using C = WsCfg<half_t, 1, NT, 8>;
-    auto kern = conv3x3_ws_kernel<half_t, 1, NT, 8, EPI, false, 0, true>;
+    auto kern = conv3x3_ws_kernel<half_t, 1, NT, 8, EPI, false, 0, CH>;
     ConvArgs args = a;
     args.tiles_x = (a.w_ + 31) / 32;
     args.tiles_y = (a.h + C::TH - 1) / C::TH;
@@ -46,15 +46,21 @@ static int launch_chain(const ConvArgs& a, ChainArgs cj, unsigned* ticket_base, 
     return RESR_OK;
 }
 
-// kind: 0 = forward at inference (LeakyReLU), 1 = forward in training (LeakyReLU + sign words), 2 = mirrored backward-data
+// kind: 0 = forward at inference (LeakyReLU), 1 = forward in training (LeakyReLU + sign words), 2 = mirrored backward-data;
+// jobs of kind "residual half" (the closing convolution inside the chain) take the instantiation with the per-job switches
+template <int NT, int CH>
+static int launch_chain_kind(const ConvArgs& a, const ChainArgs& cj, int kind, unsigned* ticket_base, double flop, double bytes, hipStream_t stream) {
+    if (kind == 2) return launch_chain<NT, 33, CH>(a, cj, ticket_base, flop, bytes, stream);
+    return kind == 1 ? launch_chain<NT, 16, CH>(a, cj, ticket_base, flop, bytes, stream) : launch_chain<NT, 0, CH>(a, cj, ticket_base, flop, bytes, stream);
+}
+
 // *ticket_base: the stream's running ticket value (conv3x3_ws.hip), advanced by this launch's workgroups per XCD
 int conv3x3_ws_chain_launch(const ConvArgs& a, const ChainArgs& cj, int tile_rows, int kind, unsigned* ticket_base, double flop, double bytes, hipStream_t stream) {
-    if (tile_rows >= 16) {
-        if (kind == 2) return launch_chain<2, 33>(a, cj, ticket_base, flop, bytes, stream);
-        return kind == 1 ? launch_chain<2, 16>(a, cj, ticket_base, flop, bytes, stream) : launch_chain<2, 0>(a, cj, ticket_base, flop, bytes, stream);
-    }
-    if (kind == 2) return launch_chain<1, 33>(a, cj, ticket_base, flop, bytes, stream);
-    return kind == 1 ? launch_chain<1, 16>(a, cj, ticket_base, flop, bytes, stream) : launch_chain<1, 0>(a, cj, ticket_base, flop, bytes, stream);
+    bool mixed = false;
+    for (int j = 0; j < cj.njobs; ++j) mixed = mixed || cj.job[j].kind == 3;
+    if (tile_rows >= 16)
+        return mixed ? launch_chain_kind<2, 2>(a, cj, kind, ticket_base, flop, bytes, stream) : launch_chain_kind<2, 1>(a, cj, kind, ticket_base, flop, bytes, stream);
+    return mixed ? launch_chain_kind<1, 2>(a, cj, kind, ticket_base, flop, bytes, stream) : launch_chain_kind<1, 1>(a, cj, kind, ticket_base, flop, bytes, stream);
 }
 
 }  // namespace resr
