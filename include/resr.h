@@ -278,7 +278,8 @@ int resr_add_mask(const void* a, const void* b, const void* mask, void* out, int
  * (W^T u is summed in 32-row groups, in a fixed order: bit-identical on every data-parallel rank) */
 int resr_spectral_norm(const float* w, float* u, float* v, int32_t rows, int32_t cols, int32_t training, float eps,
                        float* sigma2, float* tmp, void* stream);
-/* gradient wrt W_orig from the gradient wrt W = W_orig/sigma; tmp1 = 1 float */
+/* gradient wrt W_orig from the gradient wrt W = W_orig/sigma; tmp1 = 512 floats (block partials of <G, W>, added in a fixed
+ * order: no atomics, the result is bit-reproducible) */
 int resr_spectral_norm_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma2, float* dst,
                            int32_t rows, int32_t cols, int32_t accumulate, float* tmp1, void* stream);
 /* 2x2 stride-2 max pooling on NHWC [n,2*h_out,2*w_out,c] (VGG19 of ContentLoss, model.py:296-298) */

@@ -394,18 +394,24 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict
     float s = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) s += G[i] * W[i];
     const float t = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(dot, t);
+    if (threadIdx.x == 0) dot[blockIdx.x] = t;   // one partial per block, summed in a fixed order by the apply kernel (no atomics:
+                                                 // the discriminator's gradients are bit-reproducible from run to run)
 }
 
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ u,
                                                            const float* __restrict__ v, const float* __restrict__ sigma2,
-                                                           const float* __restrict__ dot, float* __restrict__ dst, int cols, long count,
-                                                           int accumulate) {
+                                                           const float* __restrict__ dot, int ndot, float* __restrict__ dst, int cols,
+                                                           long count, int accumulate) {
+    __shared__ float red[4];
+    // <G, W>: every block adds the ndot (<= 512) partials in the same order
+    float part = 0.f;
+    for (int k = threadIdx.x; k < ndot; k += 256) part += dot[k];
+    const float gw = block_sum(part, red);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
     const int r = (int)(i / cols), k = (int)(i % cols);
     const float inv = sigma2[1];
-    const float val = G[i] * inv - dot[0] * inv * inv * u[r] * v[k];
+    const float val = G[i] * inv - gw * inv * inv * u[r] * v[k];
     dst[i] = accumulate ? dst[i] + val : val;
 }
 
@@ -413,12 +419,11 @@ int spectral_norm_bwd_dispatch(const float* G, const float* W, const float* u, c
                                int rows, int cols, int accumulate, float* tmp1, hipStream_t st) {
     if (!G || !W || !u || !v || !sigma2 || !dst || !tmp1) return fail(RESR_ERR_ARG, "spectral_norm_bwd: bad argument");
     const long count = (long)rows * cols;
-    if (hipMemsetAsync(tmp1, 0, sizeof(float), st) != hipSuccess) return fail(RESR_ERR_LAUNCH, "spectral_norm_bwd: memset");
     long blocks = (count + 255) / 256;
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3((unsigned)blocks), dim3(256), 0, st, G, W, count, tmp1);
-    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, G, u, v, sigma2, tmp1, dst, cols,
-                       count, accumulate);
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, G, u, v, sigma2, tmp1, (int)blocks, dst,
+                       cols, count, accumulate);
     RESR_CHECK_LAUNCH("spectral_norm_bwd kernels");
     return RESR_OK;
 }

@@ -150,7 +150,7 @@ void carve(const DPlan& p, char* base, DBufs& b) {
         b.G0 = take(px * 64 * es); b.gxin = take(px * 32 * es);
         b.raw = (float*)take((size_t)512 * 1024 * 9 * sizeof(float));
         b.folded = (float*)take((size_t)512 * 256 * 16 * sizeof(float));
-        b.tmp1 = (float*)take(256);
+        b.tmp1 = (float*)take(512 * sizeof(float));   // block partials of the spectral-norm backward's <G, W>
         // weight-gradient slabs: the largest launch is <= 80 products (wgrad.hip kMaxJobs) x its splits
         size_t pb = 0;
         const int res[4][2] = {{p.d.h, p.d.w}, {p.d.h / 2, p.d.w / 2}, {p.d.h / 4, p.d.w / 4}, {p.d.h / 8, p.d.w / 8}};

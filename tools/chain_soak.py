@@ -11,8 +11,9 @@ from real_esrgan_pytorch_amd.degrade import Degrader
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--headline", action="store_true")
+ap.add_argument("--gan", action="store_true", help="RealESRGAN steps (B = 16, HR 256^2): generator chains next to the discriminator's launches")
 a = ap.parse_args()
-B, hr_size = (16, 1024) if a.headline else (32, 256)
+B, hr_size = (16, 1024) if a.headline else (16, 256) if a.gan else (32, 256)
 
 
 def run(no_chain):
@@ -31,6 +32,17 @@ def run(no_chain):
     # fixed LR inputs (area-downsampled + grain): the degradation pipeline draws from process-wide device RNG state, which would
     # differ between the two runs and hide the comparison
     lr = (torch.nn.functional.interpolate(hr, scale_factor=0.25, mode="area") + 0.02 * torch.randn(B, 3, hr_size // 4, hr_size // 4, device="cuda", generator=gen)).clamp(0, 1)
+    if a.gan:
+        from real_esrgan_pytorch_amd.train import RealESRGANStep
+        d = R.Discriminator().cuda().train()
+        d_opt = torch.optim.Adam(d.parameters(), 1e-4, (0.9, 0.99))
+        gstep = RealESRGANStep(g, d, ema, opt, d_opt, torch.amp.GradScaler("cuda"), None)
+        losses = []
+        for _ in range(a.steps):
+            out = gstep(hr, lr)
+            losses.append(tuple(float(v) for v in out.values()))
+        torch.cuda.synchronize()
+        return losses, torch.cat([g.flat_parameter().detach().reshape(-1)] + [p.detach().reshape(-1) for p in d.parameters()])
     step = RealESRNetStep(g, ema, opt, torch.amp.GradScaler("cuda"), None)
     losses = [float(step(hr, lr)) for _ in range(a.steps)]
     torch.cuda.synchronize()
@@ -38,8 +50,8 @@ def run(no_chain):
 
 
 l0, p0 = run(True)
-l1, p1 = run(False)
+l1, p1 = run(bool(os.environ.get("SOAK_SELFTEST")))   # SOAK_SELFTEST=1: both runs unchained (is the step itself reproducible?)
 same_loss = sum(x == y for x, y in zip(l0, l1))
 print(f"{a.steps} steps, B={B}, HR {hr_size}^2: identical losses {same_loss}/{a.steps}, final weights bit-equal: {bool(torch.equal(p0, p1))}, "
-      f"loss {l0[0]:.5f} -> {l0[-1]:.5f}, chain errors {int(R._lib.lib().resr_debug_chain_errors())}")
+      f"loss {l0[0]} -> {l0[-1]}, chain errors {int(R._lib.lib().resr_debug_chain_errors())}")
 sys.exit(0 if same_loss == a.steps and torch.equal(p0, p1) else 1)
