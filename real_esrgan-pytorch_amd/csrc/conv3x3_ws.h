@@ -683,13 +683,21 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         }
         // lean epilogue, sign-bit mask (EPI 33): the mask words of this wave's rows are requested HERE and land under the
         // tile's MFMAs (requested in the epilogue they cost one exposed memory round trip per row)
-        unsigned mword[(FAST && EPI == 33) ? NT : 1][MT];
+        unsigned mword[EPI == 33 ? NT : 1][MT];
         bool own_top = true;   // CH 2: not for the closing convolution's halves (kind 3: no mask)
         if constexpr (CH == 2) own_top = cj.job[job].kind != 3;
-        if constexpr (FAST && EPI == 33) if (own_top) {
-            const int x = c_tx * TW + (lane & 31);
-            const int y0 = c_ty * TH + row0;
-            const int n = c_n - c_grp * a.n;
+        if constexpr (EPI == 33) if (own_top) {
+            int x, y0, n;
+            if constexpr (FAST) {
+                x = c_tx * TW + (lane & 31);
+                y0 = c_ty * TH + row0;
+                n = c_n - c_grp * a.n;
+            } else {   // exact16 (general epilogue): no output groups with sign-word masks
+                const int tsp = tile % ntiles_sp;
+                x = (tsp % a.tiles_x) * TW + (lane & 31);
+                y0 = ((tsp / a.tiles_x) % a.tiles_y) * TH + row0;
+                n = tsp / (a.tiles_x * a.tiles_y);
+            }
             const unsigned xc = (unsigned)(x < a.w_ ? x : a.w_ - 1);
             const unsigned wpp = (unsigned)((a.cout + 31) >> 5);
 #pragma unroll
@@ -1048,7 +1056,6 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         constexpr int NB = RB ? 2 : 1;    // row double buffer
         half8 rmask[NB][MA][2], rres0[NB][MA][2], rres1[NB][MA][2];
         half8 rres0l[NB][MA][2], rres1l[NB][MA][2];   // X2: the residuals' lo tensors
-        unsigned mbits[NB][MA];   // EMB: the pixel's sign word of chunk m (bit c <-> channel 32m + c)
         // pieces outside the image / beyond cout read a clamped (valid) address and are dropped at the store
         auto row_p = [&](int t) {
             const int y = y0 + row0 + t;
@@ -1060,7 +1067,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         };
         auto request = [&](int b, size_t p, int m, int j0) {
             if (EMB) {
-                if (j0 == 0) mbits[b][m % MA] = reinterpret_cast<const unsigned*>(e.mask)[p * (size_t)((e.cout + 31) >> 5) + m];
+                // (the sign words of the tile's rows were requested at the top of the tile: mword)
             } else if (f_mask) {
 #pragma unroll
                 for (int j = j0; j < j0 + JB; ++j)
@@ -1139,7 +1146,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     };
                     if (f_aux_mask && ok) store8(reinterpret_cast<char*>(e.aux), p * e.out_stride + poff(m, j, e.out_chunk));
                     if (EMB) {
-                        const unsigned byte = mbits[b][m % MA] >> (8 * (2 * j + kh_e));
+                        const unsigned byte = mword[EPI == 33 ? t : 0][m] >> (8 * (2 * j + kh_e));
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] *= ((byte >> r) & 1u) ? 1.f : e.slope;
                     } else if (f_mask) {
