@@ -67,6 +67,8 @@ struct ChainArgs {
     unsigned* tickets;     // [8] per-XCD workgroup tickets (only ever grow)
     unsigned ticket_base;  // value of every ticket counter when this launch starts (each launch adds grid / 8 to each)
     unsigned pad_;
+    // CH 3 (pinned pipeline, experiment): the workgroups of an XCD with index [split[j], split[j+1]) run job j only
+    int split[kMaxChain + 2];
     ChainJob job[kMaxChain];
 };
 struct ChainNone {};

@@ -191,6 +191,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     // CH: XCD x = blockIdx & 7 walks tiles [x * T/8, (x+1) * T/8) with its G/8 workgroups (whole images per XCD)
     int first = xcd_remap(blockIdx.x, G);
     int tile_end = ntiles, tile_step = G;
+    int pin_job = 0;   // CH 3
     if constexpr (CH) {
         // Ownership follows the XCD the workgroup REALLY runs on (XCC_ID), not blockIdx: the dispatcher deals workgroups
         // to the XCDs round-robin, but where a dispatch starts is not fixed (measured: launches from a second stream
@@ -213,9 +214,15 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         first = xcd * t8 + (int)tk[1];
         tile_end = (xcd + 1) * t8;
         tile_step = G >> 3;
+        if constexpr (CH == 3) {   // pinned pipeline: this workgroup runs ONE job over every pin_nw-th tile of the XCD's range
+            const int idx = (int)tk[1];
+            while (idx >= cj.split[pin_job + 1]) ++pin_job;
+            first = xcd * t8 + (idx - cj.split[pin_job]);
+            tile_step = cj.split[pin_job + 1] - cj.split[pin_job];
+        }
     }
     int nchunks = X2 ? 3 * (a.cin >> 5) : a.cin >> 5;   // stages per tile (CH: of the current job)
-    if constexpr (CH) nchunks = cj.job[0].cin >> 5;
+    if constexpr (CH) nchunks = cj.job[CH == 3 ? pin_job : 0].cin >> 5;
     int tk = 0;
     auto stamp = [&](int role) {
         // traced workgroups: blockIdx 16k .. 16k+0 for k < 32 (a sample across the whole grid)
@@ -355,8 +362,9 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             if constexpr (CH) {
                 // ---- chain: the same pipeline over the stages of ALL jobs; ring weights; the dependent chunk polls first ----
                 const int njobs = cj.njobs;
-                int job = 0, nch = nchunks;   // job / chunk count of the stage whose halo was requested last
+                int job = CH == 3 ? pin_job : 0, nch = nchunks;   // job / chunk count of the stage whose halo was requested last
                 int it = first, ick = 0, hb = 0;
+                bool tile_settled = false;   // the current tile's neighbourhood has shown the progress its last chunk needs
                 // job jb's weights of chunk ck: fragment idx of this kernel's 32-channel output tile is fragment idx * w_mt + w_m of
                 // a buffer packed for w_mt tiles (the closing convolution's halves read the cout-64 packing in place)
                 auto issue_wj = [&](int jb, int ck, int par) {
@@ -370,14 +378,20 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     }
                 };
                 // lanes 0..8 watch the tile's 3 x 3 neighbourhood inside its image; `need` = flag value of "previous job done"
-                auto poll = [&](int tile, unsigned need) {
+                // Waits until every neighbour's progress is >= need; returns whether it is already >= all_need (then the tile
+                // needs no further polls in this job).
+                auto poll = [&](int tile, unsigned need, unsigned all_need) -> bool {
                     const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y;
                     const int dx = lane % 3 - 1, dy = lane / 3 - 1;
                     const bool watch = lane < 9 && (unsigned)(tx + dx) < (unsigned)a.tiles_x && (unsigned)(ty + dy) < (unsigned)a.tiles_y;
                     const unsigned* fp = cj.flags + (watch ? tile + dy * a.tiles_x + dx : tile);
+                    bool all_ok = false;
                     for (int spin = 0;; ++spin) {
-                        const unsigned v = watch ? __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
-                        if (__ballot((int)(v - need) < 0) == 0ull) break;
+                        const unsigned v = watch ? __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : all_need;
+                        if (__ballot((int)(v - need) < 0) == 0ull) {
+                            all_ok = __ballot((int)(v - all_need) < 0) == 0ull;
+                            break;
+                        }
                         // never hang the device: give up after ~0.5 s (the host reads the counter), and once any poll of the
                         // process has given up every later one does so within a millisecond
                         if (spin > (1 << 18) || ((spin & 1023) == 1023 && __hip_atomic_load(cj.errors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
@@ -386,6 +400,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         }
                         __builtin_amdgcn_s_sleep(2);
                     }
+                    return all_ok;
                 };
                 auto advance = [&]() -> bool {
                     if (++ick == nch) {
@@ -393,13 +408,14 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         it += tile_step;
                         if (it >= tile_end) {
                             it = first;
-                            if (++job < njobs) nch = cj.job[job].cin >> 5;
+                            if constexpr (CH == 3) job = njobs;   // pinned: this workgroup's only job is done
+                            else if (++job < njobs) nch = cj.job[job].cin >> 5;
                         }
                     }
                     return job < njobs;
                 };
                 tile_pix(it);
-                issue_wj(0, 0, 0);
+                issue_wj(job, 0, 0);
                 issue_h(0, 0);
                 __syncthreads();           // the set-up barrier
                 bool have_next = advance();   // chunk 1 of the same tile (every job has >= 2 chunks, host-checked)
@@ -418,12 +434,19 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     const bool have_next2 = advance();
                     if (have_next2) {
                         if (ick == 0) tile_pix(it);
-                        // the last chunk of a dependent job is the output plane of job `dep`
-                        if (ick == nch - 1) {
-                            int dep = job - 1;   // homogeneous chains: the previous job
-                            if constexpr (CH == 2) dep = cj.job[job].dep;
-                            if (dep >= 0) poll(it, cj.epoch + (unsigned)dep + 1u);
+                        // Chunk c >= 2 of the shared inputs is the output plane of job c - 2 of THIS launch: its halo may only be
+                        // requested once that job has finished the tile's 3 x 3 neighbourhood.  A workgroup that WALKS the jobs
+                        // only has to poll for its job's last chunk (the output of job `dep`): it requested the earlier planes
+                        // of this very tile's neighbourhood last job, behind that job's poll, and progress never decreases.  A
+                        // PINNED workgroup (CH 3) never ran the previous job on this tile: it also waits, before chunk 2, for
+                        // job - 2 (which covers chunks 2 .. nch - 2).
+                        int dep = job - 1;   // homogeneous chains and pinned pipelines: the previous job
+                        if constexpr (CH == 2) dep = cj.job[job].dep;
+                        if constexpr (CH == 3) {
+                            if (ick == 0) tile_settled = false;
+                            if (ick == 2 && dep >= 1) tile_settled = poll(it, cj.epoch + (unsigned)dep, cj.epoch + (unsigned)dep + 1u);
                         }
+                        if (ick == nch - 1 && dep >= 0 && !(CH == 3 && tile_settled)) poll(it, cj.epoch + (unsigned)dep + 1u, cj.epoch + (unsigned)dep + 1u);
                         hb = hb == 2 ? 0 : hb + 1;
                         issue_h(ick, hb);
                         wait_all_but_h();
@@ -631,7 +654,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     for (int t = 0; t < NT; ++t) acc[m][t][g * 4 + r] = b[r];
             }
     };
-    if constexpr (CH) bias_cur = reinterpret_cast<const float*>(smem + C::CHAIN_OFF);
+    if constexpr (CH) bias_cur = reinterpret_cast<const float*>(smem + C::CHAIN_OFF) + (CH == 3 ? pin_job * 32 : 0);
     init_acc();
 
     // Weight fragments: ring of (k-step, dx, dy) units -- one tap's MT fragments each -- in consumption order, fetched
@@ -655,13 +678,28 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     int pend_tile = 0;
     unsigned pend_tag = 0;
     const int njobs_c = [&] { if constexpr (CH) return cj.njobs; else return 1; }();
+    auto publish = [&]() {
+        if constexpr (CH) {
+            if (pend) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's stores of the finished tile are acknowledged (in L2)
+                if (lane == 0) {
+                    unsigned* cnt = reinterpret_cast<unsigned*>(smem + C::CHAIN_OFF + kMaxChain * 128);
+                    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((old % NWC) == NWC - 1)   // the last of the NWC consumer waves: everyone's stores are in
+                        __hip_atomic_store(cj.flags + pend_tile, pend_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                pend = false;
+            }
+        }
+    };
     // Lean epilogue: the tile's coordinates (column tile, row tile, image; output group) are carried from tile to tile --
     // derived by division they are ~65 dependent scalar instructions per tile (twice with the mask prefetch), paid
     // between two tiles where nothing overlaps them.  One division chain per job (the first tile), additions with carry after.
     int c_tx = 0, c_ty = 0, c_n = 0, c_grp = 0;
     const int s_tx = tile_step % a.tiles_x, s_t2 = tile_step / a.tiles_x;
     const int s_ty = s_t2 % a.tiles_y, s_n = s_t2 / a.tiles_y;   // s_n counts images of ALL groups (group = image / a.n)
-    for (int job = 0; job < njobs_c; ++job) {
+    // CH 3: only the pinned job
+    for (int job = (CH == 3 ? pin_job : 0); job < (CH == 3 ? pin_job + 1 : njobs_c); ++job) {
     if constexpr (CH) nchunks = cj.job[job].cin >> 5;
     for (int tile = first; tile < tile_end; tile += tile_step) {
         if constexpr (FAST) {
@@ -806,18 +844,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             par ^= 1;
             if (!X2 || (ck % 3) != 0) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
             if (wave == 0) stamp(1);
-            if constexpr (CH) {
-                if (pend) {
-                    __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's stores of the finished tile are acknowledged (in L2)
-                    if (lane == 0) {
-                        unsigned* cnt = reinterpret_cast<unsigned*>(smem + C::CHAIN_OFF + kMaxChain * 128);
-                        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if ((old % NWC) == NWC - 1)   // the last of the NWC consumer waves: everyone's stores are in
-                            __hip_atomic_store(cj.flags + pend_tile, pend_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    pend = false;
-                }
-            }
+            if constexpr (CH) publish();
         }
 
         if constexpr (FAST) {
@@ -987,7 +1014,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     pend = true;
                     pend_tile = tile;
                     pend_tag = cj.epoch + (unsigned)job + 1u;
-                    if (tile + tile_step >= tile_end)   // the next tile belongs to the next job
+                    if (CH != 3 && tile + tile_step >= tile_end)   // the next tile belongs to the next job
                         bias_cur = reinterpret_cast<const float*>(smem + C::CHAIN_OFF) + (job + 1) * 32;
                 }
             }
@@ -1213,6 +1240,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         if (wave == 0) stamp(1);  // tile done
     }
     }   // jobs
+    if constexpr (CH == 3) publish();   // a pinned workgroup's last tile has no next stage to publish it from
 }
 
 template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0>

@@ -100,7 +100,21 @@ long long conv3x3_chain_errors() {
 
 int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, const double* flop, const double* bytes, hipStream_t stream) {
     static const int rows1[] = {16, 8};
-    const int rows = pick_rows(a, rows1, 2);
+    int rows = pick_rows(a, rows1, 2);
+    // Experiment (RESR_CHAIN_PIPE="5,7,9,11"): a pinned pipeline instead of a walk -- 8-row tiles, the 32 workgroups of an XCD split
+    // over the four jobs as given, each workgroup running ONE job over the XCD's bands top to bottom behind its predecessor's
+    // flags, so that the planes a block's passes exchange stay inside the XCD's L2
+    int split[kMaxChain + 2] = {0};
+    const char* pipe_env = getenv("RESR_CHAIN_PIPE");   // read per call (a test flips it)
+    if (pipe_env && njobs == 4) {
+        int c[4] = {0, 0, 0, 0};
+        if (sscanf(pipe_env, "%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3]) == 4 && c[0] > 0 && c[1] > 0 && c[2] > 0 && c[3] > 0 &&
+            c[0] + c[1] + c[2] + c[3] == 32 && (size_t)((a.w_ + 31) / 32) * ((a.h + 7) / 8) * a.n >= 256 * 8) {
+            rows = 8;
+            for (int j = 0; j < 4; ++j) split[j + 1] = split[j] + c[j];
+            for (int j = 5; j < kMaxChain + 2; ++j) split[j] = 32;
+        }
+    }
     const size_t ntiles = (size_t)((a.w_ + 31) / 32) * ((a.h + rows - 1) / rows) * a.n;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipGetDevice");
@@ -144,6 +158,7 @@ int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, con
         cj.epoch = st->epoch;
         st->epoch += 8u;
         cj.njobs = njobs;
+        memcpy(cj.split, split, sizeof(split));
         double f = 0, b = 0;
         for (int j = 0; j < njobs; ++j) { cj.job[j] = jobs[j]; f += flop[j]; b += bytes[j]; }
         for (int j = njobs; j < kMaxChain; ++j) cj.job[j] = jobs[njobs - 1];

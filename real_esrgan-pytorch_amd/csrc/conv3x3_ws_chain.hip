@@ -56,6 +56,7 @@ static int launch_chain_kind(const ConvArgs& a, const ChainArgs& cj, int kind, u
 
 // *ticket_base: the stream's running ticket value (conv3x3_ws.hip), advanced by this launch's workgroups per XCD
 int conv3x3_ws_chain_launch(const ConvArgs& a, const ChainArgs& cj, int tile_rows, int kind, unsigned* ticket_base, double flop, double bytes, hipStream_t stream) {
+    if (cj.split[1] > 0) return launch_chain_kind<1, 3>(a, cj, kind, ticket_base, flop, bytes, stream);   // pinned pipeline (experiment): 8-row tiles
     bool mixed = false;
     for (int j = 0; j < cj.njobs; ++j) mixed = mixed || cj.job[j].kind == 3;
     if (tile_rows >= 16)

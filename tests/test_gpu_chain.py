@@ -211,3 +211,26 @@ def test_chain_training_trajectory():
     assert l0 == l1, (l0, l1)
     assert torch.equal(p0, p1)
     assert int(R._lib.lib().resr_debug_chain_errors()) == 0
+
+
+def test_pinned_pipeline_experiment():
+    """RESR_CHAIN_PIPE (experiment): the four growth convolutions as a pinned pipeline -- every workgroup of an
+    XCD runs ONE job, walking the bands behind its predecessor's flags -- gives the same bits as four launches."""
+    import real_esrgan_pytorch_amd as R
+    L = R._lib
+    torch.manual_seed(3)
+    g = R.Generator(3, 3, 4, precision="fast", n_blocks=1).cuda().train()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.rand(16, 3, 256, 256, device="cuda", generator=gen)
+    gw = torch.randn(16, 3, 1024, 1024, device="cuda", generator=gen)
+    y0, g0, gx0 = _run(g, x, gw, no_chain=True)
+    os.environ["RESR_CHAIN_PIPE"] = "5,7,9,11"
+    try:
+        for rep in range(2):
+            y1, g1, gx1 = _run(g, x, gw, no_chain=False)
+            assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+            for a, b in zip(g0, g1):
+                assert torch.equal(a, b)
+    finally:
+        os.environ.pop("RESR_CHAIN_PIPE", None)
+    assert int(L.lib().resr_debug_chain_errors()) == 0

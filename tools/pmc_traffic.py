@@ -15,7 +15,7 @@ def short(name):
     m = re.search(r"conv3x3_ws_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)ELi\d+E(Lb[01]E)?(Li\dE)?(Li\dE)?", name)  # epilogue kinds are summed
     if m:
         t = "f32" if m.group(1) != "DF16_" else ("f16x2" if m.group(5) == "Lb1E" else "f16")
-        chain = ",chain" if m.group(7) in ("Li1E", "Li2E") else ""   # the cout-32 passes of a dense block as one launch
+        chain = ",chain" if m.group(7) in ("Li1E", "Li2E", "Li3E") else ""   # the cout-32 passes of a dense block as one launch
         return f"conv3x3_ws_kernel<{t},{m.group(2)},{m.group(3)},{m.group(4)}{chain}>"
     m = re.search(r"conv3x3_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)E", name)
     if m:
