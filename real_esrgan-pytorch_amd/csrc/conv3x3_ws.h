@@ -681,7 +681,9 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     auto publish = [&]() {
         if constexpr (CH) {
             if (pend) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's stores of the finished tile are acknowledged (in L2)
+                // this wave's stores of the finished tile are acknowledged (in L2).  As asm with a memory clobber: the builtin is
+                // "no memory" to the compiler, which may then move the stores below it or the arrival above it
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) {
                     unsigned* cnt = reinterpret_cast<unsigned*>(smem + C::CHAIN_OFF + kMaxChain * 128);
                     const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
