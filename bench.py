@@ -191,6 +191,9 @@ def kernel_name(kid):
         if k >= 300:
             return f"wgrad_kernel<f16x2,{k % 100}>"
         return f"wgrad_kernel<{'f32' if k >= 100 else 'f16'},{k % 100}>"
+    if kid >= 26000:  # exact16, the cout-32 passes of a dense block as one chained launch
+        k = kid - 26000
+        return f"conv3x3_ws_kernel<f16x2,{k // 100},{(k // 10) % 10},{k % 10},chain>"
     if kid >= 25000:  # exact16: the same kernel on hi/lo f16 pairs, three stages per chunk
         k = kid - 25000
         return f"conv3x3_ws_kernel<f16x2,{k // 100},{(k // 10) % 10},{k % 10}>"

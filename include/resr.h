@@ -5,7 +5,9 @@
  * PyTorch op call sites.  Each entry point below names the reference call site(s) it replaces
  * (file:line relative to the reference root).  All pointers are raw device pointers owned by the
  * caller (PyTorch's caching allocator); the library never allocates, frees or retains device
- * memory, never synchronises the stream, and is graph-capture safe.  Every call enqueues on the
+ * memory, never synchronises the stream or the device (the two resr_debug_* read-back entries excepted), and is
+ * graph-capture safe.  What a launch needs beyond its operands -- scratch, slabs, the progress flags of the chained
+ * dense-block launches -- is part of a workspace the caller passes in.  Every call enqueues on the
  * given hipStream_t (passed as void*) of the current device and returns 0 or a negative
  * resr_status; resr_last_error() returns a thread-local message.  No C++ exception crosses.
  *
@@ -111,12 +113,26 @@ int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const 
  * SAME in0 [/ in1] tensors -- job j the first descs[j].cin channels of them -- each with its own packed weights, bias (or
  * NULL), sign-word mask (or NULL), output and aux_out (or NULL); job j's output must be the tensor that job j+1 reads as
  * its last 32 channels.  Same results as njobs calls of resr_conv3x3 (to which it falls back); where the fast-mode kernel
- * supports it (f16, cout 32, chunk-planar operands, batch a multiple of 8, even width, LeakyReLU [+ sign words] or the
- * sign-word mask) the jobs run as one persistent launch that orders them through per-tile flags instead of kernel
- * boundaries.  bias / mask / aux_out may be NULL pointers to mean "no job has one". */
+ * supports it (f16 or f16x2, cout 32, chunk-planar operands, batch a multiple of 8, even width, LeakyReLU [+ sign words] or
+ * the sign-word mask) the jobs run as one persistent launch that orders them through per-tile flags instead of kernel
+ * boundaries.  bias / mask / aux_out may be NULL pointers to mean "no job has one".
+ * chain_state: resr_conv3x3_chain_state_bytes(n, h, w) bytes of device memory OWNED BY THE CALLER (16-byte aligned), filled
+ * with zeros once before its first use and then left alone: epoch, per-XCD tickets, per-tile flags and error words of the
+ * chained launches live there (nothing is allocated, reset or synchronised by the library; consecutive launches on one
+ * stream may share it, launches that can overlap in time must not).  NULL / too small: one launch per job.
+ * A chained launch spins on its own workgroups, so only one runs at a time per device: a call from another stream first makes
+ * that stream wait (hipStreamWaitEvent) for the previous chain.  A flag poll that gives up (~4 s: a lost workgroup) is never
+ * silent -- the plane it waited for is read as NaNs, so the output (and a training loss) turns NaN, and resr_chain_errors()
+ * counts it. */
+size_t resr_conv3x3_chain_state_bytes(int32_t n, int32_t h, int32_t w);
 int resr_conv3x3_chain(int32_t njobs, const ResrConvDesc* descs, const void* in0, const void* in1,
                        const void* const* packed_w, const float* const* bias, const void* const* mask,
-                       void* const* out, void* const* aux_out, void* stream);
+                       void* const* out, void* const* aux_out, void* chain_state, size_t chain_state_bytes, void* stream);
+/* Health of the chained launches on the current device: low 32 bits = flag polls that gave up, high 32 bits = workgroups an
+ * XCD received beyond its share of the grid (tile ownership follows the XCD a workgroup really runs on and assumes the
+ * dispatcher deals every XCD grid / 8 workgroups).  Both must be 0.  Reads two host-mapped words the kernels add to: no
+ * synchronisation, cheap enough to call every few steps; it reflects the launches that have finished by then. */
+int64_t resr_chain_errors(void);
 
 /* Weight-gradient of the same convolution: dW[co][ci][tap] = sum_p G[p][co] * X[p + tap][ci]
  * (autograd backward of F.conv2d wrt weight, all conv call sites of model.py) and
@@ -181,6 +197,9 @@ typedef struct {
 size_t resr_generator_param_count(const ResrGeneratorDesc* d);
 size_t resr_generator_packed_bytes(const ResrGeneratorDesc* d, int32_t backward);
 size_t resr_generator_workspace_bytes(const ResrGeneratorDesc* d);
+/* The first resr_generator_chain_state_bytes(d) bytes of a generator workspace are the chain state of its dense-block
+ * launches (resr_conv3x3_chain): the caller fills them with zeros once, when the workspace is allocated. */
+size_t resr_generator_chain_state_bytes(const ResrGeneratorDesc* d);
 /* fills `chunks` (host memory, capacity in elements) and returns the count; forward table first,
  * then (if backward) the backward-data table; dst offsets are relative to one packed buffer */
 int64_t resr_generator_pack_table(const ResrGeneratorDesc* d, int32_t backward,
@@ -317,12 +336,12 @@ int resr_ema_update(float* shadow, const float* params, int64_t count, double de
 
 /* Debug: per-workgroup timeline of the fast-mode conv kernel (32 workgroups x 2 roles x 64 uint64 stamps, 100 MHz). */
 int resr_debug_conv_trace(void* dev_buf);
-/* Debug: health of the chained dense-block launches on the current device (the four cout-32 passes of a dense block,
- * model.py:90-93, run as one persistent launch whose jobs wait for each other through per-tile flags): low 32 bits =
- * flag polls that timed out, high 32 bits = workgroups an XCD received beyond its share of the grid (tile ownership follows
- * the XCD a workgroup really runs on and assumes the dispatcher deals every XCD grid / 8 workgroups).  Both must
- * be 0; synchronises the device.  RESR_CONV_NO_CHAIN=1 in the environment disables chaining. */
+/* Debug / test: resr_chain_errors() after a hipDeviceSynchronize() (every launch enqueued so far has reported).
+ * RESR_CONV_NO_CHAIN=1 in the environment disables chaining. */
 int64_t resr_debug_chain_errors(void);
+/* Test aid: `workgroups` single-wave workgroups that each hold `lds_bytes` of LDS and spin for `micros` microseconds -- what a
+ * collective of another stream looks like to a chained launch that wants every CU. */
+int resr_debug_occupy(int32_t workgroups, int32_t lds_bytes, int32_t micros, void* stream);
 /* Host logic of the f16 weight-gradient launch, no GPU needed: how the (X chunk, G tile) products of `nconv` convolutions
  * that read one channel-prefix workspace (conv i: the first cin[i] channels; its own cout_pad[i] gradient channels) are
  * grouped into 2x2 jobs of the quad kernel.  out[q*4 + p] = index of the product computed by slot p of job q (products are

@@ -75,7 +75,11 @@ _PROTOS = {
     "resr_version": (C.c_int, []),
     "resr_last_error": (C.c_char_p, []),
     "resr_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "resr_conv3x3_chain": (C.c_int, [C.c_int32, C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "resr_conv3x3_chain": (C.c_int, [C.c_int32, C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "resr_conv3x3_chain_state_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "resr_chain_errors": (C.c_int64, []),
+    "resr_generator_chain_state_bytes": (C.c_size_t, [C.POINTER(GeneratorDesc)]),
+    "resr_debug_occupy": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P]),
     "resr_wgrad_partial_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "resr_conv3x3_wgrad": (C.c_int, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _P, _P]),
     "resr_pack_weights": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P]),
@@ -150,11 +154,12 @@ def check(rc: int, what: str = "resr") -> None:
         raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
 
-def chain_health() -> None:
+def chain_health(sync: bool = False) -> None:
     """Raise if a chained dense-block launch (conv3x3_ws.h, CH) ever gave up waiting for a neighbouring tile or found
-    an XCD with more than its share of workgroups: results after that are not trustworthy.  Synchronises the device, so it
-    is called at epoch / benchmark ends, not per step."""
-    e = int(lib().resr_debug_chain_errors())
+    an XCD with more than its share of workgroups (such a launch also poisons its output with NaNs, so a training loss
+    shows it at once).  sync=False reads two host-mapped counters -- no synchronisation, cheap enough for every logging
+    interval; sync=True drains the device first (end of an epoch / a benchmark)."""
+    e = int(lib().resr_debug_chain_errors() if sync else lib().resr_chain_errors())
     if e != 0:
         raise RuntimeError(f"chained conv launches reported errors: {e & 0xffffffff} polls timed out, {e >> 32} workgroups beyond "
                            "their XCD's share (set RESR_CONV_NO_CHAIN=1 to run one launch per pass)")

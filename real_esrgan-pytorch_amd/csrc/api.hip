@@ -74,7 +74,8 @@ long long conv3x3_chain_errors();
 int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*, const float*, const void*,
                      const void*, const void*, void*, void*, hipStream_t);
 int conv3x3_chain_dispatch(int, const ResrConvDesc*, const void*, const void*, const void* const*, const float* const*,
-                           const void* const*, void* const*, void* const*, hipStream_t);
+                           const void* const*, void* const*, void* const*, void*, size_t, hipStream_t);
+size_t conv3x3_chain_state_bytes(int, int, int);
 int wgrad_dispatch(const ResrWgradDesc*, const void*, const void*, const void*, float*, float*, float*, hipStream_t);
 size_t wgrad_partial_bytes(const ResrWgradDesc*);
 int wgrad_debug_plan(const int*, const int*, int, int*, int);
@@ -86,6 +87,7 @@ int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int
 size_t generator_param_count(const ResrGeneratorDesc*);
 size_t generator_packed_bytes(const ResrGeneratorDesc*, int);
 size_t generator_workspace_bytes(const ResrGeneratorDesc*);
+size_t generator_chain_state_bytes(const ResrGeneratorDesc*);
 int64_t generator_pack_table(const ResrGeneratorDesc*, int, ResrPackChunk*, int64_t);
 int64_t generator_buffer_offsets(const ResrGeneratorDesc*, int64_t*, int64_t);
 int generator_forward(const ResrGeneratorDesc*, const float*, const float*, const void*, void*, size_t, float*, hipStream_t);
@@ -139,6 +141,16 @@ __global__ void tr_probe_kernel(float* out) {
     for (int j = 0; j < 4; ++j) out[l * 4 + j] = (float)r[j];
 }
 
+// test aid: `workgroups` workgroups that each hold `lds_bytes` of LDS and spin for `micros` microseconds -- what a collective
+// kernel of another stream looks like to a chained launch that needs every CU (tests/test_gpu_chain.py)
+__global__ void occupy_kernel(unsigned long long ticks, unsigned* sink) {
+    extern __shared__ unsigned occ_lds[];
+    occ_lds[threadIdx.x] = threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    if (sink && occ_lds[threadIdx.x] == 0xffffffffu) *sink = 1;
+}
+
 }  // namespace resr
 
 using namespace resr;
@@ -156,11 +168,13 @@ int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const 
 
 int resr_conv3x3_chain(int32_t njobs, const ResrConvDesc* descs, const void* in0, const void* in1,
                        const void* const* packed_w, const float* const* bias, const void* const* mask,
-                       void* const* out, void* const* aux_out, void* stream) {
+                       void* const* out, void* const* aux_out, void* chain_state, size_t chain_state_bytes, void* stream) {
     RESR_DEVICE_SCOPE(stream);
     if (!descs || !in0 || !packed_w || !out) return fail(RESR_ERR_ARG, "conv3x3_chain: null argument");
-    return conv3x3_chain_dispatch(njobs, descs, in0, in1, packed_w, bias, mask, out, aux_out, (hipStream_t)stream);
+    return conv3x3_chain_dispatch(njobs, descs, in0, in1, packed_w, bias, mask, out, aux_out, chain_state, chain_state_bytes, (hipStream_t)stream);
 }
+
+size_t resr_conv3x3_chain_state_bytes(int32_t n, int32_t h, int32_t w) { return conv3x3_chain_state_bytes(n, h, w); }
 
 size_t resr_wgrad_partial_bytes(const ResrWgradDesc* d) { return d ? wgrad_partial_bytes(d) : 0; }
 
@@ -197,6 +211,7 @@ int resr_sumpool2x2(const void* src, void* dst, const void* mask, int32_t n, int
 size_t resr_generator_param_count(const ResrGeneratorDesc* d) { return generator_param_count(d); }
 size_t resr_generator_packed_bytes(const ResrGeneratorDesc* d, int32_t backward) { return generator_packed_bytes(d, backward); }
 size_t resr_generator_workspace_bytes(const ResrGeneratorDesc* d) { return generator_workspace_bytes(d); }
+size_t resr_generator_chain_state_bytes(const ResrGeneratorDesc* d) { return generator_chain_state_bytes(d); }
 int64_t resr_generator_pack_table(const ResrGeneratorDesc* d, int32_t backward, ResrPackChunk* chunks, int64_t capacity) {
     return generator_pack_table(d, backward, chunks, capacity);
 }
@@ -395,7 +410,21 @@ int resr_debug_conv_trace(void* dev_buf) {
     return RESR_OK;
 }
 
-int64_t resr_debug_chain_errors(void) { return (int64_t)resr::conv3x3_chain_errors(); }
+int64_t resr_chain_errors(void) { return (int64_t)resr::conv3x3_chain_errors(); }
+
+int64_t resr_debug_chain_errors(void) {
+    (void)hipDeviceSynchronize();   // test / end-of-run entry: every launch enqueued so far has reported
+    return (int64_t)resr::conv3x3_chain_errors();
+}
+
+int resr_debug_occupy(int32_t workgroups, int32_t lds_bytes, int32_t micros, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    if (workgroups <= 0 || lds_bytes < 256 || lds_bytes > 160 * 1024 || micros <= 0) return fail(RESR_ERR_ARG, "debug_occupy: bad argument");
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, (unsigned long long)micros * 100ull, (unsigned*)nullptr);
+    RESR_CHECK_LAUNCH("occupy_kernel");
+    return RESR_OK;
+}
 
 int resr_debug_tr_probe(float* out256, void* stream) {
     RESR_DEVICE_SCOPE(stream);

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["api.hip", "conv3x3.hip", "conv3x3_ws.hip", "conv3x3_ws_mt1.hip", "conv3x3_ws_mt2.hip", "conv3x3_ws_x2_mt1.hip", "conv3x3_ws_x2_mt2.hip", "conv3x3_ws_sp.hip", "conv3x3_ws_chain.hip", "wgrad.hip", "pack.hip", "layout.hip", "generator.hip", "degrade.hip", "degrade_int.hip", "disc.hip", "disc_native.hip"]
+SOURCES = ["api.hip", "conv3x3.hip", "conv3x3_ws.hip", "conv3x3_ws_mt1.hip", "conv3x3_ws_mt2.hip", "conv3x3_ws_x2_mt1.hip", "conv3x3_ws_x2_mt2.hip", "conv3x3_ws_sp.hip", "conv3x3_ws_chain.hip", "conv3x3_ws_chain_x2.hip", "wgrad.hip", "pack.hip", "layout.hip", "generator.hip", "degrade.hip", "degrade_int.hip", "disc.hip", "disc_native.hip"]
 LIB = os.path.join(HERE, "libresr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", HERE,
@@ -26,7 +26,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "conv3x3.h"), os.path.join(HERE, "conv3x3_ws.h"), os.path.join(ROOT, "include", "resr.h"), os.path.abspath(__file__)]
+    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "conv3x3.h"), os.path.join(HERE, "conv3x3_ws.h"), os.path.join(HERE, "conv3x3_ws_chain.h"), os.path.join(HERE, "wgrad.h"), os.path.join(ROOT, "include", "resr.h"), os.path.abspath(__file__)]
     extra = [s for s in os.listdir(HERE) if s.endswith(".hip") and s not in SOURCES]
     srcs = SOURCES + sorted(extra)
     objs, jobs = [], []

@@ -57,16 +57,26 @@ struct ChainJob {
     const char* res0;     // kind 3: residual planes (pixel stride 32 elements) and their scales
     const char* res1;     // or null
     float s0, t0, s1, t1;
+    long out_lo, res0_lo, res1_lo;   // RESR_F16X2: element offsets hi -> lo tensor of out / res0 / res1
 };
 constexpr int kMaxChain = 6;
+// Device-side state of the chained launches: memory the CALLER owns (part of its workspace, zero-filled once before the
+// first use; include/resr.h resr_conv3x3_chain_state_bytes) -- the library neither allocates nor keeps it.  Words:
+//   [0] epoch      flag value of "job j of the current launch done" = epoch + j + 1; the last workgroup of a launch to
+//                  finish adds 8 (flags only ever grow: nothing is reset between launches; near the wrap of the signed
+//                  comparison that workgroup zeroes the flags and starts over)
+//   [1] finished   workgroups of the current launch that have finished (the last one resets it and the tickets)
+//   [2] time-outs  flag polls that gave up            [3] workgroups an XCD received beyond its share of the grid
+//   [8..15]        per-XCD workgroup tickets of the current launch
+//   [16 ...]       flags[tile]: per-tile progress
+constexpr int kChainHdr = 16;
 struct ChainArgs {
     int njobs;
-    unsigned epoch;        // flag value of "job j of this launch done" = epoch + j + 1 (flags only ever grow: no reset between launches)
-    unsigned* flags;       // [tiles] per-tile progress, device memory
-    unsigned* errors;      // [2]: poll time-outs, workgroups beyond their XCD's share of the grid
-    unsigned* tickets;     // [8] per-XCD workgroup tickets (only ever grow)
-    unsigned ticket_base;  // value of every ticket counter when this launch starts (each launch adds grid / 8 to each)
-    unsigned pad_;
+    unsigned cap;            // flag words behind the header
+    unsigned* state;         // see above
+    unsigned* host_errors;   // [2] host-mapped copies of words 2 / 3: the host reads them without synchronising
+    const char* nan16;       // 16 bytes of f16 NaNs in device memory: a dependent halo whose poll timed out is read from here,
+                             // so a broken launch poisons its output (the loss turns NaN) instead of computing on stale planes
     // CH 3 (pinned pipeline, experiment): the workgroups of an XCD with index [split[j], split[j+1]) run job j only
     int split[kMaxChain + 2];
     ChainJob job[kMaxChain];

@@ -294,7 +294,8 @@ int conv3x3_ws_f16(const ConvArgs& a, int mt, bool x2, hipStream_t stream);  // 
 bool conv3x3_ws_supported(const ConvArgs& a);
 bool conv3x3_chain_device_ok();
 
-int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, const double* flop, const double* bytes, hipStream_t stream);   // conv3x3_ws.hip
+int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, const double* flop, const double* bytes, bool x2, void* state, size_t state_bytes,
+                         hipStream_t stream);   // conv3x3_ws.hip (1 = the state buffer does not cover this geometry)
 static int conv3x3_route(const ResrConvDesc* d, ConvArgs& a, bool have_bias, bool have_in1, hipStream_t stream);
 
 // descriptor + pointers -> kernel arguments (validation included)
@@ -421,7 +422,7 @@ static int conv3x3_route(const ResrConvDesc* d, ConvArgs& a, bool have_bias, boo
 int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, const void* in1, const void* const* w,
                            const float* const* bias, const void* const* mask, void* const* out, void* const* aux,
                            const ResrConvDesc* d5, const void* w5, const float* bias5, const void* res0_5, const void* res1_5,
-                           void* out5, hipStream_t stream) {
+                           void* out5, void* chain_state, size_t chain_state_bytes, hipStream_t stream) {
     if (njobs <= 0 || njobs > 4 || !d) return fail(RESR_ERR_ARG, "conv3x3_chain: njobs=%d", njobs);
     ConvArgs a[4], a5;
     for (int j = 0; j < njobs; ++j) {
@@ -434,13 +435,28 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
         if (rc) return rc;
     }
     const char* no_chain = getenv("RESR_CONV_NO_CHAIN");   // test / A-B knob: one launch per job (read per call, so a test can flip it)
-    bool ok = !no_chain && njobs >= 2 && d[0].dtype == RESR_F16 && conv3x3_chain_device_ok();
+    const bool x2 = d[0].dtype == RESR_F16X2;
+    bool ok = !no_chain && chain_state && njobs >= 2 && (d[0].dtype == RESR_F16 || x2) && conv3x3_chain_device_ok();
+    if (ok && x2) {   // hi -> lo offsets as conv3x3_route sets them for single launches
+        const size_t es2 = 2;
+        for (int j = 0; j < njobs; ++j) {
+            if (d[j].dtype != RESR_F16X2 || d[j].in0_lo_offset == 0 || d[j].out_lo_offset == 0 || (in1 && d[j].cin0 < d[j].cin && d[j].in1_lo_offset == 0)) { ok = false; break; }
+            a[j].in0_lo_b = (size_t)d[j].in0_lo_offset * es2; a[j].in1_lo_b = (size_t)d[j].in1_lo_offset * es2;
+            a[j].out_lo = (long)d[j].out_lo_offset;
+        }
+        if (ok && d5) {
+            if (d5->dtype != RESR_F16X2 || d5->in0_lo_offset == 0 || d5->out_lo_offset == 0 || (res0_5 && d5->res0_lo_offset == 0) ||
+                (res1_5 && d5->res1_lo_offset == 0)) ok = false;
+            a5.in0_lo_b = (size_t)d5->in0_lo_offset * es2; a5.in1_lo_b = (size_t)d5->in1_lo_offset * es2;
+            a5.out_lo = (long)d5->out_lo_offset; a5.res0_lo = (long)d5->res0_lo_offset; a5.res1_lo = (long)d5->res1_lo_offset;
+        }
+    }
     const int fwd_flags = RESR_CONV_LRELU | RESR_CONV_WRITE_SIGNBITS, inf_flags = RESR_CONV_LRELU;
     const int bwd_flags = RESR_CONV_MASK | RESR_CONV_MASK_BITS | RESR_CONV_NO_BIAS;
     const ConvArgs& b = a[njobs - 1];   // the widest growth job: its in0 / in1 split describes every prefix
     for (int j = 0; ok && j < njobs; ++j) {
         const ConvArgs& c = a[j];
-        ok = d[j].dtype == RESR_F16 && d[j].cout_pad == 32 && c.cout == 32 && (c.flags == fwd_flags || c.flags == bwd_flags || c.flags == inf_flags) &&
+        ok = d[j].dtype == d[0].dtype && d[j].cout_pad == 32 && c.cout == 32 && c.in0_lo_b == b.in0_lo_b && c.in1_lo_b == b.in1_lo_b && (c.flags == fwd_flags || c.flags == bwd_flags || c.flags == inf_flags) &&
              c.flags == b.flags && c.n == b.n && c.h == b.h && c.w_ == b.w_ && c.hs == c.h && c.ws == c.w_ &&
              (c.n % 8) == 0 && (c.w_ % 2) == 0 && c.slope == b.slope &&
              c.in0_stride_b == 64 && c.in0_chunk_b == b.in0_chunk_b && c.out_stride == 32 &&
@@ -470,7 +486,7 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
         const int c0 = c.cin - 32;
         const bool seg1 = c0 >= c.cin0;
         const char* last = seg1 ? c.in1 + (size_t)((c0 - c.cin0) >> 5) * c.in1_chunk_b : c.in0 + (size_t)(c0 >> 5) * c.in0_chunk_b;
-        with5 = with5 && d5->dtype == RESR_F16 && d5->cout_pad == 64 && c.cout == 64 && c.cin == b.cin + 32 && last == b.out &&
+        with5 = with5 && d5->dtype == d[0].dtype && c.in0_lo_b == b.in0_lo_b && c.in1_lo_b == b.in1_lo_b && d5->cout_pad == 64 && c.cout == 64 && c.cin == b.cin + 32 && last == b.out &&
                 (c.flags & ~RESR_CONV_NO_BIAS) == 0 && ((c.flags & RESR_CONV_NO_BIAS) != 0) == ((b.flags & RESR_CONV_NO_BIAS) != 0) &&
                 c.n == b.n && c.h == b.h && c.w_ == b.w_ && c.hs == c.h && c.ws == c.w_ &&
                 c.in0_stride_b == 64 && c.in0_chunk_b == b.in0_chunk_b &&
@@ -493,8 +509,9 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
         jobs[j].w = a[j].w; jobs[j].bias = a[j].bias; jobs[j].out = a[j].out;
         jobs[j].aux = (a[j].flags == bwd_flags) ? (void*)a[j].mask : (void*)a[j].aux;
         jobs[j].cin = a[j].cin; jobs[j].dep = j - 1; jobs[j].kind = 0; jobs[j].w_mt = 1; jobs[j].w_m = 0;
+        jobs[j].out_lo = a[j].out_lo;
         flop[j] = 2.0 * 9 * a[j].cin * a[j].cout * (double)a[j].n * a[j].h * a[j].w_;
-        bytes[j] = conv_algorithmic_bytes(a[j], 2);
+        bytes[j] = conv_algorithmic_bytes(a[j], x2 ? 4 : 2);
     }
     ConvArgs base = b;
     if (base.cin0 == base.cin) base.cin0 = base.cin;   // single-segment prefix: every chunk of every job lies in in0
@@ -503,6 +520,7 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
         for (int m = 0; m < 2; ++m) {
             ChainJob& q = jobs[4 + m];
             q.w = a5.w; q.w_mt = 2; q.w_m = m;
+            q.out_lo = a5.out_lo; q.res0_lo = a5.res0_lo; q.res1_lo = a5.res1_lo;
             q.bias = a5.bias ? a5.bias + 32 * m : nullptr;
             q.out = a5.out + (size_t)m * a5.out_chunk * 2;
             q.aux = nullptr; q.cin = a5.cin; q.dep = 3; q.kind = 3;
@@ -510,20 +528,28 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
             q.res1 = a5.res1 ? a5.res1 + (size_t)m * a5.res1_chunk * 2 : nullptr;
             q.s0 = a5.s0; q.t0 = a5.t0; q.s1 = a5.s1; q.t1 = a5.t1;
             flop[4 + m] = 2.0 * 9 * a5.cin * 32 * (double)a5.n * a5.h * a5.w_;
-            bytes[4 + m] = conv_algorithmic_bytes(a5, 2) * 0.5;
+            bytes[4 + m] = conv_algorithmic_bytes(a5, x2 ? 4 : 2) * 0.5;
         }
         if (a5.cin0 == a5.cin) base.cin0 = a5.cin;   // the single segment now reaches the closing convolution's last chunk
         total = 6;
     }
-    const int rc = conv3x3_ws_chain_f16(base, jobs, total, flop, bytes, stream);
+    const int rc = conv3x3_ws_chain_f16(base, jobs, total, flop, bytes, x2, chain_state, chain_state_bytes, stream);
+    if (rc == 1) {   // the state buffer does not cover this geometry: one launch per job
+        for (int j = 0; j < njobs; ++j) {
+            const int r2 = conv3x3_route(&d[j], a[j], a[j].bias != nullptr, a[j].in1 != nullptr, stream);
+            if (r2) return r2;
+        }
+        return d5 ? conv3x3_route(d5, a5, a5.bias != nullptr, a5.in1 != nullptr, stream) : RESR_OK;
+    }
     if (rc || !d5 || with5) return rc;
     return conv3x3_route(d5, a5, a5.bias != nullptr, a5.in1 != nullptr, stream);
 }
 
 int conv3x3_chain_dispatch(int njobs, const ResrConvDesc* d, const void* in0, const void* in1, const void* const* w,
                            const float* const* bias, const void* const* mask, void* const* out, void* const* aux,
-                           hipStream_t stream) {
-    return conv3x3_block_dispatch(njobs, d, in0, in1, w, bias, mask, out, aux, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                           void* chain_state, size_t chain_state_bytes, hipStream_t stream) {
+    return conv3x3_block_dispatch(njobs, d, in0, in1, w, bias, mask, out, aux, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  chain_state, chain_state_bytes, stream);
 }
 
 }  // namespace resr

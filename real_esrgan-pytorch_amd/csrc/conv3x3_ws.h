@@ -126,6 +126,26 @@ __device__ __forceinline__ float mixmul_hi(unsigned h2, float t) {
     asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(t));
     return d;
 }
+// c + t * (float)half of a packed f16 pair (the lo part of an exact16 residual joins the product of its hi part)
+__device__ __forceinline__ float mixfma_lo(unsigned h2, float t, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(t), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float mixfma_hi(unsigned h2, float t, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(t), "v"(c));
+    return d;
+}
+// exact16: the lo halves of a converted pair -- f16((v - hi) * 2^12) for both values, given hi2 = the packed f16 pair
+// cvt(v0, v1), v4 = (v0, v1) * 2^12 and m = -2^12: one fused multiply-add per value, rounded once (v - hi is exact)
+__device__ __forceinline__ unsigned lo_pair(unsigned hi2, float v4_0, float v4_1, float m) {
+    unsigned d = 0;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "+v"(d) : "v"(hi2), "v"(m), "v"(v4_0), "v"(v4_1));
+    return d;
+}
 // four lane-half exchanges in one block: (a_r, b_r) of lanes lx / lx+32 -> 8 consecutive output channels per lane.
 // One pair of wait-state nops for the block (the swaps touch disjoint registers); volatile: stays behind the
 // MFMA-result wait states the epilogue issues first.
@@ -173,7 +193,8 @@ __device__ __forceinline__ unsigned signs4_x128(unsigned d0, unsigned d1, unsign
 // without waiting for their producers, and producers only poll (for stage s+2) after barrier s.
 template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0, int CH = 0>
 __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCfg<T, MT, NT, NWC>::NP) / 4) void conv3x3_ws_kernel(const ConvArgs a, const std::conditional_t<CH != 0, ChainArgs, ChainNone> cj) {
-    static_assert(!CH || (MT == 1 && !X2 && SP == 0 && (EPI == 0 || EPI == 16 || EPI == 33) && WsCfg<T, MT, NT, NWC>::NHB == 3), "chain: cout-32 dense-block passes only");
+    static_assert(!CH || (MT == 1 && SP == 0 && (EPI == 0 || EPI == 16 || EPI == 33) && WsCfg<T, MT, NT, NWC>::NHB == 3), "chain: cout-32 dense-block passes only");
+    static_assert(!(CH == 3 && X2), "the pinned-pipeline experiment is fast mode only");
     using C = WsCfg<T, MT, NT, NWC>;
     constexpr int SPP = C::SPP, KS = C::KS, PB = C::PB, TH = C::TH, TW = C::TW, HW = C::HW, BUF = C::BUF;
     constexpr int NI = C::NI, NG = C::NG, NP = C::NP, NIP = C::NIP;
@@ -192,24 +213,28 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     int first = xcd_remap(blockIdx.x, G);
     int tile_end = ntiles, tile_step = G;
     int pin_job = 0;   // CH 3
+    unsigned chain_epoch = 0;   // CH: flag value of "job j of this launch done" = chain_epoch + j + 1
     if constexpr (CH) {
         // Ownership follows the XCD the workgroup REALLY runs on (XCC_ID), not blockIdx: the dispatcher deals workgroups
         // to the XCDs round-robin, but where a dispatch starts is not fixed (measured: launches from a second stream
-        // start elsewhere).  Index inside the XCD = a ticket (the counters only grow; the host knows where this launch's
-        // tickets start as long as every launch gives each XCD grid / 8 workgroups, which is checked here).
+        // start elsewhere).  Index inside the XCD = a ticket; the last workgroup of a launch to finish resets the tickets
+        // (end of the kernel), so every launch counts from 0 as long as it gives each XCD grid / 8 workgroups -- checked here.
         unsigned* tk = reinterpret_cast<unsigned*>(smem + C::CHAIN_OFF + kMaxChain * 128 + 16);
         if (threadIdx.x == 0) {
             const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]
             const unsigned per = (unsigned)G >> 3;
-            unsigned idx = atomicAdd(cj.tickets + (xcc & 7u), 1u) - cj.ticket_base;
+            unsigned idx = atomicAdd(cj.state + 8 + (xcc & 7u), 1u);
             if (xcc >= 8u || idx >= per) {   // an XCD with more than its share: counted (the host fails loudly), kept in range
-                atomicAdd(cj.errors + 1, 1u);
+                atomicAdd(cj.state + 3, 1u);
+                __hip_atomic_fetch_add(cj.host_errors + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 idx %= per;
             }
             tk[0] = xcc & 7u;
             tk[1] = idx;
+            tk[2] = __hip_atomic_load(cj.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this launch's epoch (bumped by the previous launch's last workgroup)
         }
         __syncthreads();
+        chain_epoch = tk[2];
         const int t8 = ntiles >> 3, xcd = (int)tk[0];
         first = xcd * t8 + (int)tk[1];
         tile_end = (xcd + 1) * t8;
@@ -222,7 +247,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         }
     }
     int nchunks = X2 ? 3 * (a.cin >> 5) : a.cin >> 5;   // stages per tile (CH: of the current job)
-    if constexpr (CH) nchunks = cj.job[CH == 3 ? pin_job : 0].cin >> 5;
+    if constexpr (CH) nchunks = (cj.job[CH == 3 ? pin_job : 0].cin >> 5) * (X2 ? 3 : 1);
     int tk = 0;
     auto stamp = [&](int role) {
         // traced workgroups: blockIdx 16k .. 16k+0 for k < 32 (a sample across the whole grid)
@@ -243,18 +268,18 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         float* cb = reinterpret_cast<float*>(smem + C::CHAIN_OFF);
         if (wave < kMaxChain && lane < 32) {
             const float* bp = wave < cj.njobs ? cj.job[wave].bias : nullptr;
-            cb[wave * 32 + lane] = (bp && !(a.flags & RESR_CONV_NO_BIAS) && lane < a.cout) ? bp[lane] : 0.f;
+            cb[wave * 32 + lane] = (bp && !(a.flags & RESR_CONV_NO_BIAS) && lane < a.cout) ? bp[lane] * (X2 ? kLoScale : 1.f) : 0.f;
         }
         if (wave == 0 && lane == 0) *reinterpret_cast<unsigned*>(smem + C::CHAIN_OFF + kMaxChain * 128) = 0u;
     }
     // FAST: instantiations with the lean epilogue (the generator's hot forms: plain / LeakyReLU, residuals, sign-bit
     // output, sign-bit mask); everything else keeps the general one
-    constexpr bool FAST = !X2 && (EPI == 0 || EPI == 2 || EPI == 6 || EPI == 16 || EPI == 33);
+    constexpr bool FAST = EPI == 0 || EPI == 2 || EPI == 6 || EPI == 16 || EPI == 33;
     if constexpr (FAST && EPI == 33) {
         if (wave == 1 && lane < 16) {
             float4v m;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) m[r] = ((lane >> r) & 1) ? 1.f : a.slope;
+            for (int r = 0; r < 4; ++r) m[r] = (((lane >> r) & 1) ? 1.f : a.slope) * (X2 ? kLoInv : 1.f);   // X2: the accumulators carry 2^12
             *reinterpret_cast<float4v*>(smem + C::LUT_OFF + lane * 16) = m;
         }
     }
@@ -321,6 +346,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 voff_stride = 0;
             };
             const char* const zero = a.zero;
+            const char* poison_src = nullptr;   // CH: set by a poll that gave up, consumed by the halo request that follows it
             auto issue_h = [&](int ck, int hb) {   // halo of (current pix, chunk ck) -> halo buffer hb
                 const int ckr = X2 ? ck / 3 : ck;   // X2: stage ck = (real chunk ck / 3, part ck % 3); part 2 reads the lo tensor
                 const int c0 = ckr * 32;
@@ -337,6 +363,12 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 for (int i = 0; i < NIP; ++i) {
                     if (i * NP + pw < NI) {   // wave-uniform; false only for i = NIP-1 of the waves pw >= REM
                         const unsigned dst = lds_base + hb * BUF + (i * NP + pw) * 1024;
+                        if constexpr (CH != 0) {
+                            if (poison_src) {   // the poll for this plane timed out: NaNs instead of a plane that may be stale
+                                dma_v(poison_src, dst, val[i]);
+                                continue;
+                            }
+                        }
                         if (inb[i] == val[i]) {
                             dma_s(base, voff[i], dst, val[i]);
                         } else {
@@ -384,7 +416,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y;
                     const int dx = lane % 3 - 1, dy = lane / 3 - 1;
                     const bool watch = lane < 9 && (unsigned)(tx + dx) < (unsigned)a.tiles_x && (unsigned)(ty + dy) < (unsigned)a.tiles_y;
-                    const unsigned* fp = cj.flags + (watch ? tile + dy * a.tiles_x + dx : tile);
+                    const unsigned* fp = cj.state + kChainHdr + (watch ? tile + dy * a.tiles_x + dx : tile);
                     bool all_ok = false;
                     for (int spin = 0;; ++spin) {
                         const unsigned v = watch ? __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : all_need;
@@ -392,10 +424,16 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             all_ok = __ballot((int)(v - all_need) < 0) == 0ull;
                             break;
                         }
-                        // never hang the device: give up after ~0.5 s (the host reads the counter), and once any poll of the
-                        // process has given up every later one does so within a millisecond
-                        if (spin > (1 << 18) || ((spin & 1023) == 1023 && __hip_atomic_load(cj.errors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                            if (lane == 0) atomicAdd(cj.errors, 1u);
+                        // never hang the device: give up after ~4 s (a co-resident kernel of another stream -- a collective waiting
+                        // for a late peer -- may legitimately hold a CU this launch needs for a while), and once any poll on this
+                        // state has given up every later one does so within a millisecond.  Giving up is never silent: the plane
+                        // is replaced by NaNs (poison_src) and the counters -- device and host-mapped -- say so.
+                        if (spin > (1 << 21) || ((spin & 1023) == 1023 && __hip_atomic_load(cj.state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                            if (lane == 0) {
+                                atomicAdd(cj.state + 2, 1u);
+                                __hip_atomic_fetch_add(cj.host_errors, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
+                            poison_src = cj.nan16;
                             break;
                         }
                         __builtin_amdgcn_s_sleep(2);
@@ -409,7 +447,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         if (it >= tile_end) {
                             it = first;
                             if constexpr (CH == 3) job = njobs;   // pinned: this workgroup's only job is done
-                            else if (++job < njobs) nch = cj.job[job].cin >> 5;
+                            else if (++job < njobs) nch = (cj.job[job].cin >> 5) * (X2 ? 3 : 1);
                         }
                     }
                     return job < njobs;
@@ -418,9 +456,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 issue_wj(job, 0, 0);
                 issue_h(0, 0);
                 __syncthreads();           // the set-up barrier
+                // X2: stage (chunk, part 1) multiplies the x_hi halo of part 0 again with the second weight block: no halo of its own
+                auto needs_hc = [&](int ck) { return !X2 || (ck % 3) != 1; };
                 bool have_next = advance();   // chunk 1 of the same tile (every job has >= 2 chunks, host-checked)
                 int ck_next = ick, job_next = job;
-                if (have_next) {
+                if (have_next && needs_hc(ick)) {
                     if (ick == 0) tile_pix(it);
                     hb = 1;
                     issue_h(ick, hb);
@@ -432,7 +472,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 for (int s = 0; have_next; ++s) {   // stage s is being multiplied; H(s+1) is in flight
                     issue_wj(job_next, ck_next, (s + 1) & 1);
                     const bool have_next2 = advance();
-                    if (have_next2) {
+                    if (have_next2 && needs_hc(ick)) {
                         if (ick == 0) tile_pix(it);
                         // Chunk c >= 2 of the shared inputs is the output plane of job c - 2 of THIS launch: its halo may only be
                         // requested once that job has finished the tile's 3 x 3 neighbourhood.  A workgroup that WALKS the jobs
@@ -444,11 +484,13 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         if constexpr (CH == 2) dep = cj.job[job].dep;
                         if constexpr (CH == 3) {
                             if (ick == 0) tile_settled = false;
-                            if (ick == 2 && dep >= 1) tile_settled = poll(it, cj.epoch + (unsigned)dep, cj.epoch + (unsigned)dep + 1u);
+                            if (ick == 2 && dep >= 1) tile_settled = poll(it, chain_epoch + (unsigned)dep, chain_epoch + (unsigned)dep + 1u);
                         }
-                        if (ick == nch - 1 && dep >= 0 && !(CH == 3 && tile_settled)) poll(it, cj.epoch + (unsigned)dep + 1u, cj.epoch + (unsigned)dep + 1u);
+                        // (X2: the dependent real chunk is the job's last THREE stages; its first halo request -- the hi plane -- polls)
+                        if (ick == nch - (X2 ? 3 : 1) && dep >= 0 && !(CH == 3 && tile_settled)) poll(it, chain_epoch + (unsigned)dep + 1u, chain_epoch + (unsigned)dep + 1u);
                         hb = hb == 2 ? 0 : hb + 1;
                         issue_h(ick, hb);
+                        poison_src = nullptr;
                         wait_all_but_h();
                     } else {
                         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -688,7 +730,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     unsigned* cnt = reinterpret_cast<unsigned*>(smem + C::CHAIN_OFF + kMaxChain * 128);
                     const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if ((old % NWC) == NWC - 1)   // the last of the NWC consumer waves: everyone's stores are in
-                        __hip_atomic_store(cj.flags + pend_tile, pend_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(cj.state + kChainHdr + pend_tile, pend_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 pend = false;
             }
@@ -702,7 +744,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     const int s_ty = s_t2 % a.tiles_y, s_n = s_t2 / a.tiles_y;   // s_n counts images of ALL groups (group = image / a.n)
     // CH 3: only the pinned job
     for (int job = (CH == 3 ? pin_job : 0); job < (CH == 3 ? pin_job + 1 : njobs_c); ++job) {
-    if constexpr (CH) nchunks = cj.job[job].cin >> 5;
+    if constexpr (CH) nchunks = (cj.job[job].cin >> 5) * (X2 ? 3 : 1);
     for (int tile = first; tile < tile_end; tile += tile_step) {
         if constexpr (FAST) {
             if (tile == first) {
@@ -871,17 +913,20 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 int h, w_, cout, out_stride, res0_stride, res1_stride, flags;
                 int out_chunk, res0_chunk, res1_chunk;
                 float s0, t0, s1, t1, slope;
+                long out_lo, res0_lo, res1_lo;   // X2: element offsets hi -> lo tensor
             } e;
             e.out = ep->out; e.h = ep->h; e.w_ = ep->w_; e.cout = ep->cout; e.out_stride = ep->out_stride;
             e.out_chunk = ep->out_chunk; e.flags = ep->flags; e.slope = ep->slope;
+            if constexpr (X2) e.out_lo = ep->out_lo;
             if constexpr (CH) e.out = cj.job[job].out;
+            if constexpr (CH && X2) e.out_lo = cj.job[job].out_lo;
             constexpr bool R0c = (EPI & 2) != 0, R1c = (EPI & 4) != 0, ESB = EPI == 16, EMB = EPI == 33;
             // What the instantiation fixes at compile time a chained launch may replace per job at run time: a job of kind 3 (one
             // half of the block's closing convolution) has residuals instead of LeakyReLU / sign words / mask.  Outside chained
             // launches r0 / r1 / own are constants and the code below is what it was.
             bool r0 = R0c, r1 = R1c, own = true;
-            if constexpr (R0c) { e.res0 = ep->res0; e.res0_stride = ep->res0_stride; e.res0_chunk = ep->res0_chunk; e.s0 = ep->s0; e.t0 = ep->t0; }
-            if constexpr (R1c) { e.res1 = ep->res1; e.res1_stride = ep->res1_stride; e.res1_chunk = ep->res1_chunk; e.s1 = ep->s1; e.t1 = ep->t1; }
+            if constexpr (R0c) { e.res0 = ep->res0; e.res0_stride = ep->res0_stride; e.res0_chunk = ep->res0_chunk; e.s0 = ep->s0; e.t0 = ep->t0; if constexpr (X2) e.res0_lo = ep->res0_lo; }
+            if constexpr (R1c) { e.res1 = ep->res1; e.res1_stride = ep->res1_stride; e.res1_chunk = ep->res1_chunk; e.s1 = ep->s1; e.t1 = ep->t1; if constexpr (X2) e.res1_lo = ep->res1_lo; }
             if constexpr (ESB) e.aux = ep->aux;
             if constexpr (ESB && CH) e.aux = reinterpret_cast<uint8_t*>(cj.job[job].aux);
             if constexpr (CH == 2) {
@@ -891,6 +936,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     e.res0 = cj.job[job].res0; e.res0_stride = 32; e.res0_chunk = 0; e.s0 = cj.job[job].s0; e.t0 = cj.job[job].t0;
                     r1 = cj.job[job].res1 != nullptr;
                     e.res1 = cj.job[job].res1; e.res1_stride = 32; e.res1_chunk = 0; e.s1 = cj.job[job].s1; e.t1 = cj.job[job].t1;
+                    if constexpr (X2) { e.res0_lo = cj.job[job].res0_lo; e.res1_lo = cj.job[job].res1_lo; }
                 }
             }
             int lane_e = lane;
@@ -903,8 +949,9 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             const unsigned kh16 = (unsigned)kh_e * 16u;   // byte offset of this lane half's 8 channels inside a 16-channel piece pair
             // row double buffer of the residual pieces (cout 64): row t+1 is requested before row t is processed
             constexpr bool RESc = R0c || R1c;
-            constexpr int NB = (RESc && MT == 2) ? 2 : 1;
+            constexpr int NB = (RESc && MT == 2 && !(X2 && R1c)) ? 2 : 1;   // (exact16 with two residuals: four 16-B pieces per value pair -- no room for two rows)
             uint4v rr0[NB][MT][2], rr1[NB][MT][2];
+            uint4v rr0l[X2 ? NB : 1][MT][2], rr1l[X2 ? NB : 1][MT][2];   // X2: the residuals' lo tensors
             auto row_pix = [&](int t) {
                 const int y = y0 + row0 + t;
                 return ((unsigned)n * e.h + (unsigned)(y < e.h ? y : e.h - 1)) * e.w_ + xc;
@@ -921,10 +968,16 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const bool pair_ok = m * 32 + j * 16 < e.cout;   // wave-uniform
-                        if (r0)
-                            rr0[b][m][j] = *reinterpret_cast<const uint4v*>(e.res0 + ((size_t)p * e.res0_stride + goff + (pair_ok ? (size_t)m * e.res0_chunk + j * 16 : (size_t)0)) * 2 + kh16);
-                        if (r1)
-                            rr1[b][m][j] = *reinterpret_cast<const uint4v*>(e.res1 + ((size_t)p * e.res1_stride + goff + (pair_ok ? (size_t)m * e.res1_chunk + j * 16 : (size_t)0)) * 2 + kh16);
+                        if (r0) {
+                            const char* q0 = e.res0 + ((size_t)p * e.res0_stride + goff + (pair_ok ? (size_t)m * e.res0_chunk + j * 16 : (size_t)0)) * 2 + kh16;
+                            rr0[b][m][j] = *reinterpret_cast<const uint4v*>(q0);
+                            if constexpr (X2) rr0l[b][m][j] = *reinterpret_cast<const uint4v*>(q0 + e.res0_lo * 2);
+                        }
+                        if (r1) {
+                            const char* q1 = e.res1 + ((size_t)p * e.res1_stride + goff + (pair_ok ? (size_t)m * e.res1_chunk + j * 16 : (size_t)0)) * 2 + kh16;
+                            rr1[b][m][j] = *reinterpret_cast<const uint4v*>(q1);
+                            if constexpr (X2) rr1l[b][m][j] = *reinterpret_cast<const uint4v*>(q1 + e.res1_lo * 2);
+                        }
                     }
             };
             // MFMA results -> first non-MFMA reader: the swaps are asm, so the compiler cannot count this hazard
@@ -965,6 +1018,13 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             q[2] *= float2v{mb[0], mb[1]};
                             q[3] *= float2v{mb[2], mb[3]};
                         }
+                        if constexpr (X2) {   // the packed weights (and the bias) carry 2^12; with the sign-word mask the table does
+                            if (!(EMB && own)) {
+                                const float2v k2 = {kLoInv, kLoInv};
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) q[k] *= k2;
+                            }
+                        }
                         if (f_lrelu) {   // 0 <= slope <= 1 (host-checked): LeakyReLU(v) = max(v, slope * v)
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
@@ -977,7 +1037,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             const float2v s02 = {e.s0, e.s0};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                const float2v tr = {mixmul_lo(rr0[b][m][j][k], e.t0), mixmul_hi(rr0[b][m][j][k], e.t0)};
+                                float2v tr = {mixmul_lo(rr0[b][m][j][k], e.t0), mixmul_hi(rr0[b][m][j][k], e.t0)};
+                                if constexpr (X2) tr = float2v{mixfma_lo(rr0l[b][m][j][k], e.t0 * kLoInv, tr[0]), mixfma_hi(rr0l[b][m][j][k], e.t0 * kLoInv, tr[1])};
                                 q[k] = __builtin_elementwise_fma(q[k], s02, tr);
                             }
                         }
@@ -985,7 +1046,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             const float2v s12 = {e.s1, e.s1};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                const float2v tr = {mixmul_lo(rr1[b][m][j][k], e.t1), mixmul_hi(rr1[b][m][j][k], e.t1)};
+                                float2v tr = {mixmul_lo(rr1[b][m][j][k], e.t1), mixmul_hi(rr1[b][m][j][k], e.t1)};
+                                if constexpr (X2) tr = float2v{mixfma_lo(rr1l[b][m][j][k], e.t1 * kLoInv, tr[0]), mixfma_hi(rr1l[b][m][j][k], e.t1 * kLoInv, tr[1])};
                                 q[k] = __builtin_elementwise_fma(q[k], s12, tr);
                             }
                         }
@@ -994,9 +1056,33 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         for (int k = 0; k < 4; ++k) d[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(q[k], half2v));
                         if (in_img && piece_ok(m, j))
                             *reinterpret_cast<uint4v*>(orow + ((size_t)m * e.out_chunk + j * 16) * 2) = d;
+                        if constexpr (X2) {   // lo = f16((v - hi) * 2^12), behind the hi tensor
+                            uint4v dl;
+                            const float2v k4 = {kLoScale, kLoScale};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float2v q4 = q[k] * k4;
+                                dl[k] = lo_pair(d[k], q4[0], q4[1], -kLoScale);
+                            }
+                            if (in_img && piece_ok(m, j))
+                                *reinterpret_cast<uint4v*>(orow + ((size_t)m * e.out_chunk + j * 16 + e.out_lo) * 2) = dl;
+                        }
                         if (ESB && own) {
-                            sacc[j] = signs4_x128(d[0], d[1], 0x08040201u, 0u);
-                            sacc[j] = signs4_x128(d[2], d[3], 0x80402010u, sacc[j]);
+                            if constexpr (X2) {
+                                // the sign of the fp32 value (hi alone rounds |v| < 2^-25 to zero): its upper half as a 16-bit integer
+                                // is positive exactly when v > 0 (down to the fp32 denormals)
+                                unsigned u[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const float q0 = q[k][0], q1 = q[k][1];   // (__builtin_bit_cast on a vector-element lvalue reads element 0 in this toolchain)
+                                    u[k] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q0), 0x07060302u);
+                                }
+                                sacc[j] = signs4_x128(u[0], u[1], 0x08040201u, 0u);
+                                sacc[j] = signs4_x128(u[2], u[3], 0x80402010u, sacc[j]);
+                            } else {
+                                sacc[j] = signs4_x128(d[0], d[1], 0x08040201u, 0u);
+                                sacc[j] = signs4_x128(d[2], d[3], 0x80402010u, sacc[j]);
+                            }
                         }
                     }
                     if (ESB && own) {
@@ -1015,7 +1101,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 if (job + 1 < njobs_c) {   // the last job's tiles have no reader inside the launch
                     pend = true;
                     pend_tile = tile;
-                    pend_tag = cj.epoch + (unsigned)job + 1u;
+                    pend_tag = chain_epoch + (unsigned)job + 1u;
                     if (CH != 3 && tile + tile_step >= tile_end)   // the next tile belongs to the next job
                         bias_cur = reinterpret_cast<const float*>(smem + C::CHAIN_OFF) + (job + 1) * 32;
                 }
@@ -1243,6 +1329,24 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     }
     }   // jobs
     if constexpr (CH == 3) publish();   // a pinned workgroup's last tile has no next stage to publish it from
+    if constexpr (CH != 0) {
+        // The last workgroup of the launch to get here prepares the state for the next launch on it (which starts after this
+        // kernel has ended, so these plain stores are visible to it): tickets and the finish counter back to 0, the epoch
+        // 8 further -- or, far from wrapping the signed flag comparison, every flag back to 0 and the epoch with them.
+        if (wave == 0) {
+            unsigned last = 0;
+            if (lane == 0) last = (atomicAdd(cj.state + 1, 1u) == (unsigned)G - 1u) ? 1u : 0u;
+            if (__builtin_amdgcn_readfirstlane(last)) {
+                unsigned e = chain_epoch + 8u;
+                if (e > 0x70000000u) {
+                    for (unsigned i = lane; i < cj.cap; i += 64) cj.state[kChainHdr + i] = 0u;
+                    e = 0u;
+                }
+                if (lane < 8) cj.state[8 + lane] = 0u;
+                if (lane == 0) { cj.state[1] = 0u; cj.state[0] = e; }
+            }
+        }
+    }
 }
 
 template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0>
@@ -1251,7 +1355,7 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     ConvArgs args = a;
     args.tiles_x = (a.w_ + 31) / 32;
     args.tiles_y = (a.h + C::TH - 1) / C::TH;
-    const size_t lds = C::LDS_BYTES + ((!X2 && EPI == 33) ? C::LUT_BYTES : 0);  // halo buffers, bias, weight buffers (+ the mask-multiplier table)
+    const size_t lds = C::LDS_BYTES + (EPI == 33 ? C::LUT_BYTES : 0);  // halo buffers, bias, weight buffers (+ the mask-multiplier table)
     // per device (the boundary is callable with any current device): workgroups the device holds at once and the
     // address of this translation unit's zero page there; idempotent, so a race between two first calls is benign
     static int resident_dev[kMaxDevices] = {0};

@@ -3,7 +3,6 @@
 #include <stdlib.h>
 
 #include <mutex>
-#include <vector>
 
 #include "conv3x3.h"
 
@@ -61,44 +60,50 @@ static int pick_rows(const ConvArgs& a, const int* rows, int nrows) {
 }
 
 int conv3x3_ws_sparse(const ConvArgs& a, int tile_rows, int sp, hipStream_t stream);   // conv3x3_ws_sp.hip
-int conv3x3_ws_chain_launch(const ConvArgs& a, const ChainArgs& cj, int tile_rows, int kind, unsigned* ticket_base, double flop, double bytes, hipStream_t stream);   // conv3x3_ws_chain.hip
+int conv3x3_ws_chain_launch(const ConvArgs& a, const ChainArgs& cj, int tile_rows, int kind, bool x2, double flop, double bytes, hipStream_t stream);   // conv3x3_ws_chain.hip
 
-// ---- chained dense-block passes (conv3x3_ws.h, CH): per-(device, stream) progress flags ----
-// flags[tile] only ever grows: a launch's jobs publish epoch + 1 ... epoch + njobs, and the next launch on the stream
-// starts 8 higher, so nothing is reset between launches.  One buffer per stream: two streams would read each other's epochs.
+// ---- chained dense-block passes (conv3x3_ws.h, CH) ----
+// All device-side state (epoch, tickets, flags, error counters) lives in memory the CALLER hands in (conv3x3.h, ChainArgs):
+// nothing is allocated here and nothing is synchronised.  What the host keeps per device is (a) which stream launched the
+// last chain and an event behind it -- a chained launch waits for its own workgroups from inside, so two of them side by
+// side on different streams could each hold CUs the other's missing workgroups need: a launch from another stream first
+// WAITS (stream-side, hipStreamWaitEvent) for the previous owner's last chain -- and (b) two host-mapped error words the
+// kernels add to when a flag poll gives up or an XCD receives more than its share, so the host can look without a sync.
 namespace {
-struct ChainState {
-    int dev;
-    hipStream_t stream;
-    unsigned* buf;      // [cap] flags + [2] error counters + [8] per-XCD workgroup tickets
-    size_t cap;
-    unsigned epoch;
-    unsigned ticket_base;   // value of the ticket counters before the next launch
+struct ChainHost {
+    bool init = false, owned = false;
+    hipStream_t owner = nullptr;
+    hipEvent_t ev = nullptr;
+    unsigned* err_host = nullptr;   // [2], host-mapped
+    unsigned* err_dev = nullptr;    // device view of the same words
+    const char* nan16 = nullptr;
 };
 std::mutex g_chain_mu;
-std::vector<ChainState> g_chain;
+ChainHost g_chain[kMaxDevices];
+__device__ uint4 g_conv_nan16 = {0x7e007e00u, 0x7e007e00u, 0x7e007e00u, 0x7e007e00u};   // eight f16 quiet NaNs
 }  // namespace
 
-// sum over all streams of (poll time-outs, misplaced workgroups); synchronises the device (debug / test entry)
+// (time-outs | beyond-share << 32) seen on the current device so far; reads host memory only -- no synchronisation, so it
+// reflects the launches that have finished by now
 long long conv3x3_chain_errors() {
     std::lock_guard<std::mutex> lk(g_chain_mu);
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return -1;
-    long long polls = 0, xcd = 0;
-    for (const ChainState& c : g_chain) {
-        if (c.dev != dev) continue;
-        unsigned e[16] = {0};
-        if (hipMemcpy(e, c.buf + c.cap, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        polls += e[0];
-        xcd += e[1];
-        if (getenv("RESR_DEBUG_CHAIN"))
-            fprintf(stderr, "chain state: stream %p cap %zu epoch %u ticket_base %u | time-outs %u beyond-share %u | tickets %u %u %u %u %u %u %u %u\n",
-                    (void*)c.stream, c.cap, c.epoch, c.ticket_base, e[0], e[1], e[8], e[9], e[10], e[11], e[12], e[13], e[14], e[15]);
-    }
-    return polls + (xcd << 32);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
+    const ChainHost& c = g_chain[dev];
+    if (!c.init) return 0;
+    const volatile unsigned* e = c.err_host;
+    return (long long)e[0] + ((long long)e[1] << 32);
 }
 
-int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, const double* flop, const double* bytes, hipStream_t stream) {
+size_t conv3x3_chain_state_bytes(int n, int h, int w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    const size_t tiles = (size_t)((w + 31) / 32) * ((h + 7) / 8) * n;   // the smallest tile shape
+    return align_up((kChainHdr + tiles) * sizeof(unsigned), 256);
+}
+
+// rc: RESR_OK launched; 1 = cannot chain here (state too small / misaligned): the caller runs one launch per job
+int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, const double* flop, const double* bytes, bool x2,
+                         void* state, size_t state_bytes, hipStream_t stream) {
     static const int rows1[] = {16, 8};
     int rows = pick_rows(a, rows1, 2);
     // Experiment (RESR_CHAIN_PIPE="5,7,9,11"): a pinned pipeline instead of a walk -- 8-row tiles, the 32 workgroups of an XCD split
@@ -106,7 +111,7 @@ int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, con
     // flags, so that the planes a block's passes exchange stay inside the XCD's L2
     int split[kMaxChain + 2] = {0};
     const char* pipe_env = getenv("RESR_CHAIN_PIPE");   // read per call (a test flips it)
-    if (pipe_env && njobs == 4) {
+    if (pipe_env && njobs == 4 && !x2) {
         int c[4] = {0, 0, 0, 0};
         if (sscanf(pipe_env, "%d,%d,%d,%d", &c[0], &c[1], &c[2], &c[3]) == 4 && c[0] > 0 && c[1] > 0 && c[2] > 0 && c[3] > 0 &&
             c[0] + c[1] + c[2] + c[3] == 32 && (size_t)((a.w_ + 31) / 32) * ((a.h + 7) / 8) * a.n >= 256 * 8) {
@@ -115,55 +120,45 @@ int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, con
             for (int j = 5; j < kMaxChain + 2; ++j) split[j] = 32;
         }
     }
+    if (x2)   // exact16 with the closing convolution's halves runs on 8-row tiles only (conv3x3_ws_chain.h)
+        for (int j = 0; j < njobs; ++j)
+            if (jobs[j].kind == 3) rows = 8;
     const size_t ntiles = (size_t)((a.w_ + 31) / 32) * ((a.h + rows - 1) / rows) * a.n;
+    if (!state || ((size_t)state & 15) || state_bytes < (kChainHdr + ntiles) * sizeof(unsigned)) return 1;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipGetDevice");
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipGetDevice");
     ChainArgs cj;
     memset(&cj, 0, sizeof(cj));
     {
         std::lock_guard<std::mutex> lk(g_chain_mu);
-        // A chained launch waits for its own workgroups from inside: two of them running side by side on different streams
-        // could each hold CUs the other's missing workgroups need.  One stream per device owns chaining at a time; a
-        // launch from another stream first drains the device (once per change of owner, not per launch).
-        static hipStream_t owner[kMaxDevices] = {nullptr};
-        static bool owned[kMaxDevices] = {false};
-        if (dev >= 0 && dev < kMaxDevices) {
-            if (owned[dev] && owner[dev] != stream && hipDeviceSynchronize() != hipSuccess)   // (the old owner may be gone: drain the device)
-                return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipDeviceSynchronize");
-            owner[dev] = stream;
-            owned[dev] = true;
+        ChainHost& c = g_chain[dev];
+        if (!c.init) {   // once per device: an event, two host-mapped words, the address of the NaN page
+            void* hp = nullptr; void* dp = nullptr; void* np = nullptr;
+            if (hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess ||
+                hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess ||
+                hipGetSymbolAddress(&np, HIP_SYMBOL(g_conv_nan16)) != hipSuccess || !np)
+                return fail(RESR_ERR_LAUNCH, "conv3x3_chain: per-device set-up failed");
+            memset(hp, 0, 64);
+            c.err_host = (unsigned*)hp; c.err_dev = (unsigned*)dp; c.nan16 = (const char*)np;
+            c.init = true;
         }
-        ChainState* st = nullptr;
-        for (ChainState& c : g_chain)
-            if (c.dev == dev && c.stream == stream) st = &c;
-        if (!st) {
-            g_chain.push_back(ChainState{dev, stream, nullptr, 0, 8u, 0u});
-            st = &g_chain.back();
-        }
-        if (st->cap < ntiles) {   // first use / larger geometry: a fresh zeroed buffer (the old one may still be read by queued launches: kept)
-            const size_t cap = ntiles < 4096 ? 4096 : ntiles * 2;
-            unsigned* nb = nullptr;
-            // zeroed ON THE LAUNCHING STREAM: hipMemset runs on the null stream, which a non-blocking stream does not wait for
-            if (hipMalloc((void**)&nb, (cap + 16) * sizeof(unsigned)) != hipSuccess || hipMemsetAsync(nb, 0, (cap + 16) * sizeof(unsigned), stream) != hipSuccess)
-                return fail(RESR_ERR_LAUNCH, "conv3x3_chain: flag buffer");
-            st->buf = nb; st->cap = cap; st->epoch = 8u; st->ticket_base = 0u;
-        }
-        if (st->epoch > 0x70000000u) {   // far from wrapping the signed comparison: start over behind everything queued
-            if (hipMemsetAsync(st->buf, 0, st->cap * sizeof(unsigned), stream) != hipSuccess) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: flag reset");
-            st->epoch = 8u;
-        }
-        cj.flags = st->buf;
-        cj.errors = st->buf + st->cap;
-        cj.tickets = st->buf + st->cap + 8;
-        cj.epoch = st->epoch;
-        st->epoch += 8u;
+        if (c.owned && c.owner != stream && hipStreamWaitEvent(stream, c.ev, 0) != hipSuccess)
+            return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipStreamWaitEvent");
+        c.owner = stream;
+        c.owned = true;
+        cj.state = (unsigned*)state;
+        cj.cap = (unsigned)(state_bytes / sizeof(unsigned) - kChainHdr);
+        cj.host_errors = c.err_dev;
+        cj.nan16 = c.nan16;
         cj.njobs = njobs;
         memcpy(cj.split, split, sizeof(split));
         double f = 0, b = 0;
         for (int j = 0; j < njobs; ++j) { cj.job[j] = jobs[j]; f += flop[j]; b += bytes[j]; }
         for (int j = njobs; j < kMaxChain; ++j) cj.job[j] = jobs[njobs - 1];
         const int kind = (a.flags & RESR_CONV_MASK_BITS) ? 2 : (a.flags & RESR_CONV_WRITE_SIGNBITS) ? 1 : 0;
-        return conv3x3_ws_chain_launch(a, cj, rows, kind, &st->ticket_base, f, b, stream);   // under the lock: the ticket base follows launch order
+        const int rc = conv3x3_ws_chain_launch(a, cj, rows, kind, x2, f, b, stream);   // under the lock: owner and event follow launch order
+        if (rc == RESR_OK && hipEventRecord(c.ev, stream) != hipSuccess) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipEventRecord");
+        return rc;
     }
 }
 

@@ -37,7 +37,8 @@ size_t wgrad_batch_partial_bytes(const WgradConv*, int, int, int);
 int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, const void* in1, const void* const* w,
                            const float* const* bias, const void* const* mask, void* const* out, void* const* aux,
                            const ResrConvDesc* d5, const void* w5, const float* bias5, const void* res0_5, const void* res1_5,
-                           void* out5, hipStream_t stream);
+                           void* out5, void* chain_state, size_t chain_state_bytes, hipStream_t stream);
+size_t conv3x3_chain_state_bytes(int, int, int);
 int wgrad_batch(const WgradConv*, int, int, int, int, int, int, int, float*, hipStream_t);
 int wgrad_tile_rows(int dtype);
 int wgrad_x2_products();
@@ -139,6 +140,8 @@ bool build_plan(const ResrGeneratorDesc* d, Plan& p) {
 // workspace carving
 // ---------------------------------------------------------------------------------------------
 struct Bufs {
+    char* chain;              // device-side state of the chained dense-block launches (conv3x3.h ChainArgs): the HEAD of the workspace,
+    size_t chain_bytes;       // zero-filled once by the caller (include/resr.h resr_generator_chain_state_bytes)
     char* x_in;
     std::vector<char*> ws;
     char *bits_u2, *bits_c3;   // training: sign words (2 per pixel) of the HR activations u2, c3
@@ -186,6 +189,8 @@ void carve(const Plan& p, char* base, Bufs& b) {
         off += align_up(bytes, 256);
         return ptr;
     };
+    b.chain_bytes = conv3x3_chain_state_bytes(p.d.n, p.h, p.w);
+    b.chain = take(b.chain_bytes);
     b.x_in = take(px * p.ci_pad * es);
     const int nws = p.d.training ? p.nrdb : 3;
     b.ws.resize(nws);
@@ -258,6 +263,11 @@ size_t generator_packed_bytes(const ResrGeneratorDesc* d, int backward) {
     if (!build_plan(d, p)) return 0;
     // + two dummy (chunk,tap) of slack: conv3x3_kernel prefetches two taps past the end
     return (backward ? p.pk_total_elems : p.pk_fwd_elems) * elem_size(d->dtype) * (d->dtype == RESR_F16X2 ? 3 : 1) + 16384;
+}
+
+size_t generator_chain_state_bytes(const ResrGeneratorDesc* d) {
+    Plan p;
+    return build_plan(d, p) ? conv3x3_chain_state_bytes(p.d.n, p.h, p.w) : 0;
 }
 
 size_t generator_workspace_bytes(const ResrGeneratorDesc* d) {
@@ -438,7 +448,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
                 res1 = b.ws[(r - 2) % nws];
                 cd.s1 = 0.2f; cd.t1 = 1.f; cd.res1_stride = 32; cd.res1_chunk_stride = plane; cd.res1_lo_offset = lo_ws;
             }
-            RUN(conv3x3_block_dispatch(4, cds, cur, nullptr, ws4, bs4, nullptr, outs4, signs4, &cd, W(c), Bias(c), cur, res1, dst, st));
+            RUN(conv3x3_block_dispatch(4, cds, cur, nullptr, ws4, bs4, nullptr, outs4, signs4, &cd, W(c), Bias(c), cur, res1, dst, b.chain, b.chain_bytes, st));
         }
     }
     {   // conv2 + skip                                                   model.py:261-262
@@ -639,7 +649,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             cd.t0 = pos == 2 ? 0.2f : 1.f;       // d(rdb3_out*0.2 + x)/d(rdb3_out) reaches x3 scaled
             if (pos == 0) { res1 = b.gT[e_idx]; cd.res1_stride = 32; cd.res1_chunk_stride = plane; cd.s1 = 1.f; cd.t1 = 1.f; cd.res1_lo_offset = lo_t; }
             RUN(conv3x3_block_dispatch(4, cds, gin, b.gS, ws4, nullptr, masks4, outs4, nullptr, &cd,
-                                       pk + p.pk_bwd_trunk[(size_t)r * 5 + 4] * wes, nullptr, res0, res1, b.gT[nxt], st));
+                                       pk + p.pk_bwd_trunk[(size_t)r * 5 + 4] * wes, nullptr, res0, res1, b.gT[nxt], b.chain, b.chain_bytes, st));
             cur = nxt;
         }
         RUN(wgrad_run(wc, 5, h, w, 0));   // all five weight gradients of the block in one launch pair (they read gin and gS, not g_x)

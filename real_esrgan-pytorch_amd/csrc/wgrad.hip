@@ -37,6 +37,7 @@ namespace resr {
 
 constexpr int kMaxJobs = 80;    // (X chunk, G tile) pairs per launch
 constexpr int kMaxQuads = 40;   // 2x2 jobs per launch of the quad kernel
+constexpr int kX2WgradProductsDefault = 1;   // see wgrad_x2_products()
 constexpr int kSlab = 9 * 1024 + 32;   // floats per (job, split): 9 taps x 32 co x 32 ci, then 32 bias sums
 
 struct WgradJob {
@@ -826,17 +827,19 @@ int wgrad_debug_plan(const int* cin, const int* cout_pad, int nconv, int* out, i
 
 // One batched launch pair.  `convs` (wgrad.h) describes up to a dense block's worth of convolutions that share
 // n/h/w/flags; jobs are generated as (conv, ci chunk, co tile) -- three per product with RESR_F16X2.
-// RESR_F16X2: tap-products per algorithmic product of a weight gradient.  3 (default): X_hi^T G_hi + 2^-12 (X_hi^T G_lo +
-// X_lo^T G_hi), fp32-class.  1 ($RESR_X2_WGRAD_PRODUCTS=1): the hi tensors only -- the lo parts are rounding residues of
-// relative size 2^-12, independent from pixel to pixel, and a weight gradient sums >= 10^3 (tests) .. 10^6 (training) pixels,
-// so their contribution averages out far below the 1e-3 tolerance (measured: DESIGN.md section 5) at a third of the cost.
+// RESR_F16X2: tap-products per algorithmic product of a weight gradient.  1 (default): the hi tensors only, dW = X_hi^T G_hi --
+// a third of the matrix work.  The lo parts are rounding residues of relative size 2^-12 with zero mean, independent from pixel to
+// pixel; what they add to a weight gradient is a random walk next to the gradient's own sum, so the relative error does NOT shrink
+// with the pixel count, it sits at ~2^-11 whatever the size.  Measured on all 702 tensors of the 23-block generator against the
+// three-product form (tools/x2_wgrad_validate.py, profiles/r03_x2_wgrad_validate.json): worst tensor 9.0e-4 / 4.8e-4 / 4.1e-4 at
+// 2 x 256^2 / 16 x 64^2 / 1 x 24^2 (median 4.0e-4 / 2.7e-4 / 2.5e-4) -- inside the 1e-3 the parity tests hold every gradient
+// tensor to against the float64 evaluation of the oracle.  $RESR_X2_WGRAD_PRODUCTS=3: X_hi^T G_hi + 2^-12 (X_hi^T G_lo +
+// X_lo^T G_hi), fp32-class (5.8e-6), three times the cost.  Forward and backward-data always use the three stages.
 int wgrad_x2_products() {
-    static int v = 0;
-    if (!v) {
-        const char* e = getenv("RESR_X2_WGRAD_PRODUCTS");
-        v = (e && e[0] == '1') ? 1 : 3;
-    }
-    return v;
+    const char* e = getenv("RESR_X2_WGRAD_PRODUCTS");   // read per call: a validation run flips it inside one process
+    if (e && e[0] == '3') return 3;
+    if (e && e[0] == '1') return 1;
+    return kX2WgradProductsDefault;
 }
 
 size_t wgrad_batch_partial_bytes(const WgradConv* convs, int nconv, int splits, int dtype) {

@@ -142,8 +142,10 @@ class _Workspace:
     training-mode forwards that took it: only the graph that still owns it may release it (a stale token of an earlier
     graph, collected late, must not free a workspace a newer graph saved its activations in)."""
 
-    def __init__(self, nbytes: int, device) -> None:
+    def __init__(self, nbytes: int, device, zero_head: int = 0) -> None:
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if zero_head:      # the chain state of the dense-block launches: zero once (include/resr.h)
+            self.buf[:zero_head].zero_()
         self.busy = False
         self.owner = 0
 
@@ -366,7 +368,7 @@ class Generator(nn.Module):
         nbytes = L.resr_generator_workspace_bytes(C.byref(desc))
         if nbytes == 0:
             raise RuntimeError("resr_generator_workspace_bytes: unsupported shape")
-        ws = _Workspace(nbytes, device)
+        ws = _Workspace(nbytes, device, int(L.resr_generator_chain_state_bytes(C.byref(desc))))
         pool.append(ws)
         return ws
 

@@ -36,12 +36,14 @@ def _run(g, x, gw, no_chain):
 CASES = [(8, 16, 16, 1), (24, 18, 34, 1), (8, 24, 40, 2), (8, 64, 64, 1), (16, 36, 70, 1), (16, 128, 128, 1), (32, 64, 64, 1), (16, 256, 256, 1)]
 
 
+@pytest.mark.parametrize("precision", ["fast", "exact16"])
 @pytest.mark.parametrize("n,h,w,n_blocks", CASES)
-def test_chain_equals_separate_launches(n, h, w, n_blocks):
+def test_chain_equals_separate_launches(n, h, w, n_blocks, precision):
+    """fast and exact16 (hi/lo pairs: three stages per chunk, the dependent chunk = a job's last three stages)."""
     import real_esrgan_pytorch_amd as R
     L = R._lib
     torch.manual_seed(3)
-    g = R.Generator(3, 3, 4, precision="fast", n_blocks=n_blocks).cuda().train()
+    g = R.Generator(3, 3, 4, precision=precision, n_blocks=n_blocks).cuda().train()
     with torch.no_grad():
         g.conv4.bias.add_(0.5)
     gen = torch.Generator(device="cuda").manual_seed(7)
@@ -58,13 +60,14 @@ def test_chain_equals_separate_launches(n, h, w, n_blocks):
     assert err == 0, f"chain health counters: polls timed out {err & 0xffffffff}, misplaced workgroups {err >> 32}"
 
 
-def test_chain_is_taken():
+@pytest.mark.parametrize("precision", ["fast", "exact16"])
+def test_chain_is_taken(precision):
     """The profiling records show ONE conv launch for the passes of a block when chaining is on."""
     import ctypes as C
     import real_esrgan_pytorch_amd as R
     L = R._lib
     lib = L.lib()
-    g = R.Generator(3, 3, 4, precision="fast", n_blocks=1).cuda().train()
+    g = R.Generator(3, 3, 4, precision=precision, n_blocks=1).cuda().train()
     x = torch.rand(8, 3, 32, 32, device="cuda")
 
     def launches(no_chain):
@@ -92,8 +95,9 @@ def test_chain_is_taken():
 
 
 def test_chain_from_two_streams():
-    """Chained launches issued from two streams take turns (a change of the owning stream drains the device first): two
-    generators stepping on their own streams give what they give alone."""
+    """Chained launches issued from two streams take turns (a launch from another stream first waits -- stream-side, an event --
+    for the previous owner's last chain; nothing is synchronised on the host): two generators stepping on their own streams
+    give what they give alone."""
     import real_esrgan_pytorch_amd as R
     L = R._lib
     torch.manual_seed(5)
@@ -114,13 +118,14 @@ def test_chain_from_two_streams():
     assert int(L.lib().resr_debug_chain_errors()) == 0
 
 
+@pytest.mark.parametrize("precision", ["fast", "exact16"])
 @pytest.mark.parametrize("n,h,w", [(8, 40, 48), (16, 128, 96)])
-def test_chain_inference(n, h, w):
+def test_chain_inference(n, h, w, precision):
     """eval() forward (plain LeakyReLU epilogue, rotating workspaces): chained == four launches, bit for bit."""
     import real_esrgan_pytorch_amd as R
     L = R._lib
     torch.manual_seed(9)
-    g = R.Generator(3, 3, 4, precision="fast", n_blocks=2).cuda().eval()
+    g = R.Generator(3, 3, 4, precision=precision, n_blocks=2).cuda().eval()
     x = torch.rand(n, 3, h, w, device="cuda")
     os.environ["RESR_CONV_NO_CHAIN"] = "1"
     try:
@@ -164,9 +169,11 @@ def test_conv3x3_chain_entry_vs_torch(n, h, w):
         descs[k] = d
     arr = lambda ptrs: (C.c_void_p * 4)(*ptrs)
     outs = [ws.data_ptr() + (2 + k) * plane * 2 for k in range(4)]
+    # the chain state is the caller's: resr_conv3x3_chain_state_bytes of device memory, zero-filled once
+    state = torch.zeros(int(lib.resr_conv3x3_chain_state_bytes(n, h, w)), dtype=torch.uint8, device="cuda")
     L.check(lib.resr_conv3x3_chain(4, descs, L.ptr(ws), None, arr([p.data_ptr() for p in packed]),
                                    arr([b.data_ptr() for b in bias_d]), None, arr(outs),
-                                   arr([s.data_ptr() for s in signs]), L.stream_ptr()), "resr_conv3x3_chain")
+                                   arr([s.data_ptr() for s in signs]), L.ptr(state), state.numel(), L.stream_ptr()), "resr_conv3x3_chain")
     torch.cuda.synchronize()
     feats = [x]
     for k in range(4):   # the reference recursion on the values the kernel stored (f16 activations)
@@ -234,3 +241,63 @@ def test_pinned_pipeline_experiment():
     finally:
         os.environ.pop("RESR_CHAIN_PIPE", None)
     assert int(L.lib().resr_debug_chain_errors()) == 0
+
+
+def test_chain_next_to_a_kernel_that_holds_cus():
+    """A chained launch needs all its workgroups resident; a kernel of ANOTHER stream that holds CUs for a while (what an RCCL
+    all-reduce waiting for a peer looks like: data-parallel training overlaps them, train.DataParallel) only delays it: the
+    polls wait (up to ~4 s), nothing times out, the results are bit-equal."""
+    import real_esrgan_pytorch_amd as R
+    L = R._lib
+    lib = L.lib()
+    torch.manual_seed(3)
+    g = R.Generator(3, 3, 4, precision="fast", n_blocks=2).cuda().train()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.rand(16, 3, 128, 128, device="cuda", generator=gen)
+    gw = torch.randn(16, 3, 512, 512, device="cuda", generator=gen)
+    y0, g0, gx0 = _run(g, x, gw, no_chain=True)
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        # 24 workgroups x 150 KB of LDS: 24 CUs cannot take a conv workgroup for 30 ms (several whole passes)
+        L.check(lib.resr_debug_occupy(24, 150 * 1024, 30000, side.cuda_stream), "resr_debug_occupy")
+        y1, g1, gx1 = _run(g, x, gw, no_chain=False)
+        assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+        for a, b in zip(g0, g1):
+            assert torch.equal(a, b)
+    torch.cuda.synchronize()
+    assert int(lib.resr_chain_errors()) == 0 and int(lib.resr_debug_chain_errors()) == 0
+
+
+def test_chain_state_too_small_falls_back():
+    """A chain state that does not cover the geometry (or none at all) means one launch per job -- same results."""
+    import ctypes as C
+    from tests import gpu_util as U
+    L = U.L
+    lib = L.lib()
+    n, h, w = 8, 32, 32
+    g = torch.Generator().manual_seed(1)
+    ws = torch.zeros(6, n, h, w, 32, dtype=torch.float16, device="cuda")
+    ws[:2] = torch.randn(2, n, h, w, 32, generator=g).half().cuda()
+    plane = n * h * w * 32
+    descs = (L.ConvDesc * 4)()
+    packed, bias_d = [], []
+    for k in range(4):
+        cin = 64 + 32 * k
+        packed.append(U.pack_conv(torch.randn(32, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5, L.RESR_F16))
+        bias_d.append((torch.randn(32, generator=g) * 0.1).cuda())
+        d = L.ConvDesc(n, h, w, cin, cin, 32, 0, 32, 32, 32, 0, 0, 0, L.RESR_F16, L.CONV_LRELU, 1.0, 1.0, 1.0, 1.0, 0.2)
+        d.in0_chunk_stride = plane
+        descs[k] = d
+    arr = lambda ptrs: (C.c_void_p * 4)(*ptrs)
+    res = []
+    for state in (torch.zeros(int(lib.resr_conv3x3_chain_state_bytes(n, h, w)), dtype=torch.uint8, device="cuda"),
+                  torch.zeros(128, dtype=torch.uint8, device="cuda"), None):
+        ws[2:] = 0
+        outs = [ws.data_ptr() + (2 + k) * plane * 2 for k in range(4)]
+        L.check(lib.resr_conv3x3_chain(4, descs, L.ptr(ws), None, arr([p.data_ptr() for p in packed]), arr([b.data_ptr() for b in bias_d]),
+                                       None, arr(outs), None, L.ptr(state), 0 if state is None else state.numel(), L.stream_ptr()),
+                "resr_conv3x3_chain")
+        torch.cuda.synchronize()
+        res.append(ws[2:].clone())
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+    assert res[0].abs().sum().item() > 0
