@@ -16,7 +16,7 @@ from torch.utils.data import DataLoader, Dataset
 from . import imgproc
 from .degrade import sample_blur_kernels
 
-__all__ = ["TrainValidImageDataset", "TestImageDataset", "CUDAPrefetcher"]
+__all__ = ["TrainValidImageDataset", "TestImageDataset", "PrefetchGenerator", "PrefetchDataLoader", "CPUPrefetcher", "CUDAPrefetcher"]
 
 
 class TrainValidImageDataset(Dataset):
@@ -76,8 +76,7 @@ class CUDAPrefetcher:
     reference dataset.py:271-312) as a small HBM staging pipeline: while the step of batch i runs, batch i+1 is uploaded
     on a side HIP stream from pinned memory; `next()` orders the consumer behind that upload with an event (no stream-wide
     wait) and tells the caching allocator which stream now uses the tensors.  The device work of a batch (degradation)
-    starts one slot later, in `degrade.Degrader` / the train step.  (The reference's CPU-side prefetch helpers --
-    PrefetchGenerator, PrefetchDataLoader, CPUPrefetcher -- are used by none of its entry points and are not provided.)"""
+    starts one slot later, in `degrade.DegradationPrefetcher` / the train step."""
 
     def __init__(self, dataloader: DataLoader, device: torch.device) -> None:
         self.original_dataloader = dataloader
@@ -114,6 +113,63 @@ class CUDAPrefetcher:
     def reset(self) -> None:
         self._it = iter(self.original_dataloader)
         self._stage()
+
+    def __len__(self) -> int:
+        return len(self.original_dataloader)
+
+
+class PrefetchGenerator:
+    """Reference dataset.py:200-228: iterate `generator` on a daemon thread, `num_data_prefetch_queue` items ahead."""
+
+    def __init__(self, generator, num_data_prefetch_queue: int) -> None:
+        import queue
+        import threading
+        self._queue = queue.Queue(num_data_prefetch_queue)
+        self._end = object()
+
+        def work():
+            for item in generator:
+                self._queue.put(item)
+            self._queue.put(self._end)
+        self._thread = threading.Thread(target=work, daemon=True)
+        self._thread.start()
+
+    def __next__(self):
+        item = self._queue.get()
+        if item is self._end:
+            raise StopIteration
+        return item
+
+    def __iter__(self):
+        return self
+
+
+class PrefetchDataLoader(DataLoader):
+    """Reference dataset.py:231-245: a DataLoader whose iterator runs `num_data_prefetch_queue` batches ahead on a thread."""
+
+    def __init__(self, num_data_prefetch_queue: int, **kwargs) -> None:
+        self.num_data_prefetch_queue = num_data_prefetch_queue
+        super().__init__(**kwargs)
+
+    def __iter__(self):
+        return PrefetchGenerator(super().__iter__(), self.num_data_prefetch_queue)
+
+
+class CPUPrefetcher:
+    """Reference dataset.py:248-268: `next()` -> batch or None, `reset()`, `len()` over a DataLoader, host side only."""
+
+    def __init__(self, dataloader: DataLoader) -> None:
+        self.original_dataloader = dataloader
+        self.data = iter(dataloader)
+
+    def next(self):
+        try:
+            return next(self.data)
+        except StopIteration:
+            return None
+
+    def reset(self) -> None:
+        self.data = iter(self.original_dataloader)
 
     def __len__(self) -> int:
         return len(self.original_dataloader)

@@ -194,3 +194,61 @@ class Degrader:
         hrc.record_stream(torch.cuda.current_stream())
         self._pending = self._enqueue(hr)          # next batch degrades under this batch's generator step
         return lr, hrc
+
+
+class DegradationPrefetcher:
+    """What the two training scripts iterate over: the reference's batch source (`CUDAPrefetcher`, dataset.py:271-312) with
+    the degradation stage of train_realesrnet.py:262-377 attached ONE BATCH AHEAD on a side stream -- the device-side
+    counterpart of the prefetcher's upload slot.  `next()` returns (lr, hr_crop, batch) of the batch whose degradation was
+    enqueued during the previous call and, before returning, takes the following batch from the source and enqueues ITS
+    degradation on the side stream: those kernels run under the generator step the caller is about to issue.  The blur
+    kernels are the ones the dataset sampled per image (dataset.py:82-143); the host draws of a batch (`sample_plan`) happen
+    in the reference's order -- source batch i+1, then plan i -- so a fixed seed gives the reference's sequence.
+
+    `done_events` keeps the (start, end) events of the last enqueued degradation for tests."""
+
+    def __init__(self, source, usm: imgproc.USMSharp, jpeg: imgproc.DiffJPEG, upscale: int, crop: int,
+                 device: Optional[torch.device] = None) -> None:
+        self.source, self.usm, self.jpeg, self.upscale, self.crop = source, usm, jpeg, upscale, crop
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._pending = None
+        self.done_events = None
+
+    def __len__(self) -> int:
+        return len(self.source)
+
+    def _enqueue(self, batch):
+        if batch is None:
+            return None
+        hr = batch["hr"].to(device=self.device, non_blocking=True)
+        _lib.require_cuda(hr, "DegradationPrefetcher")
+        plan = sample_plan(hr.shape[0], hr.shape[2], hr.shape[3], self.crop, with_kernels=False)
+        plan.kernel1, plan.kernel2, plan.sinc_kernel = batch["kernel1"], batch["kernel2"], batch["sinc_kernel"]
+        main = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(main)              # the upload of `batch` was ordered into the consumer stream by the source
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self.stream):
+            start.record(self.stream)
+            lr, hrc = run_plan(hr, plan, self.usm, self.jpeg, self.upscale, self.crop)
+            end.record(self.stream)
+        for t in (hr, batch["kernel1"], batch["kernel2"], batch["sinc_kernel"]):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.stream)
+        self.done_events = (start, end)
+        return lr, hrc, batch, end
+
+    def reset(self) -> None:
+        self.source.reset()
+        self._pending = self._enqueue(self.source.next())
+
+    def next(self):
+        if self._pending is None:
+            return None
+        lr, hrc, batch, done = self._pending
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(done)
+        lr.record_stream(main)
+        hrc.record_stream(main)
+        self._pending = self._enqueue(self.source.next())     # batch i+1 degrades under step i
+        return lr, hrc, batch

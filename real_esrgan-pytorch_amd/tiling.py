@@ -45,11 +45,13 @@ class TiledGenerator:
             th, tw = (self.tile, self.tile) if isinstance(self.tile, int) else self.tile
             return max(1, math.ceil(H / th)), max(1, math.ceil(W / tw))
         s = self.model.upscale_factor
+        r = {4: 1, 2: 2, 1: 4}[s]                       # windows are rounded up to the pixel-unshuffle factor (plan()): price them that way
+        halo = math.ceil(self.halo / r) * r
         best = None
         for ny in range(1, 65):
             for nx in range(1, 65):
-                wh = min(H, math.ceil(H / ny) + 2 * self.halo)
-                ww = min(W, math.ceil(W / nx) + 2 * self.halo)
+                wh = min(H, math.ceil(math.ceil(H / ny) / r) * r + 2 * halo)
+                ww = min(W, math.ceil(math.ceil(W / nx) / r) * r + 2 * halo)
                 if n * wh * s * ww * s > _MAX_OUT_PIXELS:
                     continue
                 cost = (ny * nx * wh * ww, ny * nx)
@@ -85,12 +87,15 @@ class TiledGenerator:
             out[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = sr[:, :, (y0 - wy) * s:(y1 - wy) * s, (x0 - wx) * s:(x1 - wx) * s]
 
     @torch.no_grad()
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Returns a NEW tensor per call (or fills `out`): in graph mode the replay writes a static buffer, which the next
+        frame overwrites -- `[tg(f) for f in frames]` must not alias it.  `out=` saves the copy's allocation in a frame loop."""
         n, c, H, W = x.shape
         s = self.model.upscale_factor
         tiles, win_h, win_w = self.plan(n, H, W)
         if not self.use_graph:
-            out = torch.empty((n, self.model.out_channels, H * s, W * s), dtype=torch.float32, device=x.device)
+            if out is None:
+                out = torch.empty((n, self.model.out_channels, H * s, W * s), dtype=torch.float32, device=x.device)
             self._run_tiles(x.float(), out, tiles, win_h, win_w)
             return out
         # The captured launches bake in the addresses of the parameter arena, the packed weights and the workspace:
@@ -111,4 +116,7 @@ class TiledGenerator:
             self._held = (self.model.flat_parameters(), self.model._packed, dict(self.model._workspaces))
         self._frame_in.copy_(x)
         self._graph.replay()
-        return self._frame_out
+        if out is None:
+            return self._frame_out.clone()
+        out.copy_(self._frame_out)
+        return out

@@ -24,6 +24,8 @@ def setup_distributed(backend: Optional[str] = None) -> tuple:
     """One process per GPU: bind this process to `cuda:LOCAL_RANK` and, when launched with WORLD_SIZE > 1
     (`python -m torch.distributed.run --nproc-per-node N ...`), join the process group -- backend "nccl" is RCCL over xGMI.
     Returns (rank, world, device).  Safe to call in a single-process run (world 1, no process group)."""
+    # the HSA runtime reads its environment when the first HIP call initialises it: set it before anything touches the GPU
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -31,7 +33,6 @@ def setup_distributed(backend: Optional[str] = None) -> tuple:
     torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes
         backend = backend or os.environ.get("RESR_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -62,6 +63,29 @@ class DataParallel:
     def __init__(self, bucket_bytes: int = 12 << 20) -> None:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.backend = dist.get_backend() if dist.is_initialized() else None
+        # RCCL averages inside the collective (ncclAvg); gloo (the CPU tests) sums and the mean is one more pass
+        self._avg = self.backend == "nccl"
+        self._warm = False
+
+    def _op(self):
+        return dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+
+    def _finish_mean_(self, flat: torch.Tensor) -> None:
+        if not self._avg:
+            flat.mul_(1.0 / self.world)
+
+    def warm_up(self, device) -> None:
+        """Communicator set-up (seconds on a cold node) happens on the first collective: do it HERE, with every rank
+        waiting, not under the first training step -- a chained conv launch next to a collective that waits seconds for a
+        late peer would run into its poll time-out (conv3x3_ws.h)."""
+        if self.world > 1 and not self._warm:
+            t = torch.zeros(1024, dtype=torch.float32, device=device)
+            dist.all_reduce(t)
+            if t.is_cuda:
+                torch.cuda.synchronize(device)
+            dist.barrier()
+            self._warm = True
 
     def broadcast_(self, flat: torch.Tensor) -> None:
         if self.world > 1:
@@ -74,18 +98,28 @@ class DataParallel:
             return
         works = []
         for off in range(0, flat.numel(), self.bucket_elems):
-            works.append(dist.all_reduce(flat[off:off + self.bucket_elems], op=dist.ReduceOp.SUM, async_op=True))
+            works.append(dist.all_reduce(flat[off:off + self.bucket_elems], op=self._op(), async_op=True))
         for w in works:
             w.wait()
-        flat.mul_(1.0 / self.world)
+        self._finish_mean_(flat)
 
-    def attach(self, model: Generator, overlap: bool = True) -> None:
+    def attach(self, model: Generator, overlap: Optional[bool] = None) -> None:
         """Generator: identical initial weights, then the gradient arena is all-reduced once per backward (the generator runs
         exactly one backward per optimiser step in both training scripts: train_realesrnet.py:388, train_realesrgan.py:484).
         overlap=True: bucket by bucket on a communication stream WHILE the rest of the backward pass runs -- the native
-        backward fires an event per finished arena range (tail convs, then RRDB 22 ... 0, then conv1)."""
-        self.broadcast_(model.flat_parameters())
-        if overlap and self.world > 1:
+        backward fires an event per finished arena range (tail convs, then RRDB 22 ... 0, then conv1).
+        Default ($RESR_DP_OVERLAP=1 to turn it on): OFF.  The exchange is then issued once, right behind the backward pass,
+        and overlaps the NEXT batch's degradation on its side stream only.  Why off: the backward pass runs its dense blocks
+        as chained launches that need every CU (conv3x3_ws.h); an RCCL kernel next to them only delays them (tests/
+        test_gpu_chain.py holds CUs with a stand-in kernel), but that combination has not run on a multi-GPU box yet, and
+        what overlap buys is small -- 67 MB over xGMI is under a millisecond of a 120 ms step."""
+        flat = model.flat_parameters()
+        self.warm_up(flat.device)
+        self.broadcast_(flat)
+        if overlap is None:
+            overlap = os.environ.get("RESR_DP_OVERLAP", "0") == "1"
+        self.overlap = bool(overlap and self.world > 1)
+        if self.overlap:
             model.grad_ready_hook = self.all_reduce_ranges_
         else:
             model.grad_hook = self.all_reduce_mean_
@@ -97,29 +131,48 @@ class DataParallel:
         ranges; the caller's stream rejoins at the end."""
         if self.world == 1:
             return
+        buckets = self.merge_ranges(ranges)
+        if not flat.is_cuda:                       # host tensors (the gloo tests of this logic): no streams, same buckets
+            for lo, hi, _ in buckets:
+                dist.all_reduce(flat[lo:hi], op=self._op())
+            self._finish_mean_(flat)
+            return
         main = torch.cuda.current_stream(flat.device)
         if getattr(self, "_comm", None) is None:
             self._comm = torch.cuda.Stream(device=flat.device)
-        works, hi_open = [], None
-        for i, (lo, hi) in enumerate(ranges):
-            if hi_open is None:
-                hi_open = hi
-            if hi_open - lo >= self.bucket_elems or i == len(ranges) - 1:
-                self._comm.wait_event(events[i])
-                with torch.cuda.stream(self._comm):
-                    works.append(dist.all_reduce(flat[lo:hi_open], op=dist.ReduceOp.SUM, async_op=True))
-                hi_open = None
+        works = []
+        for lo, hi, last in buckets:
+            self._comm.wait_event(events[last])
+            with torch.cuda.stream(self._comm):
+                works.append(dist.all_reduce(flat[lo:hi], op=self._op(), async_op=True))
         for w in works:
             w.wait()
         main.wait_stream(self._comm)
-        flat.mul_(1.0 / self.world)
+        self._finish_mean_(flat)
+
+    def merge_ranges(self, ranges) -> list:
+        """Adjacent, descending (lo, hi) ranges -> buckets (lo, hi, index of the LAST range inside): a bucket closes as soon as
+        it holds >= bucket size elements; the tail of the list closes the last one whatever its size."""
+        out, hi_open = [], None
+        for i, (lo, hi) in enumerate(ranges):
+            if hi_open is None:
+                hi_open = hi
+            elif hi != prev_lo:
+                raise ValueError("all_reduce_ranges_: ranges must be adjacent and descending")
+            prev_lo = lo
+            if hi_open - lo >= self.bucket_elems or i == len(ranges) - 1:
+                out.append((lo, hi_open, i))
+                hi_open = None
+        return out
 
     def attach_discriminator(self, discriminator: nn.Module) -> None:
         """Discriminator: identical initial weights AND spectral-norm power-iteration vectors `weight_u` / `weight_v`
         (they then stay identical, being deterministic functions of identical weights).  Its gradients are the sum of TWO
         backward passes (train_realesrgan.py:503-516), so they are reduced once, explicitly, by `all_reduce_grads_` after
         the second one -- not from a per-backward hook."""
-        self.broadcast_(discriminator.flat_parameters())
+        flat = discriminator.flat_parameters()
+        self.warm_up(flat.device)
+        self.broadcast_(flat)
         if self.world > 1:
             if hasattr(discriminator, "flat_uv"):          # the eight (u, v) pairs as one message
                 dist.broadcast(discriminator.flat_uv(), src=0)

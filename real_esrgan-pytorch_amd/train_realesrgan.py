@@ -24,13 +24,14 @@ from . import config, imgproc
 from . import _lib
 from .content_loss import ContentLoss
 from .dataset import CUDAPrefetcher
-from .degrade import run_plan, sample_plan
+from .degrade import DegradationPrefetcher
 from .discriminator import Discriminator
 from .image_quality_assessment import NIQE
 from .model import EMA, Generator
 from . import train_realesrnet as _net
 from .train import DataParallel, RealESRGANStep, setup_distributed
-from .train_realesrnet import RunningStats, ScalarWriter, load_dataset, validate  # noqa: F401
+from .meters import AverageMeter, ProgressMeter, Summary  # noqa: F401
+from .train_realesrnet import ScalarWriter, load_dataset, validate  # noqa: F401
 
 
 def build_model() -> List[nn.Module]:
@@ -85,6 +86,7 @@ def main() -> None:
     rank, world, device = setup_distributed()            # one process per GPU: cuda:LOCAL_RANK, RCCL group when WORLD_SIZE > 1
     _net._RANK, _net._WORLD = rank, world
     config.device = device
+    _net.seed_rank(rank, world)
     start_epoch, best_niqe = 0, 100.0
     train_prefetcher, valid_prefetcher, test_prefetcher = load_dataset()
     discriminator, generator, ema_model = build_model()
@@ -127,7 +129,7 @@ def main() -> None:
             sampler.set_epoch(epoch)
         train(discriminator, generator, ema_model, train_prefetcher, pixel_criterion, content_criterion,
               adversarial_criterion, d_optimizer, g_optimizer, epoch, scaler, writer)
-        _lib.chain_health()   # fail loudly if a chained conv launch ever gave up on a neighbouring tile
+        _lib.chain_health(sync=True)   # fail loudly if a chained conv launch ever gave up on a neighbouring tile
         _ = validate(generator, ema_model, valid_prefetcher, epoch, writer, niqe_model, "Valid")
         niqe = validate(generator, ema_model, test_prefetcher, epoch, writer, niqe_model, "Test")
         print("\n")
@@ -161,32 +163,37 @@ def train(discriminator: nn.Module, generator: nn.Module, ema_model: nn.Module, 
     usm_sharpener = imgproc.USMSharp(50, 0).to(device=config.device)
     batches = len(train_prefetcher)
     names = ["pixel_loss", "content_loss", "adversarial_loss", "d_loss_hr", "d_loss_sr", "d_hr_probability", "d_sr_probability"]
-    stats = RunningStats("time", *names)
+    batch_time = AverageMeter("Time", ":6.3f", Summary.NONE)              # :295-309
+    meters = {k: AverageMeter(label, fmt, Summary.NONE) for k, label, fmt in (
+        ("pixel_loss", "Pixel loss", ":6.6f"), ("content_loss", "Content loss", ":6.6f"), ("adversarial_loss", "Adversarial loss", ":6.6f"),
+        ("d_loss_hr", "D(HR) loss", ":6.6f"), ("d_loss_sr", "D(SR) loss", ":6.6f"),
+        ("d_hr_probability", "D(HR)", ":6.3f"), ("d_sr_probability", "D(SR)", ":6.3f"))}
+    progress = ProgressMeter(batches, [batch_time] + [meters[k] for k in names], prefix=f"Epoch: [{epoch + 1}]")
     discriminator.train()
     generator.train()
 
-    def degrade(hr):   # host draws in the reference's order, kernels from the dataset batch (:330-452)
-        plan = sample_plan(hr.shape[0], hr.shape[2], hr.shape[3], config.image_size, with_kernels=False)
-        plan.kernel1, plan.kernel2, plan.sinc_kernel = kernels
-        return run_plan(hr, plan, usm_sharpener, jpeg_operation, config.upscale_factor, config.image_size)
-
-    step = RealESRGANStep(generator, discriminator, ema_model, g_optimizer, d_optimizer, scaler, degrade,
+    # the second-order degradation (:330-452) one batch ahead on a side stream, under the previous batch's step
+    degraded = DegradationPrefetcher(train_prefetcher, usm_sharpener, jpeg_operation, config.upscale_factor, config.image_size,
+                                     config.device)
+    step = RealESRGANStep(generator, discriminator, ema_model, g_optimizer, d_optimizer, scaler, None,
                           config.pixel_weight, config.adversarial_weight, content_criterion, config.content_weight,
                           return_probabilities=True, dp=_DP)
     step.pixel, step.adv = pixel_criterion, adversarial_criterion
     batch_index = 0
-    train_prefetcher.reset()
-    batch_data = train_prefetcher.next()
+    degraded.reset()
+    item = degraded.next()
     end = time.time()
-    while batch_data is not None:
-        hr = batch_data["hr"].to(device=config.device, non_blocking=True)
-        kernels = (batch_data["kernel1"], batch_data["kernel2"], batch_data["sinc_kernel"])
-        out = step(hr)
+    while item is not None:
+        lr, hr, _ = item
+        out = step(hr, lr)
+        zero = out["pixel_loss"].new_zeros(())
+        for k in names:                                    # :527-535 -- every batch counts; accumulated on the device, no read-back
+            meters[k].update(out.get(k, zero).float().reshape(()), hr.size(0))
+        batch_time.update(time.time() - end)
         if batch_index % config.print_frequency == 0:
-            # one D2H transfer for everything the console line and the log need (the reference does 5-12 `.item()` syncs per step)
-            zero = out["pixel_loss"].new_zeros(())
-            vals = dict(zip(names, torch.stack([out.get(k, zero).float() for k in names]).tolist()))
-            stats.update(hr.size(0), time=time.time() - end, **vals)
+            _lib.chain_health()      # two host-mapped counters, no synchronisation
+            # one D2H transfer for everything the log needs (the reference does 5-12 `.item()` syncs per step)
+            vals = dict(zip(names, torch.stack([out.get(k, zero).float().reshape(()) for k in names]).tolist()))
             iters = batch_index + epoch * batches + 1
             writer.add_scalar("Train/D_Loss", vals["d_loss_hr"] + vals["d_loss_sr"], iters)
             writer.add_scalar("Train/G_Loss", vals["pixel_loss"] + vals["content_loss"] + vals["adversarial_loss"], iters)
@@ -196,9 +203,9 @@ def train(discriminator: nn.Module, generator: nn.Module, ema_model: nn.Module, 
             writer.add_scalar("Train/D(HR)_Probability", vals["d_hr_probability"], iters)
             writer.add_scalar("Train/D(SR)_Probability", vals["d_sr_probability"], iters)
             if _net._RANK == 0:
-                print(stats.line(f"Epoch [{epoch + 1}] batch {batch_index}/{batches}  "))
+                progress.display(batch_index)
         end = time.time()
-        batch_data = train_prefetcher.next()
+        item = degraded.next()
         batch_index += 1
 
 

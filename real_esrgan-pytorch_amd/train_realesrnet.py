@@ -24,8 +24,9 @@ from torch.utils.data import DataLoader
 from . import config, imgproc
 from . import _lib
 from .dataset import CUDAPrefetcher, TestImageDataset, TrainValidImageDataset
-from .degrade import run_plan, sample_plan
+from .degrade import DegradationPrefetcher
 from .image_quality_assessment import NIQE
+from .meters import AverageMeter, ProgressMeter, Summary  # noqa: F401  (the reference's script-level names)
 from .model import EMA, Generator
 from .train import DataParallel, RealESRNetStep, setup_distributed
 
@@ -46,29 +47,17 @@ class ScalarWriter:
             f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
 
 
-class RunningStats:
-    """Sample-weighted running means of a few named scalars, for the console line of the loops."""
-
-    def __init__(self, *names: str) -> None:
-        self.names = names
-        self.total = dict.fromkeys(names, 0.0)
-        self.last = dict.fromkeys(names, 0.0)
-        self.count = 0
-
-    def update(self, n: int = 1, **values: float) -> None:
-        self.count += n
-        for k, v in values.items():
-            self.last[k] = v
-            self.total[k] += v * n
-
-    def mean(self, name: str) -> float:
-        return self.total[name] / max(1, self.count)
-
-    def line(self, prefix: str) -> str:
-        return prefix + "  ".join(f"{k} {self.last[k]:.5f} (mean {self.mean(k):.5f})" for k in self.names)
-
-
 _RANK, _WORLD = 0, 1     # set by main() through train.setup_distributed()
+
+
+def seed_rank(rank: int, world: int, base: int = 0) -> None:
+    """Data-parallel ranks must not draw the same degradation plans, sigma / quality values and crop offsets: the host and
+    device generators of rank r restart at base + r (rank 0 keeps the reference's seeds, config.py:64-66)."""
+    if world > 1:
+        import random
+        random.seed(base + rank)
+        np.random.seed(base + rank)
+        torch.manual_seed(base + rank)
 
 
 def load_dataset() -> List[CUDAPrefetcher]:
@@ -142,6 +131,7 @@ def main() -> None:
     global _RANK, _WORLD
     _RANK, _WORLD, device = setup_distributed()          # one process per GPU: cuda:LOCAL_RANK, RCCL group when WORLD_SIZE > 1
     config.device = device
+    seed_rank(_RANK, _WORLD)
     start_epoch, best_niqe = 0, 100.0
     train_prefetcher, valid_prefetcher, test_prefetcher = load_dataset()
     model, ema_model = build_model()
@@ -165,7 +155,7 @@ def main() -> None:
         if hasattr(sampler, "set_epoch"):
             sampler.set_epoch(epoch)
         train(model, ema_model, train_prefetcher, pixel_criterion, optimizer, epoch, scaler, writer)
-        _lib.chain_health()   # fail loudly if a chained conv launch ever gave up on a neighbouring tile
+        _lib.chain_health(sync=True)   # fail loudly if a chained conv launch ever gave up on a neighbouring tile
         _ = validate(model, ema_model, valid_prefetcher, epoch, writer, niqe_model, "Valid")
         niqe = validate(model, ema_model, test_prefetcher, epoch, writer, niqe_model, "Test")
         print("\n")
@@ -182,33 +172,35 @@ def train(model: nn.Module, ema_model: nn.Module, train_prefetcher: CUDAPrefetch
     jpeg_operation = imgproc.DiffJPEG(False)
     usm_sharpener = imgproc.USMSharp(50, 0).to(device=config.device)
     batches = len(train_prefetcher)
-    stats = RunningStats("time", "data", "loss")
+    batch_time = AverageMeter("Time", ":6.3f", Summary.NONE)            # :219-224
+    data_time = AverageMeter("Data", ":6.3f", Summary.NONE)
+    losses = AverageMeter("Loss", ":6.6f", Summary.NONE)
+    progress = ProgressMeter(batches, [batch_time, data_time, losses], prefix=f"Epoch: [{epoch + 1}]")
     model.train()
 
-    def degrade(hr):   # host draws in the reference's order, kernels from the dataset batch (:262-377)
-        plan = sample_plan(hr.shape[0], hr.shape[2], hr.shape[3], config.image_size, with_kernels=False)
-        plan.kernel1, plan.kernel2, plan.sinc_kernel = kernels
-        return run_plan(hr, plan, usm_sharpener, jpeg_operation, config.upscale_factor, config.image_size)
-
-    step = RealESRNetStep(model, ema_model, optimizer, scaler, degrade)
+    # The second-order degradation (:262-377: host draws in the reference's order, blur kernels from the dataset batch) runs
+    # ONE BATCH AHEAD on a side stream: batch i+1's kernels are enqueued before step i is issued and run under it.
+    degraded = DegradationPrefetcher(train_prefetcher, usm_sharpener, jpeg_operation, config.upscale_factor, config.image_size,
+                                     config.device)
+    step = RealESRNetStep(model, ema_model, optimizer, scaler, None)
     step.criterion = pixel_criterion
     batch_index = 0
-    train_prefetcher.reset()
-    batch_data = train_prefetcher.next()
+    degraded.reset()
+    item = degraded.next()
     end = time.time()
-    while batch_data is not None:
-        t_data = time.time() - end
-        hr = batch_data["hr"].to(device=config.device, non_blocking=True)
-        kernels = (batch_data["kernel1"], batch_data["kernel2"], batch_data["sinc_kernel"])
-        loss = step(hr)
+    while item is not None:
+        data_time.update(time.time() - end)
+        lr, hr, _ = item
+        loss = step(hr, lr)
+        losses.update(loss, hr.size(0))                    # :397 -- every batch counts; accumulated on the device, no read-back
+        batch_time.update(time.time() - end)
         if batch_index % config.print_frequency == 0:      # the only host read-back of the loop
-            value = loss.item()
-            stats.update(hr.size(0), time=time.time() - end, data=t_data, loss=value)
-            writer.add_scalar("Train/Loss", value, batch_index + epoch * batches + 1)
+            writer.add_scalar("Train/Loss", losses.val, batch_index + epoch * batches + 1)
+            _lib.chain_health()                            # two host-mapped counters, no synchronisation: a broken chained launch aborts here
             if _RANK == 0:
-                print(stats.line(f"Epoch [{epoch + 1}] batch {batch_index}/{batches}  "))
+                progress.display(batch_index)
         end = time.time()
-        batch_data = train_prefetcher.next()
+        item = degraded.next()
         batch_index += 1
 
 
@@ -217,7 +209,8 @@ def validate(model: nn.Module, ema_model: nn.Module, data_prefetcher: CUDAPrefet
     """Reference train_realesrnet.py:416-488: EMA weights applied for the evaluation, restored afterwards."""
     if mode not in ("Valid", "Test"):
         raise ValueError("Unsupported mode, please use `Valid` or `Test`.")
-    stats = RunningStats("time", "niqe")
+    batch_time = AverageMeter("Time", ":6.3f", Summary.NONE)
+    niqe_metrics = AverageMeter("NIQE", ":4.2f", Summary.AVERAGE)
     ema_model.apply_shadow()
     model.eval()
     batch_index = 0
@@ -229,15 +222,16 @@ def validate(model: nn.Module, ema_model: nn.Module, data_prefetcher: CUDAPrefet
             lr = batch_data["lr"].to(device=config.device, non_blocking=True)
             sr = model(lr)
             niqe = niqe_model(sr)
-            stats.update(lr.size(0), time=time.time() - end, niqe=niqe.item())
+            niqe_metrics.update(niqe.reshape(()), lr.size(0))
+            batch_time.update(time.time() - end)
             end = time.time()
             batch_data = data_prefetcher.next()
             batch_index += 1
     ema_model.restore()
     if _RANK == 0:
-        print(f"{mode}: NIQE {stats.mean('niqe'):.4f} over {stats.count} images")
-    writer.add_scalar(f"{mode}/NIQE", stats.mean("niqe"), epoch + 1)
-    return stats.mean("niqe")
+        ProgressMeter(len(data_prefetcher), [batch_time, niqe_metrics], prefix=f"{mode}: ").display_summary()
+    writer.add_scalar(f"{mode}/NIQE", niqe_metrics.avg, epoch + 1)
+    return niqe_metrics.avg
 
 
 if __name__ == "__main__":

@@ -109,3 +109,49 @@ def test_module_grad_exchange_and_buffer_broadcast_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] and r[2] and r[3] for r in res), res
+
+
+def _ranges_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd.train import DataParallel
+    g = R.Generator(3, 3, 4)                               # parameter containers only: no GPU involved
+    ranges = g.grad_ranges()                               # the 25 ranges resr_generator_backward fires events for
+    total = sum(p.numel() for p in g.parameters())
+    dp = DataParallel()                                    # the real 12 MB buckets
+    buckets = dp.merge_ranges(ranges)
+    idx = torch.arange(total, dtype=torch.float32)
+    flat = (idx % 1000) * 1e-3 + float(rank)
+    dp.all_reduce_ranges_(flat, ranges, [None] * len(ranges))
+    want = (idx % 1000) * 1e-3 + (world - 1) / 2.0
+    q.put((rank, len(ranges), total, buckets, float((flat - want).abs().max())))
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_buckets_world8_real_range_table():
+    """World 8 (the node BASELINE config 4 names), gloo, host tensors: the bucket merging of `all_reduce_ranges_` over the REAL
+    range table of the 23-block generator -- tail convs, RRDB 22 ... 0, conv1 -- reduces every element of the 16.7 M-element
+    arena exactly once (a gap or an overlap between buckets would show as a wrong mean)."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ranges_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == list(range(world))
+    nr, total, buckets = res[0][1], res[0][2], res[0][3]
+    assert nr == 25 and total == 16_697_987                     # SURVEY 8: 16,697,987 parameters
+    # buckets: disjoint, descending, covering [0, total); all but the last at least 12 MB; each closes on the event of its last range
+    assert buckets[0][1] == total and buckets[-1][0] == 0 and buckets[-1][2] == nr - 1
+    for (lo, hi, last), nxt in zip(buckets, buckets[1:] + [None]):
+        assert hi > lo and (nxt is None or nxt[1] == lo)
+        assert nxt is None or (hi - lo) * 4 >= 12 << 20
+    assert 4 <= len(buckets) <= 6, buckets                        # 66.8 MB in >= 12 MB buckets
+    assert all(r[4] < 1e-5 for r in res), [r[4] for r in res]

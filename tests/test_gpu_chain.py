@@ -301,3 +301,42 @@ def test_chain_state_too_small_falls_back():
         res.append(ws[2:].clone())
     assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
     assert res[0].abs().sum().item() > 0
+
+
+def test_chain_timeout_poisons_the_output_and_counts():
+    """A chained launch whose workgroups cannot all become resident for longer than the poll time-out (here: a stand-in kernel
+    holds 200 CUs for 9 s) must fail LOUDLY: the planes it could not wait for are read as NaNs, so the output is NaN (a
+    training loss shows it at once), and the host-mapped counter -- read without any synchronisation -- is non-zero.
+    In a subprocess: the error state is sticky for the process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, torch
+sys.path.insert(0, %r)
+import real_esrgan_pytorch_amd as R
+L = R._lib; lib = L.lib()
+torch.manual_seed(0)
+g = R.Generator(3, 3, 4, precision="fast", n_blocks=1).cuda().eval()
+x = torch.rand(8, 3, 64, 64, device="cuda")
+with torch.no_grad():
+    y_ok = g(x).clone()
+torch.cuda.synchronize()
+assert int(lib.resr_chain_errors()) == 0 and torch.isfinite(y_ok).all()
+side = torch.cuda.Stream()
+L.check(lib.resr_debug_occupy(200, 150 * 1024, 9000000, side.cuda_stream), "occupy")
+with torch.no_grad():
+    y = g(x)
+torch.cuda.synchronize()
+e = int(lib.resr_chain_errors())
+print("errors", e & 0xffffffff, "nan", bool(torch.isnan(y).any()))
+assert (e & 0xffffffff) > 0 and torch.isnan(y).any()
+try:
+    L.chain_health()
+except RuntimeError as err:
+    print("raised:", str(err)[:60])
+else:
+    raise SystemExit("chain_health did not raise")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]

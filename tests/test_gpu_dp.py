@@ -221,3 +221,72 @@ def test_bench_gan_two_ranks_prints_one_line():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and "GAN" in out["metric"] and set(out["losses"]) >= {"pixel_loss", "adversarial_loss", "d_loss_hr", "d_loss_sr", "content_loss"}
     assert "roofline" in out and "error" not in out["roofline"], out.get("roofline")
+
+
+def test_train_script_two_ranks(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 ... train_realesrnet` (reference train_realesrnet.py:105-129 loop,
+    one process per GPU; here two ranks on the box's one GPU, gloo): the DistributedSampler shards the epoch (the ranks see
+    disjoint images, together all of them), the ranks draw different degradations, only rank 0 writes checkpoints, and after
+    the epoch's three optimiser steps both replicas hold bit-identical weights."""
+    import json
+    import subprocess
+    import sys
+    import numpy as np
+    from PIL import Image
+    from tests.test_gpu_train_harness import _smooth_png
+    from real_esrgan_pytorch_amd import imgproc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sub, n in (("train", 12), ("valid", 2), ("test_hr", 2)):
+        os.makedirs(tmp_path / sub)
+        for i in range(n):
+            _smooth_png(str(tmp_path / sub / f"{i}.png"), 224, 7 * len(sub) + i)
+    os.makedirs(tmp_path / "test_lr")
+    for i in range(2):
+        hr = imgproc.read_image_rgb(str(tmp_path / "test_hr" / f"{i}.png"))
+        Image.fromarray((np.clip(imgproc.image_resize(hr, 0.25), 0, 1) * 255).round().astype(np.uint8)).save(str(tmp_path / "test_lr" / f"{i}.png"))
+    driver = tmp_path / "driver.py"
+    driver.write_text(f"""
+import json, os, sys, hashlib
+import torch
+sys.path.insert(0, {root!r})
+from real_esrgan_pytorch_amd import config
+from real_esrgan_pytorch_amd import train_realesrnet as T
+tmp = {str(tmp_path)!r}
+for k, v in dict(train_image_dir=tmp + "/train", valid_image_dir=tmp + "/valid", test_lr_image_dir=tmp + "/test_lr",
+                 test_hr_image_dir=tmp + "/test_hr", image_size=208, batch_size=2, num_workers=0, epochs=1, print_frequency=1,
+                 resume="", lr_scheduler_step_size=1, exp_name="dp_test", precision="fast",
+                 niqe_model_path={os.path.join(root, "tests", "golden", "niqe_model.mat")!r}).items():
+    setattr(config, k, v)
+os.chdir(tmp)
+rank = int(os.environ["RANK"])
+log = dict(rank=rank, hr=[], lr=[])
+Base = T.RealESRNetStep
+class Step(Base):
+    def __call__(self, hr, lr=None):
+        log["hr"].append(hashlib.sha1(hr.cpu().numpy().tobytes()).hexdigest())
+        log["lr"].append(float(lr.float().mean()))
+        return super().__call__(hr, lr)
+T.RealESRNetStep = Step
+validate = T.validate
+def validate_and_dump(model, *a, **k):
+    if "weights" not in log:
+        torch.cuda.synchronize()
+        log["weights"] = hashlib.sha1(model.flat_parameters().detach().cpu().numpy().tobytes()).hexdigest()
+    return validate(model, *a, **k)
+T.validate = validate_and_dump
+T.main()
+json.dump(log, open(tmp + f"/log_rank{{rank}}.json", "w"))
+""")
+    env = dict(os.environ, RESR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), str(driver)]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    logs = [json.load(open(tmp_path / f"log_rank{k}.json")) for k in (0, 1)]
+    assert all(len(l["hr"]) == 3 for l in logs)                                  # 12 images / 2 ranks / batch 2
+    assert not set(logs[0]["hr"]) & set(logs[1]["hr"])                          # disjoint shards
+    assert logs[0]["lr"] != logs[1]["lr"]                                        # rank-dependent degradation draws
+    assert logs[0]["weights"] == logs[1]["weights"]                              # replicas stay bit-identical
+    assert (tmp_path / "samples" / "dp_test" / "g_epoch_1.pth.tar").exists()    # written once, by rank 0
+    tags = [json.loads(l) for l in open(tmp_path / "samples" / "logs" / "dp_test" / "scalars.jsonl")]
+    assert sum(t["tag"] == "Train/Loss" for t in tags) == 3                     # one writer

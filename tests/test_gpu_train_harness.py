@@ -69,6 +69,40 @@ def test_train_validate_checkpoint_resume(tmp_path, monkeypatch):
     g.load_state_dict({k[len("model."):]: v for k, v in ck2["ema_state_dict"].items()})
 
 
+def test_degradation_runs_one_batch_ahead_on_a_side_stream(tmp_path, monkeypatch):
+    """What the train scripts run is what bench.py times: the degradation kernels of batch i+1 are enqueued on a side stream
+    BEFORE step i is issued and complete while step i is still running (reference slot: CUDAPrefetcher, dataset.py:271-312)."""
+    from real_esrgan_pytorch_amd import train_realesrnet as T
+    _tiny_dataset(tmp_path, monkeypatch)
+    made, seen = [], []
+
+    class Pre(T.DegradationPrefetcher):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            made.append(self)
+
+    class Step(T.RealESRNetStep):
+        def __call__(self, hr, lr=None):
+            assert lr is not None                       # the loop hands the step an already degraded batch
+            ahead = made[-1].done_events if made[-1]._pending is not None else None   # batch i+1: enqueued before this step
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = super().__call__(hr, lr)
+            e1.record()
+            seen.append((e0, e1, ahead))
+            return out
+
+    monkeypatch.setattr(T, "DegradationPrefetcher", Pre)
+    monkeypatch.setattr(T, "RealESRNetStep", Step)
+    T.main()
+    torch.cuda.synchronize()
+    assert len(made) == 1 and made[0].stream != torch.cuda.default_stream() and made[0].stream != torch.cuda.current_stream()
+    assert len(seen) == 2 and seen[0][2] is not None and seen[1][2] is None      # 4 images, batch 2: step 0 has a batch ahead of it
+    e0, e1, (d0, d1) = seen[0]
+    step_ms, deg_end_ms = e0.elapsed_time(e1), e0.elapsed_time(d1)
+    assert d0.elapsed_time(d1) > 0 and deg_end_ms < step_ms, (step_ms, deg_end_ms)   # batch 1's degradation finished under step 0
+
+
 def test_gan_train_checkpoints_resume_and_directory_test(tmp_path, monkeypatch):
     """`train_realesrgan.main()` from a RealESRNet checkpoint, its two checkpoint families, resume_d / resume_g, and
     `test.main()` over the LR folder with the resulting EMA weights."""

@@ -162,7 +162,7 @@ def test_wgrad_quad_plan_host_logic():
 def test_entry_points_keep_the_reference_function_names(built):
     """The train / test entry points expose the functions a user of the reference's scripts calls or patches
     (train_realesrnet.py, train_realesrgan.py, test.py, inference.py: main / load_dataset / build_model / define_* / train /
-    validate; the reference's logging meters -- SURVEY §2 #20, out of scope -- are not part of the surface)."""
+    validate, and the script-level meter classes Summary / AverageMeter / ProgressMeter)."""
     import importlib
     import inspect
     want = {
@@ -182,5 +182,23 @@ def test_entry_points_keep_the_reference_function_names(built):
     assert list(inspect.signature(g.train).parameters)[:12] == [
         "discriminator", "generator", "ema_model", "train_prefetcher", "pixel_criterion", "content_criterion",
         "adversarial_criterion", "d_optimizer", "g_optimizer", "epoch", "scaler", "writer"]
+    for mod in ("train_realesrnet", "train_realesrgan"):            # reference train_realesrnet.py:497-564
+        m = importlib.import_module(f"real_esrgan_pytorch_amd.{mod}")
+        meter = m.AverageMeter("Loss", ":6.3f", m.Summary.AVERAGE)
+        meter.update(2.0, 3)
+        meter.update(4.0, 1)
+        assert (meter.val, meter.sum, meter.count, meter.avg) == (4.0, 10.0, 4, 2.5)
+        assert str(meter) == "Loss  4.000 ( 2.500)" and meter.summary() == "Loss 2.50"
+        m.ProgressMeter(10, [meter], prefix="Epoch: [1]").display(3)
+    d = importlib.import_module("real_esrgan_pytorch_amd.dataset")    # reference dataset.py:27-30
+    assert d.__all__ == ["TrainValidImageDataset", "TestImageDataset", "PrefetchGenerator", "PrefetchDataLoader", "CPUPrefetcher", "CUDAPrefetcher"]
+    import torch
+    from torch.utils.data import TensorDataset
+    pl = d.PrefetchDataLoader(2, dataset=TensorDataset(torch.arange(6.0)), batch_size=2)
+    assert [b[0].tolist() for b in pl] == [[0.0, 1.0], [2.0, 3.0], [4.0, 5.0]]
+    cp = d.CPUPrefetcher(pl)
+    assert len(cp) == 3 and cp.next()[0].tolist() == [0.0, 1.0]
+    cp.reset()
+    assert [cp.next() is not None for _ in range(4)] == [True, True, True, False]
     n = importlib.import_module("real_esrgan_pytorch_amd.train_realesrnet")
     assert list(inspect.signature(n.validate).parameters) == ["model", "ema_model", "data_prefetcher", "epoch", "writer", "niqe_model", "mode"]
