@@ -88,15 +88,15 @@ typedef struct {
     int32_t in0_chunk_stride, in1_chunk_stride, out_chunk_stride;
     int32_t res0_chunk_stride, res1_chunk_stride, mask_chunk_stride;
     /* RESR_F16X2 only: element offset from the hi tensor of an operand to its lo tensor (a mask given as an f16
-     * activation is read from its hi tensor alone; AUX_BEFORE_* is not available in this mode). */
+     * activation is read from its hi tensor alone; the aux tensor of AUX_BEFORE_* uses out's offset). */
     int64_t in0_lo_offset, in1_lo_offset, out_lo_offset, res0_lo_offset, res1_lo_offset;
     /* 4x4 / stride-2 convolutions (model.py:140-152) run as 3x3 convolutions over the 2x2 space-to-depth image with the
      * "virtual" kernel of ResrPackChunk.virtual4x4; 20 of its 36 (tap, sub-position) blocks are zero.  These two hints let
-     * the kernel skip them (results are identical with or without; honoured for f16, 64-channel output groups and a plain
-     * epilogue):  s2d_in_channels = C > 0: the input is the space-to-depth image, C channels per sub-position (cin = 4C,
+     * the kernel skip them (results are identical with or without; honoured for f16 / f16x2, 64-channel output groups and a
+     * plain epilogue):  s2d_in_channels = C > 0: the input is the space-to-depth image, C channels per sub-position (cin = 4C,
      * forward pass);  s2d_out_channels = C > 0: the OUTPUT (all cout_groups * 64 = 4C channels of it) is the gradient of
      * such an image (backward-data pass).  0 = dense.
-     * cout_groups = G > 1: ONE launch computes G consecutive 64-channel output groups of a convolution (f16, cout =
+     * cout_groups = G > 1: ONE launch computes G consecutive 64-channel output groups of a convolution (f16 / f16x2, cout =
      * cout_pad = 64 per group, no bias, NHWC output): group g uses the packed weights at w_packed + g * (cin/32)*9*2*1024
      * elements (how resr_pack_weights lays out consecutive 64-row chunks tables) and writes / reads out, res0, res1, mask,
      * aux 64*g channels further inside the pixel.  The discriminator's 128..512-channel layers at 32^2..128^2 pixels
@@ -314,7 +314,7 @@ int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* st
  * times per GAN step, train_realesrgan.py:479,500,508) and all scratch: nothing is allocated per tensor. */
 typedef struct {
     int32_t n, h, w;       /* input [n,3,h,w], h and w multiples of 8                                  */
-    int32_t dtype;         /* RESR_F16 or RESR_F32                                                     */
+    int32_t dtype;         /* RESR_F16, RESR_F16X2 (hi/lo pairs: fp32-class results) or RESR_F32       */
     int32_t training;      /* keep activations for resr_discriminator_backward                         */
     int32_t sn_training;   /* module in training mode: one power iteration, u / v updated in place     */
 } ResrDiscriminatorDesc;

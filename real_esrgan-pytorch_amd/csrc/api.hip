@@ -119,13 +119,14 @@ int resize_u8_dispatch(const uint8_t*, uint8_t*, int, int, int, int, int, int, i
                        const int32_t*, hipStream_t);
 
 int s2d_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
-int bilinear_up_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
+int bilinear_up_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t, long, long);
 int add_mask_dispatch(const void*, const void*, const void*, void*, long, int, float, hipStream_t);
 int spectral_norm_dispatch(const float*, float*, float*, int, int, int, float, float*, float*, hipStream_t);
 int spectral_norm_bwd_dispatch(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, float*,
                                hipStream_t);
 int fold4x4_dispatch(const float*, float*, int, int, hipStream_t);
-int maxpool2x2_dispatch(const void*, void*, int, int, int, int, int, hipStream_t);
+int maxpool2x2_dispatch(const void*, void*, int, int, int, int, int, hipStream_t, long, long, uint8_t*);
+int maxpool2x2_bwd_dispatch(const void*, const uint8_t*, void*, int, int, int, int, int, hipStream_t, long, long);
 
 // probe used by tests: what does ds_read_b64_tr_b16 hand to (lane, element)?  LDS holds the element
 // index at every position; lane l supplies byte address l*8.
@@ -343,7 +344,10 @@ int resr_space_to_depth(const void* src, void* dst, int32_t n, int32_t h, int32_
 int resr_bilinear_up2x(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t dtype, int32_t backward,
                        void* stream) {
     RESR_DEVICE_SCOPE(stream);
-    return bilinear_up_dispatch(src, dst, n, h, w, c, dtype, backward, (hipStream_t)stream);
+    // RESR_F16X2: src and dst are (hi, lo) pairs, each lo tensor directly behind its hi tensor
+    const long px = (long)n * h * w * c;
+    const bool x2 = dtype == RESR_F16X2;
+    return bilinear_up_dispatch(src, dst, n, h, w, c, dtype, backward, (hipStream_t)stream, x2 ? (backward ? 4 * px : px) : 0L, x2 ? (backward ? px : 4 * px) : 0L);
 }
 
 int resr_add_mask(const void* a, const void* b, const void* mask, void* out, int64_t count, int32_t dtype, float slope,
@@ -366,7 +370,9 @@ int resr_spectral_norm_bwd(const float* g, const float* w, const float* u, const
 
 int resr_maxpool2x2(const void* src, void* dst, int32_t n, int32_t h_out, int32_t w_out, int32_t c, int32_t dtype, void* stream) {
     RESR_DEVICE_SCOPE(stream);
-    return maxpool2x2_dispatch(src, dst, n, h_out, w_out, c, dtype, (hipStream_t)stream);
+    const long px = (long)n * h_out * w_out * c;
+    const bool x2 = dtype == RESR_F16X2;
+    return maxpool2x2_dispatch(src, dst, n, h_out, w_out, c, dtype, (hipStream_t)stream, x2 ? 4 * px : 0L, x2 ? px : 0L, nullptr);
 }
 
 int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* stream) {

@@ -242,14 +242,14 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_kernel(const ConvArgs a) {
                         float u = v[r];
                         if (f_clamp) {
                             if (a.aux) a.aux[q] = (u >= 0.f && u <= 1.f) ? 1 : 0;
-                            u = fminf(fmaxf(u, 0.f), 1.f);
+                            u = u < 0.f ? 0.f : (u > 1.f ? 1.f : u);   // torch.clamp_ semantics: a NaN stays a NaN (fminf / fmaxf would drop it)
                         }
                         o[q] = u;
                     }
                 } else {
                     if (f_clamp) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], 0.f), 1.f);
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : (v[r] > 1.f ? 1.f : v[r]);
                     }
                     store4<T>(a.out, p * a.out_stride + (size_t)m * a.out_chunk + cq, v);
                     if (f_sbits) {
@@ -344,11 +344,11 @@ static int conv3x3_args(const ResrConvDesc* d, const void* in0, const void* in1,
     a.s2d_c = 0; a.tap_c = 0; a.ngroups = 1; a.w_group_b = 0;
     const int groups = d->cout_groups > 1 ? d->cout_groups : 1;
     if (groups > 1) {
-        if (d->dtype != RESR_F16 || d->cout != 64 || d->cout_pad != 64 || bias || in1 ||
+        if ((d->dtype != RESR_F16 && d->dtype != RESR_F16X2) || d->cout != 64 || d->cout_pad != 64 || bias || in1 ||
             (d->flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_WRITE_SIGNBITS | RESR_CONV_MASK_BITS | RESR_CONV_CLAMP01)) || !(d->flags & RESR_CONV_NO_BIAS))
-            return fail(RESR_ERR_ARG, "conv3x3: cout_groups > 1 needs f16, cout = cout_pad = 64 per group, no bias, NHWC output, no sign-bit tensors");
+            return fail(RESR_ERR_ARG, "conv3x3: cout_groups > 1 needs f16 / f16x2, cout = cout_pad = 64 per group, no bias, NHWC output, no sign-bit tensors");
         a.ngroups = groups;
-        a.w_group_b = (size_t)(d->cin / 32) * 9 * 2 * 1024 * es;
+        a.w_group_b = (size_t)(d->cin / 32) * 9 * 2 * 1024 * es * (d->dtype == RESR_F16X2 ? 3 : 1);
     }
     if (d->s2d_in_channels > 0) {
         if ((d->s2d_in_channels & 31) || d->cin != 4 * d->s2d_in_channels)
@@ -381,9 +381,8 @@ static int conv3x3_route(const ResrConvDesc* d, ConvArgs& a, bool have_bias, boo
     (void)have_bias;
     const int mt = d->cout_pad / 32;
     if (d->dtype == RESR_F16X2) {
-        // hi/lo pairs: only the producer/consumer kernel has the mode
-        if (d->flags & (RESR_CONV_AUX_BEFORE_MASK | RESR_CONV_AUX_BEFORE_RES))
-            return fail(RESR_ERR_ARG, "conv3x3: AUX_BEFORE_* is not available with RESR_F16X2");
+        // hi/lo pairs: only the producer/consumer kernel has the mode (an aux tensor of AUX_BEFORE_* has out's shape and out's
+        // hi -> lo offset)
         const bool nchw = d->flags & RESR_CONV_OUT_NCHW_F32;
         if (d->in0_lo_offset == 0 || (in1 && d->cin0 < d->cin && d->in1_lo_offset == 0) || (!nchw && d->out_lo_offset == 0) ||
             (res0 && d->res0_lo_offset == 0) || (res1 && d->res1_lo_offset == 0))

@@ -860,7 +860,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     default: sparse_stage(I1{}, I1{}); break;
                 }
                 par ^= 1;
-                hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;
+                if (!X2 || (ck % 3) != 0) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
                 if (wave == 0) stamp(1);
                 continue;
             }
@@ -1298,14 +1298,14 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             float u = v[r];
                             if (f_clamp) {
                                 if (e.aux) e.aux[q] = (u >= 0.f && u <= 1.f) ? 1 : 0;
-                                u = fminf(fmaxf(u, 0.f), 1.f);
+                                u = u < 0.f ? 0.f : (u > 1.f ? 1.f : u);   // torch.clamp_ semantics: a NaN stays a NaN (fminf / fmaxf would drop it)
                             }
                             o[q] = u;
                         }
                     } else {
                         if (f_clamp) {
 #pragma unroll
-                            for (int r = 0; r < 8; ++r) v[r] = fminf(fmaxf(v[r], 0.f), 1.f);
+                            for (int r = 0; r < 8; ++r) v[r] = v[r] < 0.f ? 0.f : (v[r] > 1.f ? 1.f : v[r]);
                         }
                         if (ok) store8(e.out, p * e.out_stride + poff(m, j, e.out_chunk));
                         if (ESB) {

@@ -59,7 +59,7 @@ static int pick_rows(const ConvArgs& a, const int* rows, int nrows) {
     return rows[nrows - 1];
 }
 
-int conv3x3_ws_sparse(const ConvArgs& a, int tile_rows, int sp, hipStream_t stream);   // conv3x3_ws_sp.hip
+int conv3x3_ws_sparse(const ConvArgs& a, int tile_rows, int sp, bool x2, hipStream_t stream);   // conv3x3_ws_sp.hip
 int conv3x3_ws_chain_launch(const ConvArgs& a, const ChainArgs& cj, int tile_rows, int kind, bool x2, double flop, double bytes, hipStream_t stream);   // conv3x3_ws_chain.hip
 
 // ---- chained dense-block passes (conv3x3_ws.h, CH) ----
@@ -165,9 +165,9 @@ int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, con
 int conv3x3_ws_f16(const ConvArgs& a, int mt, bool x2, hipStream_t stream) {
     static const int rows1[] = {16, 8}, rows2[] = {16, 8};
     // 4x4 / stride-2 convolutions as sparse-tap 3x3 convolutions over the space-to-depth image: plain epilogue, 64-channel groups
-    if (!x2 && mt == 2 && (a.s2d_c > 0 || a.tap_c > 0) && !a.res0 && !a.res1 && !a.mask && !a.aux &&
-        !(a.flags & ~(RESR_CONV_LRELU | RESR_CONV_NO_BIAS)) && a.cin0 == a.cin)
-        return conv3x3_ws_sparse(a, 8, a.s2d_c > 0 ? 1 : 2, stream);   // 8-row tiles: the 16-row shape of this variant spills
+    if (mt == 2 && (a.s2d_c > 0 || a.tap_c > 0) && !a.res0 && !a.res1 && !a.mask && !a.aux &&
+        !(a.flags & ~(RESR_CONV_LRELU | RESR_CONV_NO_BIAS)) && a.cin0 == a.cin && (!(a.flags & RESR_CONV_LRELU) || (a.slope >= 0.f && a.slope <= 1.f)))
+        return conv3x3_ws_sparse(a, 8, a.s2d_c > 0 ? 1 : 2, x2, stream);   // 8-row tiles: the 16-row shape of this variant spills
     if (x2) {
         if (mt == 1) return conv3x3_ws_x2_mt1(a, pick_rows(a, rows1, 2), stream);
         return conv3x3_ws_x2_mt2(a, pick_rows(a, rows2, 2), stream);

@@ -13,7 +13,43 @@
 
 namespace resr {
 
-// dst[Y][X][(i*2+j)*C + c] = src[2Y+i][2X+j][c]   (inverse: the other way round)
+// RESR_F16X2 (T = f16 with a non-zero hi -> lo element offset): every tensor is a (hi, lo) pair, value = hi + lo * 2^-12
+// (include/resr.h); the helpers below read E values of a 16-byte piece as fp32 and store them split.
+template <typename T>
+__device__ __forceinline__ void ld_vals(const T* p, long lo, float* v) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const uint4 raw = *reinterpret_cast<const uint4*>(p);
+    const T* q = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = (float)q[e];
+    if constexpr (sizeof(T) == 2) {
+        if (lo) {
+            const uint4 rawl = *reinterpret_cast<const uint4*>(p + lo);
+            const T* ql = reinterpret_cast<const T*>(&rawl);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = __builtin_fmaf((float)ql[e], kLoInv, v[e]);
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void st_vals(T* p, long lo, const float* v) {
+    constexpr int E = 16 / (int)sizeof(T);
+    uint4 o, ol;
+    T* q = reinterpret_cast<T*>(&o);
+    T* ql = reinterpret_cast<T*>(&ol);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        q[e] = (T)v[e];
+        if constexpr (sizeof(T) == 2) ql[e] = (T)((v[e] - (float)q[e]) * kLoScale);
+    }
+    *reinterpret_cast<uint4*>(p) = o;
+    if constexpr (sizeof(T) == 2) {
+        if (lo) *reinterpret_cast<uint4*>(p + lo) = ol;
+    }
+}
+
+// dst[Y][X][(i*2+j)*C + c] = src[2Y+i][2X+j][c]   (inverse: the other way round).  A pure permutation: RESR_F16X2 callers run it
+// over hi and lo at once as a batch of 2n (the lo tensor directly follows the hi tensor in both operands).
 template <typename T>
 __global__ __launch_bounds__(256) void s2d_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w, int c,
                                                   int inverse) {
@@ -33,10 +69,12 @@ __global__ __launch_bounds__(256) void s2d_kernel(const T* __restrict__ src, T* 
 
 // depth-to-space fused with the skip-gradient merge and the LeakyReLU backward that follow it in the discriminator's backward
 // pass: out[full] = (src[packed] + add[full]) * (mask[full] > 0 ? 1 : slope)   (add, mask optional) -- the same roundings as
-// s2d(inverse) followed by add_mask, one pass instead of two
+// s2d(inverse) followed by add_mask, one pass instead of two.  lo_* : RESR_F16X2 hi -> lo offsets of src / add / out (the mask is
+// an activation: its sign is its hi tensor's).
 template <typename T>
 __global__ __launch_bounds__(256) void d2s_add_mask_kernel(const T* __restrict__ src, const T* __restrict__ add, const T* __restrict__ mask,
-                                                           T* __restrict__ out, int n, int h, int w, int c, float slope) {
+                                                           T* __restrict__ out, int n, int h, int w, int c, float slope, long lo_src,
+                                                           long lo_add, long lo_out) {
     constexpr int E = 16 / (int)sizeof(T);
     const int groups = c / E;
     const long total = (long)n * h * w * groups;      // h, w = full-resolution dims
@@ -47,43 +85,50 @@ __global__ __launch_bounds__(256) void d2s_add_mask_kernel(const T* __restrict__
     const int x = (int)(p % w), y = (int)((p / w) % h), b = (int)(p / ((long)w * h));
     const size_t full = (((size_t)b * h + y) * w + x) * c + g * E;
     const size_t packed = ((((size_t)b * (h / 2) + y / 2) * (w / 2) + x / 2) * 4 + (y & 1) * 2 + (x & 1)) * c + g * E;
-    const uint4 rs = *reinterpret_cast<const uint4*>(src + packed);
-    uint4 ra = make_uint4(0, 0, 0, 0), rm = make_uint4(0, 0, 0, 0);
-    if (add) ra = *reinterpret_cast<const uint4*>(add + full);
-    if (mask) rm = *reinterpret_cast<const uint4*>(mask + full);
-    const T *ps = reinterpret_cast<const T*>(&rs), *pa = reinterpret_cast<const T*>(&ra), *pm = reinterpret_cast<const T*>(&rm);
-    uint4 o;
-    T* po = reinterpret_cast<T*>(&o);
+    float v[E], va[E];
+    ld_vals(src + packed, lo_src, v);
+    if (add) {
+        ld_vals(add + full, lo_add, va);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        float v = (float)ps[e] + (add ? (float)pa[e] : 0.f);
-        if (mask) v *= ((float)pm[e] > 0.f ? 1.f : slope);
-        po[e] = (T)v;
+        for (int e = 0; e < E; ++e) v[e] += va[e];
     }
-    *reinterpret_cast<uint4*>(out + full) = o;
+    if (mask) {
+        const uint4 rm = *reinterpret_cast<const uint4*>(mask + full);
+        const T* pm = reinterpret_cast<const T*>(&rm);
+        if (lo_out == 0) {   // plain tensors: the sum is rounded to T before the mask multiplies it (two passes' roundings)
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = (float)(T)v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] *= ((float)pm[e] > 0.f ? 1.f : slope);
+    }
+    st_vals(out + full, lo_out, v);
 }
 
 int d2s_add_mask_dispatch(const void* src, const void* add, const void* mask, void* out, int n, int h, int w, int c, int dtype, float slope,
-                          hipStream_t st) {
-    const int E = dtype == RESR_F16 ? 8 : 4;
+                          hipStream_t st, long lo_src, long lo_add, long lo_out) {
+    const int E = dtype == RESR_F32 ? 4 : 8;
     if (!src || !out || n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || c <= 0 || (c % E)) return fail(RESR_ERR_ARG, "d2s_add_mask: bad argument");
     const long total = (long)n * h * w * (c / E);
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (dtype == RESR_F16)
-        hipLaunchKernelGGL(d2s_add_mask_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (const half_t*)add, (const half_t*)mask, (half_t*)out, n, h, w, c, slope);
+    if (dtype != RESR_F32)
+        hipLaunchKernelGGL(d2s_add_mask_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (const half_t*)add, (const half_t*)mask, (half_t*)out, n, h, w, c, slope,
+                           lo_src, lo_add, lo_out);
     else
-        hipLaunchKernelGGL(d2s_add_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (const float*)add, (const float*)mask, (float*)out, n, h, w, c, slope);
+        hipLaunchKernelGGL(d2s_add_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (const float*)add, (const float*)mask, (float*)out, n, h, w, c, slope,
+                           0L, 0L, 0L);
     RESR_CHECK_LAUNCH("d2s_add_mask_kernel");
     return RESR_OK;
 }
 
 int s2d_dispatch(const void* src, void* dst, int n, int h, int w, int c, int dtype, int inverse, hipStream_t st) {
-    const int E = dtype == RESR_F16 ? 8 : 4;
+    const int E = dtype == RESR_F32 ? 4 : 8;
     if (!src || !dst || n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || c <= 0 || (c % E))
         return fail(RESR_ERR_ARG, "space_to_depth: bad argument");
+    if (dtype == RESR_F16X2) n *= 2;   // hi and lo as one batch (the lo tensor directly follows the hi tensor)
     const long total = (long)n * h * w * (c / E);
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (dtype == RESR_F16) hipLaunchKernelGGL(s2d_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, inverse);
+    if (dtype != RESR_F32) hipLaunchKernelGGL(s2d_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, inverse);
     else hipLaunchKernelGGL(s2d_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, inverse);
     RESR_CHECK_LAUNCH("s2d_kernel");
     return RESR_OK;
@@ -100,7 +145,7 @@ __device__ __forceinline__ void bil_coord(int o, int n, int& i0, int& i1, float&
 
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_up_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w,
-                                                          int c) {
+                                                          int c, long lo_src, long lo_dst) {
     constexpr int E = 16 / (int)sizeof(T);
     const int groups = c / E, oh = 2 * h, ow = 2 * w;
     const long total = (long)n * oh * ow * groups;
@@ -115,18 +160,14 @@ __global__ __launch_bounds__(256) void bilinear_up_kernel(const T* __restrict__ 
     bil_coord(ox, w, x0, x1, lx);
     const float hy = 1.f - ly, hx = 1.f - lx;
     const T* base = src + (size_t)b * h * w * c + g * E;
-    uint4 r00 = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * w + x0) * c);
-    uint4 r01 = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * w + x1) * c);
-    uint4 r10 = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * w + x0) * c);
-    uint4 r11 = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * w + x1) * c);
-    const T *a = reinterpret_cast<const T*>(&r00), *bq = reinterpret_cast<const T*>(&r01), *cq = reinterpret_cast<const T*>(&r10),
-            *d = reinterpret_cast<const T*>(&r11);
-    uint4 o;
-    T* ov = reinterpret_cast<T*>(&o);
+    float a[E], bq[E], cq[E], d[E], o[E];
+    ld_vals(base + ((size_t)y0 * w + x0) * c, lo_src, a);
+    ld_vals(base + ((size_t)y0 * w + x1) * c, lo_src, bq);
+    ld_vals(base + ((size_t)y1 * w + x0) * c, lo_src, cq);
+    ld_vals(base + ((size_t)y1 * w + x1) * c, lo_src, d);
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-        ov[e] = (T)(hy * (hx * (float)a[e] + lx * (float)bq[e]) + ly * (hx * (float)cq[e] + lx * (float)d[e]));
-    *reinterpret_cast<uint4*>(dst + p * c + g * E) = o;
+    for (int e = 0; e < E; ++e) o[e] = hy * (hx * a[e] + lx * bq[e]) + ly * (hx * cq[e] + lx * d[e]);
+    st_vals(dst + p * c + g * E, lo_dst, o);
 }
 
 // backward as a gather: input pixel (y,x) collects from the <= 4x4 outputs whose stencil touches it
@@ -134,8 +175,8 @@ __global__ __launch_bounds__(256) void bilinear_up_kernel(const T* __restrict__ 
 // itself is kept, it is a skip gradient later) -- computed from the rounded gin, like a separate add_mask pass would
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const T* __restrict__ g, T* __restrict__ gin, int n, int h, int w,
-                                                              int c, const T* __restrict__ mask = nullptr, T* __restrict__ gmasked = nullptr,
-                                                              float slope = 0.f) {
+                                                              int c, const T* __restrict__ mask, T* __restrict__ gmasked,
+                                                              float slope, long lo_g, long lo_gin) {
     constexpr int E = 16 / (int)sizeof(T);
     const int groups = c / E, oh = 2 * h, ow = 2 * w;
     const long total = (long)n * h * w * groups;
@@ -160,53 +201,50 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const T* __restric
             bil_coord(ox, w, x0, x1, lx);
             const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
             if (wx == 0.f) continue;
-            const uint4 raw = *reinterpret_cast<const uint4*>(base + ((size_t)oy * ow + ox) * c);
-            const T* v = reinterpret_cast<const T*>(&raw);
+            float v[E];
+            ld_vals(base + ((size_t)oy * ow + ox) * c, lo_g, v);
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] += wy * wx * (float)v[e];
+            for (int e = 0; e < E; ++e) acc[e] += wy * wx * v[e];
         }
     }
-    uint4 o;
-    T* ov = reinterpret_cast<T*>(&o);
-#pragma unroll
-    for (int e = 0; e < E; ++e) ov[e] = (T)acc[e];
-    *reinterpret_cast<uint4*>(gin + p * c + gi * E) = o;
+    st_vals(gin + p * c + gi * E, lo_gin, acc);
     if (gmasked) {
         const uint4 rm = *reinterpret_cast<const uint4*>(mask + p * c + gi * E);
         const T* pm = reinterpret_cast<const T*>(&rm);
-        uint4 om;
-        T* omv = reinterpret_cast<T*>(&om);
+        float m[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) omv[e] = (T)((float)ov[e] * ((float)pm[e] > 0.f ? 1.f : slope));
-        *reinterpret_cast<uint4*>(gmasked + p * c + gi * E) = om;
+        for (int e = 0; e < E; ++e) m[e] = (lo_gin ? acc[e] : (float)(T)acc[e]) * ((float)pm[e] > 0.f ? 1.f : slope);
+        st_vals(gmasked + p * c + gi * E, lo_gin, m);   // the same shape as gin: the same hi -> lo offset
     }
 }
 
 int bilinear_up_bwd_mask_dispatch(const void* g, void* gin, const void* mask, void* gmasked, int n, int h, int w, int c, int dtype, float slope,
-                                  hipStream_t st) {
-    const int E = dtype == RESR_F16 ? 8 : 4;
+                                  hipStream_t st, long lo_g, long lo_gin) {
+    const int E = dtype == RESR_F32 ? 4 : 8;
     if (!g || !gin || !mask || !gmasked || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c % E)) return fail(RESR_ERR_ARG, "bilinear_up_bwd_mask: bad argument");
     const long total = (long)n * h * w * (c / E);
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (dtype == RESR_F16)
-        hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)g, (half_t*)gin, n, h, w, c, (const half_t*)mask, (half_t*)gmasked, slope);
+    if (dtype != RESR_F32)
+        hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)g, (half_t*)gin, n, h, w, c, (const half_t*)mask, (half_t*)gmasked, slope,
+                           lo_g, lo_gin);
     else
-        hipLaunchKernelGGL(bilinear_up_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)g, (float*)gin, n, h, w, c, (const float*)mask, (float*)gmasked, slope);
+        hipLaunchKernelGGL(bilinear_up_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)g, (float*)gin, n, h, w, c, (const float*)mask, (float*)gmasked, slope,
+                           0L, 0L);
     RESR_CHECK_LAUNCH("bilinear_up_bwd_kernel");
     return RESR_OK;
 }
 
-int bilinear_up_dispatch(const void* src, void* dst, int n, int h, int w, int c, int dtype, int backward, hipStream_t st) {
-    const int E = dtype == RESR_F16 ? 8 : 4;
+int bilinear_up_dispatch(const void* src, void* dst, int n, int h, int w, int c, int dtype, int backward, hipStream_t st, long lo_src, long lo_dst) {
+    const int E = dtype == RESR_F32 ? 4 : 8;
     if (!src || !dst || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c % E)) return fail(RESR_ERR_ARG, "bilinear_up2x: bad argument");
     const long total = (long)n * h * w * (c / E) * (backward ? 1 : 4);
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (dtype == RESR_F16) {
-        if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c);
-        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, (const half_t*)nullptr, (half_t*)nullptr, 0.f);
+    if (dtype != RESR_F32) {
+        if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, lo_src, lo_dst);
+        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, (const half_t*)nullptr, (half_t*)nullptr, 0.f, lo_src, lo_dst);
     } else {
-        if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c);
-        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, (const float*)nullptr, (float*)nullptr, 0.f);
+        if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, 0L, 0L);
+        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, (const float*)nullptr, (float*)nullptr, 0.f, 0L, 0L);
     }
     RESR_CHECK_LAUNCH("bilinear_up_kernel");
     return RESR_OK;
@@ -215,39 +253,44 @@ int bilinear_up_dispatch(const void* src, void* dst, int n, int h, int w, int c,
 // out = (a + b) * (mask > 0 ? 1 : slope)      (b, mask optional)
 template <typename T>
 __global__ __launch_bounds__(256) void add_mask_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ mask,
-                                                       T* __restrict__ out, long count, float slope) {
+                                                       T* __restrict__ out, long count, float slope, long lo) {
     constexpr int E = 16 / (int)sizeof(T);
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * E;
     if (i >= count) return;
-    const uint4 ra = *reinterpret_cast<const uint4*>(a + i);
-    uint4 rb = make_uint4(0, 0, 0, 0), rm = make_uint4(0, 0, 0, 0);
-    if (b) rb = *reinterpret_cast<const uint4*>(b + i);
-    if (mask) rm = *reinterpret_cast<const uint4*>(mask + i);
-    const T *pa = reinterpret_cast<const T*>(&ra), *pb = reinterpret_cast<const T*>(&rb), *pm = reinterpret_cast<const T*>(&rm);
-    uint4 o;
-    T* po = reinterpret_cast<T*>(&o);
+    float v[E], vb[E];
+    ld_vals(a + i, lo, v);
+    if (b) {
+        ld_vals(b + i, lo, vb);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        float v = (float)pa[e] + (b ? (float)pb[e] : 0.f);
-        if (mask) v *= ((float)pm[e] > 0.f ? 1.f : slope);
-        po[e] = (T)v;
+        for (int e = 0; e < E; ++e) v[e] += vb[e];
     }
-    *reinterpret_cast<uint4*>(out + i) = o;
+    if (mask) {
+        const uint4 rm = *reinterpret_cast<const uint4*>(mask + i);
+        const T* pm = reinterpret_cast<const T*>(&rm);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] *= ((float)pm[e] > 0.f ? 1.f : slope);
+    }
+    st_vals(out + i, lo, v);
 }
 
+// RESR_F16X2: a, b, out are pairs with the lo tensor `count` elements behind the hi tensor
 int add_mask_dispatch(const void* a, const void* b, const void* mask, void* out, long count, int dtype, float slope, hipStream_t st) {
-    const int E = dtype == RESR_F16 ? 8 : 4;
+    const int E = dtype == RESR_F32 ? 4 : 8;
     if (!a || !out || count <= 0 || (count % E)) return fail(RESR_ERR_ARG, "add_mask: bad argument");
     const unsigned blocks = (unsigned)((count / E + 255) / 256);
-    if (dtype == RESR_F16) hipLaunchKernelGGL(add_mask_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)a, (const half_t*)b, (const half_t*)mask, (half_t*)out, count, slope);
-    else hipLaunchKernelGGL(add_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)mask, (float*)out, count, slope);
+    if (dtype != RESR_F32) hipLaunchKernelGGL(add_mask_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)a, (const half_t*)b, (const half_t*)mask, (half_t*)out, count, slope,
+                                              dtype == RESR_F16X2 ? count : 0L);
+    else hipLaunchKernelGGL(add_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)mask, (float*)out, count, slope, 0L);
     RESR_CHECK_LAUNCH("add_mask_kernel");
     return RESR_OK;
 }
 
-// 2x2 / stride-2 max pooling on NHWC (VGG19 perceptual branch, reference model.py:296-298)
+// 2x2 / stride-2 max pooling on NHWC (VGG19 perceptual branch, reference model.py:296-298); arg (optional, uint8 per element):
+// which of the four window positions (dy * 2 + dx, first maximum in that order -- ATen's max_pool2d picks the same) won, for the
+// backward pass of a differentiable perceptual term
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool2x2_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int ho, int wo, int c) {
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int ho, int wo, int c, long lo_src,
+                                                         long lo_dst, uint8_t* __restrict__ arg) {
     constexpr int E = 16 / (int)sizeof(T);
     const int groups = c / E;
     const long total = (long)n * ho * wo * groups;
@@ -259,32 +302,75 @@ __global__ __launch_bounds__(256) void maxpool2x2_kernel(const T* __restrict__ s
     const int wi = wo * 2;
     const T* s = src + (((size_t)b * ho * 2 + y * 2) * wi + x * 2) * c + g * E;
     float m[E];
+    uint8_t am[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) m[e] = -3.4e38f;
+    for (int e = 0; e < E; ++e) { m[e] = -3.4e38f; am[e] = 0; }
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(s + ((size_t)dy * wi + dx) * c);
-            const T* v = reinterpret_cast<const T*>(&raw);
+            float v[E];
+            ld_vals(s + ((size_t)dy * wi + dx) * c, lo_src, v);
 #pragma unroll
-            for (int e = 0; e < E; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+            for (int e = 0; e < E; ++e)
+                if (v[e] > m[e]) { m[e] = v[e]; am[e] = (uint8_t)(dy * 2 + dx); }
         }
-    uint4 o;
-    T* ov = reinterpret_cast<T*>(&o);
+    st_vals(dst + p * c + g * E, lo_dst, m);
+    if (arg) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) ov[e] = (T)m[e];
-    *reinterpret_cast<uint4*>(dst + p * c + g * E) = o;
+        for (int e = 0; e < E; ++e) arg[p * c + g * E + e] = am[e];
+    }
 }
 
-int maxpool2x2_dispatch(const void* src, void* dst, int n, int ho, int wo, int c, int dtype, hipStream_t st) {
-    const int E = dtype == RESR_F16 ? 8 : 4;
+int maxpool2x2_dispatch(const void* src, void* dst, int n, int ho, int wo, int c, int dtype, hipStream_t st, long lo_src, long lo_dst, uint8_t* arg) {
+    const int E = dtype == RESR_F32 ? 4 : 8;
     if (!src || !dst || n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || (c % E)) return fail(RESR_ERR_ARG, "maxpool2x2: bad argument");
     const long total = (long)n * ho * wo * (c / E);
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (dtype == RESR_F16) hipLaunchKernelGGL(maxpool2x2_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, ho, wo, c);
-    else hipLaunchKernelGGL(maxpool2x2_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, ho, wo, c);
+    if (dtype != RESR_F32) hipLaunchKernelGGL(maxpool2x2_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, ho, wo, c, lo_src, lo_dst, arg);
+    else hipLaunchKernelGGL(maxpool2x2_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, ho, wo, c, 0L, 0L, arg);
     RESR_CHECK_LAUNCH("maxpool2x2_kernel");
+    return RESR_OK;
+}
+
+// backward of maxpool2x2: the gradient of an output element goes to the window position that won (arg), zeros elsewhere
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const T* __restrict__ g, const uint8_t* __restrict__ arg, T* __restrict__ gin, int n,
+                                                             int ho, int wo, int c, long lo_g, long lo_gin) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const int groups = c / E;
+    const long total = (long)n * ho * wo * groups;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int gq = (int)(t % groups);
+    const long p = t / groups;
+    const int x = (int)(p % wo), y = (int)((p / wo) % ho), b = (int)(p / ((long)wo * ho));
+    const int wi = wo * 2;
+    float v[E];
+    ld_vals(g + p * c + gq * E, lo_g, v);
+    uint8_t am[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) am[e] = arg[p * c + gq * E + e];
+    T* d = gin + (((size_t)b * ho * 2 + y * 2) * wi + x * 2) * c + gq * E;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            float o[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) o[e] = am[e] == dy * 2 + dx ? v[e] : 0.f;
+            st_vals(d + ((size_t)dy * wi + dx) * c, lo_gin, o);
+        }
+}
+
+int maxpool2x2_bwd_dispatch(const void* g, const uint8_t* arg, void* gin, int n, int ho, int wo, int c, int dtype, hipStream_t st, long lo_g, long lo_gin) {
+    const int E = dtype == RESR_F32 ? 4 : 8;
+    if (!g || !arg || !gin || n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || (c % E)) return fail(RESR_ERR_ARG, "maxpool2x2_bwd: bad argument");
+    const long total = (long)n * ho * wo * (c / E);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype != RESR_F32) hipLaunchKernelGGL(maxpool2x2_bwd_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)g, arg, (half_t*)gin, n, ho, wo, c, lo_g, lo_gin);
+    else hipLaunchKernelGGL(maxpool2x2_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)g, arg, (float*)gin, n, ho, wo, c, 0L, 0L);
+    RESR_CHECK_LAUNCH("maxpool2x2_bwd_kernel");
     return RESR_OK;
 }
 

@@ -28,14 +28,14 @@ int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*,
 size_t wgrad_batch_partial_bytes(const WgradConv*, int, int, int);
 int wgrad_batch(const WgradConv*, int, int, int, int, int, int, int, float*, hipStream_t);
 int wgrad_tile_rows(int dtype);
+int wgrad_x2_products();
 int pack_dispatch(const ResrPackChunk*, int, const float*, void*, int, hipStream_t);
 int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long);
 int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t, long);
 int s2d_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
-int bilinear_up_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
-int add_mask_dispatch(const void*, const void*, const void*, void*, long, int, float, hipStream_t);
-int d2s_add_mask_dispatch(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t);
-int bilinear_up_bwd_mask_dispatch(const void*, void*, const void*, void*, int, int, int, int, int, float, hipStream_t);
+int bilinear_up_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t, long, long);
+int d2s_add_mask_dispatch(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t, long, long, long);
+int bilinear_up_bwd_mask_dispatch(const void*, void*, const void*, void*, int, int, int, int, int, float, hipStream_t, long, long);
 int spectral_norm_dispatch(const float*, float*, float*, int, int, int, float, float*, float*, hipStream_t);
 int spectral_norm_bwd_dispatch(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, float*,
                                hipStream_t);
@@ -63,7 +63,7 @@ struct DPlan {
 
 bool build(const ResrDiscriminatorDesc* d, DPlan& p) {
     if (!d || d->n <= 0 || d->h <= 0 || d->w <= 0 || (d->h & 7) || (d->w & 7)) return false;
-    if (d->dtype != RESR_F16 && d->dtype != RESR_F32) return false;
+    if (d->dtype != RESR_F16 && d->dtype != RESR_F32 && d->dtype != RESR_F16X2) return false;
     p.d = *d;
     size_t off = 0, uv = 0, pk = 0;
     int nch = 0;
@@ -113,20 +113,22 @@ int wsplits(int dtype, int jobs, int n, int h, int w) {
     const int th = wgrad_tile_rows(dtype);
     const long tiles = (long)((w + 31) / 32) * ((h + th - 1) / th) * n;
     long s;
-    if (dtype == RESR_F16) { s = 512 / ((jobs + 3) / 4); if (s >= 16) s &= ~7L; if (s > 256) s = 256; }
+    if (dtype != RESR_F32) { s = 512 / ((jobs + 3) / 4); if (s >= 16) s &= ~7L; if (s > 256) s = 256; }
     else { s = 768 / jobs; if (s > 128) s = 128; }
     if (s > tiles / 2) s = tiles / 2;
     return (int)(s < 1 ? 1 : s);
 }
 
+// RESR_F16X2: every activation / gradient buffer below holds the hi tensor and, directly behind it, the lo tensor (hi -> lo
+// element offset = the tensor's element count); packed weights take three f16 blocks per chunk.
 void carve(const DPlan& p, char* base, DBufs& b) {
-    const size_t es = elem_size(p.d.dtype);
+    const size_t es = elem_size(p.d.dtype) * act_tensors(p.d.dtype);
     const size_t px = (size_t)p.d.n * p.d.h * p.d.w;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += align_up(bytes, 256); return q; };
     b.sigma = (float*)take(kLayers * 2 * sizeof(float));
     b.uv = (float*)take(p.n_uv * sizeof(float));
-    b.packed = take(p.pk_elems * es + 16384);
+    b.packed = take(p.pk_elems * elem_size(p.d.dtype) * (p.d.dtype == RESR_F16X2 ? 3 : 1) + 16384);
     b.sn_tmp = (float*)take((512 + 16 * 4608 + 8) * sizeof(float));
     b.x_in = take(px * 32 * es);
     b.out1 = take(px * 64 * es);
@@ -155,7 +157,7 @@ void carve(const DPlan& p, char* base, DBufs& b) {
         size_t pb = 0;
         const int res[4][2] = {{p.d.h, p.d.w}, {p.d.h / 2, p.d.w / 2}, {p.d.h / 4, p.d.w / 4}, {p.d.h / 8, p.d.w / 8}};
         for (int q = 0; q < 4; ++q)
-            for (int jobs = 1; jobs <= 80; ++jobs) {
+            for (int jobs = 1; jobs <= 96; ++jobs) {
                 const size_t v = (size_t)jobs * wsplits(p.d.dtype, jobs, p.d.n, res[q][0], res[q][1]) * (9 * 1024 + 32) * sizeof(float);
                 if (v > pb) pb = v;
             }
@@ -182,10 +184,12 @@ ResrConvDesc cdesc(const DPlan& p, int n, int h, int w, int cin_pad, int in_stri
 // One layer as 3x3 conv of NHWC x (first cin_pad channels, pixel stride in_stride) into NHWC out (pixel stride out_stride), in
 // 64-channel output groups: one launch when the kernel takes groups (f16, no bias), else one per group.
 // backward = packed backward-data form (M = cin_v groups, K = cout).
+// lo_x / lo_out / lo_res0: RESR_F16X2 hi -> lo element offsets of x, out (and aux) and res0; 0 otherwise.
 int conv_layer(const DPlan& p, const DBufs& b, int li, bool backward, const char* x, int in_stride, int n, int h, int w, char* out,
                int out_stride, int flags, const float* bias, const char* res0, int res0_stride, const char* mask, int mask_stride,
-               char* aux, int s2d_in, int s2d_out, hipStream_t st, float* out_nchw = nullptr) {
+               char* aux, int s2d_in, int s2d_out, hipStream_t st, long lo_x, long lo_out, long lo_res0, float* out_nchw = nullptr) {
     const size_t es = elem_size(p.d.dtype);
+    const size_t wes = es * (p.d.dtype == RESR_F16X2 ? 3 : 1);   // bytes per element of the plain packed layout
     const int kin = backward ? p.cout_pad[li] : p.cin_pad[li];                  // K channels read
     const int mtot = backward ? p.cin_pad[li] : p.cout_pad[li];                 // M channels written (padded)
     const bool nchw = flags & RESR_CONV_OUT_NCHW_F32;
@@ -194,11 +198,12 @@ int conv_layer(const DPlan& p, const DBufs& b, int li, bool backward, const char
     const int mreal = nchw ? kL[li].cout : r32(backward ? p.cin_v[li] : kL[li].cout);
     const size_t pk0 = backward ? p.pk_bwd[li] : p.pk_fwd[li];
     const int ngroups = (mtot + 63) / 64;
-    if (ngroups > 1 && p.d.dtype == RESR_F16 && mreal == 64 * ngroups && !bias && !nchw && (flags & RESR_CONV_NO_BIAS)) {
+    if (ngroups > 1 && p.d.dtype != RESR_F32 && mreal == 64 * ngroups && !bias && !nchw && (flags & RESR_CONV_NO_BIAS)) {
         ResrConvDesc c = cdesc(p, n, h, w, kin, in_stride, 64, 64, out_stride, flags);
         c.res0_stride = res0_stride; c.mask_stride = mask_stride;
         c.cout_groups = ngroups; c.s2d_in_channels = s2d_in; c.s2d_out_channels = s2d_out;
-        return conv3x3_dispatch(&c, x, nullptr, b.packed + pk0 * es, nullptr, res0, nullptr, mask, out, aux, st);
+        c.in0_lo_offset = lo_x; c.out_lo_offset = lo_out; c.res0_lo_offset = lo_res0;
+        return conv3x3_dispatch(&c, x, nullptr, b.packed + pk0 * wes, nullptr, res0, nullptr, mask, out, aux, st);
     }
     size_t pk = pk0;
     for (int g0 = 0; g0 < mtot; g0 += 64) {
@@ -208,8 +213,9 @@ int conv_layer(const DPlan& p, const DBufs& b, int li, bool backward, const char
             ResrConvDesc c = cdesc(p, n, h, w, kin, in_stride, co, mt * 32, nchw ? 0 : out_stride, flags);
             c.res0_stride = res0_stride; c.mask_stride = mask_stride;
             c.s2d_in_channels = (ngroups == 1 ? s2d_in : 0);
+            c.in0_lo_offset = lo_x; c.out_lo_offset = lo_out; c.res0_lo_offset = lo_res0;
             auto sh = [&](const char* q) { return q ? q + (size_t)g0 * es : nullptr; };
-            DRUN(conv3x3_dispatch(&c, x, nullptr, b.packed + pk * es, bias ? bias + g0 : nullptr, sh(res0), nullptr, sh(mask),
+            DRUN(conv3x3_dispatch(&c, x, nullptr, b.packed + pk * wes, bias ? bias + g0 : nullptr, sh(res0), nullptr, sh(mask),
                                   nchw ? (void*)out_nchw : (void*)(out + (size_t)g0 * es), aux ? aux + (size_t)g0 * es : nullptr, st));
         }
         pk += (size_t)(kin / 32) * 9 * mt * 1024;
@@ -287,26 +293,31 @@ int discriminator_forward(const ResrDiscriminatorDesc* d, const float* x, const 
     if (d->training && hipMemcpyAsync(b.uv, uv, p.n_uv * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail(RESR_ERR_LAUNCH, "discriminator_forward: hipMemcpyAsync");
     DRUN(pack_dispatch(table, n_chunks, params, b.packed, dt, st));
-    DRUN(nchw_to_nhwc_dispatch(x, b.x_in, N, 3, S, W, 1, 32, dt, nullptr, st, 0));
+    const bool x2 = dt == RESR_F16X2;
+    const long px = (long)N * S * W;
+    auto LO = [&](long elems) -> long { return x2 ? elems : 0L; };   // hi -> lo offset of a buffer of `elems` elements
+    const long lo_in = LO(px * 32), lo64 = LO(px * 64), lo_d1 = LO(px / 4 * 128), lo_d2 = LO(px / 16 * 256), lo_d3 = LO(px / 64 * 512);
+    const long lo_b1 = LO(px / 16 * 512), lo_b2 = LO(px / 4 * 256), lo_b3 = LO(px * 128);
+    DRUN(nchw_to_nhwc_dispatch(x, b.x_in, N, 3, S, W, 1, 32, dt, nullptr, st, lo_in));
     const int NB = RESR_CONV_NO_BIAS, LR = RESR_CONV_LRELU;
-    DRUN(conv_layer(p, b, CONV1, false, b.x_in, 32, N, S, W, b.out1, 64, 0, params + p.b_off[CONV1], nullptr, 0, nullptr, 0, nullptr, 0, 0, st));
-    DRUN(s2d_dispatch(b.out1, b.s1, N, S, W, 64, dt, 0, st));
-    DRUN(conv_layer(p, b, DOWN1, false, b.s1, 256, N, H1, W1, b.d1, 128, LR | NB, nullptr, nullptr, 0, nullptr, 0, nullptr, 64, 0, st));
+    DRUN(conv_layer(p, b, CONV1, false, b.x_in, 32, N, S, W, b.out1, 64, 0, params + p.b_off[CONV1], nullptr, 0, nullptr, 0, nullptr, 0, 0, st, lo_in, lo64, 0));
+    DRUN(s2d_dispatch(b.out1, b.s1, N, S, W, 64, dt, 0, st));                    // (hi and lo as one batch of 2N)
+    DRUN(conv_layer(p, b, DOWN1, false, b.s1, 256, N, H1, W1, b.d1, 128, LR | NB, nullptr, nullptr, 0, nullptr, 0, nullptr, 64, 0, st, lo64, lo_d1, 0));
     DRUN(s2d_dispatch(b.d1, b.s2, N, H1, W1, 128, dt, 0, st));
-    DRUN(conv_layer(p, b, DOWN2, false, b.s2, 512, N, H2, W2, b.d2, 256, LR | NB, nullptr, nullptr, 0, nullptr, 0, nullptr, 128, 0, st));
+    DRUN(conv_layer(p, b, DOWN2, false, b.s2, 512, N, H2, W2, b.d2, 256, LR | NB, nullptr, nullptr, 0, nullptr, 0, nullptr, 128, 0, st, lo_d1, lo_d2, 0));
     DRUN(s2d_dispatch(b.d2, b.s3, N, H2, W2, 256, dt, 0, st));
-    DRUN(conv_layer(p, b, DOWN3, false, b.s3, 1024, N, H3, W3, b.d3, 512, LR | NB, nullptr, nullptr, 0, nullptr, 0, nullptr, 256, 0, st));
+    DRUN(conv_layer(p, b, DOWN3, false, b.s3, 1024, N, H3, W3, b.d3, 512, LR | NB, nullptr, nullptr, 0, nullptr, 0, nullptr, 256, 0, st, lo_d2, lo_d3, 0));
     const int FL = LR | NB | (d->training ? RESR_CONV_AUX_BEFORE_RES : 0);
-    DRUN(bilinear_up_dispatch(b.d3, b.b1, N, H3, W3, 512, dt, 0, st));
-    DRUN(conv_layer(p, b, UP1, false, b.b1, 512, N, H2, W2, b.u1, 256, FL, nullptr, b.d2, 256, nullptr, 0, b.a1, 0, 0, st));
-    DRUN(bilinear_up_dispatch(b.u1, b.b2, N, H2, W2, 256, dt, 0, st));
-    DRUN(conv_layer(p, b, UP2, false, b.b2, 256, N, H1, W1, b.u2, 128, FL, nullptr, b.d1, 128, nullptr, 0, b.a2, 0, 0, st));
-    DRUN(bilinear_up_dispatch(b.u2, b.b3, N, H1, W1, 128, dt, 0, st));
-    DRUN(conv_layer(p, b, UP3, false, b.b3, 128, N, S, W, b.u3, 64, FL, nullptr, b.out1, 64, nullptr, 0, b.a3, 0, 0, st));
-    DRUN(conv_layer(p, b, CONV2, false, b.u3, 64, N, S, W, b.c2, 64, LR | NB, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, st));
-    DRUN(conv_layer(p, b, CONV3, false, b.c2, 64, N, S, W, b.c3, 64, LR | NB, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, st));
+    DRUN(bilinear_up_dispatch(b.d3, b.b1, N, H3, W3, 512, dt, 0, st, lo_d3, lo_b1));
+    DRUN(conv_layer(p, b, UP1, false, b.b1, 512, N, H2, W2, b.u1, 256, FL, nullptr, b.d2, 256, nullptr, 0, b.a1, 0, 0, st, lo_b1, lo_d2, lo_d2));
+    DRUN(bilinear_up_dispatch(b.u1, b.b2, N, H2, W2, 256, dt, 0, st, lo_d2, lo_b2));
+    DRUN(conv_layer(p, b, UP2, false, b.b2, 256, N, H1, W1, b.u2, 128, FL, nullptr, b.d1, 128, nullptr, 0, b.a2, 0, 0, st, lo_b2, lo_d1, lo_d1));
+    DRUN(bilinear_up_dispatch(b.u2, b.b3, N, H1, W1, 128, dt, 0, st, lo_d1, lo_b3));
+    DRUN(conv_layer(p, b, UP3, false, b.b3, 128, N, S, W, b.u3, 64, FL, nullptr, b.out1, 64, nullptr, 0, b.a3, 0, 0, st, lo_b3, lo64, lo64));
+    DRUN(conv_layer(p, b, CONV2, false, b.u3, 64, N, S, W, b.c2, 64, LR | NB, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, st, lo64, lo64, 0));
+    DRUN(conv_layer(p, b, CONV3, false, b.c2, 64, N, S, W, b.c3, 64, LR | NB, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, st, lo64, lo64, 0));
     DRUN(conv_layer(p, b, CONV4, false, b.c3, 64, N, S, W, nullptr, 0, RESR_CONV_OUT_NCHW_F32, params + p.b_off[CONV4], nullptr, 0, nullptr, 0,
-                    nullptr, 0, 0, st, y));
+                    nullptr, 0, 0, st, lo64, 0, 0, y));
     return RESR_OK;
 }
 
@@ -324,22 +335,29 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
     const int H1 = S / 2, W1 = W / 2, H2 = S / 4, W2 = W / 4, H3 = S / 8, W3 = W / 8;
     const int NB = RESR_CONV_NO_BIAS, MK = RESR_CONV_MASK;
     const bool need_w = grad != nullptr;
+    const bool x2 = dt == RESR_F16X2;
+    const long px = (long)N * S * W;
+    auto LO = [&](long elems) -> long { return x2 ? elems : 0L; };   // hi -> lo offset of a buffer of `elems` elements
+    const long lo_in = LO(px * 32), lo64 = LO(px * 64), lo128 = LO(px * 128);
+    const long lo_h1_128 = LO(px / 4 * 128), lo_h1_256 = LO(px / 4 * 256), lo_h2_256 = LO(px / 16 * 256), lo_h2_512 = LO(px / 16 * 512);
+    const long lo_h3_512 = LO(px / 64 * 512), lo_h3_1024 = LO(px / 64 * 1024);
 
     // weight (and bias) gradient of layer li: X = first cin_pad channels of x (pixel stride xs), G = first cout channels of g
-    auto wgrad_layer = [&](int li, const char* x, int xs, const char* g, int gs, int h, int w) -> int {
+    auto wgrad_layer = [&](int li, const char* x, int xs, const char* g, int gs, int h, int w, long lo_xw, long lo_gw) -> int {
         if (!need_w) return RESR_OK;
         const Layer& l = kL[li];
         const int cin_pad = p.cin_pad[li], cin_v = p.cin_v[li], chunks = cin_pad / 32;
         float* dst = grad + p.w_off[li];
         float* raw = (!l.sn && !l.k4) ? dst : b.raw;
-        const int step = chunks * 2 <= 80 ? 64 : 32;     // products per launch <= wgrad.hip kMaxJobs
+        const int parts = x2 ? wgrad_x2_products() : 1;
+        const int step = chunks * 2 * parts <= 96 ? 64 : 32;     // tap-products per launch <= wgrad.hip kMaxJobs
         for (int g0 = 0; g0 < r32(l.cout); g0 += step) {
             int co = l.cout - g0; if (co > step) co = step;
             if (co <= 0) continue;
             WgradConv c;
             c.x0 = x; c.cin = cin_pad; c.in0_stride = xs; c.cin_real = cin_v;
             c.g = g + (size_t)g0 * es; c.cout = co; c.cout_pad = r32(co); c.g_stride = gs;
-            c.x_chunk_stride = c.g_chunk_stride = 0; c.x_lo_off = c.g_lo_off = 0;
+            c.x_chunk_stride = c.g_chunk_stride = 0; c.x_lo_off = lo_xw; c.g_lo_off = lo_gw;
             c.x_s2d_c = l.k4 ? l.cin : 0;      // 4x4 / stride-2 layers: X is the space-to-depth image, skip the virtual kernel's zero taps
             c.dw = raw + (size_t)g0 * cin_v * 9; c.db = (l.bias ? grad + p.b_off[li] + g0 : nullptr); c.scale = 1.f;
             const int jobs = chunks * (c.cout_pad / 32);
@@ -357,39 +375,40 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
         return RESR_OK;
     };
     auto dconv = [&](int li, const char* g, int gs, int h, int w, char* out, int out_stride, int flags, const char* mask, int mask_stride,
-                     char* aux, int s2d_out) {
-        return conv_layer(p, b, li, true, g, gs, N, h, w, out, out_stride, flags | NB, nullptr, nullptr, 0, mask, mask_stride, aux, 0, s2d_out, st);
+                     char* aux, int s2d_out, long lo_g, long lo_o) {
+        return conv_layer(p, b, li, true, g, gs, N, h, w, out, out_stride, flags | NB, nullptr, nullptr, 0, mask, mask_stride, aux, 0, s2d_out, st,
+                          lo_g, lo_o, 0);
     };
 
-    DRUN(nchw_to_nhwc_dispatch(gy, b.g4, N, 1, S, W, 1, 32, dt, nullptr, st, 0));
-    DRUN(wgrad_layer(CONV4, b.c3, 64, b.g4, 32, S, W));
-    DRUN(dconv(CONV4, b.g4, 32, S, W, b.G8, 64, MK, b.c3, 64, nullptr, 0));
-    DRUN(wgrad_layer(CONV3, b.c2, 64, b.G8, 64, S, W));
-    DRUN(dconv(CONV3, b.G8, 64, S, W, b.G7, 64, MK, b.c2, 64, nullptr, 0));
-    DRUN(wgrad_layer(CONV2, b.u3, 64, b.G7, 64, S, W));
-    DRUN(dconv(CONV2, b.G7, 64, S, W, b.G6, 64, MK | RESR_CONV_AUX_BEFORE_MASK, b.a3, 64, b.g_u3, 0));
-    DRUN(wgrad_layer(UP3, b.b3, 128, b.G6, 64, S, W));
-    DRUN(dconv(UP3, b.G6, 64, S, W, b.g_b3, 128, 0, nullptr, 0, nullptr, 0));
-    DRUN(bilinear_up_bwd_mask_dispatch(b.g_b3, b.g_u2, b.a2, b.G5, N, H1, W1, 128, dt, kSlope, st));   // g_u2 (skip gradient) and G5 = masked
-    DRUN(wgrad_layer(UP2, b.b2, 256, b.G5, 128, H1, W1));
-    DRUN(dconv(UP2, b.G5, 128, H1, W1, b.g_b2, 256, 0, nullptr, 0, nullptr, 0));
-    DRUN(bilinear_up_bwd_mask_dispatch(b.g_b2, b.g_u1, b.a1, b.G4, N, H2, W2, 256, dt, kSlope, st));
-    DRUN(wgrad_layer(UP1, b.b1, 512, b.G4, 256, H2, W2));
-    DRUN(dconv(UP1, b.G4, 256, H2, W2, b.g_b1, 512, 0, nullptr, 0, nullptr, 0));
-    DRUN(bilinear_up_bwd_mask_dispatch(b.g_b1, b.g_d3, b.d3, b.G3, N, H3, W3, 512, dt, kSlope, st));
-    DRUN(wgrad_layer(DOWN3, b.s3, 1024, b.G3, 512, H3, W3));
-    DRUN(dconv(DOWN3, b.G3, 512, H3, W3, b.g_s3, 1024, 0, nullptr, 0, nullptr, 256));
-    DRUN(d2s_add_mask_dispatch(b.g_s3, b.g_u1, b.d2, b.G2, N, H2, W2, 256, dt, kSlope, st));   // depth-to-space + skip gradient + LeakyReLU backward
-    DRUN(wgrad_layer(DOWN2, b.s2, 512, b.G2, 256, H2, W2));
-    DRUN(dconv(DOWN2, b.G2, 256, H2, W2, b.g_s2, 512, 0, nullptr, 0, nullptr, 128));
-    DRUN(d2s_add_mask_dispatch(b.g_s2, b.g_u2, b.d1, b.G1, N, H1, W1, 128, dt, kSlope, st));
-    DRUN(wgrad_layer(DOWN1, b.s1, 256, b.G1, 128, H1, W1));
-    DRUN(dconv(DOWN1, b.G1, 128, H1, W1, b.g_s1, 256, 0, nullptr, 0, nullptr, 64));
-    DRUN(d2s_add_mask_dispatch(b.g_s1, b.g_u3, nullptr, b.G0, N, S, W, 64, dt, kSlope, st));
-    DRUN(wgrad_layer(CONV1, b.x_in, 32, b.G0, 64, S, W));
+    DRUN(nchw_to_nhwc_dispatch(gy, b.g4, N, 1, S, W, 1, 32, dt, nullptr, st, lo_in));
+    DRUN(wgrad_layer(CONV4, b.c3, 64, b.g4, 32, S, W, lo64, lo_in));
+    DRUN(dconv(CONV4, b.g4, 32, S, W, b.G8, 64, MK, b.c3, 64, nullptr, 0, lo_in, lo64));
+    DRUN(wgrad_layer(CONV3, b.c2, 64, b.G8, 64, S, W, lo64, lo64));
+    DRUN(dconv(CONV3, b.G8, 64, S, W, b.G7, 64, MK, b.c2, 64, nullptr, 0, lo64, lo64));
+    DRUN(wgrad_layer(CONV2, b.u3, 64, b.G7, 64, S, W, lo64, lo64));
+    DRUN(dconv(CONV2, b.G7, 64, S, W, b.G6, 64, MK | RESR_CONV_AUX_BEFORE_MASK, b.a3, 64, b.g_u3, 0, lo64, lo64));
+    DRUN(wgrad_layer(UP3, b.b3, 128, b.G6, 64, S, W, lo128, lo64));
+    DRUN(dconv(UP3, b.G6, 64, S, W, b.g_b3, 128, 0, nullptr, 0, nullptr, 0, lo64, lo128));
+    DRUN(bilinear_up_bwd_mask_dispatch(b.g_b3, b.g_u2, b.a2, b.G5, N, H1, W1, 128, dt, kSlope, st, lo128, lo_h1_128));   // g_u2 (skip gradient) and G5 = masked
+    DRUN(wgrad_layer(UP2, b.b2, 256, b.G5, 128, H1, W1, lo_h1_256, lo_h1_128));
+    DRUN(dconv(UP2, b.G5, 128, H1, W1, b.g_b2, 256, 0, nullptr, 0, nullptr, 0, lo_h1_128, lo_h1_256));
+    DRUN(bilinear_up_bwd_mask_dispatch(b.g_b2, b.g_u1, b.a1, b.G4, N, H2, W2, 256, dt, kSlope, st, lo_h1_256, lo_h2_256));
+    DRUN(wgrad_layer(UP1, b.b1, 512, b.G4, 256, H2, W2, lo_h2_512, lo_h2_256));
+    DRUN(dconv(UP1, b.G4, 256, H2, W2, b.g_b1, 512, 0, nullptr, 0, nullptr, 0, lo_h2_256, lo_h2_512));
+    DRUN(bilinear_up_bwd_mask_dispatch(b.g_b1, b.g_d3, b.d3, b.G3, N, H3, W3, 512, dt, kSlope, st, lo_h2_512, lo_h3_512));
+    DRUN(wgrad_layer(DOWN3, b.s3, 1024, b.G3, 512, H3, W3, lo_h3_1024, lo_h3_512));
+    DRUN(dconv(DOWN3, b.G3, 512, H3, W3, b.g_s3, 1024, 0, nullptr, 0, nullptr, 256, lo_h3_512, lo_h3_1024));
+    DRUN(d2s_add_mask_dispatch(b.g_s3, b.g_u1, b.d2, b.G2, N, H2, W2, 256, dt, kSlope, st, lo_h3_1024, lo_h2_256, lo_h2_256));   // depth-to-space + skip gradient + LeakyReLU backward
+    DRUN(wgrad_layer(DOWN2, b.s2, 512, b.G2, 256, H2, W2, lo_h2_512, lo_h2_256));
+    DRUN(dconv(DOWN2, b.G2, 256, H2, W2, b.g_s2, 512, 0, nullptr, 0, nullptr, 128, lo_h2_256, lo_h2_512));
+    DRUN(d2s_add_mask_dispatch(b.g_s2, b.g_u2, b.d1, b.G1, N, H1, W1, 128, dt, kSlope, st, lo_h2_512, lo_h1_128, lo_h1_128));
+    DRUN(wgrad_layer(DOWN1, b.s1, 256, b.G1, 128, H1, W1, lo_h1_256, lo_h1_128));
+    DRUN(dconv(DOWN1, b.G1, 128, H1, W1, b.g_s1, 256, 0, nullptr, 0, nullptr, 64, lo_h1_128, lo_h1_256));
+    DRUN(d2s_add_mask_dispatch(b.g_s1, b.g_u3, nullptr, b.G0, N, S, W, 64, dt, kSlope, st, lo_h1_256, lo64, lo64));
+    DRUN(wgrad_layer(CONV1, b.x_in, 32, b.G0, 64, S, W, lo_in, lo64));
     if (gx) {
-        DRUN(dconv(CONV1, b.G0, 64, S, W, b.gxin, 32, 0, nullptr, 0, nullptr, 0));
-        DRUN(nhwc_to_nchw_dispatch(b.gxin, gx, N, 3, S, W, 1, 32, dt, st, 0));
+        DRUN(dconv(CONV1, b.G0, 64, S, W, b.gxin, 32, 0, nullptr, 0, nullptr, 0, lo64, lo_in));
+        DRUN(nhwc_to_nchw_dispatch(b.gxin, gx, N, 3, S, W, 1, 32, dt, st, lo_in));
     }
     return RESR_OK;
 }

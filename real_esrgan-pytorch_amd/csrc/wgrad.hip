@@ -35,7 +35,8 @@
 
 namespace resr {
 
-constexpr int kMaxJobs = 80;    // (X chunk, G tile) pairs per launch
+constexpr int kMaxJobs = 96;    // (X chunk, G tile) tap-products per launch (kernel arguments: 96 x 40 B + header < 4 KB)
+constexpr int kMaxReduce = 80;  // algorithmic products per launch (ReduceArgs: 80 x 48 B)
 constexpr int kMaxQuads = 40;   // 2x2 jobs per launch of the quad kernel
 constexpr int kX2WgradProductsDefault = 1;   // see wgrad_x2_products()
 constexpr int kSlab = 9 * 1024 + 32;   // floats per (job, split): 9 taps x 32 co x 32 ci, then 32 bias sums
@@ -72,11 +73,15 @@ struct ReduceJob {
     short want_bias, pad_;
 };
 
+static_assert(sizeof(WgradArgs) <= 4096, "kernel arguments");
+
 struct ReduceArgs {
-    ReduceJob jobs[kMaxJobs];
+    ReduceJob jobs[kMaxReduce];
     const float* partial;
     int splits;
 };
+
+static_assert(sizeof(ReduceArgs) <= 4096, "kernel arguments");
 
 typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_t;
 
@@ -872,7 +877,7 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
             return fail(RESR_ERR_ARG, "wgrad: cin=%d cin_real=%d cout=%d cout_pad=%d", c.cin, c.cin_real, c.cout, c.cout_pad);
         for (int ct = 0; ct < c.cout_pad / 32; ++ct)
             for (int ck = 0; ck < c.cin / 32; ++ck) {
-                if (nj + nparts > kMaxJobs) return fail(RESR_ERR_ARG, "wgrad: more than %d jobs in one batch", kMaxJobs);
+                if (nj + nparts > kMaxJobs || nr >= kMaxReduce) return fail(RESR_ERR_ARG, "wgrad: more than %d jobs in one batch", kMaxJobs);
                 const char* xh = (const char*)c.x0 + (size_t)ck * (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * es;
                 const char* gh = (const char*)c.g + (size_t)ct * (c.g_chunk_stride > 0 ? c.g_chunk_stride : 32) * es;
                 const int want_bias = (ck == 0 && c.db) ? 1 : 0;
@@ -889,7 +894,7 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
                     j.gstride_b = (unsigned)(c.g_stride * es);
                     j.slab_off = off;
                     j.want_bias = part < 2 ? want_bias : 0;
-                    j.xsub = (c.x_s2d_c > 0 && dtype == RESR_F16) ? (unsigned)((ck * 32) / c.x_s2d_c) : 4u;
+                    j.xsub = (c.x_s2d_c > 0 && dtype != RESR_F32) ? (unsigned)((ck * 32) / c.x_s2d_c) : 4u;
                     if (part == 1) q.slab_b = off;
                     if (part == 2) q.slab_c = off;
                     off += (unsigned)(splits * kSlab);

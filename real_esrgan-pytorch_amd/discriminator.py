@@ -83,15 +83,14 @@ class _DiscFn(torch.autograd.Function):
 
 
 class Discriminator(nn.Module):
-    """Reference `Discriminator()` (model.py:135-203).  Extra keyword `precision`: "fast" (f16 MFMA, fp32 accumulate) or
-    "strict" (f32 MFMA); "exact16" is a generator mode and maps to "fast" here."""
+    """Reference `Discriminator()` (model.py:135-203).  Extra keyword `precision`, as for `Generator`: "fast" (f16 MFMA, fp32
+    accumulate), "exact16" (split-operand f16 MFMA on hi/lo pairs: fp32-class results, the mode that meets the 1e-3 parity
+    tolerance) or "strict" (f32 MFMA); anything else raises."""
 
     def __init__(self, precision: Optional[str] = None) -> None:
         super().__init__()
         self.precision = precision or os.environ.get("RESR_PRECISION", "fast")
-        if self.precision == "exact16":
-            self.precision = "fast"
-        self._dtype = _precision_to_dtype(self.precision)
+        self._dtype = _precision_to_dtype(self.precision)          # ValueError for an unknown precision: never a silent downgrade
         self.conv1 = nn.Conv2d(3, 64, (3, 3), (1, 1), (1, 1))
         self.down_block1 = nn.Sequential(spectral_norm(nn.Conv2d(64, 128, (4, 4), (2, 2), (1, 1), bias=False)), nn.LeakyReLU(0.2, True))
         self.down_block2 = nn.Sequential(spectral_norm(nn.Conv2d(128, 256, (4, 4), (2, 2), (1, 1), bias=False)), nn.LeakyReLU(0.2, True))

@@ -324,12 +324,16 @@ with torch.no_grad():
 torch.cuda.synchronize()
 assert int(lib.resr_chain_errors()) == 0 and torch.isfinite(y_ok).all()
 side = torch.cuda.Stream()
+import time
 L.check(lib.resr_debug_occupy(200, 150 * 1024, 9000000, side.cuda_stream), "occupy")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
 with torch.no_grad():
     y = g(x)
+e1.record()
 torch.cuda.synchronize()
 e = int(lib.resr_chain_errors())
-print("errors", e & 0xffffffff, "nan", bool(torch.isnan(y).any()))
+print("errors", e & 0xffffffff, "nan", bool(torch.isnan(y).any()), "forward ms", e0.elapsed_time(e1))
 assert (e & 0xffffffff) > 0 and torch.isnan(y).any()
 try:
     L.chain_health()

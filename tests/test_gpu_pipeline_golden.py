@@ -153,7 +153,7 @@ def test_realesrgan_step_matches_reference(precision):
     g = R.Generator(3, 3, 4, precision=precision)
     g.load_state_dict(gsd)
     g = g.cuda().train()
-    d = R.Discriminator(precision="strict")          # the discriminator has the f16 and f32 modes
+    d = R.Discriminator(precision=precision)         # exact16: generator AND discriminator on split-operand f16 MFMA
     d.load_state_dict(M.init_discriminator_state(80 + seed))
     d = d.cuda().train()
     ema = R.EMA(g, 0.999)
