@@ -289,7 +289,8 @@ int resr_space_to_depth(const void* src, void* dst, int32_t n, int32_t h, int32_
  * backward != 0: src is the gradient [n,2h,2w,c], dst the input gradient [n,h,w,c] */
 int resr_bilinear_up2x(const void* src, void* dst, int32_t n, int32_t h, int32_t w, int32_t c, int32_t dtype,
                        int32_t backward, void* stream);
-/* out = (a + b) * (mask > 0 ? 1 : slope); b and mask optional */
+/* out = (a + b) * (mask > 0 ? 1 : slope); b and mask optional (RESR_F16X2: a, b, out are pairs with the lo tensor `count`
+ * elements behind the hi tensor; the mask is an activation, read from its hi tensor) */
 int resr_add_mask(const void* a, const void* b, const void* mask, void* out, int64_t count, int32_t dtype, float slope,
                   void* stream);
 /* torch.nn.utils.spectral_norm forward (model.py:140-168): W [rows][cols] fp32; training: one power iteration
@@ -301,9 +302,17 @@ int resr_spectral_norm(const float* w, float* u, float* v, int32_t rows, int32_t
  * order: no atomics, the result is bit-reproducible) */
 int resr_spectral_norm_bwd(const float* g, const float* w, const float* u, const float* v, const float* sigma2, float* dst,
                            int32_t rows, int32_t cols, int32_t accumulate, float* tmp1, void* stream);
-/* 2x2 stride-2 max pooling on NHWC [n,2*h_out,2*w_out,c] (VGG19 of ContentLoss, model.py:296-298) */
+/* 2x2 stride-2 max pooling on NHWC [n,2*h_out,2*w_out,c] (VGG19 of ContentLoss, model.py:296-298).  RESR_F16X2: src and dst
+ * are (hi, lo) pairs, each lo tensor directly behind its hi tensor (this holds for every helper of this group). */
 int resr_maxpool2x2(const void* src, void* dst, int32_t n, int32_t h_out, int32_t w_out, int32_t c, int32_t dtype,
                     void* stream);
+/* ... also recording which window position won (arg: uint8 [n,h_out,w_out,c], value dy * 2 + dx, the first maximum in that order
+ * like ATen's max_pool2d; may be NULL), and the backward pass through it: gin [n,2*h_out,2*w_out,c] receives g at the recorded
+ * position of every window and zeros elsewhere (the differentiable perceptual term, model.py:311-335). */
+int resr_maxpool2x2_arg(const void* src, void* dst, uint8_t* arg, int32_t n, int32_t h_out, int32_t w_out, int32_t c, int32_t dtype,
+                        void* stream);
+int resr_maxpool2x2_bwd(const void* g, const uint8_t* arg, void* gin, int32_t n, int32_t h_out, int32_t w_out, int32_t c, int32_t dtype,
+                        void* stream);
 /* virtual [cout][4C][3][3] weight gradient of a space-to-depth conv -> real [cout][C][4][4] */
 int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* stream);
 

@@ -108,6 +108,8 @@ _PROTOS = {
     "resr_spectral_norm": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
     "resr_spectral_norm_bwd": (C.c_int, [_P] * 6 + [C.c_int32] * 3 + [_P, _P]),
     "resr_maxpool2x2": (C.c_int, [_P, _P] + [C.c_int32] * 5 + [_P]),
+    "resr_maxpool2x2_arg": (C.c_int, [_P, _P, _P] + [C.c_int32] * 5 + [_P]),
+    "resr_maxpool2x2_bwd": (C.c_int, [_P, _P, _P] + [C.c_int32] * 5 + [_P]),
     "resr_fold4x4": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "resr_filter2d": (C.c_int, [_P, _P, _P] + [C.c_int32] * 7 + [_P]),
     "resr_usm_sharp": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_float, C.c_float] + [C.c_int32] * 4 + [_P]),

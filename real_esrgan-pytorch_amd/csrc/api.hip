@@ -375,6 +375,22 @@ int resr_maxpool2x2(const void* src, void* dst, int32_t n, int32_t h_out, int32_
     return maxpool2x2_dispatch(src, dst, n, h_out, w_out, c, dtype, (hipStream_t)stream, x2 ? 4 * px : 0L, x2 ? px : 0L, nullptr);
 }
 
+int resr_maxpool2x2_arg(const void* src, void* dst, uint8_t* arg, int32_t n, int32_t h_out, int32_t w_out, int32_t c, int32_t dtype,
+                        void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    const long px = (long)n * h_out * w_out * c;
+    const bool x2 = dtype == RESR_F16X2;
+    return maxpool2x2_dispatch(src, dst, n, h_out, w_out, c, dtype, (hipStream_t)stream, x2 ? 4 * px : 0L, x2 ? px : 0L, arg);
+}
+
+int resr_maxpool2x2_bwd(const void* g, const uint8_t* arg, void* gin, int32_t n, int32_t h_out, int32_t w_out, int32_t c, int32_t dtype,
+                        void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    const long px = (long)n * h_out * w_out * c;
+    const bool x2 = dtype == RESR_F16X2;
+    return maxpool2x2_bwd_dispatch(g, arg, gin, n, h_out, w_out, c, dtype, (hipStream_t)stream, x2 ? px : 0L, x2 ? 4 * px : 0L);
+}
+
 int resr_fold4x4(const float* dw3, float* dw4, int32_t cout, int32_t c, void* stream) {
     RESR_DEVICE_SCOPE(stream);
     return fold4x4_dispatch(dw3, dw4, cout, c, (hipStream_t)stream);

@@ -235,8 +235,9 @@ class RealESRGANStep:
 
     The VGG19 perceptual term (`content_criterion`, optional): the reference wraps it in `torch.Tensor(...)`
     (:477-478), which detaches it -- it is added to the logged g_loss but never back-propagated.  The same
-    happens here: `ContentLoss.forward` returns detached scalars (and, unlike the reference, stays on the
-    device: no 5 D2H syncs)."""
+    happens here with the default `ContentLoss(detached=True)`: detached scalars (and, unlike the reference, they
+    stay on the device: no 5 D2H syncs).  `ContentLoss(detached=False)` switches the quirk off: the weighted term
+    joins g_loss and back-propagates through VGG19 into the generator -- the graph the reference wrote (model.py:311-335)."""
 
     def __init__(self, generator, discriminator, ema, g_optimizer, d_optimizer, scaler=None, degrade=None,
                  pixel_weight: float = 1.0, adversarial_weight: float = 0.1, content_criterion=None,
@@ -285,6 +286,8 @@ class RealESRGANStep:
             content_loss = sum(w * c for w, c in zip(self.content_weight, cl))
         adversarial_loss = self.adversarial_weight * self.adv(self.d(sr), real)            # :478
         g_loss = pixel_loss + adversarial_loss                                             # :480 (content term detached, see class doc)
+        if content_loss is not None and not getattr(self.content, "detached", True):
+            g_loss = g_loss + content_loss                                                 # the quirk switched off
         self._backward(g_loss)                                                             # :483
         self._step(self.g_opt)                                                             # :485-486
         for p in self.d.parameters():                                                      # :491-492

@@ -164,7 +164,7 @@ def test_gan_step_vs_oracle():
     assert torch.allclose(d.state_dict()["conv2.0.weight_u"].cpu(), dp["conv2.0.weight_u"], atol=1e-5)   # three power iterations
 
 
-@pytest.mark.parametrize("precision,tol", [("strict", 1e-4), ("fast", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("strict", 1e-4), ("exact16", 1e-4), ("fast", 2e-2)])
 def test_content_loss_forward_vs_oracle(precision, tol):
     from oracle import model_ref as M
     from real_esrgan_pytorch_amd.content_loss import ContentLoss
@@ -182,6 +182,53 @@ def test_content_loss_forward_vs_oracle(precision, tol):
         for g, r in zip(got, ref):
             assert not g.requires_grad                              # detached, like torch.Tensor(...) at train_realesrgan.py:477
             assert abs(g.item() - r.item()) < tol * max(r.item(), 1e-6), (precision, aliasing, g.item(), r.item())
+
+
+@pytest.mark.parametrize("precision", ["strict", "exact16", "fast"])
+@pytest.mark.parametrize("aliasing", [True, False])
+def test_content_loss_gradient_vs_oracle_autograd(precision, aliasing, diag_dir):
+    """ContentLoss(detached=False): the perceptual term of the graph the reference wrote (model.py:311-335, weights config.py:137)
+    back-propagates into sr through VGG19 -- ReLU masks, max-pool argmax, backward-data convolutions.  d(loss)/d(sr) against
+    the oracle's autograd, relative L2; both settings of the inplace-ReLU aliasing of the tapped nodes.
+
+    ReLU'(v) jumps at 0: a pre-activation within rounding of zero flips ONE mask element between two correct evaluations, and
+    that one element costs ~1e-3 of the whole gradient here (tools/diag_content_loss.py shows the layer: every other
+    pre-activation gradient agrees to 1e-6) -- the same effect as the LeakyReLU mask in test_gpu_generator.py.  About one input
+    in two has such an element, so four inputs are run: every one must stay within 3e-3 (at most a couple of flips), and the
+    flip-free ones show the arithmetic's own class: <= 2e-5 for strict and exact16 (measured 2e-6)."""
+    from oracle import model_ref as M
+    from real_esrgan_pytorch_amd.content_loss import ContentLoss
+    nodes = ["features.2", "features.7", "features.16", "features.25", "features.34"]      # config.py:131
+    weights = [0.1, 0.1, 1.0, 1.0, 1.0]                                                   # config.py:137
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    torch.manual_seed(4)
+    cl = ContentLoss(nodes, mean, std, precision=precision, inplace_relu_aliasing=aliasing, detached=False).cuda()
+    sd = {k: v.detach().cpu() for k, v in cl.state_dict().items() if k.startswith("features.")}
+    scale = 1.0 if precision == "strict" else 4096.0                 # f16 (pair) gradients: a loss scale like GradScaler's
+    rels = []
+    for seed in (7, 8, 9, 10):
+        gen = torch.Generator().manual_seed(seed)
+        sr, hr = torch.rand(2, 3, 64, 48, generator=gen), torch.rand(2, 3, 64, 48, generator=gen)
+        sro = sr.clone().requires_grad_(True)
+        ref = M.content_loss(sro, hr, sd, nodes, mean, std, aliasing)
+        sum(w * l for w, l in zip(weights, ref)).backward()
+        srd = sr.cuda().requires_grad_(True)
+        got = cl(srd, hr.cuda())
+        for g, r in zip(got, ref):
+            assert g.requires_grad
+            assert abs(g.item() - r.item()) < (2e-2 if precision == "fast" else 1e-4) * max(r.item(), 1e-6)
+        (sum(w * l for w, l in zip(weights, got)) * scale).backward()
+        torch.cuda.synchronize()
+        rels.append(((srd.grad.cpu() / scale - sro.grad).norm() / sro.grad.norm()).item())
+    with open(os.path.join(diag_dir, f"content_grad_{precision}_{int(aliasing)}.json"), "w") as f:
+        json.dump(rels, f)
+    if precision == "fast":
+        assert max(rels) < 0.15, rels                 # f16 activations through 16 layers: the fast mode's class (measured 8-11e-2)
+    else:
+        assert max(rels) < 3e-3 and min(rels) < 2e-5, rels
+    # the default stays the reference's quirk: detached scalars, no gradient
+    cl.detached = True
+    assert not any(t.requires_grad for t in cl(sr.cuda().requires_grad_(True), hr.cuda()))
 
 
 def test_unknown_precision_raises():
