@@ -185,29 +185,33 @@ def ema_update(shadow: Dict[str, torch.Tensor], params: Dict[str, torch.Tensor],
 VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512]
 
 
-def content_loss(sr, hr, sd, nodes, mean, std, inplace_relu_aliasing: bool = True):
-    """Five L1 feature losses.  `inplace_relu_aliasing`: torchvision's ReLU(inplace=True) overwrites every tapped
-    conv output except the last one (the extractor prunes the graph after it)."""
-    m, s = torch.tensor(mean).view(1, 3, 1, 1), torch.tensor(std).view(1, 3, 1, 1)
+def vgg_features(x, sd, nodes, mean, std, inplace_relu_aliasing: bool = True):
+    """The tapped nodes of `vgg19().features` the way `create_feature_extractor` hands them back (model.py:296-303,:317-323).
+    `inplace_relu_aliasing`: torchvision's ReLU(inplace=True) overwrites every tapped conv output except the last one (the
+    extractor prunes the graph after it)."""
+    m = torch.tensor(mean, dtype=x.dtype).view(1, 3, 1, 1)
+    s = torch.tensor(std, dtype=x.dtype).view(1, 3, 1, 1)
     wanted = {int(k.split(".")[1]) for k in nodes}
     last = max(wanted)
+    x = (x - m) / s
+    out, idx = {}, 0
+    for v in VGG19_CFG:
+        if v == "M":
+            x = F.max_pool2d(x, 2)
+            idx += 1
+            continue
+        pre = F.conv2d(x, sd[f"features.{idx}.weight"], sd[f"features.{idx}.bias"], padding=1)
+        x = F.relu(pre)
+        if idx in wanted:
+            out[f"features.{idx}"] = pre if (not inplace_relu_aliasing or idx == last) else x
+        if idx == last:
+            break
+        idx += 2
+    return out
 
-    def feats(x):
-        x = (x - m) / s
-        out, idx = {}, 0
-        for v in VGG19_CFG:
-            if v == "M":
-                x = F.max_pool2d(x, 2)
-                idx += 1
-                continue
-            pre = F.conv2d(x, sd[f"features.{idx}.weight"], sd[f"features.{idx}.bias"], padding=1)
-            x = F.relu(pre)
-            if idx in wanted:
-                out[f"features.{idx}"] = pre if (not inplace_relu_aliasing or idx == last) else x
-            if idx == last:
-                break
-            idx += 2
-        return out
 
-    a, b = feats(sr), feats(hr)
+def content_loss(sr, hr, sd, nodes, mean, std, inplace_relu_aliasing: bool = True):
+    """Five L1 feature losses (model.py:311-335)."""
+    a = vgg_features(sr, sd, nodes, mean, std, inplace_relu_aliasing)
+    b = vgg_features(hr, sd, nodes, mean, std, inplace_relu_aliasing)
     return tuple(F.l1_loss(a[k], b[k]) for k in nodes)
