@@ -1,10 +1,10 @@
 #!/bin/bash
-# Profiles of one round on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r02
+# Profiles of one round on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r03
 # 1. rocprofv3 --kernel-trace --stats of the bench command (fast mode, then exact16) -> per-kernel tables
 # 2. PMC passes in their own runs (FETCH_SIZE / WRITE_SIZE separately: they do not fit one pass; SQ stall counters)
 # Everything lands under gpurun_out/prof_<tag>/; copy the reduced files you want judged into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
