@@ -375,16 +375,48 @@ int maxpool2x2_bwd_dispatch(const void* g, const uint8_t* arg, void* gin, int n,
 }
 
 // ---- spectral norm -----------------------------------------------------------------------------------------------
-// W is [rows = cout][cols = cin*k*k] row-major fp32 (the OIHW parameter viewed as a matrix).
-// W^T u in row groups of kSnRows: part[g][k] = sum over the group's rows of W[r][k] * u[r].  (cols / 256) x (rows / 32)
-// workgroups instead of cols / 256 (a 512 x 4608 matrix was 18 workgroups of 512 dependent loads each: 71 us); the groups
-// are summed in a fixed order by the normalisation kernel -- no atomics, so every rank computes bit-identical v.
+// W is [rows = cout][cols = cin*k*k] row-major fp32 (the OIHW parameter viewed as a matrix).  The power iteration of ALL
+// normalised layers of a discriminator call runs as four launches (W^T u partials / normalise v / W v / normalise u + sigma),
+// every launch covering up to kSnMaxLayers layers through a table in its arguments: one layer at a time it was 32 dependent
+// launches of 5-10 us per call, three calls per GAN step (train_realesrgan.py:479,500,508).
+// W^T u in row groups of kSnRows: part[g][k] = sum over the group's rows of W[r][k] * u[r] -- (cols / 256) x (rows / 32)
+// workgroups per layer (a 512 x 4608 matrix as cols / 256 workgroups was 18 workgroups of 512 dependent loads each: 71 us);
+// the groups are summed in a fixed order by the normalisation kernel -- no atomics, so every rank computes bit-identical v.
 constexpr int kSnRows = 32;
-__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ part,
-                                                      int rows, int cols) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= cols) return;
-    const int r0 = blockIdx.y * kSnRows, r1 = min(rows, r0 + kSnRows);
+constexpr int kSnMaxLayers = 8;
+struct SnLayer {
+    const float* W;
+    float* u;
+    float* v;
+    float* sigma2;   // [2]: sigma, 1 / sigma
+    float* wv;       // [rows] scratch
+    float* vraw;     // [groups][cols] scratch
+    int rows, cols, groups;
+    int first_a, first_b;   // first workgroup of this layer in the W^T u launch / in the W v launch
+};
+struct SnArgs {
+    SnLayer l[kSnMaxLayers];
+    int n;
+    float eps;
+};
+
+__device__ __forceinline__ int sn_layer_of(const SnArgs& a, int block, bool wv_launch) {
+    int li = 0;
+    while (li + 1 < a.n && block >= (wv_launch ? a.l[li + 1].first_b : a.l[li + 1].first_a)) ++li;
+    return li;
+}
+
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const SnArgs a) {
+    const int li = sn_layer_of(a, blockIdx.x, false);
+    const SnLayer& L = a.l[li];
+    const int local = blockIdx.x - L.first_a;
+    const int bx = (L.cols + 255) / 256;
+    const int k = (local % bx) * 256 + threadIdx.x, grp = local / bx;
+    if (k >= L.cols) return;
+    const float* __restrict__ W = L.W;
+    const float* __restrict__ u = L.u;
+    const int r0 = grp * kSnRows, r1 = min(L.rows, r0 + kSnRows);
+    const int cols = L.cols;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int r = r0;
     for (; r + 4 <= r1; r += 4) {
@@ -394,7 +426,7 @@ __global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ 
         s3 += W[(size_t)(r + 3) * cols + k] * u[r + 3];
     }
     for (; r < r1; ++r) s0 += W[(size_t)r * cols + k] * u[r];
-    part[(size_t)blockIdx.y * cols + k] = (s0 + s1) + (s2 + s3);
+    L.vraw[(size_t)grp * cols + k] = (s0 + s1) + (s2 + s3);
 }
 
 __device__ float block_sum(float v, float* red) {
@@ -407,11 +439,14 @@ __device__ float block_sum(float v, float* red) {
     return t;
 }
 
-// src = sum of `parts` consecutive [n] vectors (fixed order); dst = src / max(||src||, eps); optionally out2[0] = dot(dst, src),
-// out2[1] = 1 / out2[0].  The summed vector is written back to the first part.
-__global__ __launch_bounds__(256) void sn_normalize_kernel(float* __restrict__ src, float* __restrict__ dst, int n, float eps,
-                                                           float* __restrict__ sigma2, int parts) {
+// one workgroup per layer.  which = 0: src = the sum of the layer's `groups` partial vectors W^T u (fixed order), v = src /
+// max(||src||, eps).  which = 1: src = W v, u = src / max(||src||, eps), sigma = dot(u, src), sigma2 = (sigma, 1 / sigma).
+__global__ __launch_bounds__(256) void sn_normalize_kernel(const SnArgs a, int which) {
     __shared__ float red[4];
+    const SnLayer& L = a.l[blockIdx.x];
+    float* src = which ? L.wv : L.vraw;
+    float* dst = which ? L.u : L.v;
+    const int n = which ? L.rows : L.cols, parts = which ? 1 : L.groups;
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
         float t = src[i];
@@ -420,56 +455,76 @@ __global__ __launch_bounds__(256) void sn_normalize_kernel(float* __restrict__ s
         s += t * t;
     }
     const float nrm = sqrtf(block_sum(s, red));
-    const float inv = 1.f / fmaxf(nrm, eps);
+    const float inv = 1.f / fmaxf(nrm, a.eps);
     float d = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
         const float v = src[i] * inv;
-        if (dst) dst[i] = v;
+        dst[i] = v;
         d += v * src[i];
     }
-    if (sigma2) {
+    if (which) {
         const float dot = block_sum(d, red);
-        if (threadIdx.x == 0) { sigma2[0] = dot; sigma2[1] = 1.f / dot; }
+        if (threadIdx.x == 0) { L.sigma2[0] = dot; L.sigma2[1] = 1.f / dot; }
     }
 }
 
-__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v, float* __restrict__ wv,
-                                                     int cols) {
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const SnArgs a) {
     __shared__ float red[4];
-    const int r = blockIdx.x;
+    const int li = sn_layer_of(a, blockIdx.x, true);
+    const SnLayer& L = a.l[li];
+    const int r = blockIdx.x - L.first_b;
+    const float* __restrict__ W = L.W;
+    const float* __restrict__ v = L.v;
     float s = 0.f;
-    for (int k = threadIdx.x; k < cols; k += 256) s += W[(size_t)r * cols + k] * v[k];
+    for (int k = threadIdx.x; k < L.cols; k += 256) s += W[(size_t)r * L.cols + k] * v[k];
     const float t = block_sum(s, red);
-    if (threadIdx.x == 0) wv[r] = t;
+    if (threadIdx.x == 0) L.wv[r] = t;
 }
 
-// sigma = u . wv (eval mode: u, v are not updated)
-__global__ __launch_bounds__(256) void sn_dot_kernel(const float* __restrict__ u, const float* __restrict__ wv, int n,
-                                                     float* __restrict__ sigma2) {
+// sigma = u . wv (eval mode: u, v are not updated); one workgroup per layer
+__global__ __launch_bounds__(256) void sn_dot_kernel(const SnArgs a) {
     __shared__ float red[4];
+    const SnLayer& L = a.l[blockIdx.x];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += u[i] * wv[i];
+    for (int i = threadIdx.x; i < L.rows; i += 256) s += L.u[i] * L.wv[i];
     const float t = block_sum(s, red);
-    if (threadIdx.x == 0) { sigma2[0] = t; sigma2[1] = 1.f / t; }
+    if (threadIdx.x == 0) { L.sigma2[0] = t; L.sigma2[1] = 1.f / t; }
+}
+
+// `n` layers (<= kSnMaxLayers) at once: W[i] [rows[i]][cols[i]], u[i], v[i], sigma2[i] (2 floats), tmp[i] = rows + ceil(rows/32) * cols floats
+int spectral_norm_batch_dispatch(int n, const float* const* W, float* const* u, float* const* v, const int* rows, const int* cols, int training,
+                                 float eps, float* const* sigma2, float* const* tmp, hipStream_t st) {
+    if (n <= 0 || n > kSnMaxLayers || !W || !u || !v || !rows || !cols || !sigma2 || !tmp) return fail(RESR_ERR_ARG, "spectral_norm: bad argument");
+    SnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n; a.eps = eps;
+    int na = 0, nb = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!W[i] || !u[i] || !v[i] || !sigma2[i] || !tmp[i] || rows[i] <= 0 || cols[i] <= 0) return fail(RESR_ERR_ARG, "spectral_norm: bad argument");
+        SnLayer& L = a.l[i];
+        L.W = W[i]; L.u = u[i]; L.v = v[i]; L.sigma2 = sigma2[i];
+        L.rows = rows[i]; L.cols = cols[i]; L.groups = (rows[i] + kSnRows - 1) / kSnRows;
+        L.wv = tmp[i]; L.vraw = tmp[i] + rows[i];
+        L.first_a = na; L.first_b = nb;
+        na += ((cols[i] + 255) / 256) * L.groups;
+        nb += rows[i];
+    }
+    if (training) {               // one power iteration, u and v updated in place (torch spectral_norm, training forward)
+        hipLaunchKernelGGL(sn_wt_u_kernel, dim3(na), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(n), dim3(256), 0, st, a, 0);
+        hipLaunchKernelGGL(sn_w_v_kernel, dim3(nb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(n), dim3(256), 0, st, a, 1);   // sigma = u_new . (W v_new)
+    } else {
+        hipLaunchKernelGGL(sn_w_v_kernel, dim3(nb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(sn_dot_kernel, dim3(n), dim3(256), 0, st, a);
+    }
+    RESR_CHECK_LAUNCH("spectral_norm kernels");
+    return RESR_OK;
 }
 
 int spectral_norm_dispatch(const float* W, float* u, float* v, int rows, int cols, int training, float eps, float* sigma2,
                            float* tmp, hipStream_t st) {
-    if (!W || !u || !v || !sigma2 || !tmp || rows <= 0 || cols <= 0) return fail(RESR_ERR_ARG, "spectral_norm: bad argument");
-    const int groups = (rows + kSnRows - 1) / kSnRows;
-    float* wv = tmp;              // [rows]
-    float* vraw = tmp + rows;     // [groups][cols] partial sums of W^T u (spectral_norm_tmp_floats)
-    if (training) {               // one power iteration, u and v updated in place (torch spectral_norm, training forward)
-        hipLaunchKernelGGL(sn_wt_u_kernel, dim3((cols + 255) / 256, groups), dim3(256), 0, st, W, u, vraw, rows, cols);
-        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, vraw, v, cols, eps, (float*)nullptr, groups);
-        hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, st, W, v, wv, cols);
-        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, wv, u, rows, eps, sigma2, 1);   // sigma = u_new . (W v_new)
-    } else {
-        hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, st, W, v, wv, cols);
-        hipLaunchKernelGGL(sn_dot_kernel, dim3(1), dim3(256), 0, st, u, wv, rows, sigma2);
-    }
-    RESR_CHECK_LAUNCH("spectral_norm kernels");
-    return RESR_OK;
+    return spectral_norm_batch_dispatch(1, &W, &u, &v, &rows, &cols, training, eps, &sigma2, &tmp, st);
 }
 
 // backward of W = W_orig / sigma, sigma = u^T W_orig v (u, v constants):

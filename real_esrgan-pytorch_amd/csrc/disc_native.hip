@@ -36,7 +36,8 @@ int s2d_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
 int bilinear_up_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t, long, long);
 int d2s_add_mask_dispatch(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t, long, long, long);
 int bilinear_up_bwd_mask_dispatch(const void*, void*, const void*, void*, int, int, int, int, int, float, hipStream_t, long, long);
-int spectral_norm_dispatch(const float*, float*, float*, int, int, int, float, float*, float*, hipStream_t);
+int spectral_norm_batch_dispatch(int, const float* const*, float* const*, float* const*, const int*, const int*, int, float, float* const*,
+                                 float* const*, hipStream_t);
 int spectral_norm_bwd_dispatch(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, float*,
                                hipStream_t);
 int fold4x4_dispatch(const float*, float*, int, int, hipStream_t);
@@ -129,7 +130,12 @@ void carve(const DPlan& p, char* base, DBufs& b) {
     b.sigma = (float*)take(kLayers * 2 * sizeof(float));
     b.uv = (float*)take(p.n_uv * sizeof(float));
     b.packed = take(p.pk_elems * elem_size(p.d.dtype) * (p.d.dtype == RESR_F16X2 ? 3 : 1) + 16384);
-    b.sn_tmp = (float*)take((512 + 16 * 4608 + 8) * sizeof(float));
+    {   // spectral-norm scratch of every normalised layer (all layers iterate in the same four launches): rows + ceil(rows / 32) * cols floats each
+        size_t fl = 0;
+        for (int i = 0; i < kLayers; ++i)
+            if (kL[i].sn) fl += align_up((size_t)kL[i].cout + (size_t)((kL[i].cout + 31) / 32) * kL[i].cin * (kL[i].k4 ? 16 : 9), 64);
+        b.sn_tmp = (float*)take(fl * sizeof(float));
+    }
     b.x_in = take(px * 32 * es);
     b.out1 = take(px * 64 * es);
     b.s1 = take(px / 4 * 256 * es);   b.d1 = take(px / 4 * 128 * es);
@@ -284,11 +290,19 @@ int discriminator_forward(const ResrDiscriminatorDesc* d, const float* x, const 
     const int dt = d->dtype, N = d->n, S = d->h, W = d->w;
     const int H1 = S / 2, W1 = W / 2, H2 = S / 4, W2 = W / 4, H3 = S / 8, W3 = W / 8;
     // spectral norm: one power iteration per training-mode call, u / v updated in place like torch's hook (model.py:140-168)
-    for (int li = 0; li < kLayers; ++li) {
-        if (!kL[li].sn) continue;
-        const int cols = kL[li].cin * (kL[li].k4 ? 16 : 9);
-        DRUN(spectral_norm_dispatch(params + p.w_off[li], uv + p.u_off[li], uv + p.v_off[li], kL[li].cout, cols, d->sn_training, 1e-12f,
-                                    b.sigma + li * 2, b.sn_tmp, st));
+    {   // all eight normalised layers in the same four launches
+        const float* Ws[kLayers]; float* us[kLayers]; float* vs[kLayers]; float* sg[kLayers]; float* tm[kLayers];
+        int rws[kLayers], cls[kLayers], n = 0;
+        size_t fl = 0;
+        for (int li = 0; li < kLayers; ++li) {
+            if (!kL[li].sn) continue;
+            const int cols = kL[li].cin * (kL[li].k4 ? 16 : 9);
+            Ws[n] = params + p.w_off[li]; us[n] = uv + p.u_off[li]; vs[n] = uv + p.v_off[li]; sg[n] = b.sigma + li * 2; tm[n] = b.sn_tmp + fl;
+            rws[n] = kL[li].cout; cls[n] = cols;
+            fl += align_up((size_t)kL[li].cout + (size_t)((kL[li].cout + 31) / 32) * cols, 64);
+            ++n;
+        }
+        DRUN(spectral_norm_batch_dispatch(n, Ws, us, vs, rws, cls, d->sn_training, 1e-12f, sg, tm, st));
     }
     if (d->training && hipMemcpyAsync(b.uv, uv, p.n_uv * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail(RESR_ERR_LAUNCH, "discriminator_forward: hipMemcpyAsync");

@@ -151,7 +151,7 @@ struct Bufs {
     char *trunk_out, *feat, *u1, *u2, *c3;
     uint8_t* ymask;
     // backward
-    char *g4, *gA, *gB, *gM1, *gF, *gT[4], *gS, *gxin;
+    char *g4, *gA, *gB, *gM1, *gF, *gT[4], *gS[3], *gxin;   // gS: one slab per dense block of an RRDB (their weight gradients run as one batch)
     float* partial;
     size_t partial_bytes;
     size_t total;
@@ -215,14 +215,18 @@ void carve(const Plan& p, char* base, Bufs& b) {
         b.gM1 = take(px * 4 * 64 * es);
         b.gF = take(px * 64 * es);
         for (int i = 0; i < 4; ++i) b.gT[i] = take(px * 64 * es);
-        b.gS = take(px * 128 * es);
+        for (int i = 0; i < 3; ++i) b.gS[i] = take(px * 128 * es);
         b.gxin = take(px * p.ci_pad * es);
-        // wgrad slabs: largest batch (a dense block = 26 jobs at LR; single 64->64 convs = 4 jobs at 1x/2x/4x)
+        // wgrad slabs: largest batch (an RRDB = 78 products, a dense block = 26 at LR; single 64->64 convs = 4 jobs at 1x/2x/4x)
         const size_t slab = (9 * 1024 + 32) * sizeof(float);
         size_t pb = 0;
         for (int k = 1; k <= wm; k += 2) {          // both weight-gradient settings of RESR_F16X2 (1 or 3 jobs per product)
             const size_t q0 = (size_t)26 * k * splits_for(p, 26 * k, p.h, p.w) * slab;
             if (q0 > pb) pb = q0;
+            if (78 * k <= kWgradMaxJobs) {
+                const size_t q3 = (size_t)78 * k * splits_for(p, 78 * k, p.h, p.w) * slab;
+                if (q3 > pb) pb = q3;
+            }
             for (int m = 1; m <= 4; m *= 2) {
                 const size_t q = (size_t)4 * k * splits_for(p, 4 * k, p.h * m, p.w * m) * slab;
                 if (q > pb) pb = q;
@@ -233,8 +237,9 @@ void carve(const Plan& p, char* base, Bufs& b) {
         b.partial_bytes = pb;
         b.partial = (float*)take(b.partial_bytes);
     } else {
-        b.g4 = b.gA = b.gB = b.gM1 = b.gF = b.gS = b.gxin = nullptr;
+        b.g4 = b.gA = b.gB = b.gM1 = b.gF = b.gxin = nullptr;
         for (int i = 0; i < 4; ++i) b.gT[i] = nullptr;
+        for (int i = 0; i < 3; ++i) b.gS[i] = nullptr;
         b.partial = nullptr;
         b.partial_bytes = 0;
     }
@@ -286,7 +291,7 @@ int64_t generator_buffer_offsets(const ResrGeneratorDesc* d, int64_t* out, int64
     char* base = reinterpret_cast<char*>(4096);  // fake non-null base, only differences are used
     carve(p, base, b);
     const char* ptrs[] = {b.x_in, b.ws[0], b.out1, b.trunk_out, b.feat, b.u1, b.u2, b.c3, (char*)b.ymask, b.g4, b.gA,
-                          b.gB, b.gM1, b.gF, b.gT[0], b.gT[1], b.gT[2], b.gT[3], b.gS, b.gxin, (char*)b.partial};
+                          b.gB, b.gM1, b.gF, b.gT[0], b.gT[1], b.gT[2], b.gT[3], b.gS[0], b.gxin, (char*)b.partial};
     const int64_t n = sizeof(ptrs) / sizeof(ptrs[0]);
     if (out) {
         if (cap < n) return fail(RESR_ERR_ARG, "generator_buffer_offsets: capacity");
@@ -612,15 +617,23 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     RUN(ready(0));   // conv4, conv3, upsampling2, upsampling1, conv2: the tail of the arena
     // trunk, mirrored dense blocks.  gT ring: e (grad wrt RRDB output) must survive its three RDBs.
     int e_idx = 0;
+    // The weight gradients of the three dense blocks of an RRDB run as ONE batched launch pair behind the block's last
+    // backward-data pass (15 convolutions, 78 products): a third of the slab writes and reductions of one launch pair per
+    // dense block -- on small launches (the 64^2 training crops) the slabs are a third of the weight-gradient time.  Every
+    // block of the RRDB therefore keeps its own gradient slab gS[pos]; the gT ring already keeps the three input gradients
+    // (e, a, b) alive until the RRDB is done.  exact16 with three products per weight (234 jobs) stays per block.
+    const bool batch_rrdb = 78 * wm <= kWgradMaxJobs && !getenv("RESR_WGRAD_PER_BLOCK");
+    WgradConv wc[15];
     for (int r = p.nrdb - 1; r >= 0; --r) {
         const int pos = r % 3;  // 2: rdb3 (first in backward), 0: rdb1 (last)
         if (pos == 2) e_idx = cur;
         const char* gin = b.gT[cur];
         const char* act = b.ws[r];
+        char* gS = b.gS[pos];
         const float fold = pos == 2 ? 0.04f : 0.2f;
-        WgradConv wc[5];
-        wc[4] = wconv(p.convs[p.i_trunk0 + r * 5 + 4], act, 192, 32, gin, 32, fold, lo_ws, lo_t);   // conv5: G = fold * gin
-        wc[4].x_chunk_stride = plane; wc[4].g_chunk_stride = plane;
+        WgradConv* wcb = wc + (batch_rrdb ? 5 * pos : 0);
+        wcb[4] = wconv(p.convs[p.i_trunk0 + r * 5 + 4], act, 192, 32, gin, 32, fold, lo_ws, lo_t);   // conv5: G = fold * gin
+        wcb[4].x_chunk_stride = plane; wcb[4].g_chunk_stride = plane;
         ResrConvDesc cds[4];
         const void* ws4[4];
         const void* masks4[4];
@@ -630,12 +643,12 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             const int cin = 64 + 32 * ps;
             ResrConvDesc cd = dgrad(h, w, 64, 32, cin, 32, 32, 32, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS, lo_t, lo_gs, lo_gs);
             cd.in0_chunk_stride = plane; cd.in1_chunk_stride = plane;
-            char* out = b.gS + (size_t)ps * plane * es;
+            char* out = gS + (size_t)ps * plane * es;
             const char* mask = b.bits[r] + (size_t)(k - 1) * N * h * w * sizeof(uint32_t);   // sign plane of o_k
             cds[ps] = cd; ws4[ps] = pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * wes; masks4[ps] = mask; outs4[ps] = out;
             const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
-            wc[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f, lo_ws, lo_gs);
-            wc[k - 1].x_chunk_stride = plane;
+            wcb[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f, lo_ws, lo_gs);
+            wcb[k - 1].x_chunk_stride = plane;
         }
         {   // the four mirrored cout-32 passes, then g_x = convT(all) + (skip terms): one chained launch where the kernel supports
             // it (g_x joins on small launches), else one launch per pass
@@ -648,11 +661,12 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.s0 = 1.f; cd.res0_lo_offset = lo_t;
             cd.t0 = pos == 2 ? 0.2f : 1.f;       // d(rdb3_out*0.2 + x)/d(rdb3_out) reaches x3 scaled
             if (pos == 0) { res1 = b.gT[e_idx]; cd.res1_stride = 32; cd.res1_chunk_stride = plane; cd.s1 = 1.f; cd.t1 = 1.f; cd.res1_lo_offset = lo_t; }
-            RUN(conv3x3_block_dispatch(4, cds, gin, b.gS, ws4, nullptr, masks4, outs4, nullptr, &cd,
+            RUN(conv3x3_block_dispatch(4, cds, gin, gS, ws4, nullptr, masks4, outs4, nullptr, &cd,
                                        pk + p.pk_bwd_trunk[(size_t)r * 5 + 4] * wes, nullptr, res0, res1, b.gT[nxt], b.chain, b.chain_bytes, st));
             cur = nxt;
         }
-        RUN(wgrad_run(wc, 5, h, w, 0));   // all five weight gradients of the block in one launch pair (they read gin and gS, not g_x)
+        if (!batch_rrdb) RUN(wgrad_run(wc, 5, h, w, 0));   // all five weight gradients of the block in one launch pair (they read gin and gS, not g_x)
+        else if (pos == 0) RUN(wgrad_run(wc, 15, h, w, 0));   // ... of the RRDB's three blocks
         if (pos == 0) RUN(ready(1 + (d->n_blocks - 1 - r / 3)));   // rdb3, rdb2, rdb1 of this RRDB are done
     }
     if (debug_stop() == 4) return RESR_OK;

@@ -14,4 +14,6 @@ struct WgradConv {
     float* dw; float* db; float scale;
 };
 
+constexpr int kWgradMaxJobs = 96;   // (X chunk, G tile) tap-products per weight-gradient launch (kernel arguments: 96 x 40 B + header < 4 KB)
+
 }  // namespace resr

@@ -35,7 +35,7 @@
 
 namespace resr {
 
-constexpr int kMaxJobs = 96;    // (X chunk, G tile) tap-products per launch (kernel arguments: 96 x 40 B + header < 4 KB)
+constexpr int kMaxJobs = kWgradMaxJobs;    // (X chunk, G tile) tap-products per launch (wgrad.h)
 constexpr int kMaxReduce = 80;  // algorithmic products per launch (ReduceArgs: 80 x 48 B)
 constexpr int kMaxQuads = 40;   // 2x2 jobs per launch of the quad kernel
 constexpr int kX2WgradProductsDefault = 1;   // see wgrad_x2_products()

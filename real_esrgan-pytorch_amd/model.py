@@ -165,6 +165,7 @@ class _GeneratorFn(torch.autograd.Function):
         y, desc, ws = module._run_forward(x, training)
         ctx.module, ctx.desc, ctx.ws = module, desc, ws
         ctx.x_needs_grad = x.requires_grad
+        ctx.n_params = len(params)
         ctx.owner = 0
         if training:
             ctx.owner = ws.acquire()
@@ -180,6 +181,8 @@ class _GeneratorFn(torch.autograd.Function):
         private = module._live_graphs > 1
         grads, gx = module._run_backward(ctx.desc, ctx.ws, gy.contiguous().float(), ctx.x_needs_grad, private)
         ctx._token.finish()
+        if len(grads) != ctx.n_params:             # flat_parameter() mode: the one alias was the graph's only parameter input
+            grads = [None] * ctx.n_params
         return (None, None, gx) + tuple(grads)
 
 
@@ -442,7 +445,10 @@ class Generator(nn.Module):
     # ---- module surface ---------------------------------------------------------------------------
     def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
         self.flat_parameters()
-        params = self._ordered_params()
+        fp = self.__dict__["_flat_param"]
+        # flat_parameter() mode: the alias stands for all 702 tensors in the autograd graph (its .grad is set by hand in backward),
+        # so a backward pass does not walk 702 AccumulateGrad nodes that would each receive None
+        params = [fp] if fp is not None else self._ordered_params()
         # grad mode is off inside autograd.Function.forward, so decide here whether to keep activations
         training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         return _GeneratorFn.apply(self, training, x, *params)
