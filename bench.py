@@ -141,13 +141,14 @@ def probe_conv_kernels(batch, lr, dtype_name, reps=8):
 
 
 def kernel_sources_sha16():
-    """sha256 over the kernel sources (csrc/*.h, *.hip) the library is built from: a PMC measurement is only quoted for the
-    build it was taken on."""
+    """sha256 over the sources that decide the hot kernels' traffic (the conv / weight-gradient kernels and the generator's
+    launch plan): a PMC measurement is only quoted for the build it was taken on."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, "real_esrgan-pytorch_amd", "csrc", "*.h")) +
-                       glob.glob(os.path.join(ROOT, "real_esrgan-pytorch_amd", "csrc", "*.hip"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "real_esrgan-pytorch_amd", "csrc", "conv3x3*.h*")) +
+                       glob.glob(os.path.join(ROOT, "real_esrgan-pytorch_amd", "csrc", "wgrad.h*")) +
+                       [os.path.join(ROOT, "real_esrgan-pytorch_amd", "csrc", "generator.hip")]):
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
     return h.hexdigest()[:16]

@@ -32,6 +32,19 @@
 
 #include "conv3x3.h"
 
+// Timing experiment only (tools/winograd_bound.sh; never defined in the product build): issue the MFMAs of only the first N of
+// the nine taps of every k-step -- everything else (LDS-DMA, LDS fragment reads, barriers, epilogue) unchanged, results wrong.
+// N = 4 is the matrix work of a Winograd F(2x2,3x3) formulation (16 products per 2x2 outputs instead of 36) on this kernel's
+// memory side: an upper bound of what that formulation could gain, before its transforms and its 16/9 larger weights.
+// RESR_TIMING_VALU = V adds V packed-f16 vector instructions per remaining MFMA to the consumer waves: the input transform
+// B^T d B of that formulation is 32 adds per 4x4 patch and channel = 8 v_pk_add_f16 per MFMA of a 16-channel k-step.
+#ifndef RESR_TIMING_TAPS
+#define RESR_TIMING_TAPS 9
+#endif
+#ifndef RESR_TIMING_VALU
+#define RESR_TIMING_VALU 0
+#endif
+
 namespace resr {
 
 static __device__ uint4 g_conv_zero16 = {0, 0, 0, 0};  // one zero page per translation unit
@@ -713,6 +726,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             wr[slot][m] = *reinterpret_cast<const uint4*>(wlds + par * C::WBUF + (((dy * 3 + dx) * KS + ks) * MT + m) * 1024);
     };
 
+    unsigned timing_valu[4] = {0x3c003c00u, 0x3c003c00u, 0x38003800u, 0x34003400u};   // RESR_TIMING_VALU only
+    (void)timing_valu;
     int par = 0, hbc = 0;   // weight-buffer parity / halo buffer of the current stage
     // CH: a finished tile is published (flags[tile] = pend_tag) at the end of the NEXT stage's multiply: by then its stores
     // have long been acknowledged, and the consumers never wait for their producers between epilogue and publication
@@ -877,11 +892,17 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     const int u = gi * 3 + dy;
                     if (u + RING - 1 < NU) wload((u + RING - 1) % RING, wsel, u + RING - 1);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (RESR_TIMING_TAPS >= 9 || (gi % 3) * 3 + dy < RESR_TIMING_TAPS) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
+                        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            acc[m][t] = Frag<T>::mma(wr[u % RING][m], rowf[PP ? (gi & 1) : 0][t + dy], acc[m][t]);
+                            for (int m = 0; m < MT; ++m) {
+                                acc[m][t] = Frag<T>::mma(wr[u % RING][m], rowf[PP ? (gi & 1) : 0][t + dy], acc[m][t]);
+#pragma unroll
+                                for (int v = 0; v < RESR_TIMING_VALU; ++v)   // (timing experiment: stand-in for the transform's packed adds)
+                                    asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(timing_valu[v & 3]) : "v"(timing_valu[(v + 1) & 3]));
+                            }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
