@@ -65,4 +65,5 @@ def test_rotation_quirk_and_validation_batches():
     dl = DataLoader(ds, batch_size=1, shuffle=False, num_workers=0)
     b = next(iter(dl))
     assert tuple(b["lr"].shape) == (1, 3, 4, 4) and tuple(b["hr"].shape) == (1, 3, 16, 16) and len(dl) == 1
-    assert not hasattr(D, "CPUPrefetcher")       # the HBM stager (CUDAPrefetcher) is covered by tests/test_gpu_train_harness.py
+    cp = D.CPUPrefetcher(dl)                     # reference dataset.py:248-268 (the HBM stager, CUDAPrefetcher: tests/test_gpu_train_harness.py)
+    assert len(cp) == 1 and cp.next() is not None and cp.next() is None
