@@ -363,21 +363,32 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
         const int cin_pad = p.cin_pad[li], cin_v = p.cin_v[li], chunks = cin_pad / 32;
         float* dst = grad + p.w_off[li];
         float* raw = (!l.sn && !l.k4) ? dst : b.raw;
+        // as many 32-channel output tiles per launch as the weight-gradient launcher takes: <= 96 tap-products (wgrad.h) and <= 80
+        // algorithmic products (its reduction's argument block) -- a 128..256-channel layer is one or two launch pairs, not 2..4
         const int parts = x2 ? wgrad_x2_products() : 1;
-        const int step = chunks * 2 * parts <= 96 ? 64 : 32;     // tap-products per launch <= wgrad.hip kMaxJobs
-        for (int g0 = 0; g0 < r32(l.cout); g0 += step) {
-            int co = l.cout - g0; if (co > step) co = step;
-            if (co <= 0) continue;
-            WgradConv c;
-            c.x0 = x; c.cin = cin_pad; c.in0_stride = xs; c.cin_real = cin_v;
-            c.g = g + (size_t)g0 * es; c.cout = co; c.cout_pad = r32(co); c.g_stride = gs;
-            c.x_chunk_stride = c.g_chunk_stride = 0; c.x_lo_off = lo_xw; c.g_lo_off = lo_gw;
-            c.x_s2d_c = l.k4 ? l.cin : 0;      // 4x4 / stride-2 layers: X is the space-to-depth image, skip the virtual kernel's zero taps
-            c.dw = raw + (size_t)g0 * cin_v * 9; c.db = (l.bias ? grad + p.b_off[li] + g0 : nullptr); c.scale = 1.f;
-            const int jobs = chunks * (c.cout_pad / 32);
+        int tiles_per = kWgradMaxJobs / (chunks * parts);
+        if (tiles_per > 80 / chunks) tiles_per = 80 / chunks;
+        if (tiles_per < 1) tiles_per = 1;
+        const int step = tiles_per * 32;
+        for (int g0 = 0; g0 < r32(l.cout); g0 += step) {       // one launch pair per `step` output channels, as convolutions of <= 64
+            WgradConv cs[8];
+            int nc = 0, jobs = 0;
+            for (int q0 = g0; q0 < g0 + step && q0 < r32(l.cout) && nc < 8; q0 += 64) {
+                int co = l.cout - q0; if (co > 64) co = 64;
+                if (g0 + step - q0 < co) co = g0 + step - q0;
+                if (co <= 0) continue;
+                WgradConv& c = cs[nc++];
+                c.x0 = x; c.cin = cin_pad; c.in0_stride = xs; c.cin_real = cin_v;
+                c.g = g + (size_t)q0 * es; c.cout = co; c.cout_pad = r32(co); c.g_stride = gs;
+                c.x_chunk_stride = c.g_chunk_stride = 0; c.x_lo_off = lo_xw; c.g_lo_off = lo_gw;
+                c.x_s2d_c = l.k4 ? l.cin : 0;      // 4x4 / stride-2 layers: X is the space-to-depth image, skip the virtual kernel's zero taps
+                c.dw = raw + (size_t)q0 * cin_v * 9; c.db = (l.bias ? grad + p.b_off[li] + q0 : nullptr); c.scale = 1.f;
+                jobs += chunks * (c.cout_pad / 32);
+            }
+            if (!nc) continue;
             const int splits = wsplits(dt, jobs, N, h, w);
-            if (wgrad_batch_partial_bytes(&c, 1, splits, dt) > b.partial_bytes) return fail(RESR_ERR_WORKSPACE, "discriminator: wgrad slabs");
-            DRUN(wgrad_batch(&c, 1, N, h, w, dt, 0, splits, b.partial, st));
+            if (wgrad_batch_partial_bytes(cs, nc, splits, dt) > b.partial_bytes) return fail(RESR_ERR_WORKSPACE, "discriminator: wgrad slabs");
+            DRUN(wgrad_batch(cs, nc, N, h, w, dt, 0, splits, b.partial, st));
         }
         const float* cur = raw;
         if (l.k4) { DRUN(fold4x4_dispatch(raw, b.folded, l.cout, l.cin, st)); cur = b.folded; }

@@ -12,7 +12,7 @@ import argparse
 import numpy as np
 import torch
 
-from . import config, imgproc
+from . import _lib, config, imgproc
 from .model import Generator
 
 
@@ -33,6 +33,7 @@ def main(args) -> None:
     with torch.no_grad():
         sr_tensor = model(lr_tensor)                                                   # inference.py:53
     sr_image = imgproc.tensor_to_image(sr_tensor, False, False)
+    _lib.chain_health()             # (the image is on the host: every launch has reported) a broken chained launch must not reach the file
     Image.fromarray(sr_image).save(args.output_path)
     print(f"SR image save to `{args.output_path}`")
 

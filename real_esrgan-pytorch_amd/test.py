@@ -14,7 +14,7 @@ from typing import List
 
 import torch
 
-from . import config, imgproc
+from . import _lib, config, imgproc
 from .image_quality_assessment import NIQE
 from .model import Generator
 
@@ -51,6 +51,7 @@ def main() -> float:
             sr_tensor = model(lr_tensor)                                                   # test.py:79
         Image.fromarray(imgproc.tensor_to_image(sr_tensor, False, False)).save(os.path.join(config.sr_dir, name))
         niqe_metrics += niqe(sr_tensor).item()
+    _lib.chain_health()             # fail loudly if a chained conv launch ever gave up on a neighbouring tile
     avg_niqe = 100 if niqe_metrics / total_files > 100 else niqe_metrics / total_files    # test.py:92
     print(f"NIQE: {avg_niqe:4.2f} 100u")
     return avg_niqe

@@ -228,6 +228,7 @@ def validate(model: nn.Module, ema_model: nn.Module, data_prefetcher: CUDAPrefet
             batch_data = data_prefetcher.next()
             batch_index += 1
     ema_model.restore()
+    _lib.chain_health()             # the NIQE read-backs above synchronised: every launch of the evaluation has reported
     if _RANK == 0:
         ProgressMeter(len(data_prefetcher), [batch_time, niqe_metrics], prefix=f"{mode}: ").display_summary()
     writer.add_scalar(f"{mode}/NIQE", niqe_metrics.avg, epoch + 1)
