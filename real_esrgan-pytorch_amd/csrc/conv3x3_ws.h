@@ -38,6 +38,8 @@
 // memory side: an upper bound of what that formulation could gain, before its transforms and its 16/9 larger weights.
 // RESR_TIMING_VALU = V adds V packed-f16 vector instructions per remaining MFMA to the consumer waves: the input transform
 // B^T d B of that formulation is 32 adds per 4x4 patch and channel = 8 v_pk_add_f16 per MFMA of a 16-channel k-step.
+// RESR_TIMING_NO_W / RESR_TIMING_NO_H (chained launches): the producers skip the weight / halo requests after the first stages
+// (tools/build_variant.py ... -DRESR_TIMING_NO_H=1): what a 64^2 launch costs with an idle memory pipe.
 #ifndef RESR_TIMING_TAPS
 #define RESR_TIMING_TAPS 9
 #endif
@@ -88,7 +90,10 @@ struct WsCfg {
     // LeakyReLU-backward multipliers by 4 mask bits (16 x float4), behind the weight buffers (EPI 33 of the lean epilogue)
     static constexpr int LUT_OFF = LDS_BYTES, LUT_BYTES = 256;
     // chain launches: the biases of kMaxChain jobs + the consumers' arrival counter, behind the table
-    static constexpr int CHAIN_OFF = LUT_OFF + LUT_BYTES, CHAIN_BYTES = kMaxChain * 128 + 64;
+    // (+ 1 KB for the debug timeline of a traced workgroup: stamps go to LDS and are copied out at the end of the kernel -- a stamp
+    // written straight to global memory is a store on the in-order vector-memory counter, and the very waits the timeline is
+    // supposed to show then also wait for its acknowledgement)
+    static constexpr int CHAIN_OFF = LUT_OFF + LUT_BYTES, CHAIN_TRACE = kMaxChain * 128 + 64, CHAIN_BYTES = CHAIN_TRACE + 1024;
     static_assert(LDS_BYTES + LUT_BYTES + CHAIN_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -236,6 +241,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         if (threadIdx.x == 0) {
             const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]
             const unsigned per = (unsigned)G >> 3;
+            // (requested before the ticket so that the two round trips overlap)
+            const unsigned epoch = __hip_atomic_load(cj.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this launch's epoch (bumped by the previous launch's last workgroup)
             unsigned idx = atomicAdd(cj.state + 8 + (xcc & 7u), 1u);
             if (xcc >= 8u || idx >= per) {   // an XCD with more than its share: counted (the host fails loudly), kept in range
                 atomicAdd(cj.state + 3, 1u);
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             }
             tk[0] = xcc & 7u;
             tk[1] = idx;
-            tk[2] = __hip_atomic_load(cj.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this launch's epoch (bumped by the previous launch's last workgroup)
+            tk[2] = epoch;
         }
         __syncthreads();
         chain_epoch = tk[2];
@@ -264,8 +271,17 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     int tk = 0;
     auto stamp = [&](int role) {
         // traced workgroups: blockIdx 16k .. 16k+0 for k < 32 (a sample across the whole grid)
-        if (a.trace && (blockIdx.x & 15) == 0 && blockIdx.x < 512 && lane == 0 && tk < 64 && wave <= NWC)
-            a.trace[((blockIdx.x >> 4) * 2 + role) * 64 + tk++] = __builtin_amdgcn_s_memrealtime();
+        if (a.trace && (blockIdx.x & 15) == 0 && blockIdx.x < 512 && lane == 0 && tk < 64 && wave <= NWC) {
+            if constexpr (CH != 0) reinterpret_cast<unsigned long long*>(smem + C::CHAIN_OFF + C::CHAIN_TRACE)[role * 64 + tk++] = __builtin_amdgcn_s_memrealtime();
+            else a.trace[((blockIdx.x >> 4) * 2 + role) * 64 + tk++] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+    auto stamp_dump = [&](int role) {   // chained launches: the wave's stamps, LDS -> the trace buffer
+        if constexpr (CH != 0) {
+            if (a.trace && (blockIdx.x & 15) == 0 && blockIdx.x < 512 && lane == 0 && wave <= NWC)
+                for (int i = 0; i < tk; ++i)
+                    a.trace[((blockIdx.x >> 4) * 2 + role) * 64 + i] = reinterpret_cast<const unsigned long long*>(smem + C::CHAIN_OFF + C::CHAIN_TRACE)[role * 64 + i];
+        }
     };
 
     if (wave == 0 || wave == NWC) stamp(wave == 0 ? 1 : 0);  // kernel entry
@@ -424,7 +440,10 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 };
                 // lanes 0..8 watch the tile's 3 x 3 neighbourhood inside its image; `need` = flag value of "previous job done"
                 // Waits until every neighbour's progress is >= need; returns whether it is already >= all_need (then the tile
-                // needs no further polls in this job).
+                // needs no further polls in this job).  (Polling with scalar loads -- their own counter instead of the in-order
+                // vector-memory queue behind the LDS-DMA requests -- was tried: eight waves per workgroup re-reading the same L2
+                // lines at scalar-load rate saturate the channel the flags live in, 2.4x slower; one polling wave + an LDS
+                // sequence number for the others, still 5 % slower than this.)
                 auto poll = [&](int tile, unsigned need, unsigned all_need) -> bool {
                     const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y;
                     const int dx = lane % 3 - 1, dy = lane / 3 - 1;
@@ -483,7 +502,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 }
                 __syncthreads();           // barrier 0
                 for (int s = 0; have_next; ++s) {   // stage s is being multiplied; H(s+1) is in flight
+                    stamp(0);
+#ifndef RESR_TIMING_NO_W   // (timing experiments, never in the product build: the ring keeps the first stages' weights / halos -- results wrong)
                     issue_wj(job_next, ck_next, (s + 1) & 1);
+#endif
+                    stamp(0);
                     const bool have_next2 = advance();
                     if (have_next2 && needs_hc(ick)) {
                         if (ick == 0) tile_pix(it);
@@ -500,18 +523,29 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             if (ick == 2 && dep >= 1) tile_settled = poll(it, chain_epoch + (unsigned)dep, chain_epoch + (unsigned)dep + 1u);
                         }
                         // (X2: the dependent real chunk is the job's last THREE stages; its first halo request -- the hi plane -- polls)
+                        stamp(0);
                         if (ick == nch - (X2 ? 3 : 1) && dep >= 0 && !(CH == 3 && tile_settled)) poll(it, chain_epoch + (unsigned)dep + 1u, chain_epoch + (unsigned)dep + 1u);
+                        stamp(0);
                         hb = hb == 2 ? 0 : hb + 1;
+#ifndef RESR_TIMING_NO_H
                         issue_h(ick, hb);
+#endif
                         poison_src = nullptr;
+                        stamp(0);
+#ifndef RESR_TIMING_NO_H
                         wait_all_but_h();
+#else
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
                     } else {
                         __builtin_amdgcn_s_waitcnt(0x0F70);
                     }
+                    stamp(0);
                     __syncthreads();       // barrier s+1
                     ck_next = ick; job_next = job;
                     have_next = have_next2;
                 }
+                stamp_dump(0);
                 return;
             }
             if (first >= ntiles) { __syncthreads(); return; }
@@ -1128,6 +1162,13 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 }
             }
             init_acc();
+            // A workgroup with ONE tile per job (the 64^2 training crops) publishes right here, behind the acknowledgement of the
+            // stores it has just issued: its neighbours' producers poll for this plane during the very next stage, and a flag that
+            // only appears at that stage's end costs them that stage plus the poll's round trips (measured: 4.2 us in the poll at the
+            // first job boundary of such a launch, 0.6 us with this).  The wait overlaps the barrier wait for the next job's first stage.
+            if constexpr (CH == 1 || CH == 2) {
+                if (first + tile_step >= tile_end) publish();
+            }
             if (wave == 0) stamp(1);  // tile done
             continue;
         }
@@ -1349,6 +1390,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         if (wave == 0) stamp(1);  // tile done
     }
     }   // jobs
+    if (wave == 0) stamp_dump(1);
     if constexpr (CH == 3) publish();   // a pinned workgroup's last tile has no next stage to publish it from
     if constexpr (CH != 0) {
         // The last workgroup of the launch to get here prepares the state for the next launch on it (which starts after this

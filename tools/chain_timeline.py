@@ -27,4 +27,11 @@ for wg in map(int, a.wgs.split(",")):
     for role, name in ((0, "producer"), (1, "consumer0")):
         v = [int(q) for q in t[wg, role] if q > 0]
         print(f"wg{wg} {name}: " + " ".join(f"{(q - t0) / 100:.2f}" for q in v))
+# producer: six stamps per stage -- after the barrier | weights requested | next stage worked out | polled | halo requested | older requests landed
+for wg in map(int, a.wgs.split(",")):
+    pr = [int(q) for q in t[wg, 0] if q > 0]
+    print(f"wg{wg} producer stages (us): W issue, advance (+ tile index math), poll, halo issue, wait, to next barrier")
+    for i in range(1, len(pr) - 6, 6):
+        d = [(pr[i + k + 1] - pr[i + k]) / 100 for k in range(6)]
+        print(f"   t={(pr[i] - t0) / 100:7.2f}  " + "  ".join(f"{x:5.2f}" for x in d) + f"   period {(pr[i + 6] - pr[i]) / 100:5.2f}")
 print("chain errors:", int(lib.resr_debug_chain_errors()))

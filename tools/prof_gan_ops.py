@@ -47,6 +47,13 @@ def main():
     for e in rows[:70]:
         dev = getattr(e, "device_time", getattr(e, "cuda_time", 0.0))
         print(f"{e.key[:80]:80s} {e.count / a.steps:9.1f} {e.cpu_time:12.1f} {dev:12.1f}")
+    print()
+    print(f"{'kernels by device time':110s} {'per step':>9s} {'us/call':>9s} {'ms/step':>9s}")
+    def dev_total(e):
+        return getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0.0))
+    krows = [e for e in ev if dev_total(e) > 0 and e.cpu_time_total == 0]
+    for e in sorted(krows, key=lambda e: -dev_total(e))[:45]:
+        print(f"{e.key[:110]:110s} {e.count / a.steps:9.1f} {dev_total(e) / e.count:9.1f} {dev_total(e) / a.steps / 1e3:9.3f}")
 
 
 if __name__ == "__main__":
