@@ -293,6 +293,11 @@ int resr_bilinear_up2x(const void* src, void* dst, int32_t n, int32_t h, int32_t
  * elements behind the hi tensor; the mask is an activation, read from its hi tensor) */
 int resr_add_mask(const void* a, const void* b, const void* mask, void* out, int64_t count, int32_t dtype, float slope,
                   void* stream);
+/* partial[k] = workgroup k's share of sum |a - b| over `count` elements (nblocks workgroups, fixed order: deterministic); the
+ * caller adds the partials and divides: F.l1_loss of two feature tensors (model.py:320-327) without fp32 copies of them.
+ * RESR_F16X2: a and b are pairs with the lo tensor lo_offset elements behind the hi tensor */
+int resr_l1_partial(const void* a, const void* b, int64_t count, int32_t dtype, int64_t lo_offset, float* partial, int32_t nblocks,
+                    void* stream);
 /* torch.nn.utils.spectral_norm forward (model.py:140-168): W [rows][cols] fp32; training: one power iteration
  * updating u[rows], v[cols] in place; sigma2[0] = sigma, sigma2[1] = 1/sigma; tmp = rows + ceil(rows/32) * cols floats
  * (W^T u is summed in 32-row groups, in a fixed order: bit-identical on every data-parallel rank) */

@@ -105,6 +105,7 @@ _PROTOS = {
     "resr_space_to_depth": (C.c_int, [_P, _P] + [C.c_int32] * 6 + [_P]),
     "resr_bilinear_up2x": (C.c_int, [_P, _P] + [C.c_int32] * 6 + [_P]),
     "resr_add_mask": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "resr_l1_partial": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, _P, C.c_int32, _P]),
     "resr_spectral_norm": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
     "resr_spectral_norm_bwd": (C.c_int, [_P] * 6 + [C.c_int32] * 3 + [_P, _P]),
     "resr_maxpool2x2": (C.c_int, [_P, _P] + [C.c_int32] * 5 + [_P]),

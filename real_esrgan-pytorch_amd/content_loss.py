@@ -263,6 +263,18 @@ class ContentLoss(nn.Module):
         L.check(lib.resr_nhwc_to_nchw(g.ptr(), L.ptr(gx), b, 3, g.h, g.w, 1, 32, self._dtype, st), "resr_nhwc_to_nchw")
         return gx / self.std
 
+    def _l1_halves(self, act: _Act, b: int) -> torch.Tensor:
+        """F.l1_loss(first b images, last b images) of one tapped activation, straight from the 16-bit (pair) tensor: one pass,
+        deterministic partial sums (resr_l1_partial) instead of fp32 copies + sub + abs + mean."""
+        L = _lib
+        count = b * act.h * act.w * act.c
+        nblocks = 1024
+        partial = torch.empty(nblocks, dtype=torch.float32, device=act.t.device)
+        second = C.c_void_p(act.t.data_ptr() + count * act.es)
+        L.check(L.lib().resr_l1_partial(act.ptr(), second, count, self._dtype, act.lo, L.ptr(partial), nblocks, L.stream_ptr(act.t)),
+                "resr_l1_partial")
+        return partial.sum() / count
+
     # ---- module surface ----------------------------------------------------------------------------------------
     def forward(self, sr_tensor: torch.Tensor, hr_tensor: torch.Tensor):
         b = sr_tensor.shape[0]
@@ -270,7 +282,7 @@ class ContentLoss(nn.Module):
         if self.detached or not (torch.is_grad_enabled() and sr_tensor.requires_grad):
             with torch.no_grad():
                 feats, _ = self._features(torch.cat([sr_tensor.detach(), hr_tensor.detach()], 0))
-                return tuple(F.l1_loss(feats[k].value()[:b], feats[k].value()[b:]) for k in nodes)
+                return tuple(self._l1_halves(feats[k], b) for k in nodes)
         outs = _FeatureFn.apply(self, sr_tensor, hr_tensor)
         return tuple(F.l1_loss(outs[i], outs[len(nodes) + i]) for i in range(len(nodes)))
 

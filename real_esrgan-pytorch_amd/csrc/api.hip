@@ -121,6 +121,7 @@ int resize_u8_dispatch(const uint8_t*, uint8_t*, int, int, int, int, int, int, i
 int s2d_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
 int bilinear_up_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t, long, long);
 int add_mask_dispatch(const void*, const void*, const void*, void*, long, int, float, hipStream_t);
+int l1_partial_dispatch(const void*, const void*, long, int, long, float*, int, hipStream_t);
 int spectral_norm_dispatch(const float*, float*, float*, int, int, int, float, float*, float*, hipStream_t);
 int spectral_norm_bwd_dispatch(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, float*,
                                hipStream_t);
@@ -354,6 +355,11 @@ int resr_add_mask(const void* a, const void* b, const void* mask, void* out, int
                   void* stream) {
     RESR_DEVICE_SCOPE(stream);
     return add_mask_dispatch(a, b, mask, out, (long)count, dtype, slope, (hipStream_t)stream);
+}
+
+int resr_l1_partial(const void* a, const void* b, int64_t count, int32_t dtype, int64_t lo_offset, float* partial, int32_t nblocks, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return l1_partial_dispatch(a, b, (long)count, dtype, (long)lo_offset, partial, nblocks, (hipStream_t)stream);
 }
 
 int resr_spectral_norm(const float* w, float* u, float* v, int32_t rows, int32_t cols, int32_t training, float eps, float* sigma2,

@@ -54,13 +54,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void s2d_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w, int c,
                                                   int inverse) {
     constexpr int E = 16 / (int)sizeof(T);
-    const int groups = c / E;
-    const long total = (long)n * h * w * groups;      // h, w = full-resolution dims
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    const int g = (int)(t % groups);
-    const long p = t / groups;
-    const int x = (int)(p % w), y = (int)((p / w) % h), b = (int)(p / ((long)w * h));
+    const unsigned groups = (unsigned)c / E;          // h, w = full-resolution dims
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)w * groups) return;
+    const int x = (int)(idx / groups), g = (int)(idx - (unsigned)x * groups);
+    const int y = (int)blockIdx.y, b = (int)blockIdx.z;
     const size_t full = (((size_t)b * h + y) * w + x) * c + g * E;
     const size_t packed = ((((size_t)b * (h / 2) + y / 2) * (w / 2) + x / 2) * 4 + (y & 1) * 2 + (x & 1)) * c + g * E;
     if (!inverse) *reinterpret_cast<uint4*>(dst + packed) = *reinterpret_cast<const uint4*>(src + full);
@@ -76,13 +74,11 @@ __global__ __launch_bounds__(256) void d2s_add_mask_kernel(const T* __restrict__
                                                            T* __restrict__ out, int n, int h, int w, int c, float slope, long lo_src,
                                                            long lo_add, long lo_out) {
     constexpr int E = 16 / (int)sizeof(T);
-    const int groups = c / E;
-    const long total = (long)n * h * w * groups;      // h, w = full-resolution dims
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    const int g = (int)(t % groups);
-    const long p = t / groups;
-    const int x = (int)(p % w), y = (int)((p / w) % h), b = (int)(p / ((long)w * h));
+    const unsigned groups = (unsigned)c / E;          // h, w = full-resolution dims
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)w * groups) return;
+    const int x = (int)(idx / groups), g = (int)(idx - (unsigned)x * groups);
+    const int y = (int)blockIdx.y, b = (int)blockIdx.z;
     const size_t full = (((size_t)b * h + y) * w + x) * c + g * E;
     const size_t packed = ((((size_t)b * (h / 2) + y / 2) * (w / 2) + x / 2) * 4 + (y & 1) * 2 + (x & 1)) * c + g * E;
     float v[E], va[E];
@@ -109,13 +105,13 @@ int d2s_add_mask_dispatch(const void* src, const void* add, const void* mask, vo
                           hipStream_t st, long lo_src, long lo_add, long lo_out) {
     const int E = dtype == RESR_F32 ? 4 : 8;
     if (!src || !out || n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || c <= 0 || (c % E)) return fail(RESR_ERR_ARG, "d2s_add_mask: bad argument");
-    const long total = (long)n * h * w * (c / E);
-    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (h > 65535 || n > 65535) return fail(RESR_ERR_ARG, "d2s_add_mask: image too large");
+    const dim3 blocks((unsigned)(((long)w * (c / E) + 255) / 256), (unsigned)h, (unsigned)n);
     if (dtype != RESR_F32)
-        hipLaunchKernelGGL(d2s_add_mask_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (const half_t*)add, (const half_t*)mask, (half_t*)out, n, h, w, c, slope,
+        hipLaunchKernelGGL(d2s_add_mask_kernel<half_t>, blocks, dim3(256), 0, st, (const half_t*)src, (const half_t*)add, (const half_t*)mask, (half_t*)out, n, h, w, c, slope,
                            lo_src, lo_add, lo_out);
     else
-        hipLaunchKernelGGL(d2s_add_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (const float*)add, (const float*)mask, (float*)out, n, h, w, c, slope,
+        hipLaunchKernelGGL(d2s_add_mask_kernel<float>, blocks, dim3(256), 0, st, (const float*)src, (const float*)add, (const float*)mask, (float*)out, n, h, w, c, slope,
                            0L, 0L, 0L);
     RESR_CHECK_LAUNCH("d2s_add_mask_kernel");
     return RESR_OK;
@@ -126,10 +122,10 @@ int s2d_dispatch(const void* src, void* dst, int n, int h, int w, int c, int dty
     if (!src || !dst || n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || c <= 0 || (c % E))
         return fail(RESR_ERR_ARG, "space_to_depth: bad argument");
     if (dtype == RESR_F16X2) n *= 2;   // hi and lo as one batch (the lo tensor directly follows the hi tensor)
-    const long total = (long)n * h * w * (c / E);
-    const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (dtype != RESR_F32) hipLaunchKernelGGL(s2d_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, inverse);
-    else hipLaunchKernelGGL(s2d_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, inverse);
+    if (h > 65535 || n > 65535) return fail(RESR_ERR_ARG, "space_to_depth: image too large");
+    const dim3 blocks((unsigned)(((long)w * (c / E) + 255) / 256), (unsigned)h, (unsigned)n);
+    if (dtype != RESR_F32) hipLaunchKernelGGL(s2d_kernel<half_t>, blocks, dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, inverse);
+    else hipLaunchKernelGGL(s2d_kernel<float>, blocks, dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, inverse);
     RESR_CHECK_LAUNCH("s2d_kernel");
     return RESR_OK;
 }
@@ -143,21 +139,22 @@ __device__ __forceinline__ void bil_coord(int o, int n, int& i0, int& i1, float&
     l = f - i0;
 }
 
+// Index math of these helpers: rows and images come from blockIdx.y / blockIdx.z, (pixel, 16-byte group) inside the row from one
+// 32-bit division -- decoded from one flat 64-bit thread index they were three emulated 64-bit divisions per 16 bytes of output,
+// and the kernels ran at a quarter of the HBM rate.
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_up_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w,
                                                           int c, long lo_src, long lo_dst) {
     constexpr int E = 16 / (int)sizeof(T);
-    const int groups = c / E, oh = 2 * h, ow = 2 * w;
-    const long total = (long)n * oh * ow * groups;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    const int g = (int)(t % groups);
-    const long p = t / groups;
-    const int ox = (int)(p % ow), oy = (int)((p / ow) % oh), b = (int)(p / ((long)ow * oh));
+    const unsigned groups = (unsigned)c / E, ow = 2u * w;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // (ox, g) inside the output row
+    if (idx >= ow * groups) return;
+    const unsigned ox = idx / groups, g = idx - ox * groups;
+    const int oy = (int)blockIdx.y, b = (int)blockIdx.z, oh = 2 * h;
     int y0, y1, x0, x1;
     float ly, lx;
     bil_coord(oy, h, y0, y1, ly);
-    bil_coord(ox, w, x0, x1, lx);
+    bil_coord((int)ox, w, x0, x1, lx);
     const float hy = 1.f - ly, hx = 1.f - lx;
     const T* base = src + (size_t)b * h * w * c + g * E;
     float a[E], bq[E], cq[E], d[E], o[E];
@@ -167,7 +164,7 @@ __global__ __launch_bounds__(256) void bilinear_up_kernel(const T* __restrict__ 
     ld_vals(base + ((size_t)y1 * w + x1) * c, lo_src, d);
 #pragma unroll
     for (int e = 0; e < E; ++e) o[e] = hy * (hx * a[e] + lx * bq[e]) + ly * (hx * cq[e] + lx * d[e]);
-    st_vals(dst + p * c + g * E, lo_dst, o);
+    st_vals(dst + (((size_t)b * oh + oy) * ow + ox) * c + g * E, lo_dst, o);
 }
 
 // backward as a gather: input pixel (y,x) collects from the <= 4x4 outputs whose stencil touches it
@@ -178,43 +175,58 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const T* __restric
                                                               int c, const T* __restrict__ mask, T* __restrict__ gmasked,
                                                               float slope, long lo_g, long lo_gin) {
     constexpr int E = 16 / (int)sizeof(T);
-    const int groups = c / E, oh = 2 * h, ow = 2 * w;
-    const long total = (long)n * h * w * groups;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    const int gi = (int)(t % groups);
-    const long p = t / groups;
-    const int x = (int)(p % w), y = (int)((p / w) % h), b = (int)(p / ((long)w * h));
+    const unsigned groups = (unsigned)c / E;
+    const int oh = 2 * h, ow = 2 * w;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // (x, group) inside the input row
+    if (idx >= (unsigned)w * groups) return;
+    const int x = (int)(idx / groups), gi = (int)(idx - (unsigned)x * groups);
+    const int y = (int)blockIdx.y, b = (int)blockIdx.z;
+    // the outputs whose stencil touches (y, x): rows 2y-1 .. 2y+2, columns 2x-1 .. 2x+2 (the clamp at 0 and the repeated last
+    // row / column only change their weights); weights once per row / column, same products and order as the 5 x 5 scan had
+    float wy[4], wx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int oy = 2 * y - 1 + k, ox = 2 * x - 1 + k;
+        int i0, i1;
+        float l;
+        wy[k] = 0.f;
+        if (oy >= 0 && oy < oh) {
+            bil_coord(oy, h, i0, i1, l);
+            wy[k] = (i0 == y ? 1.f - l : 0.f) + (i1 == y ? l : 0.f);
+        }
+        wx[k] = 0.f;
+        if (ox >= 0 && ox < ow) {
+            bil_coord(ox, w, i0, i1, l);
+            wx[k] = (i0 == x ? 1.f - l : 0.f) + (i1 == x ? l : 0.f);
+        }
+    }
     float acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
     const T* base = g + (size_t)b * oh * ow * c + gi * E;
-    for (int oy = max(2 * y - 2, 0); oy <= min(2 * y + 2, oh - 1); ++oy) {
-        int y0, y1;
-        float ly;
-        bil_coord(oy, h, y0, y1, ly);
-        const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
-        if (wy == 0.f) continue;
-        for (int ox = max(2 * x - 2, 0); ox <= min(2 * x + 2, ow - 1); ++ox) {
-            int x0, x1;
-            float lx;
-            bil_coord(ox, w, x0, x1, lx);
-            const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
-            if (wx == 0.f) continue;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        if (wy[ky] == 0.f) continue;
+        const int oy = 2 * y - 1 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            if (wx[kx] == 0.f) continue;
+            const int ox = 2 * x - 1 + kx;
             float v[E];
             ld_vals(base + ((size_t)oy * ow + ox) * c, lo_g, v);
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] += wy * wx * v[e];
+            for (int e = 0; e < E; ++e) acc[e] += wy[ky] * wx[kx] * v[e];
         }
     }
-    st_vals(gin + p * c + gi * E, lo_gin, acc);
+    const size_t po = (((size_t)b * h + y) * w + x) * c + gi * E;
+    st_vals(gin + po, lo_gin, acc);
     if (gmasked) {
-        const uint4 rm = *reinterpret_cast<const uint4*>(mask + p * c + gi * E);
+        const uint4 rm = *reinterpret_cast<const uint4*>(mask + po);
         const T* pm = reinterpret_cast<const T*>(&rm);
         float m[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) m[e] = (lo_gin ? acc[e] : (float)(T)acc[e]) * ((float)pm[e] > 0.f ? 1.f : slope);
-        st_vals(gmasked + p * c + gi * E, lo_gin, m);   // the same shape as gin: the same hi -> lo offset
+        st_vals(gmasked + po, lo_gin, m);   // the same shape as gin: the same hi -> lo offset
     }
 }
 
@@ -222,13 +234,13 @@ int bilinear_up_bwd_mask_dispatch(const void* g, void* gin, const void* mask, vo
                                   hipStream_t st, long lo_g, long lo_gin) {
     const int E = dtype == RESR_F32 ? 4 : 8;
     if (!g || !gin || !mask || !gmasked || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c % E)) return fail(RESR_ERR_ARG, "bilinear_up_bwd_mask: bad argument");
-    const long total = (long)n * h * w * (c / E);
-    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (h > 32767 || n > 65535) return fail(RESR_ERR_ARG, "bilinear_up_bwd_mask: image too large");
+    const dim3 grid((unsigned)(((long)w * (c / E) + 255) / 256), (unsigned)h, (unsigned)n);
     if (dtype != RESR_F32)
-        hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)g, (half_t*)gin, n, h, w, c, (const half_t*)mask, (half_t*)gmasked, slope,
+        hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)g, (half_t*)gin, n, h, w, c, (const half_t*)mask, (half_t*)gmasked, slope,
                            lo_g, lo_gin);
     else
-        hipLaunchKernelGGL(bilinear_up_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)g, (float*)gin, n, h, w, c, (const float*)mask, (float*)gmasked, slope,
+        hipLaunchKernelGGL(bilinear_up_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)g, (float*)gin, n, h, w, c, (const float*)mask, (float*)gmasked, slope,
                            0L, 0L);
     RESR_CHECK_LAUNCH("bilinear_up_bwd_kernel");
     return RESR_OK;
@@ -237,14 +249,15 @@ int bilinear_up_bwd_mask_dispatch(const void* g, void* gin, const void* mask, vo
 int bilinear_up_dispatch(const void* src, void* dst, int n, int h, int w, int c, int dtype, int backward, hipStream_t st, long lo_src, long lo_dst) {
     const int E = dtype == RESR_F32 ? 4 : 8;
     if (!src || !dst || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c % E)) return fail(RESR_ERR_ARG, "bilinear_up2x: bad argument");
-    const long total = (long)n * h * w * (c / E) * (backward ? 1 : 4);
-    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (h > 32767 || n > 65535) return fail(RESR_ERR_ARG, "bilinear_up2x: image too large");
+    const dim3 gf((unsigned)((2L * w * (c / E) + 255) / 256), (unsigned)(2 * h), (unsigned)n);   // forward: one thread per output piece
+    const dim3 gb((unsigned)(((long)w * (c / E) + 255) / 256), (unsigned)h, (unsigned)n);       // backward: per input piece
     if (dtype != RESR_F32) {
-        if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, lo_src, lo_dst);
-        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, (const half_t*)nullptr, (half_t*)nullptr, 0.f, lo_src, lo_dst);
+        if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<half_t>, gf, dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, lo_src, lo_dst);
+        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, gb, dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, (const half_t*)nullptr, (half_t*)nullptr, 0.f, lo_src, lo_dst);
     } else {
-        if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, 0L, 0L);
-        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, (const float*)nullptr, (float*)nullptr, 0.f, 0L, 0L);
+        if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<float>, gf, dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, 0L, 0L);
+        else hipLaunchKernelGGL(bilinear_up_bwd_kernel<float>, gb, dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, (const float*)nullptr, (float*)nullptr, 0.f, 0L, 0L);
     }
     RESR_CHECK_LAUNCH("bilinear_up_kernel");
     return RESR_OK;
@@ -282,6 +295,37 @@ int add_mask_dispatch(const void* a, const void* b, const void* mask, void* out,
                                               dtype == RESR_F16X2 ? count : 0L);
     else hipLaunchKernelGGL(add_mask_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)mask, (float*)out, count, slope, 0L);
     RESR_CHECK_LAUNCH("add_mask_kernel");
+    return RESR_OK;
+}
+
+// sum |a - b| over `count` elements as per-workgroup partial sums (fixed grid, fixed order: deterministic; the caller adds the
+// partials): the L1 distance of two halves of a feature batch (perceptual loss, reference model.py:320-327) in one pass over the
+// 16-bit tensors -- as torch ops it was two f16 -> f32 copies of the whole batch, a subtraction, an abs and a reduction per node.
+template <typename T>
+__global__ __launch_bounds__(256) void l1_partial_kernel(const T* __restrict__ a, const T* __restrict__ b, long count, long lo, float* __restrict__ partial) {
+    constexpr int E = 16 / (int)sizeof(T);
+    float acc = 0.f;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * E; i < count; i += (long)gridDim.x * 256 * E) {
+        float va[E], vb[E];
+        ld_vals(a + i, lo, va);
+        ld_vals(b + i, lo, vb);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc += fabsf(va[e] - vb[e]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+int l1_partial_dispatch(const void* a, const void* b, long count, int dtype, long lo, float* partial, int nblocks, hipStream_t st) {
+    const int E = dtype == RESR_F32 ? 4 : 8;
+    if (!a || !b || !partial || count <= 0 || (count % E) || nblocks <= 0) return fail(RESR_ERR_ARG, "l1_partial: bad argument");
+    if (dtype != RESR_F32) hipLaunchKernelGGL(l1_partial_kernel<half_t>, dim3(nblocks), dim3(256), 0, st, (const half_t*)a, (const half_t*)b, count, dtype == RESR_F16X2 ? lo : 0L, partial);
+    else hipLaunchKernelGGL(l1_partial_kernel<float>, dim3(nblocks), dim3(256), 0, st, (const float*)a, (const float*)b, count, 0L, partial);
+    RESR_CHECK_LAUNCH("l1_partial_kernel");
     return RESR_OK;
 }
 
