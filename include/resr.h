@@ -348,7 +348,8 @@ int resr_discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy_
 /* EMA.update (model.py:43-48) over the flat parameter arena, one launch. */
 int resr_ema_update(float* shadow, const float* params, int64_t count, double decay, void* stream);
 
-/* Debug: per-workgroup timeline of the fast-mode conv kernel (32 workgroups x 2 roles x 64 uint64 stamps, 100 MHz). */
+/* Debug: per-workgroup timeline of the fast-mode conv kernel (32 workgroups x 2 roles x 64 uint64 stamps, 100 MHz).  The stamps
+ * are compiled in by a trace build only (-DRESR_TRACE=1, tools/build_variant.py); in the product build the buffer stays untouched. */
 int resr_debug_conv_trace(void* dev_buf);
 /* Debug / test: resr_chain_errors() after a hipDeviceSynchronize() (every launch enqueued so far has reported).
  * RESR_CONV_NO_CHAIN=1 in the environment disables chaining. */

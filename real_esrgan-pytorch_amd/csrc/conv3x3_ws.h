@@ -270,6 +270,10 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     if constexpr (CH) nchunks = (cj.job[CH == 3 ? pin_job : 0].cin >> 5) * (X2 ? 3 : 1);
     int tk = 0;
     auto stamp = [&](int role) {
+#ifndef RESR_TRACE   // The timeline hooks are compiled in only by a trace build (python tools/build_variant.py trace -DRESR_TRACE=1; the
+        (void)role;    // timeline tools load it through RESR_LIB_PATH): switched off at run time they still cost the 64^2
+        return;        // configurations 2 % (six uniform branches per stage on the producers' serial path -- measured).
+#endif
         // traced workgroups: blockIdx 16k .. 16k+0 for k < 32 (a sample across the whole grid)
         if (a.trace && (blockIdx.x & 15) == 0 && blockIdx.x < 512 && lane == 0 && tk < 64 && wave <= NWC) {
             if constexpr (CH != 0) reinterpret_cast<unsigned long long*>(smem + C::CHAIN_OFF + C::CHAIN_TRACE)[role * 64 + tk++] = __builtin_amdgcn_s_memrealtime();
@@ -388,16 +392,18 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     for (int i = 0; i < NIP; ++i) voff[i] = __umul24(pix[i], stride_b) + ((cst[i] >> 16) & 0xfff0u);   // tensor < 4 GB (host-checked)
                     voff_stride = stride_b;
                 }
+                if constexpr (CH != 0) {
+                    if (poison_src) {   // the poll for this plane timed out: NaNs instead of a plane that may be stale
+#pragma unroll
+                        for (int i = 0; i < NIP; ++i)
+                            if (i * NP + pw < NI) dma_v(poison_src, lds_base + hb * BUF + (i * NP + pw) * 1024, val[i]);
+                        return;
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < NIP; ++i) {
                     if (i * NP + pw < NI) {   // wave-uniform; false only for i = NIP-1 of the waves pw >= REM
                         const unsigned dst = lds_base + hb * BUF + (i * NP + pw) * 1024;
-                        if constexpr (CH != 0) {
-                            if (poison_src) {   // the poll for this plane timed out: NaNs instead of a plane that may be stale
-                                dma_v(poison_src, dst, val[i]);
-                                continue;
-                            }
-                        }
                         if (inb[i] == val[i]) {
                             dma_s(base, voff[i], dst, val[i]);
                         } else {
@@ -428,6 +434,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 bool tile_settled = false;   // the current tile's neighbourhood has shown the progress its last chunk needs
                 // job jb's weights of chunk ck: fragment idx of this kernel's 32-channel output tile is fragment idx * w_mt + w_m of
                 // a buffer packed for w_mt tiles (the closing convolution's halves read the cout-64 packing in place)
+                // (Tried: the job's fields cached in registers per job instead of re-read from the argument segment per stage, and the
+                // launch's input arguments pinned in SGPRs -- 1.2 % slower on the 64^2 configurations; the scalar loads are not the cost.)
                 auto issue_wj = [&](int jb, int ck, int par) {
                     int wmt = 1, wm = 0;
                     if constexpr (CH == 2) { wmt = cj.job[jb].w_mt; wm = cj.job[jb].w_m; }

@@ -1,4 +1,7 @@
-"""Timeline of the LAST chained dense-block launch of a generator forward (RESR_TRACE_CHAIN_ONLY=1 keeps the trace buffer for
+"""Needs a TRACE BUILD of the library (the hooks are compiled out of the product build):
+    python tools/build_variant.py trace -DRESR_TRACE=1 && RESR_LIB_PATH=$PWD/tools/ab/trace.so python tools/chain_timeline.py ...
+
+Timeline of the LAST chained dense-block launch of a generator forward (RESR_TRACE_CHAIN_ONLY=1 keeps the trace buffer for
 chained launches): producer / consumer stamps of a few workgroups, in us."""
 import argparse, os, sys
 os.environ["RESR_TRACE_CHAIN_ONLY"] = "1"

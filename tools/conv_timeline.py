@@ -1,4 +1,7 @@
-"""Per-workgroup timeline of the fast-mode conv kernel (resr_debug_conv_trace): producer / consumer stamps in us."""
+"""Needs a TRACE BUILD of the library (the hooks are compiled out of the product build):
+    python tools/build_variant.py trace -DRESR_TRACE=1 && RESR_LIB_PATH=$PWD/tools/ab/trace.so python tools/conv_timeline.py ...
+
+Per-workgroup timeline of the fast-mode conv kernel (resr_debug_conv_trace): producer / consumer stamps in us."""
 import argparse, ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
