@@ -5,8 +5,9 @@
  * PyTorch op call sites.  Each entry point below names the reference call site(s) it replaces
  * (file:line relative to the reference root).  All pointers are raw device pointers owned by the
  * caller (PyTorch's caching allocator); the library never allocates, frees or retains device
- * memory, never synchronises the stream or the device (the two resr_debug_* read-back entries excepted), and is
- * graph-capture safe.  What a launch needs beyond its operands -- scratch, slabs, the progress flags of the chained
+ * memory, never synchronises the stream or the device, and is graph-capture safe (chained dense-block launches inside a
+ * captured graph: see resr_conv3x3_chain).  Test / measurement aids (resr_debug_*, resr_profile_*) are exported too but are NOT
+ * part of this contract: they are declared in resr_debug.h.  What a launch needs beyond its operands -- scratch, slabs, the progress flags of the chained
  * dense-block launches -- is part of a workspace the caller passes in.  Every call enqueues on the
  * given hipStream_t (passed as void*) of the current device and returns 0 or a negative
  * resr_status; resr_last_error() returns a thread-local message.  No C++ exception crosses.
@@ -123,7 +124,10 @@ int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const 
  * A chained launch spins on its own workgroups, so only one runs at a time per device: a call from another stream first makes
  * that stream wait (hipStreamWaitEvent) for the previous chain.  A flag poll that gives up (~4 s: a lost workgroup) is never
  * silent -- the plane it waited for is read as NaNs, so the output (and a training loss) turns NaN, and resr_chain_errors()
- * counts it. */
+ * counts it.
+ * Under stream capture the call neither waits for, records, nor takes ownership of anything (none of it would mean anything at
+ * replay time): inside one graph the chained launches are ordered by the capture itself, and the CALLER guarantees that a graph
+ * holding chained launches is not replayed while another stream runs chained launches on the same device. */
 size_t resr_conv3x3_chain_state_bytes(int32_t n, int32_t h, int32_t w);
 int resr_conv3x3_chain(int32_t njobs, const ResrConvDesc* descs, const void* in0, const void* in1,
                        const void* const* packed_w, const float* const* bias, const void* const* mask,
@@ -347,36 +351,6 @@ int resr_discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy_
 
 /* EMA.update (model.py:43-48) over the flat parameter arena, one launch. */
 int resr_ema_update(float* shadow, const float* params, int64_t count, double decay, void* stream);
-
-/* Debug: per-workgroup timeline of the fast-mode conv kernel (32 workgroups x 2 roles x 64 uint64 stamps, 100 MHz).  The stamps
- * are compiled in by a trace build only (-DRESR_TRACE=1, tools/build_variant.py); in the product build the buffer stays untouched. */
-int resr_debug_conv_trace(void* dev_buf);
-/* Debug / test: resr_chain_errors() after a hipDeviceSynchronize() (every launch enqueued so far has reported).
- * RESR_CONV_NO_CHAIN=1 in the environment disables chaining. */
-int64_t resr_debug_chain_errors(void);
-/* Test aid: `workgroups` single-wave workgroups that each hold `lds_bytes` of LDS and spin for `micros` microseconds -- what a
- * collective of another stream looks like to a chained launch that wants every CU. */
-int resr_debug_occupy(int32_t workgroups, int32_t lds_bytes, int32_t micros, void* stream);
-/* Host logic of the f16 weight-gradient launch, no GPU needed: how the (X chunk, G tile) products of `nconv` convolutions
- * that read one channel-prefix workspace (conv i: the first cin[i] channels; its own cout_pad[i] gradient channels) are
- * grouped into 2x2 jobs of the quad kernel.  out[q*4 + p] = index of the product computed by slot p of job q (products are
- * numbered conv-major, then G tile, then X chunk), -1 = slot unused.  Returns the number of jobs (<= max_jobs) or < 0. */
-int resr_debug_wgrad_plan(const int32_t* cin, const int32_t* cout_pad, int32_t nconv, int32_t* out, int32_t max_jobs);
-/* test probe: lane/element map of ds_read_b64_tr_b16 (256 floats out) */
-int resr_debug_tr_probe(float* out256, void* stream);
-
-/* In-situ kernel timing for bench.py: between begin and end every conv3x3 / wgrad launch is bracketed by HIP events
- * on its launch stream.  kernel_id = dtype*10000 + MT*100 + NT*10 + NW for conv3x3_kernel<T,MT,NT,NW>,
- * 50000 + dtype*100 + RPW for wgrad_kernel<T,RPW>.  resr_profile_end synchronises the events (host-side, test/bench
- * only), fills up to `capacity` entries and returns the number recorded. */
-typedef struct {
-    int32_t kernel_id;
-    float ms;
-    double flop;  /* algorithmic FLOP of the launch: 2*9*cin*cout*pixels */
-    double bytes; /* algorithmic HBM bytes of the launch: every operand plane read / written once (no halo, no re-reads) */
-} ResrProfEntry;
-int resr_profile_begin(void);
-int64_t resr_profile_end(ResrProfEntry* out, int64_t capacity);
 
 const char* resr_last_error(void);
 int resr_version(void);

@@ -54,7 +54,14 @@ random.seed(0)
 torch.manual_seed(0)
 np.random.seed(0)
 device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-precision = os.environ.get("RESR_PRECISION", "fast")     # "fast": f16 MFMA / "strict": f32 MFMA
+# Kernel arithmetic, following the reference's own call sites:
+#   train / validate run under amp.autocast (train_realesrnet.py:383,461; train_realesrgan.py:471,...)  ->  `precision`, default
+#     "fast" = f16 operands on the MFMA pipe, fp32 accumulation (the autocast numerics class);
+#   inference.py:52-53 and test.py:79-80 run the generator in plain fp32 (no autocast)               ->  `inference_precision`,
+#     default "exact16" = split-operand f16 MFMA, fp32-class results (the mode inside the 1e-3 parity tolerance).
+# "strict" (f32 MFMA) is accepted by both; inference.py --precision, $RESR_PRECISION (train) and $RESR_INFERENCE_PRECISION override.
+precision = os.environ.get("RESR_PRECISION", "fast")
+inference_precision = os.environ.get("RESR_INFERENCE_PRECISION", "exact16")
 niqe_model_path = "./results/pretrained_models/niqe_model.mat"
 in_channels = 3
 out_channels = 3

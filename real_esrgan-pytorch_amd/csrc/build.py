@@ -26,7 +26,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "conv3x3.h"), os.path.join(HERE, "conv3x3_ws.h"), os.path.join(HERE, "conv3x3_ws_chain.h"), os.path.join(HERE, "wgrad.h"), os.path.join(ROOT, "include", "resr.h"), os.path.abspath(__file__)]
+    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "conv3x3.h"), os.path.join(HERE, "conv3x3_ws.h"), os.path.join(HERE, "conv3x3_ws_chain.h"), os.path.join(HERE, "wgrad.h"), os.path.join(ROOT, "include", "resr.h"), os.path.join(ROOT, "include", "resr_debug.h"), os.path.abspath(__file__)]
     extra = [s for s in os.listdir(HERE) if s.endswith(".hip") and s not in SOURCES]
     srcs = SOURCES + sorted(extra)
     objs, jobs = [], []

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "resr.h"
+#include "resr_debug.h"
 
 namespace resr {
 

@@ -142,10 +142,21 @@ int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, con
             c.err_host = (unsigned*)hp; c.err_dev = (unsigned*)dp; c.nan16 = (const char*)np;
             c.init = true;
         }
-        if (c.owned && c.owner != stream && hipStreamWaitEvent(stream, c.ev, 0) != hipSuccess)
-            return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipStreamWaitEvent");
-        c.owner = stream;
-        c.owned = true;
+        // Under stream capture nothing runs now: the launch becomes a node of a graph that is replayed later, possibly many times,
+        // and neither a wait on the owner's event nor a record of it would mean anything at replay time (a captured record turns
+        // the event into a graph-internal dependency that is never "really" recorded; an eager chain waiting on it afterwards is
+        // an error or a no-op depending on the runtime).  So a capturing stream neither waits, nor records, nor takes ownership:
+        // inside ONE graph the chain nodes are ordered by the capture itself; what the caller must guarantee (include/resr.h) is
+        // that a graph holding chained launches is not replayed while ANOTHER stream runs chained launches on the same device.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+        const bool capturing = cap == hipStreamCaptureStatusActive;
+        if (!capturing) {
+            if (c.owned && c.owner != stream && hipStreamWaitEvent(stream, c.ev, 0) != hipSuccess)
+                return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipStreamWaitEvent");
+            c.owner = stream;
+            c.owned = true;
+        }
         cj.state = (unsigned*)state;
         cj.cap = (unsigned)(state_bytes / sizeof(unsigned) - kChainHdr);
         cj.host_errors = c.err_dev;
@@ -157,7 +168,7 @@ int conv3x3_ws_chain_f16(const ConvArgs& a, const ChainJob* jobs, int njobs, con
         for (int j = njobs; j < kMaxChain; ++j) cj.job[j] = jobs[njobs - 1];
         const int kind = (a.flags & RESR_CONV_MASK_BITS) ? 2 : (a.flags & RESR_CONV_WRITE_SIGNBITS) ? 1 : 0;
         const int rc = conv3x3_ws_chain_launch(a, cj, rows, kind, x2, f, b, stream);   // under the lock: owner and event follow launch order
-        if (rc == RESR_OK && hipEventRecord(c.ev, stream) != hipSuccess) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipEventRecord");
+        if (rc == RESR_OK && !capturing && hipEventRecord(c.ev, stream) != hipSuccess) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: hipEventRecord");
         return rc;
     }
 }

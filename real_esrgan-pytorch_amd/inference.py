@@ -20,7 +20,7 @@ def main(args) -> None:
     from PIL import Image
     torch.cuda.set_device(config.device)            # one process per GPU: every launch and side stream on this device
     model = Generator(config.in_channels, config.out_channels, config.upscale_factor,
-                      precision=getattr(args, "precision", None))
+                      precision=getattr(args, "precision", None) or config.inference_precision)   # fp32 call site: inference.py:52-53
     model = model.to(memory_format=torch.channels_last, device=config.device)        # inference.py:28
     print("Build Real_ESRGAN model successfully.")
     checkpoint = torch.load(args.weights_path, map_location=lambda storage, loc: storage, weights_only=False)
@@ -43,5 +43,6 @@ if __name__ == "__main__":
     parser.add_argument("--inputs_path", type=str, help="Low-resolution image path.")
     parser.add_argument("--output_path", type=str, help="Super-resolution image path.")
     parser.add_argument("--weights_path", type=str, help="Model weights file path.")
-    parser.add_argument("--precision", type=str, default=None, choices=["fast", "exact16", "strict"])
+    parser.add_argument("--precision", type=str, default=None, choices=["fast", "exact16", "strict"],
+                        help="kernel arithmetic; default config.inference_precision = exact16 (the reference runs fp32 here)")
     main(parser.parse_args())

@@ -28,7 +28,7 @@ def main() -> float:
     torch.cuda.set_device(config.device)            # one process per GPU: every launch and side stream on this device
     from PIL import Image
     model = Generator(config.in_channels, config.out_channels, config.upscale_factor,
-                      precision=getattr(config, "precision", "fast"))
+                      precision=config.inference_precision)                     # fp32 call site: test.py:79-80 (no autocast)
     model = model.to(device=config.device, memory_format=torch.channels_last)              # test.py:32
     print("Build Real_ESRGAN model successfully.")
     checkpoint = torch.load(config.model_path, map_location=lambda storage, loc: storage, weights_only=False)

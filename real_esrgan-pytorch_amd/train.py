@@ -124,6 +124,19 @@ class DataParallel:
         else:
             model.grad_hook = self.all_reduce_mean_
 
+    def attach_ema(self, ema: EMA) -> None:
+        """The EMA shadow of every rank = rank 0's.  `EMA.register()` runs inside build_model(), i.e. BEFORE attach() broadcasts
+        rank 0's weights, and the ranks' generators restart at different seeds (train_realesrnet.seed_rank): without this the
+        ranks other than 0 would average from their own random init, validate a different model and disagree on `is_best`."""
+        if self.world == 1:
+            return
+        flat = getattr(ema, "_flat_shadow", None)
+        if flat is not None:
+            dist.broadcast(flat, src=0)
+        else:
+            for k in sorted(ema.shadow):
+                dist.broadcast(ema.shadow[k], src=0)
+
     def all_reduce_ranges_(self, flat: torch.Tensor, ranges, events) -> None:
         """`ranges` are adjacent, descending element ranges of `flat`, events[i] fires (on the producing stream) when
         ranges[i] is final.  Neighbouring ranges are merged into buckets of >= bucket size; each bucket's all-reduce is

@@ -115,6 +115,7 @@ def main() -> None:
     # generator gradients reduced from its backward hook, discriminator gradients once after its second backward
     _DP = DataParallel()
     _DP.attach(generator)
+    _DP.attach_ema(ema_model)                             # registered from each rank's own init in build_model(): rank 0's everywhere
     _DP.attach_discriminator(discriminator)
     samples_dir = os.path.join("samples", config.exp_name)
     results_dir = os.path.join("results", config.exp_name)
@@ -137,7 +138,7 @@ def main() -> None:
         g_scheduler.step()
         is_best = niqe < best_niqe
         best_niqe = min(niqe, best_niqe)
-        if rank != 0:        # replicas are identical: one writer
+        if rank != 0:        # weights, EMA shadow and optimiser states are identical on every rank: one writer
             continue
         d_path = os.path.join(samples_dir, f"d_epoch_{epoch + 1}.pth.tar")
         g_path = os.path.join(samples_dir, f"g_epoch_{epoch + 1}.pth.tar")

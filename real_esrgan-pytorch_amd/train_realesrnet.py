@@ -137,12 +137,15 @@ def main() -> None:
     model, ema_model = build_model()
     dp = DataParallel()
     dp.attach(model)                                     # broadcast of the initial weights + all-reduce of the gradient arena per step
+    dp.attach_ema(ema_model)                             # ... and of the EMA shadow (registered from each rank's own init above)
     pixel_criterion = define_loss()
     optimizer = define_optimizer(model)
     scheduler = define_scheduler(optimizer)
     if config.resume:
         start_epoch, best_niqe = load_checkpoint(config.resume, model, ema_model, optimizer, scheduler)
         print("Loaded pretrained model weights.")
+        dp.broadcast_(model.flat_parameters())           # every rank read the same file; keep the replicas bit-identical anyway
+        dp.attach_ema(ema_model)
     samples_dir = os.path.join("samples", config.exp_name)
     results_dir = os.path.join("results", config.exp_name)
     os.makedirs(samples_dir, exist_ok=True)
@@ -162,7 +165,7 @@ def main() -> None:
         scheduler.step()
         is_best = niqe < best_niqe
         best_niqe = min(niqe, best_niqe)
-        if _RANK == 0:       # replicas are identical: one writer
+        if _RANK == 0:       # weights, EMA shadow and optimiser state are identical on every rank: one writer
             save_checkpoint(epoch, best_niqe, is_best, model, ema_model, optimizer, scheduler, samples_dir, results_dir)
 
 
@@ -228,11 +231,12 @@ def validate(model: nn.Module, ema_model: nn.Module, data_prefetcher: CUDAPrefet
             batch_data = data_prefetcher.next()
             batch_index += 1
     ema_model.restore()
-    _lib.chain_health()             # the NIQE read-backs above synchronised: every launch of the evaluation has reported
+    avg_niqe = niqe_metrics.avg     # the meters accumulate on the device: THIS read-back is the evaluation's first synchronisation
+    _lib.chain_health()             # ... after which every launch of the evaluation has reported
     if _RANK == 0:
         ProgressMeter(len(data_prefetcher), [batch_time, niqe_metrics], prefix=f"{mode}: ").display_summary()
-    writer.add_scalar(f"{mode}/NIQE", niqe_metrics.avg, epoch + 1)
-    return niqe_metrics.avg
+    writer.add_scalar(f"{mode}/NIQE", avg_niqe, epoch + 1)
+    return avg_niqe
 
 
 if __name__ == "__main__":

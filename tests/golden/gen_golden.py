@@ -103,15 +103,19 @@ def gen_init(ref):
          total_sum=torch.stack([v.double().sum() for v in sdd.values()]))
 
 
-def gen_discriminator(ref):
-    sd = M.init_discriminator_state(201)
+def gen_discriminator(ref, seed=201, name="discriminator"):
+    """seed 201: the round-1 case; one LeakyReLU pre-activation of its 8 x 8 level lies within fp32 rounding of zero, so two
+    correct evaluations may differ by that mask element (~1e-2 in the affected gradients).  seed 231: chosen (a search over
+    seeds 200..239 with the oracle in fp32 and float64: worst gradient distance 7.6e-7) so that NO pre-activation is that
+    close -- the case the strict / exact16 gradients are held to 1e-3 on."""
+    sd = M.init_discriminator_state(seed)
     d = ref.Discriminator()
     d.load_state_dict(sd)
     d.train()
-    gen = torch.Generator().manual_seed(201)
+    gen = torch.Generator().manual_seed(seed)
     x = torch.rand(2, 3, 64, 64, generator=gen).requires_grad_(True)
     gw = torch.randn(2, 1, 64, 64, generator=gen)
-    arrs = {"x": x.detach(), "gw": gw, "seed": 201}
+    arrs = {"x": x.detach(), "gw": gw, "seed": seed}
     for call in range(3):                     # three training-mode calls per GAN step (train_realesrgan.py:479,500,508)
         d.zero_grad()
         if x.grad is not None:
@@ -130,7 +134,7 @@ def gen_discriminator(ref):
     d.eval()
     with torch.no_grad():
         arrs["y_eval"] = d(x.detach())
-    save("discriminator", **arrs)
+    save(name, **arrs)
 
 
 def gen_ema(ref):
@@ -158,6 +162,7 @@ if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("imgpro
     gen_blocks(ref)
     gen_generator(ref)
     gen_discriminator(ref)
+    gen_discriminator(ref, 231, "discriminator_flipfree")
     gen_ema(ref)
 
 

@@ -268,11 +268,14 @@ class Step(Base):
         return super().__call__(hr, lr)
 T.RealESRNetStep = Step
 validate = T.validate
-def validate_and_dump(model, *a, **k):
+def validate_and_dump(model, ema_model, *a, **k):
     if "weights" not in log:
         torch.cuda.synchronize()
         log["weights"] = hashlib.sha1(model.flat_parameters().detach().cpu().numpy().tobytes()).hexdigest()
-    return validate(model, *a, **k)
+        log["ema"] = hashlib.sha1(torch.cat([ema_model.shadow[n].reshape(-1) for n in sorted(ema_model.shadow)]).cpu().numpy().tobytes()).hexdigest()
+    out = validate(model, ema_model, *a, **k)
+    log.setdefault("niqe", []).append(float(out))
+    return out
 T.validate = validate_and_dump
 T.main()
 json.dump(log, open(tmp + f"/log_rank{{rank}}.json", "w"))
@@ -287,6 +290,8 @@ json.dump(log, open(tmp + f"/log_rank{{rank}}.json", "w"))
     assert not set(logs[0]["hr"]) & set(logs[1]["hr"])                          # disjoint shards
     assert logs[0]["lr"] != logs[1]["lr"]                                        # rank-dependent degradation draws
     assert logs[0]["weights"] == logs[1]["weights"]                              # replicas stay bit-identical
+    assert logs[0]["ema"] == logs[1]["ema"]                                      # ... and so do their EMA shadows (rank 0's init, then identical updates)
+    assert logs[0]["niqe"][1] == logs[1]["niqe"][1]                              # the "Test" evaluation (same images on every rank) scores the same model
     assert (tmp_path / "samples" / "dp_test" / "g_epoch_1.pth.tar").exists()    # written once, by rank 0
     tags = [json.loads(l) for l in open(tmp_path / "samples" / "logs" / "dp_test" / "scalars.jsonl")]
     assert sum(t["tag"] == "Train/Loss" for t in tags) == 3                     # one writer

@@ -120,8 +120,11 @@ def test_state_dict_surface_and_channels_last():
         g(x.cpu())
 
 
-def test_inference_entry_point(tmp_path):
-    """reference inference.py flow: checkpoint with 'model.'-prefixed keys -> PNG in -> PNG out, vs the oracle."""
+@pytest.mark.parametrize("precision", [None, "strict"])
+def test_inference_entry_point(tmp_path, precision):
+    """reference inference.py flow: checkpoint with 'model.'-prefixed keys -> PNG in -> PNG out, vs the oracle.
+    precision None = the entry point's DEFAULT (no --precision): the reference runs this call site in fp32
+    (inference.py:52-53, no autocast), so the default must be a mode inside the 1e-3 tolerance (config.inference_precision)."""
     import numpy as np
     from PIL import Image
     from oracle import model_ref as M
@@ -134,7 +137,12 @@ def test_inference_entry_point(tmp_path):
     Image.fromarray(lr).save(tmp_path / "lr.png")
 
     class A:
-        inputs_path, output_path, weights_path, precision = str(tmp_path / "lr.png"), str(tmp_path / "sr.png"), str(tmp_path / "g.pth.tar"), "strict"
+        inputs_path, output_path, weights_path = str(tmp_path / "lr.png"), str(tmp_path / "sr.png"), str(tmp_path / "g.pth.tar")
+    if precision is not None:
+        A.precision = precision
+    else:
+        from real_esrgan_pytorch_amd import config
+        assert config.inference_precision == "exact16" and config.precision == "fast"   # fp32 call sites / autocast call sites
     inference.main(A)
     got = np.asarray(Image.open(tmp_path / "sr.png")).astype(np.int32)
     x = torch.from_numpy(lr.astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
@@ -142,6 +150,45 @@ def test_inference_entry_point(tmp_path):
     assert got.shape == (96, 112, 3)
     d = np.abs(got - ref)
     assert d.max() <= 1 and (d > 0).mean() < 1e-3      # truncating uint8 conversion: ties within 2e-6 may flip a level
+
+
+def test_directory_test_entry_point_default_precision(tmp_path, monkeypatch):
+    """reference test.py flow on its DEFAULT precision (test.py:79-80 runs fp32, no autocast): EMA weights from a checkpoint,
+    every LR PNG of a folder -> SR PNG + NIQE.  The written images equal the oracle's uint8 images (<= 1 LSB on < 0.1 % of the
+    values) and the reported NIQE equals the NIQE of the oracle's SR tensors."""
+    import numpy as np
+    from PIL import Image
+    from oracle import model_ref as M
+    from real_esrgan_pytorch_amd import config, image_quality_assessment as IQA
+    from real_esrgan_pytorch_amd import test as E
+    sd = M.init_generator_state(23, bias_noise=0.02)
+    sd["conv4.bias"] = sd["conv4.bias"] + 0.5
+    torch.save({"ema_state_dict": {"model." + k: v for k, v in sd.items()}}, tmp_path / "g.pth.tar")
+    os.makedirs(tmp_path / "lr")
+    rng = np.random.RandomState(1)
+    lrs = {}
+    for name, (h, w) in (("a.png", (40, 36)), ("b.png", (32, 48))):
+        # smooth + grain: NIQE wants image-like statistics
+        base = np.kron(rng.rand(h // 4, w // 4, 3), np.ones((4, 4, 1)))
+        lrs[name] = np.clip((0.8 * base + 0.2 * rng.rand(h, w, 3)) * 255, 0, 255).astype(np.uint8)
+        Image.fromarray(lrs[name]).save(tmp_path / "lr" / name)
+    here = os.path.dirname(os.path.abspath(__file__))
+    for k, v in dict(lr_dir=str(tmp_path / "lr"), sr_dir=str(tmp_path / "sr"), model_path=str(tmp_path / "g.pth.tar"),
+                     niqe_model_path=os.path.join(here, "golden", "niqe_model.mat"), device=torch.device("cuda", 0)).items():
+        monkeypatch.setattr(config, k, v, raising=False)
+    assert config.inference_precision == "exact16"
+    score = E.main()
+    niqe = IQA.NIQE(4, config.niqe_model_path).cuda()
+    ref_scores = []
+    for name, lr in lrs.items():
+        x = torch.from_numpy(lr.astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+        yo = M.generator_forward(x, sd, 4)
+        ref = yo.squeeze(0).permute(1, 2, 0).mul(255).clamp(0, 255).numpy().astype("uint8").astype(np.int32)
+        got = np.asarray(Image.open(tmp_path / "sr" / name)).astype(np.int32)
+        d = np.abs(got - ref)
+        assert got.shape == ref.shape and d.max() <= 1 and (d > 0).mean() < 1e-3, (name, d.max(), (d > 0).mean())
+        ref_scores.append(niqe(yo.cuda()).item())
+    assert abs(score - sum(ref_scores) / len(ref_scores)) < 1e-3 * max(1.0, abs(score)), (score, ref_scores)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -224,10 +271,10 @@ def test_two_backwards_accumulate():
 
 
 def test_exact16_three_product_weight_gradients_knob():
-    """exact16's weight gradients come from the hi tensors only by default (a third of the matrix work; every tensor within
-    1e-3 of the float64 evaluation -- asserted by test_generator_forward_backward -- measured 3-9e-4 on 24^2 ... 2 x 256^2,
-    profiles/r03_x2_wgrad_validate.json).  RESR_X2_WGRAD_PRODUCTS=3 adds the two cross products with the lo tensors: then every
-    one of the 702 tensors of the 23-block case sits within 2e-5 (measured 5.8e-6).  The knob is read per call."""
+    """exact16's weight gradients use all three tap-products by default (X_hi^T G_hi + 2^-12 (X_hi^T G_lo + X_lo^T G_hi)): every
+    one of the 702 tensors of the 23-block case within 2e-5 of the float64 evaluation (measured 5.8e-6).  RESR_X2_WGRAD_PRODUCTS=1
+    is the opt-in hi-tensors-only form (a third of the matrix work, 3-9e-4 on 24^2 ... 2 x 256^2,
+    profiles/r03_x2_wgrad_validate.json: inside 1e-3 without real margin, hence not the default).  The knob is read per call."""
     g, sd, M = _setup(4, 23, 11, "exact16")
     gen = torch.Generator().manual_seed(5)
     x = torch.rand(1, 3, 24, 24, generator=gen)
@@ -235,7 +282,7 @@ def test_exact16_three_product_weight_gradients_knob():
     sdo = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
     (M.generator_forward(x.double(), sdo, 4, 23) * gw.double()).sum().backward()
     worst = {}
-    for products in ("1", "3"):
+    for products in ("1", "3", ""):
         os.environ["RESR_X2_WGRAD_PRODUCTS"] = products
         try:
             g.zero_grad(set_to_none=True)
@@ -246,4 +293,5 @@ def test_exact16_three_product_weight_gradients_knob():
         worst[products] = max(((p.grad.cpu().double() / 1024.0 - sdo[n].grad).norm() / sdo[n].grad.norm().clamp_min(1e-12)).item()
                               for n, p in g.named_parameters())
     assert worst["3"] < 2e-5, worst
+    assert worst[""] == worst["3"], worst          # the default IS the three-product form
     assert worst["3"] < worst["1"] < 1e-3, worst

@@ -3,6 +3,7 @@
 (train_realesrnet.py:379-388) on the resulting LR / HR pair.  Fixtures: tests/golden/pipeline_seed*.npz
 (tests/golden/gen_pipeline_golden.py ran the reference's `train()`)."""
 import glob
+import json
 import os
 
 import numpy as np
@@ -139,7 +140,7 @@ def test_realesrnet_step_matches_reference(precision):
 
 
 @pytest.mark.parametrize("precision", ["strict", "exact16"])
-def test_realesrgan_step_matches_reference(precision):
+def test_realesrgan_step_matches_reference(precision, diag_dir):
     """train.RealESRGANStep (generator update with the discriminator frozen, USM on sr, three discriminator calls;
     train_realesrgan.py:459-521) on the LR/HR pair of tests/golden/gan_step_seed5.npz against the values the reference's own
     train() produced: the four losses, SR, every gradient norm of both networks and the spectral-norm vectors afterwards."""
@@ -169,8 +170,13 @@ def test_realesrgan_step_matches_reference(precision):
     gn = torch.stack([p.grad.norm() for p in g.parameters()]).cpu()
     dn = torch.stack([p.grad.norm() for p in d.parameters()]).cpu()
     rg, rd = torch.from_numpy(z["g_grad_norms"]), torch.from_numpy(z["d_grad_norms"])
-    assert ((gn - rg).abs() / rg.clamp_min(1e-12)).max().item() < 5e-3
-    assert ((dn - rd).abs() / rd.clamp_min(1e-12)).max().item() < 5e-3
+    eg = ((gn - rg).abs() / rg.clamp_min(1e-12)).max().item()
+    ed = ((dn - rd).abs() / rd.clamp_min(1e-12)).max().item()
+    with open(os.path.join(diag_dir, f"gan_step_golden_{precision}.json"), "w") as f:
+        json.dump({"g_grad_norm_worst_rel": eg, "d_grad_norm_worst_rel": ed}, f)
+    # exact16 (three-product weight gradients): every gradient norm of both networks within 1e-3 of the reference's own
+    tol_n = 1e-3 if precision == "exact16" else 5e-3
+    assert eg < tol_n and ed < tol_n, (eg, ed)
     sd = d.state_dict()
     for k in z.files:
         if k.startswith("uv_"):

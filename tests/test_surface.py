@@ -22,12 +22,17 @@ def built():
 
 
 def test_library_exports_every_declared_symbol(built):
-    hdr = open(os.path.join(ROOT, "include", "resr.h")).read()
-    declared = sorted(set(re.findall(r"\b(resr_[a-z0-9_]+)\s*\(", hdr)))
-    assert len(declared) >= 18
     lib = ctypes.CDLL(built._lib.LIB_PATH)
-    for name in declared:
-        assert hasattr(lib, name), f"{name} declared in include/resr.h but not exported"
+    declared = []
+    for h in ("resr.h", "resr_debug.h"):      # the drop-in contract / the test and measurement aids
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        names = sorted(set(re.findall(r"\b(resr_[a-z0-9_]+)\s*\(", hdr)))
+        if h == "resr.h":
+            assert len(names) >= 18
+            assert not [n for n in names if n.startswith(("resr_debug_", "resr_profile_"))], "debug aids belong in resr_debug.h"
+        for name in names:
+            assert hasattr(lib, name), f"{name} declared in include/{h} but not exported"
+        declared += names
     assert set(built._lib.exported_symbols()) <= set(declared)
     assert lib.resr_version() == 1
 

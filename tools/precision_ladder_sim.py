@@ -1,0 +1,162 @@
+"""CPU emulation of the precision rungs between `fast` (every operand one f16) and `exact16` (every operand an f16 pair).
+
+The MFMA path multiplies f16 operands exactly and accumulates in fp32, so a rung is fully described by WHICH stored tensors
+are single f16 and which are hi + lo pairs (~22 significand bits: emulated as "not rounded").  This script runs the oracle's
+generator (oracle/model_ref.py restated with rounding hooks) in float64 with those roundings applied at the points where the
+HIP path stores a tensor, forward and backward, and reports the two numbers the parity gate is about:
+
+    forward max-abs vs the float64 evaluation, worst per-tensor relative L2 of the 702 weight gradients (+ input gradient)
+
+so that only rungs that can pass are built as kernels.  Test infrastructure only (imports oracle/).
+
+    python tools/precision_ladder_sim.py [--blocks 23] [--size 24] [--seeds 11,12,13]
+"""
+import argparse
+import itertools
+import json
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import model_ref as M  # noqa: E402
+
+
+def q16(t):
+    return t.to(torch.float16).to(t.dtype)
+
+
+class Store(torch.autograd.Function):
+    """A tensor the HIP path stores: value rounded to `fa` on the way forward, its gradient to `fg` on the way back."""
+
+    @staticmethod
+    def forward(ctx, x, fa, fg):
+        ctx.fg = fg
+        return q16(x) if fa == "f16" else x
+
+    @staticmethod
+    def backward(ctx, g):
+        return (q16(g) if ctx.fg == "f16" else g), None, None
+
+
+class Conv(torch.autograd.Function):
+    """3x3 conv whose weight operand is f16 or split (exact), and whose weight-gradient operands (x, g) may be rounded to
+    f16 separately from the data path (exact16's hi-only weight gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, fw, fwg, fwb):
+        wq = q16(w) if fw == "f16" else w
+        ctx.save_for_backward(x, w)
+        ctx.fwg, ctx.fwb = fwg, fwb
+        return F.conv2d(x, wq, b, padding=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = torch.nn.grad.conv2d_input(x.shape, q16(w) if ctx.fwb == "f16" else w, g, padding=1)
+        fx, fg = ctx.fwg if isinstance(ctx.fwg, tuple) else (ctx.fwg, ctx.fwg)
+        gw = torch.nn.grad.conv2d_weight(q16(x) if fx == "f16" else x, w.shape, q16(g) if fg == "f16" else g, padding=1)
+        return gx, gw, g.sum((0, 2, 3)), None, None, None
+
+
+def generator(x, sd, cfg, upscale=4, n_blocks=23):
+    """oracle.model_ref.generator_forward (model.py:255-272) with the storage roundings of `cfg`."""
+    S = lambda t, cls: Store.apply(t, cfg["a_" + cls], cfg["g_" + cls])   # noqa: E731
+
+    def conv(t, key):
+        return Conv.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["w"], cfg["wg"], cfg.get("wb", cfg["w"]))
+
+    x = S(x, "in")
+    out1 = S(conv(x, "conv1"), "stream")
+    t = out1
+    for i in range(n_blocks):
+        t0 = t
+        for r in (1, 2, 3):
+            feats = [t]
+            for c in range(1, 5):
+                feats.append(S(F.leaky_relu(conv(torch.cat(feats, 1), f"trunk.{i}.rdb{r}.conv{c}"), 0.2), "dense"))
+            t = S(conv(torch.cat(feats, 1), f"trunk.{i}.rdb{r}.conv5") * 0.2 + t, "stream") if r < 3 else \
+                S((conv(torch.cat(feats, 1), f"trunk.{i}.rdb{r}.conv5") * 0.2 + t) * 0.2 + t0, "stream")
+    t = S(out1 + conv(t, "conv2"), "stream")
+    t = S(F.leaky_relu(conv(F.interpolate(t, scale_factor=2, mode="nearest"), "upsampling1.0"), 0.2), "tail")
+    t = S(F.leaky_relu(conv(F.interpolate(t, scale_factor=2, mode="nearest"), "upsampling2.0"), 0.2), "tail")
+    t = S(F.leaky_relu(conv(t, "conv3.0"), 0.2), "tail")
+    return torch.clamp(conv(t, "conv4"), 0.0, 1.0)
+
+
+def mk(a_stream, a_dense, a_tail, w, wg, g_stream=None, g_dense=None, g_tail=None, a_in=None, wb=None):
+    return {"wb": wb or w, "a_stream": a_stream, "a_dense": a_dense, "a_tail": a_tail, "a_in": a_in or a_stream,
+            "g_stream": g_stream or a_stream, "g_dense": g_dense or a_dense, "g_tail": g_tail or a_tail, "g_in": "pair",
+            "w": w, "wg": wg}
+
+
+RUNGS = {
+    "fast (all f16)":                                   mk("f16", "f16", "f16", "f16", "f16"),
+    "W split only (x_hi W0 + x_hi W1)":                 mk("f16", "f16", "f16", "split", "f16"),
+    "acts pair, W f16 (x_hi W + x_lo W)":               mk("pair", "pair", "pair", "f16", "f16"),
+    "stream pair, dense+tail f16, W f16":               mk("pair", "f16", "f16", "f16", "f16"),
+    "stream pair, dense+tail f16, W split":             mk("pair", "f16", "f16", "split", "f16"),
+    "stream+tail pair, dense f16, W f16":               mk("pair", "f16", "pair", "f16", "f16"),
+    "stream+tail pair, dense f16, W split":             mk("pair", "f16", "pair", "split", "f16"),
+    "stream+tail pair, dense f16 fwd / pair bwd, W split": mk("pair", "f16", "pair", "split", "f16", g_dense="pair"),
+    "fwd exact; bwd: g f16 all, W split (2 products)":   mk("pair", "pair", "pair", "split", ("pair", "f16"), g_stream="f16", g_dense="f16", g_tail="f16"),
+    "fwd exact; bwd: g f16 all, W f16 (1 product)":      mk("pair", "pair", "pair", "split", ("pair", "f16"), g_stream="f16", g_dense="f16", g_tail="f16", wb="f16"),
+    "fwd exact; bwd: g_dense f16, g_stream/tail pair, W split": mk("pair", "pair", "pair", "split", ("pair", "f16"), g_dense="f16"),
+    "fwd exact; bwd: g pair, W f16 in bwd-data (2 products)":   mk("pair", "pair", "pair", "split", "pair", wb="f16"),
+    "exact16, wgrad x_hi (g pair): 2 products":          mk("pair", "pair", "pair", "split", ("f16", "pair")),
+    "exact16, wgrad g_hi (x pair): 2 products":          mk("pair", "pair", "pair", "split", ("pair", "f16")),
+    "exact16 (all pair, W split, wgrad hi-only)":       mk("pair", "pair", "pair", "split", "f16"),
+    "exact16x3 (all pair, W split, wgrad pairs)":       mk("pair", "pair", "pair", "split", "pair"),
+}
+
+
+def run(seed, n_blocks, size, upscale=4, only=None):
+    sd = M.init_generator_state(seed, 3, 3, upscale, bias_noise=0.02)
+    sd = {k: v for k, v in sd.items() if not k.startswith("trunk.") or int(k.split(".")[1]) < n_blocks}
+    sd["conv4.bias"] = sd["conv4.bias"] + 0.5
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(1, 3, size, size, generator=gen).double()
+    gw = torch.randn(1, 3, size * upscale, size * upscale, generator=gen).double()
+    exact = mk("pair", "pair", "pair", "split", "pair")
+
+    def one(cfg, scale):
+        p = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+        xi = x.clone().requires_grad_(True)
+        y = generator(xi, p, cfg, upscale, n_blocks)
+        (y * gw).sum().mul(scale).backward()
+        return y.detach(), {k: v.grad / scale for k, v in p.items()}, xi.grad / scale
+    y0, g0, gx0 = one(exact, 1.0)
+    rows = {}
+    for name, cfg in RUNGS.items():
+        if only and not any(o in name for o in only):
+            continue
+        y, g, gx = one(cfg, 1024.0)
+        rel = {k: ((g[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)).item() for k in g0}
+        worst_k = max(rel, key=rel.get)
+        vals = sorted(rel.values())
+        rows[name] = {"fwd_max_abs": (y - y0).abs().max().item(), "grad_worst": rel[worst_k], "grad_worst_tensor": worst_k,
+                      "grad_median": vals[len(vals) // 2], "gx": ((gx - gx0).norm() / gx0.norm()).item()}
+    return rows
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--blocks", type=int, default=23)
+    ap.add_argument("--size", type=int, default=24)
+    ap.add_argument("--seeds", type=str, default="11")
+    ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--json", type=str, default="")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    allrows = {}
+    for seed in [int(s) for s in a.seeds.split(",")]:
+        rows = run(seed, a.blocks, a.size, only=[o for o in a.only.split(",") if o])
+        allrows[seed] = rows
+        print(f"== seed {seed}, {a.blocks} blocks, {a.size}^2 LR")
+        for name, r in rows.items():
+            print(f"{name:58s} fwd {r['fwd_max_abs']:.2e}  grad worst {r['grad_worst']:.2e} ({r['grad_worst_tensor']})  median {r['grad_median']:.2e}  gx {r['gx']:.2e}")
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump(allrows, f, indent=1)
