@@ -178,11 +178,41 @@ def pmc_traffic(kernel, batch):
     return None, stale
 
 
+_LIVE_FRONTIER = None
+
+
+def measure_sustained_frontier(seconds=1.5):
+    """The power-cap frontier of THIS board, measured in this process before the timed steps (resr_debug_sustained: 256 workgroups
+    back to back for `seconds` per arm, last third timed): the matrix waves alone, and the matrix waves next to an LDS-DMA stream.
+    The box-to-box spread of one build is +-5 %: a frontier from another box (the committed profiles/ file) cannot price this
+    run's kernels.  ~3 s; stored for sustained_frontier()."""
+    global _LIVE_FRONTIER
+    import real_esrgan_pytorch_amd as R
+    L = R._lib
+    try:
+        src = torch.ones(1 << 29, dtype=torch.uint8, device="cuda")       # 512 MB: beyond the Infinity Cache
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        tb, pf = C.c_double(0), C.c_double(0)
+        L.check(L.lib().resr_debug_sustained(2, seconds, L.ptr(src), src.numel(), L.ptr(cnt), C.byref(tb), C.byref(pf), L.stream_ptr()), "sustained")
+        alone = pf.value
+        L.check(L.lib().resr_debug_sustained(3, seconds, L.ptr(src), src.numel(), L.ptr(cnt), C.byref(tb), C.byref(pf), L.stream_ptr()), "sustained")
+        _LIVE_FRONTIER = (alone, tb.value, pf.value, f"this box, this process (resr_debug_sustained, each arm held {seconds} s)")
+        del src, cnt
+        torch.cuda.empty_cache()
+    except Exception as e:  # pragma: no cover
+        _LIVE_FRONTIER = None
+        sys.stderr.write(f"sustained frontier not measured: {e!r}\n")
+    return _LIVE_FRONTIER
+
+
 def sustained_frontier():
-    """(matrix PFLOP/s alone, stream TB/s, matrix PFLOP/s next to that stream, file) from the committed run of
-    tools/micro/sustained.hip (profiles/r*_micro_sustained.txt: each arm held for 1.5 s), or None."""
+    """(matrix PFLOP/s alone, stream TB/s, matrix PFLOP/s next to that stream, source): the live measurement of this box
+    (measure_sustained_frontier) when there is one, else the committed run of tools/micro/sustained.hip
+    (profiles/r*_micro_sustained.txt, another box), or None."""
     import glob
     import re
+    if _LIVE_FRONTIER:
+        return _LIVE_FRONTIER
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_micro_sustained.txt")), reverse=True):
         try:
             alone = both_s = both_m = None
@@ -198,7 +228,7 @@ def sustained_frontier():
                 elif mx > 0.0:
                     both_s, both_m = st, mx
             if alone and both_s:
-                return alone, both_s, both_m, os.path.basename(path)
+                return alone, both_s, both_m, "profiles/" + os.path.basename(path) + " (tools/micro/sustained.hip, each arm held 1.5 s; an EARLIER box)"
         except Exception:
             pass
     return None
@@ -342,7 +372,7 @@ def roofline_in_situ(step_fn, precision, batch):
         r["vs_sustained"] = {"matrix_alone_tflops": round(alone * 1e3, 1), "matrix_next_to_stream_tflops": round(mx * 1e3, 1),
                              "stream_tbs": st, "kernel_hbm_tbs": round(tbs, 2), "frontier_tflops": round(frontier, 1),
                              "executed_tflops": round(executed, 2), "frac": round(executed / frontier, 4),
-                             "source": "profiles/" + fsrc + " (tools/micro/sustained.hip, each arm held 1.5 s; an earlier box)"}
+                             "source": fsrc}
     return r
 
 
@@ -605,7 +635,7 @@ def run_gan(args, world, rank):
     ema = R.EMA(g, 0.999)
     ema.register()
     g_opt = torch.optim.Adam(g.parameters() if args.per_tensor_adam else [g.flat_parameter()], 1e-4, (0.9, 0.99), fused=True)   # config.py:141-142
-    d_opt = torch.optim.Adam(d.parameters(), 1e-4, (0.9, 0.99), fused=True)
+    d_opt = torch.optim.Adam(d.parameters() if args.per_tensor_adam else [d.flat_parameter()], 1e-4, (0.9, 0.99), fused=True)
     content = R.ContentLoss(["features.2", "features.7", "features.16", "features.25", "features.34"], [0.485, 0.456, 0.406],
                             [0.229, 0.224, 0.225], precision=args.precision).cuda()
     B = args.batch
@@ -700,7 +730,8 @@ def compact_roofline(r):
 def dist_record(world):
     """What the collective layer saw: a SCALE line must show that RCCL ran with N ranks."""
     rec = {"world": world, "backend": dist.get_backend() if dist.is_initialized() else None,
-           "overlap_with_backward": os.environ.get("RESR_DP_OVERLAP", "0") == "1"}
+           "overlap_with_backward": os.environ.get("RESR_DP_OVERLAP", "0") == "1",
+           "forced_collectives": os.environ.get("RESR_DP_FORCE", "0") == "1"}
     try:
         v = torch.cuda.nccl.version()
         rec["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
@@ -844,14 +875,28 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    elif os.environ.get("RESR_BENCH_FORCE_NCCL", "0") == "1":
+        # One GPU, but the RCCL path for real: a world-1 `nccl` group launches genuine RCCL kernels (ReduceOp.AVG on arena slices,
+        # the communication stream, RCCL next to chained conv launches) -- the collective code a SCALE run uses, minus the peers.
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ["RESR_DP_FORCE"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
     if rank == 0:
         ensure_built()
     if world > 1:
         dist.barrier()
+    if rank == 0 and not args.no_probe and args.precision != "strict":
+        measure_sustained_frontier()         # this box's power-cap frontier (~3 s), before the timed steps
 
     if args.gan:
         gan_main(args, world, rank)
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
     B, lr_edge = args.batch, args.lr_size
@@ -936,7 +981,7 @@ def main():
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

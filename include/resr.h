@@ -302,6 +302,23 @@ int resr_add_mask(const void* a, const void* b, const void* mask, void* out, int
  * RESR_F16X2: a and b are pairs with the lo tensor lo_offset elements behind the hi tensor */
 int resr_l1_partial(const void* a, const void* b, int64_t count, int32_t dtype, int64_t lo_offset, float* partial, int32_t nblocks,
                     void* stream);
+/* ---- scalar losses of the train steps, forward value and unit gradient in ONE launch each --------------------------------
+ * scratch: resr_loss_scratch_bytes() bytes of device memory owned by the caller, zero-filled once (an arrival counter + one
+ * partial sum per workgroup; the last workgroup adds them in a fixed order and re-arms the counter: deterministic values).
+ * Launches that may overlap in time need their own scratch.
+ * resr_bce_logits_const: loss[0] = weight * mean_i BCEWithLogits(logits_i, label) against a CONSTANT label -- nn.BCEWithLogitsLoss
+ *   on torch.full(..., 1.0 / 0.0) (train_realesrgan.py:460-461,478,500,509) without the label tensor; grad (nullable, [count]) =
+ *   d loss / d logits_i = weight / count * (sigmoid(logits_i) - label).
+ * resr_l1_mean: loss[0] = weight * mean_i |a_i - b_i| -- nn.L1Loss (train_realesrnet.py:385, train_realesrgan.py:475); grad_a
+ *   (nullable) = weight / count * sign(a_i - b_i).  All tensors fp32, 16-byte aligned. */
+size_t resr_loss_scratch_bytes(void);
+int resr_bce_logits_const(const float* logits, int64_t count, float label, float weight, float* loss, float* grad, float* scratch,
+                          void* stream);
+int resr_l1_mean(const float* a, const float* b, int64_t count, float weight, float* loss, float* grad_a, float* scratch, void* stream);
+/* out[r] = coef_host[r] * sum_k partial[r * cols + k] for r < rows (<= 8), out[rows] = their total: the weighted feature
+ * distances of the perceptual term (model.py:320-335) from resr_l1_partial's partial sums, one launch; coef_host is HOST memory. */
+int resr_weighted_row_sums(const float* partial, int32_t rows, int32_t cols, const float* coef_host, float* out, void* stream);
+
 /* torch.nn.utils.spectral_norm forward (model.py:140-168): W [rows][cols] fp32; training: one power iteration
  * updating u[rows], v[cols] in place; sigma2[0] = sigma, sigma2[1] = 1/sigma; tmp = rows + ceil(rows/32) * cols floats
  * (W^T u is summed in 32-row groups, in a fixed order: bit-identical on every data-parallel rank) */

@@ -29,6 +29,13 @@ int resr_debug_wgrad_plan(const int32_t* cin, const int32_t* cout_pad, int32_t n
 /* test probe: lane/element map of ds_read_b64_tr_b16 (256 floats out) */
 int resr_debug_tr_probe(float* out256, void* stream);
 
+/* What THIS board sustains once it sits at its power cap (bench.py's `roofline.vs_sustained`): 256 workgroups launched back to
+ * back for `seconds` (last third timed) -- mode 1: an LDS-DMA stream over `src` (`bytes` >= 64 MB of readable device memory),
+ * mode 2: eight waves per workgroup issuing v_mfma_f32_32x32x16_f16 on random f16 operands, mode 3: both at once.  Returns the
+ * stream's TB/s and the matrix waves' executed PFLOP/s; counter8 = 8 bytes of device scratch.  Synchronises. */
+int resr_debug_sustained(int32_t mode, double seconds, const void* src, size_t bytes, void* counter8, double* stream_tbs,
+                         double* matrix_pflops, void* stream);
+
 /* In-situ kernel timing for bench.py: between begin and end every conv3x3 / wgrad launch is bracketed by HIP events
  * on its launch stream.  kernel_id = dtype*10000 + MT*100 + NT*10 + NW for conv3x3_kernel<T,MT,NT,NW>,
  * 50000 + dtype*100 + RPW for wgrad_kernel<T,RPW>.  resr_profile_end synchronises the events (host-side, test/bench

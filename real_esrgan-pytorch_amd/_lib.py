@@ -100,12 +100,17 @@ _PROTOS = {
     "resr_debug_conv_trace": (C.c_int, [_P]),
     "resr_debug_chain_errors": (C.c_int64, []),
     "resr_debug_wgrad_plan": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
+    "resr_debug_sustained": (C.c_int, [C.c_int32, C.c_double, _P, C.c_size_t, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     "resr_profile_begin": (C.c_int, []),
     "resr_profile_end": (C.c_int64, [_P, C.c_int64]),
     "resr_space_to_depth": (C.c_int, [_P, _P] + [C.c_int32] * 6 + [_P]),
     "resr_bilinear_up2x": (C.c_int, [_P, _P] + [C.c_int32] * 6 + [_P]),
     "resr_add_mask": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "resr_l1_partial": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int64, _P, C.c_int32, _P]),
+    "resr_loss_scratch_bytes": (C.c_size_t, []),
+    "resr_bce_logits_const": (C.c_int, [_P, C.c_int64, C.c_float, C.c_float, _P, _P, _P, _P]),
+    "resr_l1_mean": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P, _P, _P, _P]),
+    "resr_weighted_row_sums": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), _P, _P]),
     "resr_spectral_norm": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
     "resr_spectral_norm_bwd": (C.c_int, [_P] * 6 + [C.c_int32] * 3 + [_P, _P]),
     "resr_maxpool2x2": (C.c_int, [_P, _P] + [C.c_int32] * 5 + [_P]),

@@ -122,6 +122,10 @@ int s2d_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
 int bilinear_up_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t, long, long);
 int add_mask_dispatch(const void*, const void*, const void*, void*, long, int, float, hipStream_t);
 int l1_partial_dispatch(const void*, const void*, long, int, long, float*, int, hipStream_t);
+int bce_logits_const_dispatch(const float*, long, float, float, float*, float*, float*, hipStream_t);   // loss.hip
+int l1_mean_dispatch(const float*, const float*, long, float, float*, float*, float*, hipStream_t);
+int weighted_rows_dispatch(const float*, int, int, const float*, float*, hipStream_t);
+int sustained_run(int, double, const void*, size_t, void*, double*, double*, hipStream_t);   // sustained.hip
 int spectral_norm_dispatch(const float*, float*, float*, int, int, int, float, float*, float*, hipStream_t);
 int spectral_norm_bwd_dispatch(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, float*,
                                hipStream_t);
@@ -360,6 +364,30 @@ int resr_add_mask(const void* a, const void* b, const void* mask, void* out, int
 int resr_l1_partial(const void* a, const void* b, int64_t count, int32_t dtype, int64_t lo_offset, float* partial, int32_t nblocks, void* stream) {
     RESR_DEVICE_SCOPE(stream);
     return l1_partial_dispatch(a, b, (long)count, dtype, (long)lo_offset, partial, nblocks, (hipStream_t)stream);
+}
+
+int resr_debug_sustained(int32_t mode, double seconds, const void* src, size_t bytes, void* counter8, double* stream_tbs, double* matrix_pflops,
+                         void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return sustained_run(mode, seconds, src, bytes, counter8, stream_tbs, matrix_pflops, (hipStream_t)stream);
+}
+
+size_t resr_loss_scratch_bytes(void) { return (1 + 1024) * sizeof(float); }
+
+int resr_bce_logits_const(const float* logits, int64_t count, float label, float weight, float* loss, float* grad, float* scratch,
+                          void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return bce_logits_const_dispatch(logits, (long)count, label, weight, loss, grad, scratch, (hipStream_t)stream);
+}
+
+int resr_l1_mean(const float* a, const float* b, int64_t count, float weight, float* loss, float* grad_a, float* scratch, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return l1_mean_dispatch(a, b, (long)count, weight, loss, grad_a, scratch, (hipStream_t)stream);
+}
+
+int resr_weighted_row_sums(const float* partial, int32_t rows, int32_t cols, const float* coef_host, float* out, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return weighted_rows_dispatch(partial, rows, cols, coef_host, out, (hipStream_t)stream);
 }
 
 int resr_spectral_norm(const float* w, float* u, float* v, int32_t rows, int32_t cols, int32_t training, float eps, float* sigma2,

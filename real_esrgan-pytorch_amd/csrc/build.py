@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["api.hip", "conv3x3.hip", "conv3x3_ws.hip", "conv3x3_ws_mt1.hip", "conv3x3_ws_mt2.hip", "conv3x3_ws_x2_mt1.hip", "conv3x3_ws_x2_mt2.hip", "conv3x3_ws_sp.hip", "conv3x3_ws_chain.hip", "conv3x3_ws_chain_x2.hip", "wgrad.hip", "pack.hip", "layout.hip", "generator.hip", "degrade.hip", "degrade_int.hip", "disc.hip", "disc_native.hip"]
+SOURCES = ["api.hip", "conv3x3.hip", "conv3x3_ws.hip", "conv3x3_ws_mt1.hip", "conv3x3_ws_mt2.hip", "conv3x3_ws_x2_mt1.hip", "conv3x3_ws_x2_mt2.hip", "conv3x3_ws_sp.hip", "conv3x3_ws_chain.hip", "conv3x3_ws_chain_x2.hip", "wgrad.hip", "pack.hip", "layout.hip", "generator.hip", "degrade.hip", "degrade_int.hip", "disc.hip", "disc_native.hip", "loss.hip", "sustained.hip"]
 LIB = os.path.join(HERE, "libresr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", HERE,

@@ -106,6 +106,7 @@ class Discriminator(nn.Module):
         self._offsets: Dict[str, int] = {}
         self._workspaces: Dict[tuple, List[_DWorkspace]] = {}
         self.grad_hook = None   # optional callable(flat_grad) after a backward that produced weight gradients
+        self.__dict__["_flat_param"] = None   # see flat_parameter(); kept out of nn.Module's parameter registry
 
     # ---- arenas ---------------------------------------------------------------------------------------------
     def _ordered_params(self) -> List[nn.Parameter]:
@@ -140,6 +141,42 @@ class Discriminator(nn.Module):
             self._flat = flat
             self._workspaces.clear()
         return self._flat
+
+    def flat_parameter(self) -> nn.Parameter:
+        """One leaf Parameter aliasing the whole fp32 arena (as `Generator.flat_parameter`): `optim.Adam([d.flat_parameter()],
+        fused=True)` and the GradScaler's unscale / inf check are single launches, and the autograd graph carries ONE parameter
+        input instead of 19 (no per-tensor AccumulateGrad copies / adds: the two backward passes of a GAN step,
+        train_realesrgan.py:503-516, meet in one `add_` over the arena).  After this call backward ACCUMULATES the gradient arena
+        into this Parameter's `.grad` (autograd semantics) and hands out no per-tensor gradients; `zero_grad()` clears it; setting
+        `requires_grad` on the module's parameters (the frozen discriminator of the generator step, :465-466) is mirrored onto it
+        by `requires_grad_`.  `state_dict()` is unchanged."""
+        flat = self.flat_parameters()
+        fp = self.__dict__["_flat_param"]
+        if fp is None:
+            fp = nn.Parameter(flat, requires_grad=True)
+            self.__dict__["_flat_param"] = fp
+        elif fp.data_ptr() != flat.data_ptr():
+            fp.data = flat
+        return fp
+
+    def flat_grad(self) -> Optional[torch.Tensor]:
+        fp = self.__dict__["_flat_param"]
+        return None if fp is None else fp.grad
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        super().zero_grad(set_to_none=set_to_none)
+        fp = self.__dict__["_flat_param"]
+        if fp is not None and fp.grad is not None:
+            if set_to_none:
+                fp.grad = None
+            else:
+                fp.grad.zero_()
+
+    def requires_grad_(self, requires_grad: bool = True):
+        fp = self.__dict__["_flat_param"]
+        if fp is not None:
+            fp.requires_grad_(requires_grad)
+        return super().requires_grad_(requires_grad)
 
     def flat_uv(self) -> torch.Tensor:
         """The spectral-norm vectors (`weight_u`, `weight_v` of the eight normalised convs, named_buffers order) as views of
@@ -204,6 +241,15 @@ class Discriminator(nn.Module):
             return [None] * len(self._ordered_params()), gx
         if self.grad_hook is not None:
             self.grad_hook(gflat)
+        fp = self.__dict__["_flat_param"]
+        if fp is not None:                        # flat_parameter() mode: accumulate into the alias, no per-tensor gradients
+            if fp.data_ptr() != flat.data_ptr():
+                fp.data = flat
+            if fp.grad is None:
+                fp.grad = gflat
+            else:
+                fp.grad.add_(gflat)
+            return [None], gx
         grads = []
         for name, p in self.named_parameters():
             off = self._offsets[name]
@@ -213,7 +259,8 @@ class Discriminator(nn.Module):
     # ---- module surface -----------------------------------------------------------------------------------------
     def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
         self.flat_parameters()
-        params = self._ordered_params()
+        fp = self.__dict__["_flat_param"]
+        params = [fp] if fp is not None else self._ordered_params()     # flat_parameter() mode: one graph input for all 19 tensors
         training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         return _DiscFn.apply(self, training, x, *params)
 

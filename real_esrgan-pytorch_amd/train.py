@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
+from . import losses
 from .model import EMA, Generator
 
 
@@ -60,8 +61,14 @@ class DataParallel:
     weights, every step all-reduces (mean) the flat gradient arena.  With backend "nccl" this is
     RCCL over xGMI; "gloo" serves the CPU tests of the host logic."""
 
-    def __init__(self, bucket_bytes: int = 12 << 20) -> None:
+    def __init__(self, bucket_bytes: int = 12 << 20, force: Optional[bool] = None) -> None:
+        """force (default $RESR_DP_FORCE=1): run every collective branch even with a world of ONE rank -- a world-1 `nccl` group
+        launches real RCCL kernels on one GPU, which is how the single-GPU tests and `RESR_BENCH_FORCE_NCCL=1 bench.py` execute
+        the RCCL path (ReduceOp.AVG on arena slices, the communication stream, RCCL kernels next to chained conv launches)."""
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        if force is None:
+            force = os.environ.get("RESR_DP_FORCE", "0") == "1"
+        self.active = self.world > 1 or bool(force and dist.is_initialized())
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.backend = dist.get_backend() if dist.is_initialized() else None
         # RCCL averages inside the collective (ncclAvg); gloo (the CPU tests) sums and the mean is one more pass
@@ -79,7 +86,7 @@ class DataParallel:
         """Communicator set-up (seconds on a cold node) happens on the first collective: do it HERE, with every rank
         waiting, not under the first training step -- a chained conv launch next to a collective that waits seconds for a
         late peer would run into its poll time-out (conv3x3_ws.h)."""
-        if self.world > 1 and not self._warm:
+        if self.active and not self._warm:
             t = torch.zeros(1024, dtype=torch.float32, device=device)
             dist.all_reduce(t)
             if t.is_cuda:
@@ -88,13 +95,13 @@ class DataParallel:
             self._warm = True
 
     def broadcast_(self, flat: torch.Tensor) -> None:
-        if self.world > 1:
+        if self.active:
             dist.broadcast(flat, src=0)
 
     def all_reduce_mean_(self, flat: torch.Tensor) -> None:
         """Bucketed so that consecutive ring all-reduces pipeline over the 7 xGMI links instead of
         one 67 MB message serialising on a single ring step."""
-        if self.world == 1:
+        if not self.active:
             return
         works = []
         for off in range(0, flat.numel(), self.bucket_elems):
@@ -118,7 +125,7 @@ class DataParallel:
         self.broadcast_(flat)
         if overlap is None:
             overlap = os.environ.get("RESR_DP_OVERLAP", "0") == "1"
-        self.overlap = bool(overlap and self.world > 1)
+        self.overlap = bool(overlap and self.active)
         if self.overlap:
             model.grad_ready_hook = self.all_reduce_ranges_
         else:
@@ -128,7 +135,7 @@ class DataParallel:
         """The EMA shadow of every rank = rank 0's.  `EMA.register()` runs inside build_model(), i.e. BEFORE attach() broadcasts
         rank 0's weights, and the ranks' generators restart at different seeds (train_realesrnet.seed_rank): without this the
         ranks other than 0 would average from their own random init, validate a different model and disagree on `is_best`."""
-        if self.world == 1:
+        if not self.active:
             return
         flat = getattr(ema, "_flat_shadow", None)
         if flat is not None:
@@ -142,7 +149,7 @@ class DataParallel:
         ranges[i] is final.  Neighbouring ranges are merged into buckets of >= bucket size; each bucket's all-reduce is
         enqueued on the communication stream behind its last event, so it runs under the kernels still producing the next
         ranges; the caller's stream rejoins at the end."""
-        if self.world == 1:
+        if not self.active:
             return
         buckets = self.merge_ranges(ranges)
         if not flat.is_cuda:                       # host tensors (the gloo tests of this logic): no streams, same buckets
@@ -186,7 +193,7 @@ class DataParallel:
         flat = discriminator.flat_parameters()
         self.warm_up(flat.device)
         self.broadcast_(flat)
-        if self.world > 1:
+        if self.active:
             if hasattr(discriminator, "flat_uv"):          # the eight (u, v) pairs as one message
                 dist.broadcast(discriminator.flat_uv(), src=0)
             else:
@@ -196,7 +203,7 @@ class DataParallel:
     def all_reduce_grads_(self, params: Iterable[nn.Parameter]) -> None:
         """Mean over ranks of the `.grad` of `params`, as ONE bucketed all-reduce: in place when the gradients already
         sit back to back in one arena (the discriminator's backward hands out views of one), else through a flat copy."""
-        if self.world == 1:
+        if not self.active:
             return
         grads = [p.grad for p in params if p.grad is not None]
         if not grads:
@@ -228,7 +235,7 @@ class RealESRNetStep:
             lr, hr = self.degrade(hr)                      # train_realesrnet.py:268-377
         self.model.zero_grad(set_to_none=True)             # :380
         sr = self.model(lr)                                # :384
-        loss = self.criterion(sr, hr)                      # :385
+        loss = losses.l1_loss(self.criterion, sr, hr)      # :385 -- value and unit gradient in one launch (csrc/loss.hip)
         if self.scaler is not None:
             self.scaler.scale(loss).backward()             # :388
             self.scaler.step(self.optimizer)               # :390
@@ -268,6 +275,25 @@ class RealESRGANStep:
         dev = next(generator.parameters()).device
         self.usm = imgproc.USMSharp(50, 0).to(dev)
 
+    def _d_requires_grad(self, flag: bool) -> None:
+        """train_realesrgan.py:465-466 / :491-492, including the one-tensor alias of `Discriminator.flat_parameter()`."""
+        for p in self.d.parameters():
+            p.requires_grad = flag
+        fp = self.d.__dict__.get("_flat_param")
+        if fp is not None:
+            fp.requires_grad = flag
+
+    def _d_grad_holders(self):
+        fp = self.d.__dict__.get("_flat_param")
+        return [fp] if fp is not None else list(self.d.parameters())
+
+    def _content_w(self, device) -> torch.Tensor:
+        w = getattr(self, "_content_w_dev", None)
+        if w is None or w.device != device:
+            w = torch.tensor([float(v) for v in self.content_weight], dtype=torch.float32, device=device)
+            self._content_w_dev = w
+        return w
+
     def _backward(self, loss):
         if self.scaler is not None:
             self.scaler.scale(loss).backward()
@@ -284,36 +310,37 @@ class RealESRGANStep:
     def __call__(self, hr: torch.Tensor, lr: Optional[torch.Tensor] = None) -> dict:
         if lr is None:
             lr, hr = self.degrade(hr)
-        b, _, h, w = hr.shape
-        real = torch.full([b, 1, h, w], 1.0, dtype=torch.float, device=hr.device)          # :460
-        fake = torch.full([b, 1, h, w], 0.0, dtype=torch.float, device=hr.device)          # :461
-        for p in self.d.parameters():                                                      # :465-466
-            p.requires_grad = False
+        # :460-461 build `real` / `fake` label tensors; here the constant label is an argument of the fused BCE launch
+        # (losses.bce_with_logits_const: value + unit gradient in one launch, csrc/loss.hip)
+        self._d_requires_grad(False)                                                       # :465-466
         self.g.zero_grad(set_to_none=True)                                                 # :469
         sr = self.g(lr)                                                                    # :474
         sr_usm = self.usm(sr, 0.5, 10)
-        pixel_loss = self.pixel_weight * self.pixel(sr_usm, hr)                            # :475
+        pixel_loss = losses.l1_loss(self.pixel, sr_usm, hr, self.pixel_weight, "pixel")    # :475
         content_loss = None
         if self.content is not None:                                                       # :476-477 (detached)
             cl = self.content(sr_usm, hr)
-            content_loss = sum(w * c for w, c in zip(self.content_weight, cl))
-        adversarial_loss = self.adversarial_weight * self.adv(self.d(sr), real)            # :478
+            packed = getattr(self.content, "last_losses", None)     # the five values as one device tensor (detached path)
+            if packed is not None and packed.numel() == len(self.content_weight) and cl[0].data_ptr() == packed.data_ptr():
+                content_loss = torch.dot(packed, self._content_w(packed.device))           # one launch instead of five mul + four add
+            else:
+                content_loss = sum(w * c for w, c in zip(self.content_weight, cl))
+        adversarial_loss = losses.bce_with_logits_const(self.adv, self.d(sr), 1.0, self.adversarial_weight, "adv")   # :478
         g_loss = pixel_loss + adversarial_loss                                             # :480 (content term detached, see class doc)
         if content_loss is not None and not getattr(self.content, "detached", True):
             g_loss = g_loss + content_loss                                                 # the quirk switched off
         self._backward(g_loss)                                                             # :483
         self._step(self.g_opt)                                                             # :485-486
-        for p in self.d.parameters():                                                      # :491-492
-            p.requires_grad = True
+        self._d_requires_grad(True)                                                        # :491-492
         self.d.zero_grad(set_to_none=True)                                                 # :495
         hr_out = self.d(hr)                                                                # :499
-        d_loss_hr = self.adv(hr_out, real)
+        d_loss_hr = losses.bce_with_logits_const(self.adv, hr_out, 1.0, 1.0, "d_hr")
         self._backward(d_loss_hr)                                                          # :503
-        sr_out = self.d(sr.detach().clone())                                               # :507
-        d_loss_sr = self.adv(sr_out, fake)
+        sr_out = self.d(sr.detach())                                                       # :507 (the module copies its input: no clone needed)
+        d_loss_sr = losses.bce_with_logits_const(self.adv, sr_out, 0.0, 1.0, "d_sr")
         self._backward(d_loss_sr)                                                          # :513
         if self.dp is not None:                                                            # one exchange for both backwards
-            self.dp.all_reduce_grads_(self.d.parameters())
+            self.dp.all_reduce_grads_(self._d_grad_holders())
         self._step(self.d_opt)                                                             # :515-516
         if self.ema is not None:
             self.ema.update()                                                              # :520

@@ -279,3 +279,44 @@ def test_unknown_precision_raises():
     with pytest.raises(ValueError):
         R.Discriminator(precision="bf16")
     assert R.Discriminator(precision="exact16").precision == "exact16"
+
+
+def test_flat_parameter_mode_matches_per_tensor_mode():
+    """`Discriminator.flat_parameter()`: one graph input / one gradient arena.  Two accumulated backward passes (the GAN step's
+    D(hr) + D(sr), train_realesrgan.py:503-516), the frozen pass in between, zero_grad and a fused Adam step over the alias give
+    the per-tensor mode's results bit for bit."""
+    import real_esrgan_pytorch_amd as R
+    from oracle import model_ref as M
+    sd = M.init_discriminator_state(5)
+    gen = torch.Generator().manual_seed(6)
+    xa, xb = torch.rand(2, 3, 32, 40, generator=gen).cuda(), torch.rand(2, 3, 32, 40, generator=gen).cuda()
+
+    def run(flat):
+        d = R.Discriminator(precision="fast")
+        d.load_state_dict(sd)
+        d = d.cuda().train()
+        params = [d.flat_parameter()] if flat else list(d.parameters())
+        opt = torch.optim.Adam(params, 1e-3, (0.9, 0.99), fused=True)
+        outs = []
+        for _ in range(2):
+            for p in list(d.parameters()) + ([d.flat_parameter()] if flat else []):       # the generator step's frozen pass
+                p.requires_grad = False
+            xg = xa.clone().requires_grad_(True)
+            d(xg).sum().mul(64.0).backward()
+            outs.append(xg.grad.clone())
+            assert all(p.grad is None for p in d.parameters()) and (not flat or d.flat_parameter().grad is None)
+            for p in list(d.parameters()) + ([d.flat_parameter()] if flat else []):
+                p.requires_grad = True
+            d.zero_grad(set_to_none=True)
+            d(xa).sum().mul(64.0).backward()
+            d(xb).square().sum().mul(64.0).backward()
+            g = d.flat_grad().clone() if flat else torch.cat([p.grad.reshape(-1) for p in d.parameters()])
+            outs.append(g)
+            opt.step()
+            d.zero_grad(set_to_none=True)
+            assert not flat or d.flat_grad() is None
+        outs.append(d.flat_parameters().detach().clone())
+        outs.append(d.flat_uv().clone())
+        return outs
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)

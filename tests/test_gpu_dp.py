@@ -295,3 +295,115 @@ json.dump(log, open(tmp + f"/log_rank{{rank}}.json", "w"))
     assert (tmp_path / "samples" / "dp_test" / "g_epoch_1.pth.tar").exists()    # written once, by rank 0
     tags = [json.loads(l) for l in open(tmp_path / "samples" / "logs" / "dp_test" / "scalars.jsonl")]
     assert sum(t["tag"] == "Train/Loss" for t in tags) == 3                     # one writer
+
+
+# ---- the RCCL path itself, on the one GPU of the test box ------------------------------------------------------------------
+# RCCL refuses two ranks on one device, so the two-rank tests above use gloo.  A WORLD-1 `nccl` group, however, launches genuine
+# RCCL kernels: with DataParallel(force=True) every collective branch runs (warm-up, broadcast, ReduceOp.AVG on arena slices,
+# the communication stream behind the backward pass's range events) -- next to the chained dense-block launches that want
+# every CU.  World 1 makes the expected result exact: the averaged gradient IS the local gradient, bit for bit.
+def _nccl_world1_worker(port, q, overlap):
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        import real_esrgan_pytorch_amd as R
+        from real_esrgan_pytorch_amd.train import DataParallel, RealESRGANStep
+
+        def make():
+            torch.manual_seed(0)
+            m = R.Generator(3, 3, 4, precision="fast", n_blocks=3).cuda()
+            with torch.no_grad():
+                m.conv4.bias.add_(0.5)
+            return m
+        gen = torch.Generator().manual_seed(4)
+        lr = torch.rand(8, 3, 64, 64, generator=gen).cuda()      # batch % 8 == 0: the dense blocks run as chained launches
+        hr = torch.rand(8, 3, 256, 256, generator=gen).cuda()
+        ref_m = make()
+        (ref_m(lr) - hr).abs().mean().mul(1024.0).backward()
+        torch.cuda.synchronize()
+        ref = ref_m.flat_grad().clone()
+        m = make()
+        dp = DataParallel(bucket_bytes=256 << 10, force=True)
+        assert dp.active and dp.backend == "nccl" and dp._avg
+        dp.attach(m, overlap=overlap)
+        assert dp.overlap == overlap
+        calls = []
+        if overlap:
+            inner = m.grad_ready_hook
+
+            def spy(flat, ranges, events):
+                calls.append(len(dp.merge_ranges(ranges)))
+                return inner(flat, ranges, events)
+            m.grad_ready_hook = spy
+        outs = []
+        for _ in range(3):                                       # RCCL kernels of step i's exchange next to step i+1's chains
+            m.zero_grad(set_to_none=True)
+            (m(lr) - hr).abs().mean().mul(1024.0).backward()
+            outs.append(m.flat_grad().clone())
+        torch.cuda.synchronize()
+        res = {"bit_equal": all(torch.equal(o, ref) for o in outs), "chain_errors": int(R._lib.lib().resr_debug_chain_errors()),
+               "buckets": calls, "comm_stream": getattr(dp, "_comm", None) is not None,
+               "weights_equal": torch.equal(m.flat_parameters(), ref_m.flat_parameters())}
+        # the discriminator leg: one GAN step with its single exchange after the second backward (train_realesrgan.py:503-516)
+        torch.manual_seed(1)
+        d = R.Discriminator(precision="fast").cuda().train()
+        d_ref_grads = None
+        for use_dp in (False, True):
+            torch.manual_seed(2)
+            g2 = make()
+            d2 = R.Discriminator(precision="fast").cuda().train()
+            d2.load_state_dict(d.state_dict())
+            dp2 = None
+            if use_dp:
+                dp2 = DataParallel(force=True)
+                dp2.attach(g2, overlap=overlap)
+                dp2.attach_discriminator(d2)
+            step = RealESRGANStep(g2, d2, None, torch.optim.SGD(g2.parameters(), 0.0), torch.optim.SGD(d2.parameters(), 0.0),
+                                  scaler=torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=10 ** 9), dp=dp2)
+            step(hr, lr)
+            torch.cuda.synchronize()
+            grads = torch.cat([p.grad.reshape(-1) for p in d2.parameters()] + [g2.flat_grad()])
+            if not use_dp:
+                d_ref_grads = grads
+            else:
+                res["gan_bit_equal"] = bool(torch.equal(grads, d_ref_grads))
+        res["chain_errors_after_gan"] = int(R._lib.lib().resr_debug_chain_errors())
+        dist.destroy_process_group()
+        q.put(res)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put({"error": repr(e), "trace": traceback.format_exc()})
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_rccl_world1_collectives_next_to_chained_launches(overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(_port(), q, overlap))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert "error" not in res, res
+    assert res["bit_equal"] and res["weights_equal"], res          # ReduceOp.AVG over one rank: the gradient itself
+    assert res["gan_bit_equal"], res
+    assert res["chain_errors"] == 0 and res["chain_errors_after_gan"] == 0, res
+    if overlap:
+        assert res["comm_stream"] and res["buckets"] and all(b >= 2 for b in res["buckets"]), res   # several buckets behind range events
+
+
+def test_bench_force_nccl_one_gpu():
+    """RESR_BENCH_FORCE_NCCL=1 python bench.py --gpus 1: the bench's own steps with a world-1 RCCL group (dist.backend "nccl")."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RESR_BENCH_FORCE_NCCL="1", RESR_DP_OVERLAP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--lr-size", "64", "--no-other-configs", "--no-cpu-baseline", "--no-parity-mode"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["dist"]["backend"] == "nccl" and out["dist"]["forced_collectives"] and out["dist"]["overlap_with_backward"]
+    assert out["chain_errors"] == 0 and out["value"] > 0

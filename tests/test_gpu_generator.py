@@ -165,12 +165,14 @@ def test_directory_test_entry_point_default_precision(tmp_path, monkeypatch):
     sd["conv4.bias"] = sd["conv4.bias"] + 0.5
     torch.save({"ema_state_dict": {"model." + k: v for k, v in sd.items()}}, tmp_path / "g.pth.tar")
     os.makedirs(tmp_path / "lr")
-    rng = np.random.RandomState(1)
+    import torch.nn.functional as F
     lrs = {}
-    for name, (h, w) in (("a.png", (40, 36)), ("b.png", (32, 48))):
-        # smooth + grain: NIQE wants image-like statistics
-        base = np.kron(rng.rand(h // 4, w // 4, 3), np.ones((4, 4, 1)))
-        lrs[name] = np.clip((0.8 * base + 0.2 * rng.rand(h, w, 3)) * 255, 0, 255).astype(np.uint8)
+    for i, (name, (h, w)) in enumerate((("a.png", (56, 56)), ("b.png", (48, 64)))):
+        # smooth + grain: NIQE wants image-like statistics and several 96 x 96 blocks of the x4 output
+        g = torch.Generator().manual_seed(50 + i)
+        x = F.interpolate(torch.rand(1, 3, h // 8, w // 8, generator=g), size=(h, w), mode="bicubic").clamp(0, 1)
+        x = (0.85 * x + 0.15 * torch.rand(1, 3, h, w, generator=g)).clamp(0, 1)
+        lrs[name] = (x[0].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
         Image.fromarray(lrs[name]).save(tmp_path / "lr" / name)
     here = os.path.dirname(os.path.abspath(__file__))
     for k, v in dict(lr_dir=str(tmp_path / "lr"), sr_dir=str(tmp_path / "sr"), model_path=str(tmp_path / "g.pth.tar"),
@@ -188,6 +190,7 @@ def test_directory_test_entry_point_default_precision(tmp_path, monkeypatch):
         d = np.abs(got - ref)
         assert got.shape == ref.shape and d.max() <= 1 and (d > 0).mean() < 1e-3, (name, d.max(), (d > 0).mean())
         ref_scores.append(niqe(yo.cuda()).item())
+    assert score == score and 0 < score <= 100, score
     assert abs(score - sum(ref_scores) / len(ref_scores)) < 1e-3 * max(1.0, abs(score)), (score, ref_scores)
 
 

@@ -332,3 +332,54 @@ def test_ema_bit_exact(U):
         L.check(L.lib().resr_ema_update(L.ptr(sd), L.ptr(pd), sd.numel(), 0.999, L.stream_ptr()))
         ref = (1.0 - 0.999) * p + 0.999 * ref     # reference model.py:47
     assert torch.equal(sd.cpu(), ref)
+
+
+# ---- fused scalar losses (csrc/loss.hip, losses.py): value + unit gradient in one launch -----------------------------------
+@pytest.mark.parametrize("shape", [(16, 1, 64, 64), (3, 1, 17, 23), (1, 3, 5, 7)])
+@pytest.mark.parametrize("label,weight", [(1.0, 0.1), (0.0, 1.0)])
+def test_fused_bce_with_logits_const_vs_torch(shape, label, weight):
+    """nn.BCEWithLogitsLoss against torch.full(..., label) (train_realesrgan.py:460-461,478,500,509): value, gradient (through a
+    loss scale like GradScaler's), determinism, and the generic path for a non-stock criterion."""
+    from real_esrgan_pytorch_amd import losses
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randn(*shape, generator=gen) * 4).cuda()
+    x.view(-1)[:3] = torch.tensor([60.0, -60.0, 0.0]).cuda()              # saturated logits: no overflow in sigmoid / log1p
+    crit = torch.nn.BCEWithLogitsLoss()
+    xr = x.clone().requires_grad_(True)
+    ref = weight * crit(xr, torch.full_like(xr, label))
+    (ref * 512.0).backward()
+    xf = x.clone().requires_grad_(True)
+    got = losses.bce_with_logits_const(crit, xf, label, weight)
+    (got * 512.0).backward()
+    assert got.shape == () and abs(got.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    assert (xf.grad - xr.grad).abs().max().item() <= 1e-6 * xr.grad.abs().max().item() + 1e-12
+    again = losses.bce_with_logits_const(crit, x.clone().requires_grad_(True), label, weight)
+    assert again.item() == got.item()                                        # fixed-order partial sums: bit-reproducible
+    with torch.no_grad():
+        assert abs(losses.bce_with_logits_const(crit, x, label, weight).item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    summed = losses.bce_with_logits_const(torch.nn.BCEWithLogitsLoss(reduction="sum"), x, label, weight)   # not the stock form: called as is
+    assert abs(summed.item() - weight * torch.nn.functional.binary_cross_entropy_with_logits(x, torch.full_like(x, label), reduction="sum").item()) < 1e-2
+
+
+@pytest.mark.parametrize("shape", [(16, 3, 256, 256), (2, 3, 33, 17)])
+def test_fused_l1_mean_vs_torch(shape):
+    from real_esrgan_pytorch_amd import losses
+    gen = torch.Generator().manual_seed(4)
+    a, b = torch.rand(*shape, generator=gen).cuda(), torch.rand(*shape, generator=gen).cuda()
+    b.view(-1)[:5] = a.view(-1)[:5]                                           # ties: gradient 0 like ATen's sgn
+    crit = torch.nn.L1Loss()
+    ar = a.clone().requires_grad_(True)
+    ref = 0.7 * crit(ar, b)
+    (ref * 1024.0).backward()
+    af = a.clone().requires_grad_(True)
+    got = losses.l1_loss(crit, af, b, 0.7)
+    (got * 1024.0).backward()
+    assert abs(got.item() - ref.item()) <= 2e-6 * abs(ref.item())
+    assert torch.equal(af.grad, ar.grad) or (af.grad - ar.grad).abs().max().item() <= 1e-6 * ar.grad.abs().max().item()
+    bf = b.clone().requires_grad_(True)                                       # gradient wrt the second operand as well
+    losses.l1_loss(crit, a, bf).backward()
+    br = b.clone().requires_grad_(True)
+    crit(a, br).backward()
+    assert (bf.grad - br.grad).abs().max().item() <= 1e-6 * br.grad.abs().max().item()
+    sm = losses.l1_loss(torch.nn.SmoothL1Loss(), a, b, 0.5)                   # not nn.L1Loss: the criterion is simply called
+    assert abs(sm.item() - 0.5 * torch.nn.functional.smooth_l1_loss(a, b).item()) < 1e-6

@@ -18,8 +18,9 @@ torch.manual_seed(0)
 g = R.Generator(3, 3, 4).cuda().train()
 d = R.Discriminator().cuda().train()
 ema = R.EMA(g, 0.999); ema.register()
-go = torch.optim.Adam(g.parameters(), 1e-4, (0.9, 0.99), fused=True)
-do = torch.optim.Adam(d.parameters(), 1e-4, (0.9, 0.99), fused=True)
+ap_flat = not os.environ.get("RESR_PER_TENSOR_ADAM")
+go = torch.optim.Adam([g.flat_parameter()] if ap_flat else g.parameters(), 1e-4, (0.9, 0.99), fused=True)
+do = torch.optim.Adam([d.flat_parameter()] if ap_flat else d.parameters(), 1e-4, (0.9, 0.99), fused=True)
 cl = R.ContentLoss(["features.2", "features.7", "features.16", "features.25", "features.34"], [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]).cuda() if a.content else None
 deg = Degrader(batch=a.batch, hr_size=a.tile, upscale=4, crop=a.hr, seed=0)
 step = RealESRGANStep(g, d, ema, go, do, torch.amp.GradScaler("cuda"), deg, content_criterion=cl)
