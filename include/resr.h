@@ -152,6 +152,9 @@ typedef struct {
     int32_t splits;                            /* pixel splits (partial slabs)                    */
     float scale;
     int64_t x_lo_offset, g_lo_offset;          /* RESR_F16X2: hi -> lo element offsets of X and G */
+    /* elements between consecutive 32-channel chunks of X / G (0 = 32: interleaved NHWC; a chunk-planar tensor
+     * [C/32][N,H,W,32] has pixel stride 32 and chunk stride N*H*W*32 -- how the generator keeps its dense-block workspaces) */
+    int64_t x_chunk_stride, g_chunk_stride;
 } ResrWgradDesc;
 
 size_t resr_wgrad_partial_bytes(const ResrWgradDesc* d);

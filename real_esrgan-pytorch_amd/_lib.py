@@ -39,7 +39,7 @@ class WgradDesc(C.Structure):
                 ("cin", C.c_int32), ("cin0", C.c_int32), ("in0_stride", C.c_int32), ("in1_stride", C.c_int32),
                 ("cin_real", C.c_int32), ("cout", C.c_int32), ("cout_pad", C.c_int32), ("g_stride", C.c_int32),
                 ("dtype", C.c_int32), ("flags", C.c_int32), ("splits", C.c_int32), ("scale", C.c_float),
-                ("x_lo_offset", C.c_int64), ("g_lo_offset", C.c_int64)]
+                ("x_lo_offset", C.c_int64), ("g_lo_offset", C.c_int64), ("x_chunk_stride", C.c_int64), ("g_chunk_stride", C.c_int64)]
 
 
 class PackChunk(C.Structure):

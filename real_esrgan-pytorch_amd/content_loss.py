@@ -167,6 +167,20 @@ class ContentLoss(nn.Module):
         """One 3x3 convolution as launches of 64 output channels: x (first r32(k_real) channels) -> out (m_real channels)."""
         L, lib = _lib, _lib.lib()
         packed = self._packed[0]
+        # All 64-channel output groups of a 128..512-channel layer as ONE launch (ResrConvDesc.cout_groups: tile index = group x
+        # spatial tiles, per-group packed weights, biases and channel offsets).  One launch per group left the deep layers --
+        # 512 channels at 32^2 / 16^2 pixels: 128 / 32 tiles per launch -- on an eighth of the 256 CUs.
+        if (len(groups) > 1 and len(groups) <= 8 and self._dtype != L.RESR_F32 and m_real == 64 * len(groups)
+                and all(mt == 2 for _, mt in groups) and os.environ.get("RESR_VGG_PER_GROUP") != "1"):
+            d = L.ConvDesc(n, x.h, x.w, _r32(k_real), _r32(k_real), x.c, 0, 64, 64, out.c,
+                           0, 0, 0 if mask is None else mask.c, self._dtype, flags, 1.0, 1.0, 1.0, 1.0, 0.0)
+            d.in0_lo_offset, d.out_lo_offset = x.lo, out.lo
+            d.cout_groups = len(groups)
+            L.check(lib.resr_conv3x3(C.byref(d), x.ptr(), None, C.c_void_p(packed.data_ptr() + groups[0][0] * self._wes),
+                                     None if bias is None else L.ptr(bias), None, None,
+                                     None if mask is None else mask.ptr(), out.ptr(), None if aux is None else aux.ptr(), st),
+                    "resr_conv3x3")
+            return
         for gi, (off, mt) in enumerate(groups):
             g0 = gi * 64
             d = L.ConvDesc(n, x.h, x.w, _r32(k_real), _r32(k_real), x.c, 0, min(mt * 32, m_real - g0), mt * 32, out.c,

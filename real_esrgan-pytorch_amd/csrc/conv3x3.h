@@ -60,6 +60,7 @@ struct ChainJob {
     long out_lo, res0_lo, res1_lo;   // RESR_F16X2: element offsets hi -> lo tensor of out / res0 / res1
 };
 constexpr int kMaxChain = 6;
+constexpr int kMaxBiasGroups = 8;   // output-group launches WITH a bias keep <= 8 x 64 bias values in LDS (conv3x3_ws.h, GB_OFF)
 // Device-side state of the chained launches: memory the CALLER owns (part of its workspace, zero-filled once before the
 // first use; include/resr.h resr_conv3x3_chain_state_bytes) -- the library neither allocates nor keeps it.  Words:
 //   [0] epoch      flag value of "job j of the current launch done" = epoch + j + 1; the last workgroup of a launch to

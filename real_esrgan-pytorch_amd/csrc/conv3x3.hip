@@ -344,9 +344,10 @@ static int conv3x3_args(const ResrConvDesc* d, const void* in0, const void* in1,
     a.s2d_c = 0; a.tap_c = 0; a.ngroups = 1; a.w_group_b = 0;
     const int groups = d->cout_groups > 1 ? d->cout_groups : 1;
     if (groups > 1) {
-        if ((d->dtype != RESR_F16 && d->dtype != RESR_F16X2) || d->cout != 64 || d->cout_pad != 64 || bias || in1 ||
-            (d->flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_WRITE_SIGNBITS | RESR_CONV_MASK_BITS | RESR_CONV_CLAMP01)) || !(d->flags & RESR_CONV_NO_BIAS))
-            return fail(RESR_ERR_ARG, "conv3x3: cout_groups > 1 needs f16 / f16x2, cout = cout_pad = 64 per group, no bias, NHWC output, no sign-bit tensors");
+        const bool biased = bias && !(d->flags & RESR_CONV_NO_BIAS);
+        if ((d->dtype != RESR_F16 && d->dtype != RESR_F16X2) || d->cout != 64 || d->cout_pad != 64 || in1 || (biased && groups > kMaxBiasGroups) ||
+            (d->flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_WRITE_SIGNBITS | RESR_CONV_MASK_BITS | RESR_CONV_CLAMP01)))
+            return fail(RESR_ERR_ARG, "conv3x3: cout_groups > 1 needs f16 / f16x2, cout = cout_pad = 64 per group, NHWC output, no sign-bit tensors, and at most %d groups with a bias", kMaxBiasGroups);
         a.ngroups = groups;
         a.w_group_b = (size_t)(d->cin / 32) * 9 * 2 * 1024 * es * (d->dtype == RESR_F16X2 ? 3 : 1);
     }

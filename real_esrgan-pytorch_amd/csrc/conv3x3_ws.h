@@ -95,6 +95,10 @@ struct WsCfg {
     // supposed to show then also wait for its acknowledgement)
     static constexpr int CHAIN_OFF = LUT_OFF + LUT_BYTES, CHAIN_TRACE = kMaxChain * 128 + 64, CHAIN_BYTES = CHAIN_TRACE + 1024;
     static_assert(LDS_BYTES + LUT_BYTES + CHAIN_BYTES <= 160 * 1024, "LDS");
+    // output-group launches WITH a bias (cout 64 shape; VGG19's 128..512-channel layers): the biases of up to kMaxBiasGroups
+    // groups, 64 floats each, where the chained launches (cout 32 shape only) keep their state
+    static constexpr int GB_OFF = CHAIN_OFF, GB_BYTES = MT == 2 ? kMaxBiasGroups * 256 : 0;
+    static_assert(LDS_BYTES + LUT_BYTES + GB_BYTES <= 160 * 1024, "LDS");
 };
 
 __device__ __forceinline__ void conv_glds16(const char* gsrc, char* lds_wave_base) {
@@ -296,6 +300,14 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     if (wave == 0) {
         const bool f_bias = !(a.flags & RESR_CONV_NO_BIAS) && a.bias != nullptr;
         bias_lds[lane] = (f_bias && lane < a.cout) ? a.bias[lane] * (X2 ? kLoScale : 1.f) : 0.f;
+    }
+    if constexpr (MT == 2 && CH == 0) {   // output groups with a bias: every group's 64 values (the tile loop points bias_cur at its group's)
+        // (a grouped launch WITHOUT a bias -- the discriminator's layers, up to 16 groups -- keeps the zeros of bias_lds)
+        if (a.ngroups > 1 && !(a.flags & RESR_CONV_NO_BIAS) && a.bias != nullptr) {
+            float* gb = reinterpret_cast<float*>(smem + C::GB_OFF);
+            for (int i = tid; i < a.ngroups * 64 && i < kMaxBiasGroups * 64; i += C::NTHR)
+                gb[i] = a.bias[i] * (X2 ? kLoScale : 1.f);
+        }
     }
     if constexpr (CH) {   // the biases of all jobs (kMaxChain x 32 floats) and the consumers' arrival counter
         float* cb = reinterpret_cast<float*>(smem + C::CHAIN_OFF);
@@ -752,6 +764,14 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             }
     };
     if constexpr (CH) bias_cur = reinterpret_cast<const float*>(smem + C::CHAIN_OFF) + (CH == 3 ? pin_job * 32 : 0);
+    // output groups: the accumulators of a tile start from ITS group's bias
+    auto group_bias = [&](int tile) {
+        if constexpr (MT == 2 && CH == 0) {
+            if (a.ngroups > 1 && !(a.flags & RESR_CONV_NO_BIAS) && a.bias != nullptr && tile < ntiles)   // (host-checked: <= kMaxBiasGroups groups)
+                bias_cur = reinterpret_cast<const float*>(smem + C::GB_OFF) + (tile / ntiles_sp) * 64;
+        }
+    };
+    group_bias(first);
     init_acc();
 
     // Weight fragments: ring of (k-step, dx, dy) units -- one tap's MT fragments each -- in consumption order, fetched
@@ -1169,6 +1189,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         bias_cur = reinterpret_cast<const float*>(smem + C::CHAIN_OFF) + (job + 1) * 32;
                 }
             }
+            group_bias(tile + tile_step);
             init_acc();
             // A workgroup with ONE tile per job (the 64^2 training crops) publishes right here, behind the acknowledgement of the
             // stores it has just issued: its neighbours' producers poll for this plane during the very next stage, and a flag that
@@ -1394,6 +1415,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 }
             }
         }
+        group_bias(tile + tile_step);
         init_acc();
         if (wave == 0) stamp(1);  // tile done
     }
@@ -1426,7 +1448,9 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     ConvArgs args = a;
     args.tiles_x = (a.w_ + 31) / 32;
     args.tiles_y = (a.h + C::TH - 1) / C::TH;
-    const size_t lds = C::LDS_BYTES + (EPI == 33 ? C::LUT_BYTES : 0);  // halo buffers, bias, weight buffers (+ the mask-multiplier table)
+    // halo buffers, bias, weight buffers (+ the mask-multiplier table; + the biases of the output groups of a grouped launch)
+    const bool gbias = MT == 2 && a.ngroups > 1 && !(a.flags & RESR_CONV_NO_BIAS) && a.bias != nullptr;
+    const size_t lds = C::LDS_BYTES + ((EPI == 33 || gbias) ? C::LUT_BYTES : 0) + (gbias ? C::GB_BYTES : 0);
     // per device (the boundary is callable with any current device): workgroups the device holds at once and the
     // address of this translation unit's zero page there; idempotent, so a race between two first calls is benign
     static int resident_dev[kMaxDevices] = {0};
@@ -1436,12 +1460,14 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     int& resident = resident_dev[cur_dev];
     const char*& zero = zero_dev[cur_dev];
     if (!resident) {
+        // (the attribute is an upper bound set once per device: the largest request this instantiation can make)
+        const size_t lds_max = C::LDS_BYTES + C::LUT_BYTES + C::GB_BYTES;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2, SP>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         int per_cu = 0;
         hipDeviceProp_t prop;
         void* zp = nullptr;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2, SP>, C::NTHR, lds) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2, SP>, C::NTHR, lds_max) != hipSuccess ||
             hipGetDeviceProperties(&prop, cur_dev) != hipSuccess || per_cu <= 0 ||
             hipGetSymbolAddress(&zp, HIP_SYMBOL(g_conv_zero16)) != hipSuccess || !zp)
             return fail(RESR_ERR_LAUNCH, "conv3x3: occupancy / zero-page query failed");

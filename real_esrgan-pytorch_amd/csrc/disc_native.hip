@@ -386,7 +386,9 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
                 jobs += chunks * (c.cout_pad / 32);
             }
             if (!nc) continue;
-            const int splits = wsplits(dt, jobs, N, h, w);
+            // slabs are per TAP-product (three per algorithmic product in exact16's default form): split by that count, which is
+            // also what carve() sized the slab buffer for
+            const int splits = wsplits(dt, jobs * parts, N, h, w);
             if (wgrad_batch_partial_bytes(cs, nc, splits, dt) > b.partial_bytes) return fail(RESR_ERR_WORKSPACE, "discriminator: wgrad slabs");
             DRUN(wgrad_batch(cs, nc, N, h, w, dt, 0, splits, b.partial, st));
         }

@@ -942,7 +942,7 @@ int wgrad_dispatch(const ResrWgradDesc* d, const void* x0, const void* x1, const
     WgradConv c;
     c.x0 = x0; c.cin = d->cin; c.in0_stride = d->in0_stride; c.cin_real = d->cin_real;
     c.g = g; c.cout = d->cout; c.cout_pad = d->cout_pad; c.g_stride = d->g_stride;
-    c.x_chunk_stride = c.g_chunk_stride = 0;
+    c.x_chunk_stride = (long)d->x_chunk_stride; c.g_chunk_stride = (long)d->g_chunk_stride;
     c.x_lo_off = (long)d->x_lo_offset; c.g_lo_off = (long)d->g_lo_offset; c.x_s2d_c = 0;
     c.dw = dw; c.db = db; c.scale = d->scale;
     return wgrad_batch(&c, 1, d->n, d->h, d->w, d->dtype, d->flags, d->splits, partial, stream);

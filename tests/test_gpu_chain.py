@@ -344,3 +344,39 @@ else:
 """ % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_chained_launches_inside_a_captured_graph():
+    """Batch 8 (n % 8 == 0: the dense blocks run as chained launches) captured into a hipGraph and replayed: under capture the
+    launcher neither waits for, records, nor takes ownership of its per-device event (none of that would mean anything at replay
+    time, csrc/conv3x3_ws.hip); replays are bit-equal to the eager pass, an EAGER chained pass from another stream afterwards
+    still orders itself against the last eager owner, and no poll ever times out."""
+    import real_esrgan_pytorch_amd as R
+    lib = R._lib.lib()
+    torch.manual_seed(0)
+    g = R.Generator(3, 3, 4, precision="fast", n_blocks=2).cuda().eval()
+    x = torch.rand(8, 3, 64, 64, device="cuda")
+    with torch.no_grad():
+        y_eager = g(x).clone()
+        for _ in range(2):
+            g(x)
+        torch.cuda.synchronize()
+        static_x = x.clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_y = g(static_x)
+        for i in range(3):
+            static_x.copy_(x if i != 1 else x.flip(0))
+            graph.replay()
+            torch.cuda.synchronize()
+            want = y_eager if i != 1 else y_eager.flip(0)
+            assert torch.equal(static_y, want), i
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            y_side = g(x)                                     # eager, another stream: waits for the last EAGER owner's event
+        side.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(y_side, y_eager) and torch.equal(static_y, y_eager)
+    assert int(lib.resr_debug_chain_errors()) == 0

@@ -320,3 +320,27 @@ def test_flat_parameter_mode_matches_per_tensor_mode():
         return outs
     for a, b in zip(run(False), run(True)):
         assert torch.equal(a, b)
+
+
+def test_exact16_weight_gradients_at_a_size_with_many_pixel_tiles():
+    """exact16's default three tap-products per weight-gradient product at a size where the pixel splits are not capped by the
+    tile count (>= 128 tiles of 8 x 32 pixels per level): the slab buffer of the workspace must hold jobs x 3 x splits slabs
+    (round 3 sized the splits by the algorithmic product count: `discriminator: wgrad slabs` at 16 x 256^2).  Gradients against
+    strict's (a flipped LeakyReLU mask element between two correct evaluations costs ~1e-2 in a tensor, see above)."""
+    import real_esrgan_pytorch_amd as R
+    from oracle import model_ref as M
+    sd = M.init_discriminator_state(9)
+    gen = torch.Generator().manual_seed(10)
+    x = torch.rand(4, 3, 128, 128, generator=gen).cuda()
+    gw = torch.randn(4, 1, 128, 128, generator=gen).cuda()
+    grads = {}
+    for precision, scale in (("strict", 1.0), ("exact16", 256.0)):
+        d = R.Discriminator(precision=precision)
+        d.load_state_dict(sd)
+        d = d.cuda().train()
+        (d(x) * gw).sum().mul(scale).backward()
+        torch.cuda.synchronize()
+        grads[precision] = {n: p.grad.clone() / scale for n, p in d.named_parameters()}
+    for n, ref in grads["strict"].items():
+        rel = ((grads["exact16"][n] - ref).norm() / ref.norm().clamp_min(1e-12)).item()
+        assert rel < 2e-2, (n, rel)

@@ -383,3 +383,47 @@ def test_fused_l1_mean_vs_torch(shape):
     assert (bf.grad - br.grad).abs().max().item() <= 1e-6 * br.grad.abs().max().item()
     sm = losses.l1_loss(torch.nn.SmoothL1Loss(), a, b, 0.5)                   # not nn.L1Loss: the criterion is simply called
     assert abs(sm.item() - 0.5 * torch.nn.functional.smooth_l1_loss(a, b).item()) < 1e-6
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 128, 2, 24, 40), (128, 512, 4, 16, 16), (256, 256, 1, 33, 20)])
+def test_output_groups_with_bias_equal_one_launch_per_group(cin, cout, n, h, w):
+    """ResrConvDesc.cout_groups with a BIAS (VGG19's 128..512-channel layers, model.py:296-298, as one launch instead of one per
+    64-channel group): bit-equal to the per-group launches, and right against torch."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from tests import gpu_util as U
+    L = U.L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = U.quant(torch.randn(n, cin, h, w, generator=g), L.RESR_F16)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    xd = U.to_nhwc(x, L.RESR_F16)
+    groups = cout // 64
+    packed = torch.cat([U.pack_conv(wt[q * 64:(q + 1) * 64], L.RESR_F16)[:(cin // 32) * 9 * 2 * 1024 * 2] for q in range(groups)]
+                       + [torch.zeros(16384, dtype=torch.uint8, device="cuda")])
+    bd = bias.cuda()
+    per_group = (cin // 32) * 9 * 2 * 1024 * 2          # bytes of one group's packed weights
+    outs = []
+    for grouped in (True, False):
+        y = torch.zeros(n, h, w, cout, dtype=torch.float16, device="cuda")
+        if grouped:
+            d = L.ConvDesc(n, h, w, cin, cin, cin, 0, 64, 64, cout, 0, 0, 0, L.RESR_F16, L.CONV_LRELU, 1.0, 1.0, 1.0, 1.0, 0.0)
+            d.cout_groups = groups
+            L.check(lib.resr_conv3x3(C.byref(d), L.ptr(xd), None, L.ptr(packed), L.ptr(bd), None, None, None, L.ptr(y), None, L.stream_ptr()),
+                    "resr_conv3x3")
+        else:
+            for q in range(groups):
+                d = L.ConvDesc(n, h, w, cin, cin, cin, 0, 64, 64, cout, 0, 0, 0, L.RESR_F16, L.CONV_LRELU, 1.0, 1.0, 1.0, 1.0, 0.0)
+                L.check(lib.resr_conv3x3(C.byref(d), L.ptr(xd), None, C.c_void_p(packed.data_ptr() + q * per_group), U.sptr(bd, q * 64), None, None,
+                                         None, U.sptr(y, q * 64), None, L.stream_ptr()), "resr_conv3x3")
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    ref = F.relu(F.conv2d(x, U.quant(wt, L.RESR_F16), bias, padding=1))
+    got = U.from_nhwc(outs[0], cout)
+    assert (got - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+    # more groups with a bias than the kernel keeps in LDS: refused loudly, not computed wrongly
+    d = L.ConvDesc(n, h, w, cin, cin, cin, 0, 64, 64, 64 * 9, 0, 0, 0, L.RESR_F16, L.CONV_LRELU, 1.0, 1.0, 1.0, 1.0, 0.0)
+    d.cout_groups = 9
+    assert lib.resr_conv3x3(C.byref(d), L.ptr(xd), None, L.ptr(packed), L.ptr(bd), None, None, None, L.ptr(outs[0]), None, L.stream_ptr()) != 0
