@@ -26,6 +26,13 @@ int resr_debug_occupy(int32_t workgroups, int32_t lds_bytes, int32_t micros, voi
  * grouped into 2x2 jobs of the quad kernel.  out[q*4 + p] = index of the product computed by slot p of job q (products are
  * numbered conv-major, then G tile, then X chunk), -1 = slot unused.  Returns the number of jobs (<= max_jobs) or < 0. */
 int resr_debug_wgrad_plan(const int32_t* cin, const int32_t* cout_pad, int32_t nconv, int32_t* out, int32_t max_jobs);
+/* Measurement aid (tools/energy.py): the weight-gradient launch pair the generator's backward pass issues per RRDB -- the five
+ * convolutions of `nblocks` (1..3) dense blocks, 26 products each, as ONE batched launch -- on caller-made f16 operands.
+ * x_ws[b]: chunk-planar [6][n,h,w,32] (conv_k reads the first 2 + (k - 1) planes); g_ws[b]: chunk-planar [6][n,h,w,32] (planes
+ * 0,1 = the closing convolution's 64 gradient channels, plane 1 + k = conv_k's 32); dw: nblocks * 26624 * 9 floats;
+ * partial: `partial_bytes` of slab scratch (26 * nblocks * splits * (9 * 1024 + 32) floats). */
+int resr_debug_wgrad_dense_blocks(int32_t nblocks, const void* const* x_ws, const void* const* g_ws, int32_t n, int32_t h, int32_t w,
+                                  int32_t splits, float* partial, size_t partial_bytes, float* dw, void* stream);
 /* test probe: lane/element map of ds_read_b64_tr_b16 (256 floats out) */
 int resr_debug_tr_probe(float* out256, void* stream);
 

@@ -100,6 +100,7 @@ _PROTOS = {
     "resr_debug_conv_trace": (C.c_int, [_P]),
     "resr_debug_chain_errors": (C.c_int64, []),
     "resr_debug_wgrad_plan": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
+    "resr_debug_wgrad_dense_blocks": (C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t, _P, _P]),
     "resr_debug_sustained": (C.c_int, [C.c_int32, C.c_double, _P, C.c_size_t, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     "resr_profile_begin": (C.c_int, []),
     "resr_profile_end": (C.c_int64, [_P, C.c_int64]),

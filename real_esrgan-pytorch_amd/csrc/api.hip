@@ -79,6 +79,7 @@ size_t conv3x3_chain_state_bytes(int, int, int);
 int wgrad_dispatch(const ResrWgradDesc*, const void*, const void*, const void*, float*, float*, float*, hipStream_t);
 size_t wgrad_partial_bytes(const ResrWgradDesc*);
 int wgrad_debug_plan(const int*, const int*, int, int*, int);
+int wgrad_debug_dense_blocks(int, const void* const*, const void* const*, int, int, int, int, float*, size_t, float*, hipStream_t);
 int pack_dispatch(const ResrPackChunk*, int, const float*, void*, int, hipStream_t);
 int ema_dispatch(float*, const float*, long, double, hipStream_t);
 int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long);
@@ -456,6 +457,12 @@ int64_t resr_profile_end(ResrProfEntry* out, int64_t capacity) {
 }
 
 // host logic probe (no GPU): 2x2 grouping of a weight-gradient launch's products
+int resr_debug_wgrad_dense_blocks(int32_t nblocks, const void* const* x_ws, const void* const* g_ws, int32_t n, int32_t h, int32_t w, int32_t splits,
+                                  float* partial, size_t partial_bytes, float* dw, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return wgrad_debug_dense_blocks(nblocks, x_ws, g_ws, n, h, w, splits, partial, partial_bytes, dw, (hipStream_t)stream);
+}
+
 int resr_debug_wgrad_plan(const int32_t* cin, const int32_t* cout_pad, int32_t nconv, int32_t* out, int32_t max_jobs) {
     return wgrad_debug_plan(cin, cout_pad, nconv, out, max_jobs);
 }

@@ -930,6 +930,32 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
     return RESR_OK;
 }
 
+// resr_debug_wgrad_dense_blocks (include/resr_debug.h): the batched launch pair the generator's backward pass issues per RRDB --
+// the five convolutions of `nblocks` dense blocks (26 products each) in ONE wgrad_batch call -- on caller-made operands, so that
+// tools/energy.py can hold exactly that launch in a loop.  x[b]: chunk-planar workspace [6][n,h,w,32] f16 (conv_k reads the
+// prefix of 2 + (k - 1) planes), g[b]: chunk-planar gradients [6][n,h,w,32] -- planes 0,1 the closing convolution's 64
+// channels, plane 1 + k conv_k's 32; dw: 26624 * 9 floats per block (every convolution's OIHW gradient back to back).
+int wgrad_debug_dense_blocks(int nblocks, const void* const* x, const void* const* g, int n, int h, int w, int splits, float* partial,
+                             size_t partial_bytes, float* dw, hipStream_t stream) {
+    if (nblocks < 1 || nblocks > 3 || !x || !g || !partial || !dw) return fail(RESR_ERR_ARG, "wgrad_dense_blocks: bad argument");
+    WgradConv wc[15];
+    const long plane = (long)n * h * w * 32;
+    int nc = 0;
+    float* out = dw;
+    for (int b = 0; b < nblocks; ++b)
+        for (int k = 1; k <= 5; ++k) {
+            WgradConv& c = wc[nc++];
+            const int cin = 64 + 32 * (k - 1), cout = k < 5 ? 32 : 64;
+            c.x0 = x[b]; c.cin = cin; c.in0_stride = 32; c.cin_real = cin;
+            c.g = (const char*)g[b] + (k < 5 ? (size_t)(1 + k) * plane * 2 : 0); c.cout = cout; c.cout_pad = cout; c.g_stride = 32;
+            c.x_chunk_stride = plane; c.g_chunk_stride = plane; c.x_lo_off = c.g_lo_off = 0; c.x_s2d_c = 0;
+            c.dw = out; c.db = nullptr; c.scale = 1.f;
+            out += (size_t)cout * cin * 9;
+        }
+    if (wgrad_batch_partial_bytes(wc, nc, splits, RESR_F16) > partial_bytes) return fail(RESR_ERR_WORKSPACE, "wgrad_dense_blocks: slab buffer too small");
+    return wgrad_batch(wc, nc, n, h, w, RESR_F16, 0, splits, partial, stream);
+}
+
 // single-conv C-ABI entry (include/resr.h resr_conv3x3_wgrad)
 size_t wgrad_partial_bytes(const ResrWgradDesc* d) {
     return (size_t)(d->cin / 32) * (d->cout_pad / 32) * (d->dtype == RESR_F16X2 ? wgrad_x2_products() : 1) * d->splits * kSlab * sizeof(float);

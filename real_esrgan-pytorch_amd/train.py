@@ -352,3 +352,59 @@ class RealESRGANStep:
             out["d_hr_probability"] = torch.sigmoid(hr_out.detach().float().mean())
             out["d_sr_probability"] = torch.sigmoid(sr_out.detach().float().mean())
         return out
+
+
+class GraphedStep:
+    """The fixed-shape part of a train step -- everything AFTER the degradation: generator / discriminator / VGG19 forward and
+    backward, the fused losses, GradScaler bookkeeping, both Adam steps, EMA -- captured once per geometry into ONE hipGraph and
+    replayed: ~600 dependent launches per RealESRGAN step leave the host in one call.  The degradation keeps running eagerly on its
+    side stream (its plan changes per batch); its LR / HR outputs are copied into the graph's static inputs.
+
+    Requirements (checked): optimisers built with `capturable=True` (the step counter lives on the device; `fused=True` as
+    usual), no data-parallel exchange inside the step (`dp` inactive), the same shapes on every call.  The first `warmup` calls
+    run eagerly (one-time allocations, kernel attributes, optimizer state); a change of shape or of any optimiser's learning rate
+    (a scheduler stepped) re-captures.  Returns what the wrapped step returns -- tensors that the NEXT replay overwrites.
+    Chained dense-block launches are captured like any other (csrc/conv3x3_ws.hip): do not replay while ANOTHER stream runs
+    chained launches on the same device (include/resr.h)."""
+
+    def __init__(self, step, warmup: int = 3) -> None:
+        self.step, self.warmup = step, max(1, int(warmup))
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._key = None
+        self._calls = 0
+        self._hr = self._lr = self._out = None
+        for opt in self._optimizers():
+            if not opt.defaults.get("capturable", False):
+                raise ValueError("GraphedStep: build the optimisers with capturable=True (their step counters must live on the device)")
+        dp = getattr(step, "dp", None)
+        if dp is not None and getattr(dp, "active", False):
+            raise ValueError("GraphedStep: a data-parallel exchange inside the step is not captured; run the step eagerly")
+
+    def _optimizers(self):
+        return [o for o in (getattr(self.step, n, None) for n in ("optimizer", "g_opt", "d_opt")) if o is not None]
+
+    def _lrs(self):
+        return tuple(float(g["lr"]) for o in self._optimizers() for g in o.param_groups)
+
+    def __call__(self, hr: torch.Tensor, lr: Optional[torch.Tensor] = None):
+        if lr is None:
+            lr, hr = self.step.degrade(hr)
+        key = (tuple(hr.shape), tuple(lr.shape), str(hr.device), self._lrs())
+        if self._graph is None or key != self._key:
+            if key != self._key:
+                self._graph, self._calls, self._key = None, 0, key
+            if self._calls < self.warmup:
+                self._calls += 1
+                return self.step(hr, lr)
+            self._hr, self._lr = hr.clone(), lr.clone()
+            torch.cuda.synchronize(hr.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._out = self.step(self._hr, self._lr)
+            self._graph = g
+            g.replay()                  # the capture itself executes nothing: this call's step is the first replay
+            return self._out
+        self._hr.copy_(hr)
+        self._lr.copy_(lr)
+        self._graph.replay()
+        return self._out

@@ -152,3 +152,50 @@ def test_gan_train_checkpoints_resume_and_directory_test(tmp_path, monkeypatch):
     from PIL import Image
     assert Image.open(tmp_path / "sr" / "0.png").size == (224, 224)                     # 56x56 LR, x4
 
+
+
+@pytest.mark.parametrize("gan", [False, True])
+def test_graphed_step_equals_eager_step(gan):
+    """train.GraphedStep: everything after the degradation replayed from one hipGraph (chained dense-block launches, fused losses,
+    GradScaler bookkeeping, capturable fused Adam, EMA) -- losses of every step and the final weights bit-equal to the eager step."""
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd.train import GraphedStep, RealESRGANStep, RealESRNetStep
+
+    def run(graph):
+        torch.manual_seed(0)
+        g = R.Generator(3, 3, 4, n_blocks=2).cuda().train()
+        with torch.no_grad():
+            g.conv4.bias.add_(0.5)
+        ema = R.EMA(g, 0.999)
+        ema.register()
+        go = torch.optim.Adam([g.flat_parameter()], 1e-4, (0.9, 0.99), fused=True, capturable=True)
+        gen = torch.Generator(device="cuda").manual_seed(1)
+        hr = torch.rand(8, 3, 128, 128, device="cuda", generator=gen)      # batch 8: chained launches inside the graph
+        lr = torch.nn.functional.interpolate(hr, scale_factor=0.25, mode="area")
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        d = None
+        if gan:
+            d = R.Discriminator().cuda().train()
+            do = torch.optim.Adam([d.flat_parameter()], 1e-4, (0.9, 0.99), fused=True, capturable=True)
+            step = RealESRGANStep(g, d, ema, go, do, scaler, None)
+        else:
+            step = RealESRNetStep(g, ema, go, scaler, None)
+        if graph:
+            step = GraphedStep(step, warmup=2)
+        outs = []
+        for _ in range(6):
+            o = step(hr, lr)
+            outs.append(torch.stack([o[k] for k in sorted(o)]).clone() if isinstance(o, dict) else o.clone())
+        torch.cuda.synchronize()
+        return outs, [g.flat_parameters().detach().clone()] + ([d.flat_parameters().detach().clone()] if gan else []), ema._flat_shadow.clone()
+    oe, we, se = run(False)
+    og, wg, sg = run(True)
+    for a, b in zip(oe, og):
+        assert torch.equal(a, b)
+    for a, b in zip(we, wg):
+        assert torch.equal(a, b)
+    assert torch.equal(se, sg)
+    assert int(R._lib.lib().resr_debug_chain_errors()) == 0
+    with pytest.raises(ValueError):          # the step counter must live on the device
+        g = R.Generator(3, 3, 4, n_blocks=1).cuda()
+        GraphedStep(RealESRNetStep(g, None, torch.optim.Adam([g.flat_parameter()], 1e-4, fused=True), None, None))

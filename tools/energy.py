@@ -3,7 +3,7 @@
 
     chain32   the chained cout-32 launch of a dense block, training form (conv1..4, LeakyReLU + sign words), B x res^2
     cout64    the closing convolution 192 -> 64 (conv3x3_ws_kernel<f16,2,4,4>)
-    wgrad     wgrad_quad_kernel + its slab reduction, 48 products in one launch pair (the step batches 78 per RRDB)
+    wgrad     wgrad_quad_kernel + its slab reduction: the batched launch pair of one RRDB (three dense blocks, 78 products)
 
 The step sits on the board's power cap: what limits it is joules, so the kernel to work on is the one with the
 worst pJ/FLOP, not the one with the most milliseconds.  Columns: us / launch, algorithmic TFLOP/s and TB/s, average W and MHz over
@@ -84,22 +84,25 @@ def make_cout64():
 
 
 def make_wgrad():
-    # The step launches the weight gradients of an RRDB as ONE batch (78 products = 20 quad jobs x ~12 pixel splits, 340 pixel
-    # tiles per workgroup, 12 x 78 slabs to reduce).  The public entry takes one convolution: 768 -> 64 channels is 48 products =
-    # 12 quad jobs x 21 splits = 252 workgroups, 195 tiles each, 21 x 48 slabs -- the same regime (a 192 -> 64 launch on its own
-    # is 3 quad jobs x 84 splits: 49 tiles per workgroup and 84 x 12 slabs, i.e. mostly fill, drain and reduction).
-    cin, cout = 768, 64
-    # chunk-planar operands, as the generator keeps them ([C/32][N,H,W,32]: 64-byte pieces of x-neighbours are contiguous)
-    x = (torch.rand(cin // 32, n, h, w, 32, device="cuda", generator=gen) - 0.5).half()
-    g = (torch.rand(cout // 32, n, h, w, 32, device="cuda", generator=gen) - 0.5).half()
-    d = L.WgradDesc(n, h, w, cin, cin, 32, 0, cin, cout, cout, 32, L.RESR_F16, 0, 21, 1.0)
-    d.x_chunk_stride = d.g_chunk_stride = px * 32
-    partial = torch.empty(lib.resr_wgrad_partial_bytes(C.byref(d)) // 4, device="cuda")
-    dw, db = torch.empty(cout, cin, 3, 3, device="cuda"), torch.empty(cout, device="cuda")
+    # Exactly the launch pair the step issues per RRDB: the five convolutions of three dense blocks as ONE batch (78 products = 20
+    # quad jobs x 24 pixel splits by the generator's own rule, generator.hip splits_for; the jobs of a split share an XCD's L2),
+    # on chunk-planar operands ([6][N,H,W,32] per block, as the generator keeps them) -- resr_debug_wgrad_dense_blocks.
+    nb = 3
+    xs = [(torch.rand(6, n, h, w, 32, device="cuda", generator=gen) - 0.5).half() for _ in range(nb)]
+    gs = [(torch.rand(6, n, h, w, 32, device="cuda", generator=gen) - 0.5).half() for _ in range(nb)]
+    quads = (26 * nb + 3) // 4
+    splits = 512 // quads
+    if splits >= 16:
+        splits &= ~7
+    splits = max(1, min(splits, 256, (n * ((h + 7) // 8) * ((w + 31) // 32)) // 2))
+    partial = torch.empty(26 * nb * splits * (9 * 1024 + 32), device="cuda")
+    dw = torch.empty(nb * 26624 * 9, device="cuda")
+    xp = (C.c_void_p * nb)(*[t.data_ptr() for t in xs])
+    gp = (C.c_void_p * nb)(*[t.data_ptr() for t in gs])
 
     def launch():
-        L.check(lib.resr_conv3x3_wgrad(C.byref(d), L.ptr(x), None, L.ptr(g), L.ptr(partial), L.ptr(dw), L.ptr(db), L.stream_ptr()), "wgrad")
-    return launch, 2.0 * 9 * cin * cout * px, (cin + cout) * 2.0 * px, (x, g, partial, dw, db)
+        L.check(lib.resr_debug_wgrad_dense_blocks(nb, xp, gp, n, h, w, splits, L.ptr(partial), partial.numel() * 4, L.ptr(dw), L.stream_ptr()), "wgrad")
+    return launch, 2.0 * 9 * 26624 * nb * px, nb * 12 * 64.0 * px, (xs, gs, partial, dw)
 
 
 def sample_idle(seconds=1.0):
@@ -149,7 +152,7 @@ def run(name, make):
 IDLE = sample_idle()
 rows = []
 for name, make in (("chain32 (conv1..4 of a dense block, training form)", make_chain), ("cout64 (192 -> 64)", make_cout64),
-                   ("wgrad_quad + reduce (768 -> 64: 48 products)", make_wgrad)):
+                   ("wgrad_quad + reduce (one RRDB: 78 products)", make_wgrad)):
     if a.only and a.only not in name:
         continue
     rows.append(run(name, make))

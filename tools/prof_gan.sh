@@ -10,6 +10,6 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/tools/bench_gan.py --content --steps 10 > $OUT/plain.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $R/tools/bench_gan.py --content --steps 10 > $OUT/traced.json 2> $OUT/trace.err
 DB=$(find $OUT/trace -name "*.db" | head -1)
-if [ -n "$DB" ]; then python3 $R/tools/rocpd_steady.py $DB 4 60 > $OUT/kernel_stats.txt; fi
+if [ -n "$DB" ]; then python3 $R/tools/rocpd_steady.py $DB 4 60 > $OUT/kernel_stats.txt; python3 $R/tools/rocpd_steady.py $DB --list "*" > $OUT/last_step_launches.txt; fi
 rm -rf $OUT/trace
 tail -1 $OUT/plain.json | cut -c1-200; tail -1 $OUT/traced.json | cut -c1-200

@@ -76,5 +76,24 @@ def main(path, steps=4, top=45, marker="ema_kernel"):
         print(f"  {k:70s} n={n / steps:7.1f} total {t / 1e6 / steps:8.3f} ms  avg {t / n / 1e3:7.2f} us")
 
 
+def list_last_step(path, substr, marker="ema_kernel"):
+    """Every launch of the LAST step whose name contains `substr`, in launch order: start offset in the step, duration."""
+    db = sqlite3.connect(path)
+    tables = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
+    tab = "kernels" if "kernels" in tables else [t for t in tables if "kernel_dispatch" in t][0]
+    cols = [r[1] for r in db.execute(f"pragma table_info({tab})")]
+    name_col = "name" if "name" in cols else "kernel_name"
+    rows = db.execute(f"select {name_col}, start, end from {tab} order by start").fetchall()
+    marks = [e for n, s, e in rows if marker in n]
+    t0, t1 = marks[-2], marks[-1]
+    print(f"launches of the last step matching `{substr}` (offset ms, duration us, name):")
+    for n, s, e in rows:
+        if s >= t0 and e <= t1 and (substr in n or substr == "*"):
+            print(f"  {(s - t0) / 1e6:8.3f}  {(e - s) / 1e3:8.2f}  {short(n)[:90]}")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4, int(sys.argv[3]) if len(sys.argv) > 3 else 45)
+    if len(sys.argv) > 2 and sys.argv[2] == "--list":
+        list_last_step(sys.argv[1], sys.argv[3])
+    else:
+        main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4, int(sys.argv[3]) if len(sys.argv) > 3 else 45)
