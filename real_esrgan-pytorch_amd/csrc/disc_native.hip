@@ -28,6 +28,8 @@ int conv3x3_dispatch(const ResrConvDesc*, const void*, const void*, const void*,
 size_t wgrad_batch_partial_bytes(const WgradConv*, int, int, int);
 int wgrad_batch(const WgradConv*, int, int, int, int, int, int, int, float*, hipStream_t);
 int wgrad_tile_rows(int dtype);
+int wgrad_layer(const WgradConv*, int, int, int, int, int, int, float*, hipStream_t);   // (called as resr::wgrad_layer below: a lambda shares the name)
+size_t wgrad_layer_partial_bytes(int cin, int cout_pad, int splits);
 int wgrad_x2_products();
 int pack_dispatch(const ResrPackChunk*, int, const float*, void*, int, hipStream_t);
 int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long);
@@ -120,6 +122,19 @@ int wsplits(int dtype, int jobs, int n, int h, int w) {
     return (int)(s < 1 ? 1 : s);
 }
 
+// Layers with more products than a launch's job table holds (>= 96: the 256..512-channel layers) run their weight gradients as ONE
+// layer-mode launch pair (wgrad.hip, WgradLayer): one residency round of workgroups -- 256 / quad jobs pixel splits -- instead of
+// 2..8 launch pairs of 24 splits each (the 512-channel 4x4 layer at 16 x 32^2: eight pairs of 52 us for 69 GFLOP).
+constexpr int kLayerModeProducts = 96;
+int layer_splits(int products, int n, int h, int w) {
+    const long tiles = (long)((w + 31) / 32) * ((h + 7) / 8) * n;
+    const int nq = (products + 3) / 4;
+    long s = 256 / nq;
+    if (s >= 16) s &= ~7L;
+    if (s > tiles / 2) s = tiles / 2;
+    return (int)(s < 1 ? 1 : s);
+}
+
 // RESR_F16X2: every activation / gradient buffer below holds the hi tensor and, directly behind it, the lo tensor (hi -> lo
 // element offset = the tensor's element count); packed weights take three f16 blocks per chunk.
 void carve(const DPlan& p, char* base, DBufs& b) {
@@ -165,6 +180,14 @@ void carve(const DPlan& p, char* base, DBufs& b) {
         for (int q = 0; q < 4; ++q)
             for (int jobs = 1; jobs <= 96; ++jobs) {
                 const size_t v = (size_t)jobs * wsplits(p.d.dtype, jobs, p.d.n, res[q][0], res[q][1]) * (9 * 1024 + 32) * sizeof(float);
+                if (v > pb) pb = v;
+            }
+        if (p.d.dtype == RESR_F16)   // layer-mode launches (one per 256..512-channel layer)
+            for (int li = 0; li < kLayers; ++li) {
+                const int products = (p.cin_pad[li] / 32) * (p.cout_pad[li] / 32);
+                if (products < kLayerModeProducts) continue;
+                const int q = li == DOWN1 || li == UP2 ? 1 : li == DOWN2 || li == UP1 ? 2 : li == DOWN3 ? 3 : 0;
+                const size_t v = wgrad_layer_partial_bytes(p.cin_pad[li], p.cout_pad[li], layer_splits(products, p.d.n, res[q][0], res[q][1]));
                 if (v > pb) pb = v;
             }
         b.partial_bytes = pb;
@@ -366,6 +389,18 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
         // as many 32-channel output tiles per launch as the weight-gradient launcher takes: <= 96 tap-products (wgrad.h) and <= 80
         // algorithmic products (its reduction's argument block) -- a 128..256-channel layer is one or two launch pairs, not 2..4
         const int parts = x2 ? wgrad_x2_products() : 1;
+        const char* no_layer_mode = getenv("RESR_WGRAD_NO_LAYER_MODE");   // A/B knob, read per call: the table-mode launch pairs
+        if (dt == RESR_F16 && chunks * (r32(l.cout) / 32) >= kLayerModeProducts && !no_layer_mode) {
+            WgradConv c;
+            c.x0 = x; c.cin = cin_pad; c.in0_stride = xs; c.cin_real = cin_v;
+            c.g = g; c.cout = l.cout; c.cout_pad = r32(l.cout); c.g_stride = gs;
+            c.x_chunk_stride = c.g_chunk_stride = 0; c.x_lo_off = c.g_lo_off = 0;
+            c.x_s2d_c = l.k4 ? l.cin : 0;
+            c.dw = raw; c.db = (l.bias ? grad + p.b_off[li] : nullptr); c.scale = 1.f;
+            const int splits = layer_splits(chunks * (c.cout_pad / 32), N, h, w);
+            if (wgrad_layer_partial_bytes(cin_pad, c.cout_pad, splits) > b.partial_bytes) return fail(RESR_ERR_WORKSPACE, "discriminator: wgrad slabs (layer mode)");
+            DRUN(resr::wgrad_layer(&c, N, h, w, dt, 0, splits, b.partial, st));
+        } else {
         int tiles_per = kWgradMaxJobs / (chunks * parts);
         if (tiles_per > 80 / chunks) tiles_per = 80 / chunks;
         if (tiles_per < 1) tiles_per = 1;
@@ -391,6 +426,7 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
             const int splits = wsplits(dt, jobs * parts, N, h, w);
             if (wgrad_batch_partial_bytes(cs, nc, splits, dt) > b.partial_bytes) return fail(RESR_ERR_WORKSPACE, "discriminator: wgrad slabs");
             DRUN(wgrad_batch(cs, nc, N, h, w, dt, 0, splits, b.partial, st));
+        }
         }
         const float* cur = raw;
         if (l.k4) { DRUN(fold4x4_dispatch(raw, b.folded, l.cout, l.cin, st)); cur = b.folded; }

@@ -79,6 +79,7 @@ struct ReduceArgs {
     ReduceJob jobs[kMaxReduce];
     const float* partial;
     int splits;
+    int layer_nck;   // > 0: layer mode (WgradLayer) -- workgroup row b reduces product (b / nck, b % nck) of the convolution jobs[0] describes
 };
 
 static_assert(sizeof(ReduceArgs) <= 4096, "kernel arguments");
@@ -362,14 +363,30 @@ struct WgradQuad {
     unsigned xsub;          // byte xi: tap pattern of X chunk xi (WgradJob::xsub)
 };
 
+// "Layer mode": ONE convolution whose products form a regular (X chunk, G tile) grid -- nck x nct of them, more than the
+// argument block's job table holds (the discriminator's 256..512-channel layers: 128..512 products on 16 K..65 K pixels).  Quad
+// job j = (X chunk pair j % nxp, G tile pair j / nxp); everything a table entry would hold follows from the indices, so a
+// whole layer is one launch pair whatever its product count: product (ct, ck) has its slabs at (ct * nck + ck) * splits * kSlab.
+struct WgradLayer {
+    const char* x; const char* g;       // first X chunk / first G tile
+    long x_chunk_b, g_chunk_b;          // bytes between consecutive 32-channel chunks / tiles
+    unsigned xstride_b, gstride_b;
+    int nck, nct, nxp;                  // X chunks, G tiles, X chunk pairs ((nck + 1) / 2); nxp == 0: table mode
+    int x_s2d_c;                        // > 0: X is a space-to-depth image with this many channels per sub-position (sparse taps)
+    int want_bias;
+};
+
 struct WgradQuadArgs {
     WgradQuad jobs[kMaxQuads];
+    WgradLayer layer;
     float* partial;
     const char* zero;
     int n, h, w_, hs, ws;
     int up, splits, njobs;
     int tiles_x, tiles_y, ntiles;
 };
+
+static_assert(sizeof(WgradQuadArgs) <= 4096, "kernel arguments");
 
 constexpr int kQXW = 22;                          // waves of LDS-DMA lanes per X chunk (10 x 34 px x 4 pieces = 1360 slots)
 constexpr int kQXCH = kQXW * 1024;                // bytes per X chunk image in LDS
@@ -385,11 +402,36 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
     const int bx = blockIdx.x & 7, bk = blockIdx.x >> 3;   // all jobs of one pixel split on one XCD (see wgrad_kernel)
     const int split = bx + 8 * (bk / a.njobs);
     if (split >= a.splits) return;
-    const WgradQuad& job = a.jobs[bk % a.njobs];
     // scalar copies: a field read inside the MFMA loop would be an s_load + lgkmcnt(0) in the middle of the LDS reads
-    const char* const jx0 = job.x[0]; const char* const jx1 = job.x[1];
-    const char* const jg0 = job.g[0]; const char* const jg1 = job.g[1];
-    const unsigned sx0 = job.xstride_b[0], sx1 = job.xstride_b[1], sg0 = job.gstride_b[0], sg1 = job.gstride_b[1];
+    const char *jx0, *jx1, *jg0, *jg1;
+    unsigned sx0, sx1, sg0, sg1, j_xsub, j_bias_mask, j_slab0, j_slab1, j_slab2, j_slab3;
+    if (a.layer.nxp > 0) {   // layer mode: the quad's operands and slabs from its grid position
+        const WgradLayer& L = a.layer;
+        const int jq = bk % a.njobs;
+        const int xp = jq % L.nxp, gp = jq / L.nxp;
+        const int ck0 = 2 * xp, ct0 = 2 * gp;
+        const bool x2nd = ck0 + 1 < L.nck, g2nd = ct0 + 1 < L.nct;
+        jx0 = L.x + (size_t)ck0 * L.x_chunk_b; jx1 = x2nd ? jx0 + L.x_chunk_b : nullptr;
+        jg0 = L.g + (size_t)ct0 * L.g_chunk_b; jg1 = g2nd ? jg0 + L.g_chunk_b : nullptr;
+        sx0 = sx1 = L.xstride_b; sg0 = sg1 = L.gstride_b;
+        const unsigned sub0 = L.x_s2d_c > 0 ? (unsigned)((ck0 * 32) / L.x_s2d_c) : 4u;
+        const unsigned sub1 = (L.x_s2d_c > 0 && x2nd) ? (unsigned)(((ck0 + 1) * 32) / L.x_s2d_c) : 4u;
+        j_xsub = sub0 | (sub1 << 8);
+        const unsigned per = (unsigned)a.splits * (unsigned)kSlab;        // floats per product
+        auto slab = [&](int ct, int ck) { return (unsigned)(ct * L.nck + ck) * per; };
+        j_slab0 = slab(ct0, ck0);
+        j_slab1 = x2nd ? slab(ct0, ck0 + 1) : ~0u;
+        j_slab2 = g2nd ? slab(ct0 + 1, ck0) : ~0u;
+        j_slab3 = (x2nd && g2nd) ? slab(ct0 + 1, ck0 + 1) : ~0u;
+        j_bias_mask = (L.want_bias && ck0 == 0) ? 0x5u : 0u;             // products p = 0 (x0, g0) and p = 2 (x0, g1)
+    } else {
+        const WgradQuad& job = a.jobs[bk % a.njobs];
+        jx0 = job.x[0]; jx1 = job.x[1]; jg0 = job.g[0]; jg1 = job.g[1];
+        sx0 = job.xstride_b[0]; sx1 = job.xstride_b[1]; sg0 = job.gstride_b[0]; sg1 = job.gstride_b[1];
+        j_xsub = job.xsub; j_bias_mask = job.bias_mask;
+        j_slab0 = job.slab_off[0]; j_slab1 = job.slab_off[1]; j_slab2 = job.slab_off[2]; j_slab3 = job.slab_off[3];
+    }
+    auto slab_of = [&](int p) { return p == 0 ? j_slab0 : p == 1 ? j_slab1 : p == 2 ? j_slab2 : j_slab3; };
     const char* const zero = a.zero;
     const int img_h = a.h, img_w = a.w_, src_w = a.ws, up = a.up;
     const bool two_x = jx1 != nullptr, two_g = jg1 != nullptr;
@@ -554,7 +596,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
     using M2 = std::integral_constant<int, 2>;
     using M3 = std::integral_constant<int, 3>;
     using M4 = std::integral_constant<int, 4>;
-    switch ((job.xsub >> (8 * xi)) & 0xffu) {   // wave-uniform
+    switch ((j_xsub >> (8 * xi)) & 0xffu) {   // wave-uniform
         case 0: tile_loop(M0{}); break;
         case 1: tile_loop(M1{}); break;
         case 2: tile_loop(M2{}); break;
@@ -576,7 +618,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
             const int r = q >> 6, l = q & 63;
             const float s = red[(2 * p) * 1024 + q] + red[(2 * p + 1) * 1024 + q];
             const int co = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ci = l & 31;
-            if (job.slab_off[p] != ~0u) a.partial[job.slab_off[p] + (size_t)split * kSlab + tap * 1024 + co * 32 + ci] = s;
+            const unsigned so = slab_of(p);
+            if (so != ~0u) a.partial[so + (size_t)split * kSlab + tap * 1024 + co * 32 + ci] = s;
         }
         __syncthreads();
     }
@@ -585,8 +628,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
     if (tid < 128) {
         const int p = tid >> 5, c = tid & 31;
         const float s = (red[(2 * p) * 64 + c] + red[(2 * p) * 64 + 32 + c]) + (red[(2 * p + 1) * 64 + c] + red[(2 * p + 1) * 64 + 32 + c]);
-        if (((job.bias_mask >> p) & 1) && job.slab_off[p] != ~0u)
-            a.partial[job.slab_off[p] + (size_t)split * kSlab + 9 * 1024 + c] = s;
+        const unsigned so = slab_of(p);
+        if (((j_bias_mask >> p) & 1) && so != ~0u)
+            a.partial[so + (size_t)split * kSlab + 9 * 1024 + c] = s;
     }
 }
 
@@ -595,7 +639,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
 // groups of 64 elements -- and the slabs of a full-size dense block are 69 MB) and combined in a fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     __shared__ float red[8][32];
-    const ReduceJob job = a.jobs[blockIdx.x];
+    ReduceJob job = a.jobs[a.layer_nck > 0 ? 0 : blockIdx.x];
+    if (a.layer_nck > 0) {
+        const int ct = blockIdx.x / a.layer_nck, ck = blockIdx.x - ct * a.layer_nck;
+        job.slab_off = blockIdx.x * (unsigned)a.splits * (unsigned)kSlab;
+        job.co_base = (short)(ct * 32); job.ci_base = (short)(ck * 32);
+        job.want_bias = (short)((ck == 0 && job.db) ? 1 : 0);
+    }
     const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int e = blockIdx.y * 32 + lane;
     float s = 0.f;
@@ -853,6 +903,72 @@ size_t wgrad_batch_partial_bytes(const WgradConv* convs, int nconv, int splits, 
     size_t jobs = 0;
     for (int i = 0; i < nconv; ++i) jobs += (size_t)(convs[i].cin / 32) * (convs[i].cout_pad / 32);
     return jobs * (dtype == RESR_F16X2 ? wgrad_x2_products() : 1) * splits * kSlab * sizeof(float);
+}
+
+// One convolution with a regular grid of more products than a launch's job table holds (WgradLayer): one launch pair for the
+// whole layer.  f16 only; cout_pad any multiple of 32.
+static int wgrad_layer_launch(const WgradConv& c, int n, int h, int w, int flags, int splits, float* partial, hipStream_t stream) {
+    const bool up = flags & RESR_CONV_UPSAMPLE_IN;
+    const size_t es = 2;
+    static thread_local WgradQuadArgs q;
+    static thread_local ReduceArgs r;
+    memset(&q, 0, sizeof(q));
+    memset(&r, 0, sizeof(r));
+    const int nck = c.cin / 32, nct = c.cout_pad / 32;
+    WgradLayer& L = q.layer;
+    L.x = (const char*)c.x0; L.g = (const char*)c.g;
+    L.x_chunk_b = (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * (long)es;
+    L.g_chunk_b = (c.g_chunk_stride > 0 ? c.g_chunk_stride : 32) * (long)es;
+    L.xstride_b = (unsigned)(c.in0_stride * es); L.gstride_b = (unsigned)(c.g_stride * es);
+    L.nck = nck; L.nct = nct; L.nxp = (nck + 1) / 2;
+    L.x_s2d_c = c.x_s2d_c; L.want_bias = c.db ? 1 : 0;
+    const int nq = L.nxp * ((nct + 1) / 2);
+    {   // 32-bit lane offsets: every operand below 2^24 pixels and 4 GB
+        const size_t px = (size_t)n * h * w;
+        const size_t smax = L.xstride_b > L.gstride_b ? L.xstride_b : L.gstride_b;
+        if (!(px <= (1u << 24) && smax < (1u << 24) && px * smax + 64 < (1ull << 32))) return fail(RESR_ERR_ARG, "wgrad (layer mode): operand too large for 32-bit offsets");
+        if ((size_t)nck * nct * splits * kSlab >= (1ull << 32)) return fail(RESR_ERR_ARG, "wgrad (layer mode): slab offsets exceed 32 bits");
+    }
+    q.partial = partial;
+    q.n = n; q.h = h; q.w_ = w; q.hs = up ? h / 2 : h; q.ws = up ? w / 2 : w; q.up = up ? 1 : 0; q.splits = splits; q.njobs = nq;
+    q.tiles_x = (w + 31) / 32; q.tiles_y = (h + 7) / 8; q.ntiles = q.tiles_x * q.tiles_y * n;
+    const size_t lds = 2 * kQBUF;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_quad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(RESR_ERR_LAUNCH, "wgrad: cannot reserve %zu B of LDS", lds);
+        attr_done = true;
+    }
+    void* zp = nullptr;
+    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess || !zp) return fail(RESR_ERR_LAUNCH, "wgrad: zero page");
+    q.zero = (const char*)zp;
+    const int splits8 = (splits + 7) / 8 * 8;
+    const double sparse = c.x_s2d_c > 0 ? 4.0 / 9.0 : 1.0;
+    prof_before(stream);
+    hipLaunchKernelGGL(wgrad_quad_kernel, dim3(nq * splits8), dim3(512), lds, stream, q);
+    prof_after(stream, 50200, 2.0 * 9 * 32 * 32 * sparse * nck * nct * (double)n * h * w, (double)(nck + nct) * 64.0 * (double)n * h * w);
+    RESR_CHECK_LAUNCH("wgrad_quad_kernel (layer mode)");
+    ReduceJob& j = r.jobs[0];
+    j.dw = c.dw; j.db = c.db; j.slab_off = 0; j.slab_b = j.slab_c = ~0u; j.co_base = j.ci_base = 0;
+    j.cout = c.cout; j.cin_real = c.cin_real; j.scale = c.scale; j.want_bias = 0; j.pad_ = 0;
+    r.partial = partial; r.splits = splits; r.layer_nck = nck;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nck * nct, (kSlab + 31) / 32), dim3(256), 0, stream, r);
+    RESR_CHECK_LAUNCH("wgrad_reduce_kernel (layer mode)");
+    return RESR_OK;
+}
+
+// floats of slab scratch a layer-mode launch needs
+size_t wgrad_layer_partial_bytes(int cin, int cout_pad, int splits) { return (size_t)(cin / 32) * (cout_pad / 32) * splits * kSlab * sizeof(float); }
+
+// entry for the whole-network planners: one f16 convolution, cout_pad any multiple of 32, as one layer-mode launch pair
+int wgrad_layer(const WgradConv* c, int n, int h, int w, int dtype, int flags, int splits, float* partial, hipStream_t stream) {
+    if (!c || !partial || !c->x0 || !c->g || !c->dw) return fail(RESR_ERR_ARG, "wgrad_layer: null argument");
+    if (dtype != RESR_F16) return fail(RESR_ERR_ARG, "wgrad_layer: f16 only");
+    if (splits <= 0 || splits > 65535) return fail(RESR_ERR_ARG, "wgrad_layer: splits=%d", splits);
+    if (c->cin <= 0 || (c->cin & 31) || c->cout_pad <= 0 || (c->cout_pad & 31) || c->cout <= 0 || c->cout > c->cout_pad || c->cin_real <= 0 || c->cin_real > c->cin)
+        return fail(RESR_ERR_ARG, "wgrad_layer: cin=%d cin_real=%d cout=%d cout_pad=%d", c->cin, c->cin_real, c->cout, c->cout_pad);
+    if ((flags & RESR_CONV_UPSAMPLE_IN) && ((h | w) & 1)) return fail(RESR_ERR_ARG, "wgrad_layer: upsampled input needs even h,w");
+    return wgrad_layer_launch(*c, n, h, w, flags, splits, partial, stream);
 }
 
 int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtype, int flags, int splits,

@@ -344,3 +344,36 @@ def test_exact16_weight_gradients_at_a_size_with_many_pixel_tiles():
     for n, ref in grads["strict"].items():
         rel = ((grads["exact16"][n] - ref).norm() / ref.norm().clamp_min(1e-12)).item()
         assert rel < 2e-2, (n, rel)
+
+
+def test_layer_mode_weight_gradients_equal_table_mode():
+    """The 256..512-channel layers' weight gradients as ONE layer-mode launch pair each (wgrad.hip WgradLayer: the quad jobs'
+    operands and slabs follow from their grid position, no job table) against the table-mode launch pairs
+    (RESR_WGRAD_NO_LAYER_MODE=1, read per call): the same products in another split order -- equal to fp32 summation noise -- and
+    against strict."""
+    import real_esrgan_pytorch_amd as R
+    from oracle import model_ref as M
+    sd = M.init_discriminator_state(12)
+    gen = torch.Generator().manual_seed(13)
+    x = torch.rand(4, 3, 64, 96, generator=gen).cuda()
+    gw = torch.randn(4, 1, 64, 96, generator=gen).cuda()
+
+    def grads(precision, env):
+        if env:
+            os.environ["RESR_WGRAD_NO_LAYER_MODE"] = "1"
+        try:
+            d = R.Discriminator(precision=precision)
+            d.load_state_dict(sd)
+            d = d.cuda().train()
+            scale = 1.0 if precision == "strict" else 256.0
+            (d(x) * gw).sum().mul(scale).backward()
+            torch.cuda.synchronize()
+            return {n: p.grad.clone() / scale for n, p in d.named_parameters()}
+        finally:
+            os.environ.pop("RESR_WGRAD_NO_LAYER_MODE", None)
+    layer, table, strict = grads("fast", False), grads("fast", True), grads("strict", False)
+    rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+    for n in layer:
+        assert rel(layer[n], table[n]) < 2e-5, (n, rel(layer[n], table[n]))
+        assert rel(layer[n], strict[n]) < 0.12, (n, rel(layer[n], strict[n]))
+    assert sum(n.startswith(("down_block2", "down_block3", "up_block1")) for n in layer) == 3      # the three layers that take it
