@@ -344,6 +344,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// The same reduction for launches of at most eight pixel splits (the discriminator's deep layers: 2..8 splits of 128..512
+// products): one thread per slab element adds its <= 8 slabs in the tree the kernel above uses (bit-identical results), 256
+// elements per workgroup -- the 32-element workgroups above are 148 K workgroups of mostly idle threads for a 512-product layer.
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const ReduceArgs a) {
+    ReduceJob job = a.jobs[a.layer_nck > 0 ? 0 : blockIdx.x];
+    if (a.layer_nck > 0) {
+        const int ct = blockIdx.x / a.layer_nck, ck = blockIdx.x - ct * a.layer_nck;
+        job.slab_off = blockIdx.x * (unsigned)a.splits * (unsigned)kSlab;
+        job.co_base = (short)(ct * 32); job.ci_base = (short)(ck * 32);
+        job.want_bias = (short)((ck == 0 && job.db) ? 1 : 0);
+    }
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    if (e >= kSlab) return;
+    const float* p = a.partial + job.slab_off + e;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = k < a.splits ? p[(size_t)k * kSlab] : 0.f;
+    const float s = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) * job.scale;
+    if (e < 9 * 1024) {
+        const int tap = e >> 10, co = job.co_base + ((e >> 5) & 31), ci = job.ci_base + (e & 31);
+        if (co < job.cout && ci < job.cin_real) job.dw[((size_t)co * job.cin_real + ci) * 9 + tap] = s;
+    } else if (job.want_bias && job.db) {
+        const int co = job.co_base + (e - 9 * 1024);
+        if (co < job.cout) job.db[co] = s;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // f16 quad kernel: one job = up to 2 X chunks x 2 G tiles (four 32x32x9 products) on one staged pixel tile.
 //
@@ -400,14 +427,23 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bx = blockIdx.x & 7, bk = blockIdx.x >> 3;   // all jobs of one pixel split on one XCD (see wgrad_kernel)
-    const int split = bx + 8 * (bk / a.njobs);
-    if (split >= a.splits) return;
+    int split = bx + 8 * (bk / a.njobs), jq = bk % a.njobs;
+    if (a.layer.nxp > 0) {
+        // layer mode: the (quad job, split) pairs as one list -- X chunk pair fastest, then the split, then the G tile pair -- cut
+        // into eight contiguous ranges, one per XCD (block b runs on XCD b % 8): the 16..32 workgroups an XCD holds share their
+        // G tiles and pixel range.  (Table mode's "split s on XCD s % 8" leaves six XCDs idle when a layer has two splits.)
+        const int W = a.njobs * a.splits, per = (W + 7) >> 3;
+        const int wi = bx * per + bk;
+        if (bk >= per || wi >= W) return;
+        const int xp = wi % a.layer.nxp, t = wi / a.layer.nxp;
+        split = t % a.splits;
+        jq = (t / a.splits) * a.layer.nxp + xp;
+    } else if (split >= a.splits) return;
     // scalar copies: a field read inside the MFMA loop would be an s_load + lgkmcnt(0) in the middle of the LDS reads
     const char *jx0, *jx1, *jg0, *jg1;
     unsigned sx0, sx1, sg0, sg1, j_xsub, j_bias_mask, j_slab0, j_slab1, j_slab2, j_slab3;
     if (a.layer.nxp > 0) {   // layer mode: the quad's operands and slabs from its grid position
         const WgradLayer& L = a.layer;
-        const int jq = bk % a.njobs;
         const int xp = jq % L.nxp, gp = jq / L.nxp;
         const int ck0 = 2 * xp, ct0 = 2 * gp;
         const bool x2nd = ck0 + 1 < L.nck, g2nd = ct0 + 1 < L.nct;
@@ -425,7 +461,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
         j_slab3 = (x2nd && g2nd) ? slab(ct0 + 1, ck0 + 1) : ~0u;
         j_bias_mask = (L.want_bias && ck0 == 0) ? 0x5u : 0u;             // products p = 0 (x0, g0) and p = 2 (x0, g1)
     } else {
-        const WgradQuad& job = a.jobs[bk % a.njobs];
+        const WgradQuad& job = a.jobs[jq];
         jx0 = job.x[0]; jx1 = job.x[1]; jg0 = job.g[0]; jg1 = job.g[1];
         sx0 = job.xstride_b[0]; sx1 = job.xstride_b[1]; sg0 = job.gstride_b[0]; sg1 = job.gstride_b[1];
         j_xsub = job.xsub; j_bias_mask = job.bias_mask;
@@ -942,17 +978,18 @@ static int wgrad_layer_launch(const WgradConv& c, int n, int h, int w, int flags
     void* zp = nullptr;
     if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess || !zp) return fail(RESR_ERR_LAUNCH, "wgrad: zero page");
     q.zero = (const char*)zp;
-    const int splits8 = (splits + 7) / 8 * 8;
+    const int per_xcd = (nq * splits + 7) / 8;          // (quad job, split) pairs per XCD: eight contiguous ranges
     const double sparse = c.x_s2d_c > 0 ? 4.0 / 9.0 : 1.0;
     prof_before(stream);
-    hipLaunchKernelGGL(wgrad_quad_kernel, dim3(nq * splits8), dim3(512), lds, stream, q);
+    hipLaunchKernelGGL(wgrad_quad_kernel, dim3(per_xcd * 8), dim3(512), lds, stream, q);
     prof_after(stream, 50200, 2.0 * 9 * 32 * 32 * sparse * nck * nct * (double)n * h * w, (double)(nck + nct) * 64.0 * (double)n * h * w);
     RESR_CHECK_LAUNCH("wgrad_quad_kernel (layer mode)");
     ReduceJob& j = r.jobs[0];
     j.dw = c.dw; j.db = c.db; j.slab_off = 0; j.slab_b = j.slab_c = ~0u; j.co_base = j.ci_base = 0;
     j.cout = c.cout; j.cin_real = c.cin_real; j.scale = c.scale; j.want_bias = 0; j.pad_ = 0;
     r.partial = partial; r.splits = splits; r.layer_nck = nck;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nck * nct, (kSlab + 31) / 32), dim3(256), 0, stream, r);
+    if (splits <= 8) hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(nck * nct, (kSlab + 255) / 256), dim3(256), 0, stream, r);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nck * nct, (kSlab + 31) / 32), dim3(256), 0, stream, r);
     RESR_CHECK_LAUNCH("wgrad_reduce_kernel (layer mode)");
     return RESR_OK;
 }
@@ -1041,7 +1078,8 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
     else if (dtype == RESR_F32) rc = launch_wgrad<float, 1>(a, nj, nr, stream);
     else return fail(RESR_ERR_ARG, "wgrad: dtype=%d", dtype);
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nr, (kSlab + 31) / 32), dim3(256), 0, stream, r);
+    if (splits <= 8 && !x2) hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(nr, (kSlab + 255) / 256), dim3(256), 0, stream, r);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nr, (kSlab + 31) / 32), dim3(256), 0, stream, r);
     RESR_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RESR_OK;
 }
