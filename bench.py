@@ -63,6 +63,7 @@ def _parser():
                          "run 10-20 %% faster than on real gradients (DESIGN.md section 5)")
     ap.add_argument("--per-tensor-adam", action="store_true", help="optimizer over the 702 per-tensor Parameters instead of the flat arena")
     ap.add_argument("--no-probe", action="store_true", help="skip the in-situ roofline step")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the 3 s measurement of this box's power-cap frontier (kernel traces: it is ~13 K launches)")
     ap.add_argument("--centre-output", action="store_true",
                     help="conv4.bias + 0.5 before the run (what the config-3 probe does): at LR 64^2 a random init whose first Adam step overshoots the "
                          "training-time clamp leaves a step with zero gradients, which draws less power and times ~8 %% faster than a real one")
@@ -904,7 +905,7 @@ def main():
         ensure_built()
     if world > 1:
         dist.barrier()
-    if rank == 0 and not args.no_probe and args.precision != "strict":
+    if rank == 0 and not args.no_probe and not args.no_sustained and args.precision != "strict":
         measure_sustained_frontier()         # this box's power-cap frontier (~3 s), before the timed steps
 
     if args.gan:

@@ -155,3 +155,83 @@ def test_overlapped_exchange_buckets_world8_real_range_table():
         assert nxt is None or (hi - lo) * 4 >= 12 << 20
     assert 4 <= len(buckets) <= 6, buckets                        # 66.8 MB in >= 12 MB buckets
     assert all(r[4] < 1e-5 for r in res), [r[4] for r in res]
+
+
+def _forced_world1_worker(port, q):
+    """`DataParallel(force=True)` with a world of ONE rank: every collective branch runs (this is how the single-GPU tests and
+    `RESR_BENCH_FORCE_NCCL=1 bench.py` execute the RCCL path); with gloo on the CPU the host logic of the same branches."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        from real_esrgan_pytorch_amd.train import DataParallel
+        assert not DataParallel().active                      # a world of one is inactive unless forced
+        os.environ["RESR_DP_FORCE"] = "1"
+        assert DataParallel().active                          # ... by the environment
+        os.environ.pop("RESR_DP_FORCE")
+        dp = DataParallel(bucket_bytes=4 * 1000, force=True)
+        assert dp.active and dp.world == 1 and not dp._avg     # gloo sums and scales; nccl averages inside the collective
+        flat = torch.randn(10_007, generator=torch.Generator().manual_seed(1))
+        ref = flat.clone()
+        dp.all_reduce_mean_(flat)
+        ok = torch.equal(flat, ref)
+        ranges = [(8000, 10_007), (5000, 8000), (1200, 5000), (0, 1200)]
+        dp.all_reduce_ranges_(flat, ranges, [None] * 4)
+        ok = ok and torch.equal(flat, ref)
+        p = torch.nn.Parameter(torch.zeros(7))
+        p.grad = torch.arange(7.0)
+        dp.all_reduce_grads_([p])
+        ok = ok and torch.equal(p.grad, torch.arange(7.0))
+
+        class E:
+            _flat_shadow = torch.arange(5.0)
+            shadow = {}
+        dp.attach_ema(E)
+        dist.destroy_process_group()
+        q.put(bool(ok))
+    except Exception as e:  # pragma: no cover
+        q.put(repr(e))
+
+
+def test_forced_collectives_with_a_world_of_one():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_world1_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=120)
+    p.join(timeout=60)
+    assert res is True, res
+
+
+def test_graphed_step_refuses_what_it_cannot_capture():
+    """train.GraphedStep: optimisers must be capturable (device-side step counters) and the step must not hold an active
+    data-parallel exchange -- checked at construction, on the host."""
+    import pytest
+    from real_esrgan_pytorch_amd.train import GraphedStep
+
+    class Step:
+        def __init__(self, opt, dp=None):
+            self.optimizer, self.dp = opt, dp
+    w = torch.nn.Parameter(torch.zeros(3))
+    with pytest.raises(ValueError):
+        GraphedStep(Step(torch.optim.Adam([w], 1e-3)))
+
+    class DP:
+        active = True
+    with pytest.raises(ValueError):
+        GraphedStep(Step(torch.optim.Adam([w], 1e-3, capturable=True), DP()))
+    GraphedStep(Step(torch.optim.Adam([w], 1e-3, capturable=True)))
+
+
+def test_loss_helpers_call_a_non_stock_criterion():
+    """losses.l1_loss / bce_with_logits_const fuse ONLY the stock criteria in their default configuration; anything else (and any
+    tensor the fused launch does not take -- here: CPU tensors) is handed to the criterion as the reference's loop would."""
+    from real_esrgan_pytorch_amd import losses
+    a, b = torch.rand(2, 3, 4, 4), torch.rand(2, 3, 4, 4)
+    assert torch.allclose(losses.l1_loss(torch.nn.SmoothL1Loss(), a, b, 0.5), 0.5 * torch.nn.functional.smooth_l1_loss(a, b))
+    assert torch.allclose(losses.l1_loss(torch.nn.L1Loss(), a, b), torch.nn.functional.l1_loss(a, b))
+    x = torch.randn(2, 1, 4, 4)
+    want = 0.1 * torch.nn.functional.binary_cross_entropy_with_logits(x, torch.ones_like(x))
+    assert torch.allclose(losses.bce_with_logits_const(torch.nn.BCEWithLogitsLoss(), x, 1.0, 0.1), want)
+    summed = losses.bce_with_logits_const(torch.nn.BCEWithLogitsLoss(reduction="sum"), x, 0.0)
+    assert torch.allclose(summed, torch.nn.functional.binary_cross_entropy_with_logits(x, torch.zeros_like(x), reduction="sum"))

@@ -207,3 +207,19 @@ def test_entry_points_keep_the_reference_function_names(built):
     assert [cp.next() is not None for _ in range(4)] == [True, True, True, False]
     n = importlib.import_module("real_esrgan_pytorch_amd.train_realesrnet")
     assert list(inspect.signature(n.validate).parameters) == ["model", "ema_model", "data_prefetcher", "epoch", "writer", "niqe_model", "mode"]
+
+
+def test_precision_defaults_follow_the_reference_call_sites(built):
+    """The reference trains / validates under amp.autocast (train_realesrnet.py:383,461) and runs inference.py:52-53 / test.py:79-80
+    in plain fp32: `config.precision` (training) defaults to the f16 mode, `config.inference_precision` to the mode inside the 1e-3
+    parity tolerance; the entry points read exactly these."""
+    import inspect
+    from real_esrgan_pytorch_amd import config, inference, test as dirtest
+    if "RESR_PRECISION" not in os.environ:
+        assert config.precision == "fast"
+    if "RESR_INFERENCE_PRECISION" not in os.environ:
+        assert config.inference_precision == "exact16"
+    assert "config.inference_precision" in inspect.getsource(inference.main)
+    assert "config.inference_precision" in inspect.getsource(dirtest.main)
+    with pytest.raises(ValueError):
+        built.Generator(3, 3, 4, precision="bf16")

@@ -25,7 +25,7 @@ def short(name):
     m = re.search(r"wgrad_kernelI(DF16_|f)Li(\d)E", name)
     if m:
         return f"wgrad_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'},{m.group(2)}>"
-    return re.sub(r"\(.*", "", name)[:60]
+    return re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))[:60]
 
 
 def load(path, counter):

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-other-configs --no-parity-mode"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-other-configs --no-parity-mode --no-sustained"
 for P in fast exact16; do
   rocprofv3 --kernel-trace --stats -d $OUT/trace_$P -o t -- $BENCH --precision $P --steps 5 --warmup 2 > $OUT/bench_trace_$P.json 2> $OUT/bench_trace_$P.err
   DB=$(find $OUT/trace_$P -name "*.db" | head -1)

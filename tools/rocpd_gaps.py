@@ -31,7 +31,7 @@ def main(path):
           f"gaps {gsum / 1e6:.3f} ms in {len(gaps)} ({100 * gsum / span:.1f} %), median gap {sorted(g for g, _ in gaps)[len(gaps) // 2] / 1e3:.2f} us")
     by = {}
     for g, name in gaps:
-        k = re.sub(r"\(.*", "", name.replace("resr::", "").replace("void ", ""))[:70]
+        k = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "").replace("resr::", "").replace("void ", ""))[:70]
         a = by.setdefault(k, [0, 0])
         a[0] += 1
         a[1] += g

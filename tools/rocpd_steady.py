@@ -12,7 +12,7 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"^void ", "", name).replace("resr::", "")
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "").replace("resr::", "")
     name = re.sub(r"\(.*\)$", "", name)
     m = re.match(r"_ZN4resr\d+([a-z0-9_]+?)I(.*?)EEv", name)
     if m:   # _ZN4resr17conv3x3_ws_kernelIDF16_Li1ELi2ELi8ELi33ELb1ELi0ELi2EEEv... -> conv3x3_ws_kernel<f16,1,2,8,33,1,0,2>

@@ -6,7 +6,7 @@ import sys
 
 def short(name):
     name = re.sub(r"^void ", "", name)
-    name = name.replace("resr::", "")
+    name = name.replace("(anonymous namespace)::", "").replace("resr::", "")
     name = re.sub(r"\(.*\)$", "", name)
     return name[:110]
 
