@@ -1125,6 +1125,9 @@ int wgrad_dispatch(const ResrWgradDesc* d, const void* x0, const void* x1, const
     c.x_chunk_stride = (long)d->x_chunk_stride; c.g_chunk_stride = (long)d->g_chunk_stride;
     c.x_lo_off = (long)d->x_lo_offset; c.g_lo_off = (long)d->g_lo_offset; c.x_s2d_c = 0;
     c.dw = dw; c.db = db; c.scale = d->scale;
+    // more products than one launch's job table holds (or an output wider than 64 channels): the layer mode (f16)
+    if (d->dtype == RESR_F16 && (c.cout_pad > 64 || (c.cin / 32) * (c.cout_pad / 32) > kMaxReduce))
+        return wgrad_layer(&c, d->n, d->h, d->w, d->dtype, d->flags, d->splits, partial, stream);
     return wgrad_batch(&c, 1, d->n, d->h, d->w, d->dtype, d->flags, d->splits, partial, stream);
 }
 

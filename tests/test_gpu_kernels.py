@@ -280,6 +280,48 @@ def test_wgrad(U, case, dtype_name, diag_dir):
     assert err_b < tol * max(1.0, ref_b.abs().max().item()), f"db max abs err {err_b}"
 
 
+LAYER_CASES = [
+    ("layer_odd", 352, 288, 0, 2, 16, 40, 3),        # 11 chunks x 9 tiles = 99 products: odd counts (half-filled quad jobs on both edges)
+    ("layer_wide", 512, 256, 0, 4, 16, 32, 2),       # the discriminator's 512 -> 256 layer: 128 products, two pixel splits
+    ("layer_up_bias", 128, 200, 1, 1, 24, 64, 12),   # cout not a multiple of 32 (rows of the last tile masked), upsampled input, > 8 splits
+]
+
+
+@pytest.mark.parametrize("case", LAYER_CASES, ids=[c[0] for c in LAYER_CASES])
+def test_wgrad_layer_mode(U, case, diag_dir):
+    """Weight gradients in layer mode (wgrad.hip WgradLayer: an output wider than 64 channels or more than 80 products; quad jobs and
+    slabs from the grid position, work spread over all XCDs, <= 8 splits through the wide reduction) through the public entry
+    against autograd."""
+    L = U.L
+    dtype = L.RESR_F16
+    name, cin, cout, up, n, h, w, splits = case
+    g = torch.Generator().manual_seed(11)
+    hs, ws = (h // 2, w // 2) if up else (h, w)
+    x = U.quant(torch.randn(n, cin, hs, ws, generator=g), dtype)
+    gy = U.quant(torch.randn(n, cout, h, w, generator=g), dtype)
+    cin_pad, cout_pad = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+    xb = U.to_nhwc(x, dtype, c_pad=cin_pad, stride=cin_pad + 32)
+    gb = U.to_nhwc(gy, dtype, c_pad=cout_pad, stride=cout_pad + 32)
+    d = L.WgradDesc(n, h, w, cin_pad, cin_pad, cin_pad + 32, 0, cin, cout, cout_pad, cout_pad + 32, dtype,
+                    L.CONV_UPSAMPLE_IN if up else 0, splits, 1.0)
+    partial = torch.empty(L.lib().resr_wgrad_partial_bytes(C.byref(d)) // 4, device="cuda")
+    dw = torch.full((cout, cin, 3, 3), -7.0, device="cuda")
+    db = torch.full((cout,), -7.0, device="cuda")
+    L.check(L.lib().resr_conv3x3_wgrad(C.byref(d), L.ptr(xb), None, L.ptr(gb), L.ptr(partial), L.ptr(dw), L.ptr(db), L.stream_ptr()),
+            "resr_conv3x3_wgrad")
+    torch.cuda.synchronize()
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    bs = torch.zeros(cout, requires_grad=True)
+    (F.conv2d(xin, wt, bs, padding=1) * gy).sum().backward()
+    err_w = (dw.cpu() - wt.grad).abs().max().item()
+    err_b = (db.cpu() - bs.grad).abs().max().item()
+    scale = max(1.0, wt.grad.abs().max().item())
+    with open(os.path.join(diag_dir, f"wgrad_{name}.json"), "w") as f:
+        json.dump({"err_w": err_w, "err_b": err_b, "ref_absmax": scale}, f)
+    assert err_w < 2e-3 * scale and err_b < 2e-3 * max(1.0, bs.grad.abs().max().item()), (err_w, err_b, scale)
+
+
 @pytest.mark.parametrize("knob", ["RESR_WGRAD_PAIR_KERNEL", "RESR_WGRAD_GENERIC_ADDR"])
 def test_wgrad_fallback_kernels(knob):
     """The f16 pair kernel (used when the quad kernel's grouping or 32-bit addressing preconditions fail) and its 64-bit
@@ -288,7 +330,7 @@ def test_wgrad_fallback_kernels(knob):
     env = dict(os.environ, **{knob: "1"})
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "test_wgrad and not fallback"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+                        "-k", "test_wgrad and not fallback and not layer"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
