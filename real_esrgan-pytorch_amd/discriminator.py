@@ -258,8 +258,10 @@ class Discriminator(nn.Module):
 
     # ---- module surface -----------------------------------------------------------------------------------------
     def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
-        self.flat_parameters()
+        flat = self.flat_parameters()
         fp = self.__dict__["_flat_param"]
+        if fp is not None and fp.data_ptr() != flat.data_ptr():
+            fp.data = flat                                               # the arena was rebuilt (.to(), new tensors loaded): keep the alias on it
         params = [fp] if fp is not None else self._ordered_params()     # flat_parameter() mode: one graph input for all 19 tensors
         training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         return _DiscFn.apply(self, training, x, *params)

@@ -444,8 +444,10 @@ class Generator(nn.Module):
 
     # ---- module surface ---------------------------------------------------------------------------
     def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
-        self.flat_parameters()
+        flat = self.flat_parameters()
         fp = self.__dict__["_flat_param"]
+        if fp is not None and fp.data_ptr() != flat.data_ptr():
+            fp.data = flat                       # the arena was rebuilt (.to(), new tensors loaded): keep the alias on it
         # flat_parameter() mode: the alias stands for all 702 tensors in the autograd graph (its .grad is set by hand in backward),
         # so a backward pass does not walk 702 AccumulateGrad nodes that would each receive None
         params = [fp] if fp is not None else self._ordered_params()
