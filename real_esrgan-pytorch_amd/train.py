@@ -69,6 +69,10 @@ class DataParallel:
         if force is None:
             force = os.environ.get("RESR_DP_FORCE", "0") == "1"
         self.active = self.world > 1 or bool(force and dist.is_initialized())
+        # exchange issued once behind the backward pass (overlap off, the default): ONE message -- RCCL chunks and pipelines a
+        # large all-reduce itself, and every extra collective is a launch plus a stream join (a world-1 RCCL group on one GPU:
+        # 0.66 ms per RealESRGAN step for eight bucketed collectives).  $RESR_DP_BUCKETED=1: bucket_bytes pieces.
+        self.bucketed = os.environ.get("RESR_DP_BUCKETED", "0") == "1"
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.backend = dist.get_backend() if dist.is_initialized() else None
         # RCCL averages inside the collective (ncclAvg); gloo (the CPU tests) sums and the mean is one more pass
@@ -99,13 +103,14 @@ class DataParallel:
             dist.broadcast(flat, src=0)
 
     def all_reduce_mean_(self, flat: torch.Tensor) -> None:
-        """Bucketed so that consecutive ring all-reduces pipeline over the 7 xGMI links instead of
-        one 67 MB message serialising on a single ring step."""
+        """Mean over ranks of a whole arena, issued behind the pass that produced it: one message (`bucketed`: pieces of
+        bucket_bytes, the form the overlapped exchange `all_reduce_ranges_` uses because its ranges become final one by one)."""
         if not self.active:
             return
         works = []
-        for off in range(0, flat.numel(), self.bucket_elems):
-            works.append(dist.all_reduce(flat[off:off + self.bucket_elems], op=self._op(), async_op=True))
+        step = self.bucket_elems if self.bucketed else max(1, flat.numel())
+        for off in range(0, flat.numel(), step):
+            works.append(dist.all_reduce(flat[off:off + step], op=self._op(), async_op=True))
         for w in works:
             w.wait()
         self._finish_mean_(flat)

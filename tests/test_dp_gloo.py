@@ -26,8 +26,12 @@ def _worker(rank, world, port, q):
     g = torch.Generator().manual_seed(100 + rank)
     flat = torch.randn(10_007, generator=g)
     ref = sum(torch.randn(10_007, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
-    dp.all_reduce_mean_(flat)
+    dp.all_reduce_mean_(flat)                           # one message (the default behind the backward pass)
     ok1 = torch.allclose(flat, ref, atol=1e-6)
+    dp.bucketed = True                                  # ... and as bucket_bytes pieces ($RESR_DP_BUCKETED=1)
+    flat2 = torch.randn(10_007, generator=torch.Generator().manual_seed(100 + rank))
+    dp.all_reduce_mean_(flat2)
+    ok1 = ok1 and torch.allclose(flat2, ref, atol=1e-6)
     w = torch.full((33,), float(rank))
     dp.broadcast_(w)
     ok2 = bool((w == 0).all())

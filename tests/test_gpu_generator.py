@@ -86,8 +86,10 @@ def test_generator_forward_backward(upscale, n_blocks, n, h, w, precision, diag_
     elif precision == "strict":
         assert worst32 < 1e-2, f"worst rel grad err vs the fp32 oracle {worst32}"
     else:
-        # every gradient tensor (702 at full depth) and the input gradient within 1e-3 relative L2
-        assert worst < 1e-3 and egx < 1e-3, f"exact16 worst rel grad err vs f64 {worst}, gx {egx} (fp32 oracle's own: {own32})"
+        # every gradient tensor (702 at full depth) and the input gradient: the gate is 1e-3 relative L2; with the default
+        # three-product weight gradients the measured worst tensor is 6.5e-6 over the five cases -- held to 5e-5 so that a
+        # regression to the hi-only class (3-9e-4, still inside the gate) cannot pass unnoticed
+        assert worst < 5e-5 and egx < 1e-5, f"exact16 worst rel grad err vs f64 {worst}, gx {egx} (fp32 oracle's own: {own32})"
         assert worst32 < max(1e-3, 1.5 * own32), f"exact16 vs the fp32 oracle {worst32} (its own distance to f64: {own32})"
 
 
