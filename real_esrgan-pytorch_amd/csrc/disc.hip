@@ -613,6 +613,101 @@ int spectral_norm_bwd_dispatch(const float* G, const float* W, const float* u, c
     return RESR_OK;
 }
 
+// The same two steps for ALL normalised layers of a discriminator backward pass in two launches (and the 4x4 folds in one): 38
+// launches of 5-10 us per backward were 70 per RealESRGAN step.  Same per-layer block counts and summation orders as the
+// single-layer kernels above: bit-identical results.
+struct SnBwdLayer {
+    const float* G; const float* W; const float* u; const float* v; const float* sigma2; float* dst;
+    long count; int cols; int dot0, ndot;      // first partial / number of partials of this layer in `dot`
+    long ablk0;                                // first workgroup of the apply launch that belongs to this layer
+};
+struct SnBwdBatch {
+    SnBwdLayer l[8];
+    int n;
+    float* dot;
+};
+
+__global__ __launch_bounds__(256) void sn_bwd_dot_batch_kernel(const SnBwdBatch a) {
+    __shared__ float red[4];
+    int li = 0;
+    while (li + 1 < a.n && (int)blockIdx.x >= a.l[li + 1].dot0) ++li;
+    const SnBwdLayer& L = a.l[li];
+    const int b = (int)blockIdx.x - L.dot0;
+    float s = 0.f;
+    for (long i = (long)b * 256 + threadIdx.x; i < L.count; i += (long)L.ndot * 256) s += L.G[i] * L.W[i];
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) a.dot[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_apply_batch_kernel(const SnBwdBatch a) {
+    __shared__ float red[4];
+    int li = 0;
+    while (li + 1 < a.n && (long)blockIdx.x >= a.l[li + 1].ablk0) ++li;
+    const SnBwdLayer& L = a.l[li];
+    float part = 0.f;
+    for (int k = threadIdx.x; k < L.ndot; k += 256) part += a.dot[L.dot0 + k];
+    const float gw = block_sum(part, red);
+    const long i = ((long)blockIdx.x - L.ablk0) * 256 + threadIdx.x;
+    if (i >= L.count) return;
+    const int r = (int)(i / L.cols), k = (int)(i % L.cols);
+    const float inv = L.sigma2[1];
+    L.dst[i] = L.G[i] * inv - gw * inv * inv * L.u[r] * L.v[k];
+}
+
+// n <= 8 layers; G[i] = gradient wrt W = W_orig / sigma of layer i ([rows][cols]), dst[i] = gradient wrt W_orig; dot: 8 x 512 floats
+int spectral_norm_bwd_batch_dispatch(int n, const float* const* G, const float* const* W, const float* const* u, const float* const* v,
+                                     const float* const* sigma2, float* const* dst, const int* rows, const int* cols, float* dot, hipStream_t st) {
+    if (n <= 0 || n > 8 || !G || !W || !u || !v || !sigma2 || !dst || !rows || !cols || !dot) return fail(RESR_ERR_ARG, "spectral_norm_bwd_batch: bad argument");
+    SnBwdBatch a;
+    memset(&a, 0, sizeof(a));
+    a.n = n; a.dot = dot;
+    int dots = 0;
+    long ablk = 0;
+    for (int i = 0; i < n; ++i) {
+        SnBwdLayer& L = a.l[i];
+        L.G = G[i]; L.W = W[i]; L.u = u[i]; L.v = v[i]; L.sigma2 = sigma2[i]; L.dst = dst[i];
+        L.count = (long)rows[i] * cols[i]; L.cols = cols[i];
+        long blocks = (L.count + 255) / 256;
+        L.ndot = (int)(blocks > 512 ? 512 : blocks);
+        L.dot0 = dots; dots += L.ndot;
+        L.ablk0 = ablk; ablk += blocks;
+    }
+    hipLaunchKernelGGL(sn_bwd_dot_batch_kernel, dim3((unsigned)dots), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(sn_bwd_apply_batch_kernel, dim3((unsigned)ablk), dim3(256), 0, st, a);
+    RESR_CHECK_LAUNCH("spectral_norm_bwd batch kernels");
+    return RESR_OK;
+}
+
+struct FoldBatch {
+    const float* src[4]; float* dst[4]; int cout[4], C[4]; long blk0[5]; int n;
+};
+__global__ __launch_bounds__(256) void fold4x4_batch_kernel(const FoldBatch a) {
+    int li = 0;
+    while (li + 1 < a.n && (long)blockIdx.x >= a.blk0[li + 1]) ++li;
+    const int C = a.C[li];
+    const long total = (long)a.cout[li] * C * 16;
+    const long t = ((long)blockIdx.x - a.blk0[li]) * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int kx = (int)(t % 4), ky = (int)((t / 4) % 4), c = (int)((t / 16) % C), co = (int)(t / (16L * C));
+    const int ty = (ky + 1) >> 1, i = (ky + 1) & 1, tx = (kx + 1) >> 1, j = (kx + 1) & 1;
+    a.dst[li][t] = a.src[li][(((size_t)co * 4 * C + (i * 2 + j) * C + c) * 3 + ty) * 3 + tx];
+}
+int fold4x4_batch_dispatch(int n, const float* const* src, float* const* dst, const int* cout, const int* C, hipStream_t st) {
+    if (n <= 0 || n > 4 || !src || !dst || !cout || !C) return fail(RESR_ERR_ARG, "fold4x4_batch: bad argument");
+    FoldBatch a;
+    memset(&a, 0, sizeof(a));
+    a.n = n;
+    long blk = 0;
+    for (int i = 0; i < n; ++i) {
+        a.src[i] = src[i]; a.dst[i] = dst[i]; a.cout[i] = cout[i]; a.C[i] = C[i];
+        a.blk0[i] = blk; blk += ((long)cout[i] * C[i] * 16 + 255) / 256;
+    }
+    a.blk0[n] = blk;
+    hipLaunchKernelGGL(fold4x4_batch_kernel, dim3((unsigned)blk), dim3(256), 0, st, a);
+    RESR_CHECK_LAUNCH("fold4x4_batch_kernel");
+    return RESR_OK;
+}
+
 // virtual [cout][4C][3][3] gradient -> real [cout][C][4][4]:  ky = 2*ty + i - 1, kx = 2*tx + j - 1, virtual ci = (i*2+j)*C + c
 __global__ __launch_bounds__(256) void fold4x4_kernel(const float* __restrict__ dw3, float* __restrict__ dw4, int cout, int C) {
     const long total = (long)cout * C * 16;

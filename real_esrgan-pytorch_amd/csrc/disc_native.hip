@@ -43,6 +43,9 @@ int spectral_norm_batch_dispatch(int, const float* const*, float* const*, float*
 int spectral_norm_bwd_dispatch(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, float*,
                                hipStream_t);
 int fold4x4_dispatch(const float*, float*, int, int, hipStream_t);
+int spectral_norm_bwd_batch_dispatch(int, const float* const*, const float* const*, const float* const*, const float* const*, const float* const*,
+                                     float* const*, const int*, const int*, float*, hipStream_t);
+int fold4x4_batch_dispatch(int, const float* const*, float* const*, const int*, const int*, hipStream_t);
 
 namespace {
 
@@ -109,6 +112,9 @@ struct DBufs {
     char *g4, *G8, *G7, *G6, *g_u3, *g_b3, *g_u2, *G5, *g_b2, *g_u1, *G4, *g_b1, *g_d3, *G3, *g_s3, *G2, *g_s2, *G1, *g_s1,
         *G0, *gxin;
     float *raw, *folded, *tmp1, *partial;
+    float* raw_l[kLayers];      // per normalised layer: the gradient wrt W = W_orig / sigma (virtual 3x3 form for the 4x4 layers) ...
+    float* fold_l[kLayers];     // ... and its [cout][C][4][4] form (4x4 layers): all layers' folds and spectral-norm backward steps
+                                // run as three batched launches at the end of the pass
     size_t partial_bytes, total;
 };
 
@@ -173,7 +179,13 @@ void carve(const DPlan& p, char* base, DBufs& b) {
         b.G0 = take(px * 64 * es); b.gxin = take(px * 32 * es);
         b.raw = (float*)take((size_t)512 * 1024 * 9 * sizeof(float));
         b.folded = (float*)take((size_t)512 * 256 * 16 * sizeof(float));
-        b.tmp1 = (float*)take(512 * sizeof(float));   // block partials of the spectral-norm backward's <G, W>
+        b.tmp1 = (float*)take(8 * 512 * sizeof(float));   // block partials of the spectral-norm backward's <G, W>, all layers
+        for (int li = 0; li < kLayers; ++li) {
+            b.raw_l[li] = b.fold_l[li] = nullptr;
+            if (!kL[li].sn) continue;
+            b.raw_l[li] = (float*)take((size_t)kL[li].cout * p.cin_v[li] * 9 * sizeof(float));
+            if (kL[li].k4) b.fold_l[li] = (float*)take((size_t)kL[li].cout * kL[li].cin * 16 * sizeof(float));
+        }
         // weight-gradient slabs: the largest launch is <= 80 products (wgrad.hip kMaxJobs) x its splits
         size_t pb = 0;
         const int res[4][2] = {{p.d.h, p.d.w}, {p.d.h / 2, p.d.w / 2}, {p.d.h / 4, p.d.w / 4}, {p.d.h / 8, p.d.w / 8}};
@@ -385,7 +397,7 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
         const Layer& l = kL[li];
         const int cin_pad = p.cin_pad[li], cin_v = p.cin_v[li], chunks = cin_pad / 32;
         float* dst = grad + p.w_off[li];
-        float* raw = (!l.sn && !l.k4) ? dst : b.raw;
+        float* raw = (!l.sn && !l.k4) ? dst : (l.sn ? b.raw_l[li] : b.raw);
         // as many 32-channel output tiles per launch as the weight-gradient launcher takes: <= 96 tap-products (wgrad.h) and <= 80
         // algorithmic products (its reduction's argument block) -- a 128..256-channel layer is one or two launch pairs, not 2..4
         const int parts = x2 ? wgrad_x2_products() : 1;
@@ -428,14 +440,26 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
             DRUN(wgrad_batch(cs, nc, N, h, w, dt, 0, splits, b.partial, st));
         }
         }
-        const float* cur = raw;
-        if (l.k4) { DRUN(fold4x4_dispatch(raw, b.folded, l.cout, l.cin, st)); cur = b.folded; }
-        if (l.sn) {   // gradient wrt weight_orig from the gradient wrt W = weight_orig / sigma, with THIS call's u, v, sigma
-            const int cols = l.cin * (l.k4 ? 16 : 9);
-            DRUN(spectral_norm_bwd_dispatch(cur, params + p.w_off[li], b.uv + p.u_off[li], b.uv + p.v_off[li], b.sigma + li * 2, dst, l.cout,
-                                            cols, 0, b.tmp1, st));
-        }
+        if (l.sn) return RESR_OK;   // fold + spectral-norm backward of all normalised layers: batched at the end of the pass
+        if (l.k4) { DRUN(fold4x4_dispatch(raw, b.folded, l.cout, l.cin, st)); }   // (no such layer: every 4x4 layer is normalised)
         return RESR_OK;
+    };
+    // gradient wrt weight_orig from the gradient wrt W = weight_orig / sigma, with THIS call's u, v, sigma -- every normalised layer
+    // in three launches (fold of the 4x4 layers, <G, W> partials, apply) instead of 38
+    auto finish_sn = [&]() -> int {
+        if (!need_w) return RESR_OK;
+        const float* fs[4]; float* fd[4]; int fco[4], fc[4]; int nf = 0;
+        const float* G[8]; const float* Wp[8]; const float* up[8]; const float* vp[8]; const float* sg[8]; float* ds[8]; int rws[8], cls[8]; int n = 0;
+        for (int li = 0; li < kLayers; ++li) {
+            const Layer& l = kL[li];
+            if (!l.sn) continue;
+            if (l.k4) { fs[nf] = b.raw_l[li]; fd[nf] = b.fold_l[li]; fco[nf] = l.cout; fc[nf] = l.cin; ++nf; }
+            G[n] = l.k4 ? b.fold_l[li] : b.raw_l[li]; Wp[n] = params + p.w_off[li]; up[n] = b.uv + p.u_off[li]; vp[n] = b.uv + p.v_off[li];
+            sg[n] = b.sigma + li * 2; ds[n] = grad + p.w_off[li]; rws[n] = l.cout; cls[n] = l.cin * (l.k4 ? 16 : 9);
+            ++n;
+        }
+        if (nf) DRUN(fold4x4_batch_dispatch(nf, fs, fd, fco, fc, st));
+        return spectral_norm_bwd_batch_dispatch(n, G, Wp, up, vp, sg, ds, rws, cls, b.tmp1, st);
     };
     auto dconv = [&](int li, const char* g, int gs, int h, int w, char* out, int out_stride, int flags, const char* mask, int mask_stride,
                      char* aux, int s2d_out, long lo_g, long lo_o) {
@@ -469,6 +493,7 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
     DRUN(dconv(DOWN1, b.G1, 128, H1, W1, b.g_s1, 256, 0, nullptr, 0, nullptr, 64, lo_h1_128, lo_h1_256));
     DRUN(d2s_add_mask_dispatch(b.g_s1, b.g_u3, nullptr, b.G0, N, S, W, 64, dt, kSlope, st, lo_h1_256, lo64, lo64));
     DRUN(wgrad_layer(CONV1, b.x_in, 32, b.G0, 64, S, W, lo_in, lo64));
+    DRUN(finish_sn());
     if (gx) {
         DRUN(dconv(CONV1, b.G0, 64, S, W, b.gxin, 32, 0, nullptr, 0, nullptr, 0, lo64, lo_in));
         DRUN(nhwc_to_nchw_dispatch(b.gxin, gx, N, 3, S, W, 1, 32, dt, st, lo_in));
