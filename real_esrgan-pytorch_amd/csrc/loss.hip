@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kLossThreads) void l1_mean_kernel(const float* __re
 
 // out[r] = coef[r] * sum_k partial[r][k] for r < rows, out[rows] = sum_r out[r]: the five weighted feature distances of the
 // perceptual term (model.py:320-335) and their total from the partial sums of resr_l1_partial, one launch.
-__global__ __launch_bounds__(256) void weighted_rows_kernel(const float* __restrict__ partial, int rows, int cols, const float* __restrict__ coef_dev,
+__global__ __launch_bounds__(256) void weighted_rows_kernel(const float* __restrict__ partial, int rows, int cols,
                                                             float c0, float c1, float c2, float c3, float c4, float c5, float c6, float c7,
                                                             float* __restrict__ out) {
     const float coef[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void weighted_rows_kernel(const float* __restr
         for (int k = lane; k < cols; k += 64) acc += partial[(size_t)r * cols + k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) rowv[r] = acc * (coef_dev ? coef_dev[r] : coef[r]);
+        if (lane == 0) rowv[r] = acc * coef[r];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -162,7 +162,7 @@ int weighted_rows_dispatch(const float* partial, int rows, int cols, const float
     if (!partial || !coef || !out || rows <= 0 || rows > 8 || cols <= 0) return fail(RESR_ERR_ARG, "weighted_rows: bad argument");
     float c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = 0; r < rows; ++r) c[r] = coef[r];
-    hipLaunchKernelGGL(weighted_rows_kernel, dim3(1), dim3(256), 0, st, partial, rows, cols, (const float*)nullptr, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], out);
+    hipLaunchKernelGGL(weighted_rows_kernel, dim3(1), dim3(256), 0, st, partial, rows, cols, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], out);
     RESR_CHECK_LAUNCH("weighted_rows_kernel");
     return RESR_OK;
 }
