@@ -66,6 +66,11 @@ def main(path, steps=4, top=45, marker="ema_kernel"):
     print(f"window {span / 1e6 / steps:.3f} ms/step  busy {busy / 1e6 / steps:.3f} ms/step ({100 * busy / span:.1f} %)  gaps {sum(gs) / 1e6 / steps:.3f} ms/step in "
           f"{len(gaps) / steps:.0f} ({100 * sum(gs) / span:.1f} %), median gap {gs[len(gs) // 2] / 1e3:.2f} us, gaps > 50 us: {sum(1 for g in gs if g > 50e3) / steps:.1f} per step "
           f"= {sum(g for g in gs if g > 50e3) / 1e6 / steps:.3f} ms/step")
+    small = sum(g for g in gs if g <= 50e3)
+    big = sum(g for g in gs if g > 50e3)
+    print(f"  of which launch latency between dependent kernels (gaps <= 50 us): {small / 1e6 / steps:.3f} ms/step = {100 * small / max(1, span - big):.1f} % of the span "
+          f"without the > 50 us gaps -- those are the HOST falling behind under the tracer (the untraced step is printed by the tool's plain run: "
+          f"its length is kernel time + launch latency, the host enqueues ahead)")
     by = {}
     for g, n in gaps:
         a = by.setdefault(short(n)[:70], [0, 0])
