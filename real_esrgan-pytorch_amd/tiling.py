@@ -12,6 +12,11 @@ output pixels per tensor) and that compute the fewest pixels: fewer, larger wind
 shift -- a 3840x2160 frame of the x2 model is three full-height columns (windows 2160x1344: 1.05x the frame's pixels;
 fixed 1024-pixel tiles computed 1.71x).
 
+Precision: the tiler runs the `Generator` it is given, in that model's arithmetic.  The reference has no tiler; its whole-image
+inference call sites run fp32 (inference.py:52-53), so a caller that wants the reference's numbers builds the model the way
+`inference.py` does -- `Generator(..., precision=config.inference_precision)`, i.e. "exact16" -- and one that wants frames per
+second (BASELINE config 5: "fp16-class" tiled inference) builds it with precision="fast".
+
 hipGraph: the WHOLE frame loop -- for every tile: window gather, the ~350 launches of the generator, the stitch copy --
 is captured once per (frame shape, parameter arena) into one graph over static frame-in / frame-out buffers and replayed
 per frame: one host call per frame instead of ~355 per tile.
