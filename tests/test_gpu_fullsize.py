@@ -170,3 +170,34 @@ def test_tiled_4k_frame_two_tilings_agree():
     b = TiledGenerator(g, tile=(720, 1280), halo=32, use_graph=False)(frame)
     assert a.shape == b.shape == (1, 3, 4320, 7680) and torch.isfinite(a).all()
     assert torch.equal(a, b)
+
+
+def test_discriminator_layer_mode_at_config4_size():
+    """BASELINE config 4's per-GPU discriminator batch (16 x 256^2): the 256..512-channel layers' weight gradients in layer mode
+    (one launch pair per layer, 2..8 pixel splits, work cut into eight XCD ranges) against the table-mode launch pairs -- equal to
+    fp32 summation noise -- and the batched spectral-norm backward leaves every gradient finite."""
+    import os
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(5)
+    sd = R.Discriminator(precision="fast").state_dict()
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    x = torch.rand(16, 3, 256, 256, device="cuda", generator=gen)
+    gw = torch.randn(16, 1, 256, 256, device="cuda", generator=gen)
+
+    def grads(table_mode):
+        if table_mode:
+            os.environ["RESR_WGRAD_NO_LAYER_MODE"] = "1"
+        try:
+            d = R.Discriminator(precision="fast")
+            d.load_state_dict(sd)
+            d = d.cuda().train()
+            (d(x) * gw).sum().mul(64.0).backward()
+            torch.cuda.synchronize()
+            return {n: p.grad.clone() for n, p in d.named_parameters()}
+        finally:
+            os.environ.pop("RESR_WGRAD_NO_LAYER_MODE", None)
+    layer, table = grads(False), grads(True)
+    for n in layer:
+        assert torch.isfinite(layer[n]).all(), n
+        rel = ((layer[n] - table[n]).norm() / table[n].norm().clamp_min(1e-12)).item()
+        assert rel < 2e-5, (n, rel)
