@@ -193,6 +193,32 @@ def test_content_loss_forward_vs_oracle(precision, tol):
             assert abs(g.item() - r.item()) < tol * max(r.item(), 1e-6), (precision, aliasing, g.item(), r.item())
 
 
+@pytest.mark.parametrize("precision", ["fast", "exact16"])
+def test_vgg_grouped_launches_equal_one_launch_per_group(precision):
+    """VGG19's 128..512-channel layers as ONE launch each (`ResrConvDesc.cout_groups` with a bias) against one launch per 64-channel
+    group (RESR_VGG_PER_GROUP=1, read per call): the same tiles, weights and biases -- every tapped feature bit-equal, forward and
+    through the native backward."""
+    from real_esrgan_pytorch_amd.content_loss import _FeatureFn
+    cl, sd, nodes, mean, std = _vgg_case(precision, True)
+    gen = torch.Generator().manual_seed(21)
+    x, other = torch.rand(2, 3, 64, 96, generator=gen).cuda(), torch.rand(2, 3, 64, 96, generator=gen).cuda()
+    res = []
+    for per_group in (False, True):
+        if per_group:
+            os.environ["RESR_VGG_PER_GROUP"] = "1"
+        try:
+            xd = x.clone().requires_grad_(True)
+            outs = _FeatureFn.apply(cl, xd, other)
+            sum(o.square().sum() for o in outs).mul(4.0).backward()
+            torch.cuda.synchronize()
+            res.append([o.detach().clone() for o in outs] + [xd.grad.clone()])
+        finally:
+            os.environ.pop("RESR_VGG_PER_GROUP", None)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert res[0][-1].abs().sum().item() > 0
+
+
 def _vgg_case(precision, aliasing):
     from real_esrgan_pytorch_amd.content_loss import ContentLoss
     nodes = ["features.2", "features.7", "features.16", "features.25", "features.34"]      # config.py:131
