@@ -37,7 +37,15 @@ static int launch_chain(const ConvArgs& a, const ChainArgs& cj, double flop, dou
     const int ntiles = args.tiles_x * args.tiles_y * a.n;   // a multiple of 8 (n is)
     // every workgroup must be resident (the flags are waited for inside the launch): the grid never exceeds what the device
     // holds at once, and is a multiple of 8 so that each XCD gets the same number of workgroups
-    const unsigned grid = (unsigned)((ntiles < resident ? ntiles : resident) & ~7);
+    unsigned grid = (unsigned)((ntiles < resident ? ntiles : resident) & ~7);
+    // $RESR_CHAIN_CUS_PER_XCD = k (1..32, read per call): at most k workgroups per XCD, i.e. 32 - k CUs of every XCD stay free for a
+    // co-resident kernel of another stream -- an RCCL collective overlapped with the backward pass (RESR_DP_OVERLAP=1) then runs NEXT
+    // to the chained launches instead of delaying their polls.  Costs the launches tiles / (8 k) instead of tiles / 256 rounds:
+    // ~3 % at the headline geometry with k = 31, a whole round at one tile per CU (the 64^2 crops).  Results do not depend on it.
+    if (const char* e = getenv("RESR_CHAIN_CUS_PER_XCD")) {
+        const int k = atoi(e);
+        if (k >= 1 && k < 32 && grid > (unsigned)k * 8u) grid = (unsigned)k * 8u;
+    }
     if (grid == 0) return fail(RESR_ERR_LAUNCH, "conv3x3_chain: empty grid");
     prof_before(stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), lds, stream, args, cj);

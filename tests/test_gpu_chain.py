@@ -380,3 +380,27 @@ def test_chained_launches_inside_a_captured_graph():
         torch.cuda.synchronize()
     assert torch.equal(y_side, y_eager) and torch.equal(static_y, y_eager)
     assert int(lib.resr_debug_chain_errors()) == 0
+
+
+def test_chain_grid_headroom_knob_keeps_results():
+    """RESR_CHAIN_CUS_PER_XCD (read per call): the chained launches on at most k workgroups per XCD -- room for a co-resident
+    collective -- produce bit-equal outputs and gradients (tile ownership follows a workgroup's XCD ticket, whatever the grid)."""
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(0)
+    g = R.Generator(3, 3, 4, precision="fast", n_blocks=2).cuda().train()
+    x = torch.rand(8, 3, 64, 64, device="cuda")
+    res = []
+    for k in (None, "31", "7"):
+        if k:
+            os.environ["RESR_CHAIN_CUS_PER_XCD"] = k
+        try:
+            g.zero_grad(set_to_none=True)
+            y = g(x)
+            y.square().sum().mul(64.0).backward()
+            torch.cuda.synchronize()
+            res.append((y.detach().clone(), g.flat_grad().clone()))
+        finally:
+            os.environ.pop("RESR_CHAIN_CUS_PER_XCD", None)
+    for y, gr in res[1:]:
+        assert torch.equal(y, res[0][0]) and torch.equal(gr, res[0][1])
+    assert int(R._lib.lib().resr_debug_chain_errors()) == 0
