@@ -167,6 +167,66 @@ __global__ __launch_bounds__(256) void bilinear_up_kernel(const T* __restrict__ 
     st_vals(dst + (((size_t)b * oh + oy) * ow + ox) * c + g * E, lo_dst, o);
 }
 
+// The same outputs, four per thread: the output quad rows {2y+1, 2y+2} x columns {2x+1, 2x+2} interpolates between the SAME four
+// source pixels (y, y+1) x (x, x+1) with weights 0.25 / 0.75 -- four 16-byte loads for four 16-byte stores instead of four for one
+// (the one-output kernel spent its time in the texture-address path: 2.8 TB/s on 335 MB).  Quads y = -1 / x = -1 (output row /
+// column 0) and the quads of the last source row / column take the one-output path per pixel (their clamped coordinates); the
+// interior arithmetic is bil_coord's, term for term: bit-identical outputs.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up_quad_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int h, int w,
+                                                               int c, long lo_src, long lo_dst) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const unsigned groups = (unsigned)c / E, ow = 2u * w;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // (quad column + 1, g) inside the quad row
+    if (idx >= (unsigned)(w + 1) * groups) return;
+    const unsigned qx1 = idx / groups, g = idx - qx1 * groups;
+    const int x = (int)qx1 - 1, y = (int)blockIdx.y - 1, b = (int)blockIdx.z, oh = 2 * h;
+    const T* base = src + (size_t)b * h * w * c + g * E;
+    T* obase = dst + (size_t)b * oh * ow * c + g * E;
+    if (y >= 0 && y < h - 1 && x >= 0 && x < w - 1) {
+        float a[E], bq[E], cq[E], d[E], o[E];
+        ld_vals(base + ((size_t)y * w + x) * c, lo_src, a);
+        ld_vals(base + ((size_t)y * w + x + 1) * c, lo_src, bq);
+        ld_vals(base + ((size_t)(y + 1) * w + x) * c, lo_src, cq);
+        ld_vals(base + ((size_t)(y + 1) * w + x + 1) * c, lo_src, d);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float ly = r ? 0.75f : 0.25f, hy = 1.f - ly;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float lx = q ? 0.75f : 0.25f, hx = 1.f - lx;
+#pragma unroll
+                for (int e = 0; e < E; ++e) o[e] = hy * (hx * a[e] + lx * bq[e]) + ly * (hx * cq[e] + lx * d[e]);
+                st_vals(obase + ((size_t)(2 * y + 1 + r) * ow + (2 * x + 1 + q)) * c, lo_dst, o);
+            }
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+        const int oy = 2 * y + 1 + r;
+        if (oy < 0 || oy >= oh) continue;
+#pragma unroll 1
+        for (int q = 0; q < 2; ++q) {
+            const int ox = 2 * x + 1 + q;
+            if (ox < 0 || ox >= (int)ow) continue;
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bil_coord(oy, h, y0, y1, ly);
+            bil_coord(ox, w, x0, x1, lx);
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            float a[E], bq[E], cq[E], d[E], o[E];
+            ld_vals(base + ((size_t)y0 * w + x0) * c, lo_src, a);
+            ld_vals(base + ((size_t)y0 * w + x1) * c, lo_src, bq);
+            ld_vals(base + ((size_t)y1 * w + x0) * c, lo_src, cq);
+            ld_vals(base + ((size_t)y1 * w + x1) * c, lo_src, d);
+#pragma unroll
+            for (int e = 0; e < E; ++e) o[e] = hy * (hx * a[e] + lx * bq[e]) + ly * (hx * cq[e] + lx * d[e]);
+            st_vals(obase + ((size_t)oy * ow + ox) * c, lo_dst, o);
+        }
+    }
+}
+
 // backward as a gather: input pixel (y,x) collects from the <= 4x4 outputs whose stencil touches it
 // optional second output: gmasked = gin * (mask > 0 ? 1 : slope) (the LeakyReLU backward that follows in the discriminator; gin
 // itself is kept, it is a skip gradient later) -- computed from the rounded gin, like a separate add_mask pass would
@@ -252,8 +312,11 @@ int bilinear_up_dispatch(const void* src, void* dst, int n, int h, int w, int c,
     if (h > 32767 || n > 65535) return fail(RESR_ERR_ARG, "bilinear_up2x: image too large");
     const dim3 gf((unsigned)((2L * w * (c / E) + 255) / 256), (unsigned)(2 * h), (unsigned)n);   // forward: one thread per output piece
     const dim3 gb((unsigned)(((long)w * (c / E) + 255) / 256), (unsigned)h, (unsigned)n);       // backward: per input piece
+    const dim3 gq((unsigned)(((long)(w + 1) * (c / E) + 255) / 256), (unsigned)(h + 1), (unsigned)n);   // forward: one thread per output quad piece
+    static const bool one_px = getenv("RESR_BILINEAR_ONE_PX") != nullptr;                                 // the one-output-per-thread forward kernel (A/B)
     if (dtype != RESR_F32) {
-        if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<half_t>, gf, dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, lo_src, lo_dst);
+        if (!backward && !one_px) hipLaunchKernelGGL(bilinear_up_quad_kernel<half_t>, gq, dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, lo_src, lo_dst);
+        else if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<half_t>, gf, dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, lo_src, lo_dst);
         else hipLaunchKernelGGL(bilinear_up_bwd_kernel<half_t>, gb, dim3(256), 0, st, (const half_t*)src, (half_t*)dst, n, h, w, c, (const half_t*)nullptr, (half_t*)nullptr, 0.f, lo_src, lo_dst);
     } else {
         if (!backward) hipLaunchKernelGGL(bilinear_up_kernel<float>, gf, dim3(256), 0, st, (const float*)src, (float*)dst, n, h, w, c, 0L, 0L);

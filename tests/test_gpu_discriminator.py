@@ -403,3 +403,33 @@ def test_layer_mode_weight_gradients_equal_table_mode():
         assert rel(layer[n], table[n]) < 2e-5, (n, rel(layer[n], table[n]))
         assert rel(layer[n], strict[n]) < 0.12, (n, rel(layer[n], strict[n]))
     assert sum(n.startswith(("down_block2", "down_block3", "up_block1")) for n in layer) == 3      # the three layers that take it
+
+
+@pytest.mark.parametrize("shape", [(2, 7, 5, 64), (1, 1, 9, 8), (3, 6, 1, 16), (2, 16, 24, 128), (1, 2, 2, 8)])
+def test_bilinear_up2x_quad_kernel_vs_torch_and_f32_kernel(shape):
+    """resr_bilinear_up2x (F.interpolate(scale_factor=2, mode="bilinear", align_corners=False), discriminator_arch: model.py:170-184).
+    The f16 forward computes four outputs per thread; the f32 forward one per thread.  Same fp32 arithmetic per output, so the f16
+    result must be the ROUNDED f32 result bit for bit, on ragged shapes too (single rows / columns, odd sizes); both within fp32
+    rounding of torch; the backward gather is the adjoint (torch autograd)."""
+    import real_esrgan_pytorch_amd as R
+    L = R._lib.lib()
+    n, h, w, c = shape
+    torch.manual_seed(h * 100 + w)
+    src16 = torch.randn(n, h, w, c, device="cuda").half()
+    src32 = src16.float()
+    out16 = torch.empty(n, 2 * h, 2 * w, c, device="cuda", dtype=torch.half)
+    out32 = torch.empty(n, 2 * h, 2 * w, c, device="cuda", dtype=torch.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.resr_bilinear_up2x(src16.data_ptr(), out16.data_ptr(), n, h, w, c, R._lib.RESR_F16, 0, st) == 0
+    assert L.resr_bilinear_up2x(src32.data_ptr(), out32.data_ptr(), n, h, w, c, R._lib.RESR_F32, 0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out16, out32.half())
+    x = src32.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    assert (out32 - ref.detach().permute(0, 2, 3, 1)).abs().max().item() <= 2e-6
+    g32 = torch.randn(n, 2 * h, 2 * w, c, device="cuda")
+    gin32 = torch.empty(n, h, w, c, device="cuda")
+    assert L.resr_bilinear_up2x(g32.data_ptr(), gin32.data_ptr(), n, h, w, c, R._lib.RESR_F32, 1, st) == 0
+    ref.backward(g32.permute(0, 3, 1, 2))
+    torch.cuda.synchronize()
+    assert (gin32 - x.grad.permute(0, 2, 3, 1)).abs().max().item() <= 1e-5
