@@ -500,6 +500,7 @@ struct SnLayer {
     float* vraw;     // [groups][cols] scratch
     int rows, cols, groups;
     int first_a, first_b;   // first workgroup of this layer in the W^T u launch / in the W v launch
+    int first_c;            // ... in the launch that adds the groups' partial vectors
 };
 struct SnArgs {
     SnLayer l[kSnMaxLayers];
@@ -511,6 +512,20 @@ __device__ __forceinline__ int sn_layer_of(const SnArgs& a, int block, bool wv_l
     int li = 0;
     while (li + 1 < a.n && block >= (wv_launch ? a.l[li + 1].first_b : a.l[li + 1].first_a)) ++li;
     return li;
+}
+
+// vraw[0][k] = sum over the groups of vraw[g][k], one thread per column, groups in ascending order.  (As a loop inside the
+// one-workgroup-per-layer normalisation this was 16 groups x 18 columns of dependent loads per thread: 62 us per call for the
+// 512 x 4608 layer; the sums and everything after them are unchanged.)
+__global__ __launch_bounds__(256) void sn_sum_groups_kernel(const SnArgs a) {
+    int li = 0;
+    while (li + 1 < a.n && (int)blockIdx.x >= a.l[li + 1].first_c) ++li;
+    const SnLayer& L = a.l[li];
+    const int k = ((int)blockIdx.x - L.first_c) * 256 + (int)threadIdx.x;
+    if (k >= L.cols) return;
+    float t = L.vraw[k];
+    for (int g = 1; g < L.groups; ++g) t += L.vraw[(size_t)g * L.cols + k];
+    L.vraw[k] = t;
 }
 
 __global__ __launch_bounds__(256) void sn_wt_u_kernel(const SnArgs a) {
@@ -546,19 +561,17 @@ __device__ float block_sum(float v, float* red) {
     return t;
 }
 
-// one workgroup per layer.  which = 0: src = the sum of the layer's `groups` partial vectors W^T u (fixed order), v = src /
+// one workgroup per layer.  which = 0: src = W^T u (the groups' partial vectors already added by sn_sum_groups_kernel), v = src /
 // max(||src||, eps).  which = 1: src = W v, u = src / max(||src||, eps), sigma = dot(u, src), sigma2 = (sigma, 1 / sigma).
 __global__ __launch_bounds__(256) void sn_normalize_kernel(const SnArgs a, int which) {
     __shared__ float red[4];
     const SnLayer& L = a.l[blockIdx.x];
     float* src = which ? L.wv : L.vraw;
     float* dst = which ? L.u : L.v;
-    const int n = which ? L.rows : L.cols, parts = which ? 1 : L.groups;
+    const int n = which ? L.rows : L.cols;
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
-        float t = src[i];
-        for (int g = 1; g < parts; ++g) t += src[(size_t)g * n + i];
-        src[i] = t;
+        const float t = src[i];
         s += t * t;
     }
     const float nrm = sqrtf(block_sum(s, red));
@@ -605,19 +618,21 @@ int spectral_norm_batch_dispatch(int n, const float* const* W, float* const* u, 
     SnArgs a;
     memset(&a, 0, sizeof(a));
     a.n = n; a.eps = eps;
-    int na = 0, nb = 0;
+    int na = 0, nb = 0, nc = 0;
     for (int i = 0; i < n; ++i) {
         if (!W[i] || !u[i] || !v[i] || !sigma2[i] || !tmp[i] || rows[i] <= 0 || cols[i] <= 0) return fail(RESR_ERR_ARG, "spectral_norm: bad argument");
         SnLayer& L = a.l[i];
         L.W = W[i]; L.u = u[i]; L.v = v[i]; L.sigma2 = sigma2[i];
         L.rows = rows[i]; L.cols = cols[i]; L.groups = (rows[i] + kSnRows - 1) / kSnRows;
         L.wv = tmp[i]; L.vraw = tmp[i] + rows[i];
-        L.first_a = na; L.first_b = nb;
+        L.first_a = na; L.first_b = nb; L.first_c = nc;
         na += ((cols[i] + 255) / 256) * L.groups;
         nb += rows[i];
+        nc += (cols[i] + 255) / 256;
     }
     if (training) {               // one power iteration, u and v updated in place (torch spectral_norm, training forward)
         hipLaunchKernelGGL(sn_wt_u_kernel, dim3(na), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(sn_sum_groups_kernel, dim3(nc), dim3(256), 0, st, a);
         hipLaunchKernelGGL(sn_normalize_kernel, dim3(n), dim3(256), 0, st, a, 0);
         hipLaunchKernelGGL(sn_w_v_kernel, dim3(nb), dim3(256), 0, st, a);
         hipLaunchKernelGGL(sn_normalize_kernel, dim3(n), dim3(256), 0, st, a, 1);   // sigma = u_new . (W v_new)
