@@ -142,9 +142,10 @@ int64_t resr_chain_errors(void);
  * (autograd backward of F.conv2d wrt weight, all conv call sites of model.py) and
  * db[co] = sum_p G[p][co].  Two launches: partial sums over pixel splits into `partial`
  * (fp32, resr_wgrad_partial_bytes), then a deterministic reduce that writes dW (OIHW fp32,
- * scaled by `scale`) and db.  cout_pad is 32 or 64 -- or, for RESR_F16, any multiple of 32: a convolution of more than 80
- * (32-channel chunk x 32-channel tile) products runs as ONE "layer mode" launch pair whose jobs follow from their grid
- * position instead of a job table (the discriminator's 256..512-channel layers, model.py:140-160). */
+ * scaled by `scale`) and db.  cout_pad is 32 or 64 -- or, for RESR_F16 / RESR_F16X2, any multiple of 32: a convolution of
+ * more than 80 (32-channel chunk x 32-channel tile) products (RESR_F16X2: more than 96 tap-products) runs as ONE "layer mode"
+ * launch pair whose jobs follow from their grid position instead of a job table (the discriminator's 256..512-channel
+ * layers, model.py:140-160). */
 typedef struct {
     int32_t n, h, w;
     int32_t cin, cin0, in0_stride, in1_stride; /* X operand, same addressing as ResrConvDesc      */

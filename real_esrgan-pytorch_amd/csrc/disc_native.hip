@@ -29,7 +29,8 @@ size_t wgrad_batch_partial_bytes(const WgradConv*, int, int, int);
 int wgrad_batch(const WgradConv*, int, int, int, int, int, int, int, float*, hipStream_t);
 int wgrad_tile_rows(int dtype);
 int wgrad_layer(const WgradConv*, int, int, int, int, int, int, float*, hipStream_t);   // (called as resr::wgrad_layer below: a lambda shares the name)
-size_t wgrad_layer_partial_bytes(int cin, int cout_pad, int splits);
+size_t wgrad_layer_partial_bytes(int cin, int cout_pad, int splits, int dtype);
+int wgrad_x2_products();
 int wgrad_x2_products();
 int pack_dispatch(const ResrPackChunk*, int, const float*, void*, int, hipStream_t);
 int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long);
@@ -132,11 +133,21 @@ int wsplits(int dtype, int jobs, int n, int h, int w) {
 // layer-mode launch pair (wgrad.hip, WgradLayer): one residency round of workgroups -- 256 / quad jobs pixel splits -- instead of
 // 2..8 launch pairs of 24 splits each (the 512-channel 4x4 layer at 16 x 32^2: eight pairs of 52 us for 69 GFLOP).
 constexpr int kLayerModeProducts = 96;
-int layer_splits(int products, int n, int h, int w) {
+int layer_splits(int products, int n, int h, int w, int parts = 1) {
     const long tiles = (long)((w + 31) / 32) * ((h + 7) / 8) * n;
-    const int nq = (products + 3) / 4;
+    const int nq = ((products + 3) / 4) * parts;
     long s = 256 / nq;
     if (s >= 16) s &= ~7L;
+    if (parts > 1) {
+        // exact16's three tap-products per product: up to 384 quad jobs -- more than one residency round.  The split count (<= 8)
+        // whose workgroups fill whole rounds of 256 best, the smaller one on a tie (fewer slabs)
+        double best = -1.0;
+        for (long c = 1; c <= 8; ++c) {
+            const long wg = (long)nq * c, rounds = (wg + 255) / 256;
+            const double fill = (double)wg / (double)(rounds * 256);
+            if (fill > best + 1e-9) { best = fill; s = c; }
+        }
+    }
     if (s > tiles / 2) s = tiles / 2;
     return (int)(s < 1 ? 1 : s);
 }
@@ -194,13 +205,16 @@ void carve(const DPlan& p, char* base, DBufs& b) {
                 const size_t v = (size_t)jobs * wsplits(p.d.dtype, jobs, p.d.n, res[q][0], res[q][1]) * (9 * 1024 + 32) * sizeof(float);
                 if (v > pb) pb = v;
             }
-        if (p.d.dtype == RESR_F16)   // layer-mode launches (one per 256..512-channel layer)
+        if (p.d.dtype == RESR_F16 || p.d.dtype == RESR_F16X2)   // layer-mode launches (one per 256..512-channel layer)
             for (int li = 0; li < kLayers; ++li) {
                 const int products = (p.cin_pad[li] / 32) * (p.cout_pad[li] / 32);
                 if (products < kLayerModeProducts) continue;
                 const int q = li == DOWN1 || li == UP2 ? 1 : li == DOWN2 || li == UP1 ? 2 : li == DOWN3 ? 3 : 0;
-                const size_t v = wgrad_layer_partial_bytes(p.cin_pad[li], p.cout_pad[li], layer_splits(products, p.d.n, res[q][0], res[q][1]));
-                if (v > pb) pb = v;
+                // exact16: one or three tap-products per product ($RESR_X2_WGRAD_PRODUCTS is read per call) -- room for either
+                for (int parts = 1; parts <= (p.d.dtype == RESR_F16X2 ? 3 : 1); parts += 2) {
+                    const size_t v = (size_t)products * parts * layer_splits(products, p.d.n, res[q][0], res[q][1], parts) * (9 * 1024 + 32) * sizeof(float);
+                    if (v > pb) pb = v;
+                }
             }
         b.partial_bytes = pb;
         b.partial = (float*)take(pb);
@@ -402,15 +416,15 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
         // algorithmic products (its reduction's argument block) -- a 128..256-channel layer is one or two launch pairs, not 2..4
         const int parts = x2 ? wgrad_x2_products() : 1;
         const char* no_layer_mode = getenv("RESR_WGRAD_NO_LAYER_MODE");   // A/B knob, read per call: the table-mode launch pairs
-        if (dt == RESR_F16 && chunks * (r32(l.cout) / 32) >= kLayerModeProducts && !no_layer_mode) {
+        if ((dt == RESR_F16 || dt == RESR_F16X2) && chunks * (r32(l.cout) / 32) >= kLayerModeProducts && !no_layer_mode) {
             WgradConv c;
             c.x0 = x; c.cin = cin_pad; c.in0_stride = xs; c.cin_real = cin_v;
             c.g = g; c.cout = l.cout; c.cout_pad = r32(l.cout); c.g_stride = gs;
-            c.x_chunk_stride = c.g_chunk_stride = 0; c.x_lo_off = c.g_lo_off = 0;
+            c.x_chunk_stride = c.g_chunk_stride = 0; c.x_lo_off = x2 ? lo_xw : 0; c.g_lo_off = x2 ? lo_gw : 0;
             c.x_s2d_c = l.k4 ? l.cin : 0;
             c.dw = raw; c.db = (l.bias ? grad + p.b_off[li] : nullptr); c.scale = 1.f;
-            const int splits = layer_splits(chunks * (c.cout_pad / 32), N, h, w);
-            if (wgrad_layer_partial_bytes(cin_pad, c.cout_pad, splits) > b.partial_bytes) return fail(RESR_ERR_WORKSPACE, "discriminator: wgrad slabs (layer mode)");
+            const int splits = layer_splits(chunks * (c.cout_pad / 32), N, h, w, parts);
+            if (wgrad_layer_partial_bytes(cin_pad, c.cout_pad, splits, dt) > b.partial_bytes) return fail(RESR_ERR_WORKSPACE, "discriminator: wgrad slabs (layer mode)");
             DRUN(resr::wgrad_layer(&c, N, h, w, dt, 0, splits, b.partial, st));
         } else {
         int tiles_per = kWgradMaxJobs / (chunks * parts);

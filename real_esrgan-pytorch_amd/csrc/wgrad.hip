@@ -80,6 +80,7 @@ struct ReduceArgs {
     const float* partial;
     int splits;
     int layer_nck;   // > 0: layer mode (WgradLayer) -- workgroup row b reduces product (b / nck, b % nck) of the convolution jobs[0] describes
+    unsigned layer_part_stride;   // layer mode, RESR_F16X2 with three tap-products: floats from a product's (hi, hi) slabs to its (hi, lo) and on to its (lo, hi) slabs; else 0
 };
 
 static_assert(sizeof(ReduceArgs) <= 4096, "kernel arguments");
@@ -352,16 +353,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const ReduceArgs
     if (a.layer_nck > 0) {
         const int ct = blockIdx.x / a.layer_nck, ck = blockIdx.x - ct * a.layer_nck;
         job.slab_off = blockIdx.x * (unsigned)a.splits * (unsigned)kSlab;
+        if (a.layer_part_stride) { job.slab_b = job.slab_off + a.layer_part_stride; job.slab_c = job.slab_b + a.layer_part_stride; }
         job.co_base = (short)(ct * 32); job.ci_base = (short)(ck * 32);
         job.want_bias = (short)((ck == 0 && job.db) ? 1 : 0);
     }
     const int e = blockIdx.y * 256 + threadIdx.x;
     if (e >= kSlab) return;
-    const float* p = a.partial + job.slab_off + e;
-    float v[8];
+    auto tree = [&](unsigned off) {
+        const float* p = a.partial + off + e;
+        float v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = k < a.splits ? p[(size_t)k * kSlab] : 0.f;
-    const float s = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) * job.scale;
+        for (int k = 0; k < 8; ++k) v[k] = k < a.splits ? p[(size_t)k * kSlab] : 0.f;
+        return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    };
+    float s = tree(job.slab_off);
+    if (job.slab_b != ~0u) {   // RESR_F16X2: dW = A + (B + C) * 2^-12, bias sums: only the g_lo product
+        float s2 = tree(job.slab_b);
+        if (e < 9 * 1024) s2 += tree(job.slab_c);
+        s = __builtin_fmaf(s2, kLoInv, s);
+    }
+    s *= job.scale;
     if (e < 9 * 1024) {
         const int tap = e >> 10, co = job.co_base + ((e >> 5) & 31), ci = job.ci_base + (e & 31);
         if (co < job.cout && ci < job.cin_real) job.dw[((size_t)co * job.cin_real + ci) * 9 + tap] = s;
@@ -401,6 +412,11 @@ struct WgradLayer {
     int nck, nct, nxp;                  // X chunks, G tiles, X chunk pairs ((nck + 1) / 2); nxp == 0: table mode
     int x_s2d_c;                        // > 0: X is a space-to-depth image with this many channels per sub-position (sparse taps)
     int want_bias;
+    // RESR_F16X2 with three tap-products per product: quad job j >= nq repeats quad j - nq on (x_hi, g_lo), j >= 2 nq on (x_lo, g_hi);
+    // part p's slabs start p * part_slabs floats behind part 0's
+    int nparts, ngp;                    // 1 or 3; G tile pairs ((nct + 1) / 2)
+    long x_lo_b, g_lo_b;                // bytes from the hi to the lo tensor
+    unsigned part_slabs;
 };
 
 struct WgradQuadArgs {
@@ -444,22 +460,24 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
     unsigned sx0, sx1, sg0, sg1, j_xsub, j_bias_mask, j_slab0, j_slab1, j_slab2, j_slab3;
     if (a.layer.nxp > 0) {   // layer mode: the quad's operands and slabs from its grid position
         const WgradLayer& L = a.layer;
-        const int xp = jq % L.nxp, gp = jq / L.nxp;
+        const int xp = jq % L.nxp, gpt = jq / L.nxp;
+        const int part = L.nparts > 1 ? gpt / L.ngp : 0, gp = gpt - part * L.ngp;
         const int ck0 = 2 * xp, ct0 = 2 * gp;
         const bool x2nd = ck0 + 1 < L.nck, g2nd = ct0 + 1 < L.nct;
-        jx0 = L.x + (size_t)ck0 * L.x_chunk_b; jx1 = x2nd ? jx0 + L.x_chunk_b : nullptr;
-        jg0 = L.g + (size_t)ct0 * L.g_chunk_b; jg1 = g2nd ? jg0 + L.g_chunk_b : nullptr;
+        jx0 = L.x + (size_t)ck0 * L.x_chunk_b + (part == 2 ? L.x_lo_b : 0L); jx1 = x2nd ? jx0 + L.x_chunk_b : nullptr;
+        jg0 = L.g + (size_t)ct0 * L.g_chunk_b + (part == 1 ? L.g_lo_b : 0L); jg1 = g2nd ? jg0 + L.g_chunk_b : nullptr;
         sx0 = sx1 = L.xstride_b; sg0 = sg1 = L.gstride_b;
         const unsigned sub0 = L.x_s2d_c > 0 ? (unsigned)((ck0 * 32) / L.x_s2d_c) : 4u;
         const unsigned sub1 = (L.x_s2d_c > 0 && x2nd) ? (unsigned)(((ck0 + 1) * 32) / L.x_s2d_c) : 4u;
         j_xsub = sub0 | (sub1 << 8);
         const unsigned per = (unsigned)a.splits * (unsigned)kSlab;        // floats per product
-        auto slab = [&](int ct, int ck) { return (unsigned)(ct * L.nck + ck) * per; };
+        const unsigned pbase = (unsigned)part * L.part_slabs;
+        auto slab = [&](int ct, int ck) { return pbase + (unsigned)(ct * L.nck + ck) * per; };
         j_slab0 = slab(ct0, ck0);
         j_slab1 = x2nd ? slab(ct0, ck0 + 1) : ~0u;
         j_slab2 = g2nd ? slab(ct0 + 1, ck0) : ~0u;
         j_slab3 = (x2nd && g2nd) ? slab(ct0 + 1, ck0 + 1) : ~0u;
-        j_bias_mask = (L.want_bias && ck0 == 0) ? 0x5u : 0u;             // products p = 0 (x0, g0) and p = 2 (x0, g1)
+        j_bias_mask = (L.want_bias && ck0 == 0 && part < 2) ? 0x5u : 0u;  // products p = 0 (x0, g0) and p = 2 (x0, g1); not of (x_lo, g_hi)
     } else {
         const WgradQuad& job = a.jobs[jq];
         jx0 = job.x[0]; jx1 = job.x[1]; jg0 = job.g[0]; jg1 = job.g[1];
@@ -679,6 +697,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     if (a.layer_nck > 0) {
         const int ct = blockIdx.x / a.layer_nck, ck = blockIdx.x - ct * a.layer_nck;
         job.slab_off = blockIdx.x * (unsigned)a.splits * (unsigned)kSlab;
+        if (a.layer_part_stride) { job.slab_b = job.slab_off + a.layer_part_stride; job.slab_c = job.slab_b + a.layer_part_stride; }
         job.co_base = (short)(ct * 32); job.ci_base = (short)(ck * 32);
         job.want_bias = (short)((ck == 0 && job.db) ? 1 : 0);
     }
@@ -942,8 +961,9 @@ size_t wgrad_batch_partial_bytes(const WgradConv* convs, int nconv, int splits, 
 }
 
 // One convolution with a regular grid of more products than a launch's job table holds (WgradLayer): one launch pair for the
-// whole layer.  f16 only; cout_pad any multiple of 32.
-static int wgrad_layer_launch(const WgradConv& c, int n, int h, int w, int flags, int splits, float* partial, hipStream_t stream) {
+// whole layer.  RESR_F16 and RESR_F16X2 (nparts = 3: the (hi, lo) and (lo, hi) tap-products as two more rounds of quad jobs with
+// their own slab regions, combined by the reduction exactly as in table mode); cout_pad any multiple of 32.
+static int wgrad_layer_launch(const WgradConv& c, int n, int h, int w, int flags, int splits, int nparts, float* partial, hipStream_t stream) {
     const bool up = flags & RESR_CONV_UPSAMPLE_IN;
     const size_t es = 2;
     static thread_local WgradQuadArgs q;
@@ -958,12 +978,15 @@ static int wgrad_layer_launch(const WgradConv& c, int n, int h, int w, int flags
     L.xstride_b = (unsigned)(c.in0_stride * es); L.gstride_b = (unsigned)(c.g_stride * es);
     L.nck = nck; L.nct = nct; L.nxp = (nck + 1) / 2;
     L.x_s2d_c = c.x_s2d_c; L.want_bias = c.db ? 1 : 0;
-    const int nq = L.nxp * ((nct + 1) / 2);
+    L.nparts = nparts; L.ngp = (nct + 1) / 2;
+    L.x_lo_b = c.x_lo_off * (long)es; L.g_lo_b = c.g_lo_off * (long)es;
+    L.part_slabs = (unsigned)((size_t)nck * nct * splits * kSlab);
+    const int nq = L.nxp * L.ngp * nparts;
     {   // 32-bit lane offsets: every operand below 2^24 pixels and 4 GB
         const size_t px = (size_t)n * h * w;
         const size_t smax = L.xstride_b > L.gstride_b ? L.xstride_b : L.gstride_b;
         if (!(px <= (1u << 24) && smax < (1u << 24) && px * smax + 64 < (1ull << 32))) return fail(RESR_ERR_ARG, "wgrad (layer mode): operand too large for 32-bit offsets");
-        if ((size_t)nck * nct * splits * kSlab >= (1ull << 32)) return fail(RESR_ERR_ARG, "wgrad (layer mode): slab offsets exceed 32 bits");
+        if ((size_t)nck * nct * splits * kSlab * nparts >= (1ull << 32)) return fail(RESR_ERR_ARG, "wgrad (layer mode): slab offsets exceed 32 bits");
     }
     q.partial = partial;
     q.n = n; q.h = h; q.w_ = w; q.hs = up ? h / 2 : h; q.ws = up ? w / 2 : w; q.up = up ? 1 : 0; q.splits = splits; q.njobs = nq;
@@ -982,12 +1005,12 @@ static int wgrad_layer_launch(const WgradConv& c, int n, int h, int w, int flags
     const double sparse = c.x_s2d_c > 0 ? 4.0 / 9.0 : 1.0;
     prof_before(stream);
     hipLaunchKernelGGL(wgrad_quad_kernel, dim3(per_xcd * 8), dim3(512), lds, stream, q);
-    prof_after(stream, 50200, 2.0 * 9 * 32 * 32 * sparse * nck * nct * (double)n * h * w, (double)(nck + nct) * 64.0 * (double)n * h * w);
+    prof_after(stream, 50200, 2.0 * 9 * 32 * 32 * sparse * nck * nct * nparts * (double)n * h * w, (double)(nck + nct) * 64.0 * nparts * (double)n * h * w);
     RESR_CHECK_LAUNCH("wgrad_quad_kernel (layer mode)");
     ReduceJob& j = r.jobs[0];
     j.dw = c.dw; j.db = c.db; j.slab_off = 0; j.slab_b = j.slab_c = ~0u; j.co_base = j.ci_base = 0;
     j.cout = c.cout; j.cin_real = c.cin_real; j.scale = c.scale; j.want_bias = 0; j.pad_ = 0;
-    r.partial = partial; r.splits = splits; r.layer_nck = nck;
+    r.partial = partial; r.splits = splits; r.layer_nck = nck; r.layer_part_stride = nparts > 1 ? L.part_slabs : 0u;
     if (splits <= 8) hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(nck * nct, (kSlab + 255) / 256), dim3(256), 0, stream, r);
     else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nck * nct, (kSlab + 31) / 32), dim3(256), 0, stream, r);
     RESR_CHECK_LAUNCH("wgrad_reduce_kernel (layer mode)");
@@ -995,17 +1018,20 @@ static int wgrad_layer_launch(const WgradConv& c, int n, int h, int w, int flags
 }
 
 // floats of slab scratch a layer-mode launch needs
-size_t wgrad_layer_partial_bytes(int cin, int cout_pad, int splits) { return (size_t)(cin / 32) * (cout_pad / 32) * splits * kSlab * sizeof(float); }
+size_t wgrad_layer_partial_bytes(int cin, int cout_pad, int splits, int dtype) {
+    return (size_t)(cin / 32) * (cout_pad / 32) * (dtype == RESR_F16X2 ? wgrad_x2_products() : 1) * splits * kSlab * sizeof(float);
+}
 
 // entry for the whole-network planners: one f16 convolution, cout_pad any multiple of 32, as one layer-mode launch pair
 int wgrad_layer(const WgradConv* c, int n, int h, int w, int dtype, int flags, int splits, float* partial, hipStream_t stream) {
     if (!c || !partial || !c->x0 || !c->g || !c->dw) return fail(RESR_ERR_ARG, "wgrad_layer: null argument");
-    if (dtype != RESR_F16) return fail(RESR_ERR_ARG, "wgrad_layer: f16 only");
+    if (dtype != RESR_F16 && dtype != RESR_F16X2) return fail(RESR_ERR_ARG, "wgrad_layer: RESR_F16 or RESR_F16X2 only");
+    if (dtype == RESR_F16X2 && (c->x_lo_off <= 0 || c->g_lo_off <= 0)) return fail(RESR_ERR_ARG, "wgrad_layer: RESR_F16X2 needs the hi -> lo offsets of X and G");
     if (splits <= 0 || splits > 65535) return fail(RESR_ERR_ARG, "wgrad_layer: splits=%d", splits);
     if (c->cin <= 0 || (c->cin & 31) || c->cout_pad <= 0 || (c->cout_pad & 31) || c->cout <= 0 || c->cout > c->cout_pad || c->cin_real <= 0 || c->cin_real > c->cin)
         return fail(RESR_ERR_ARG, "wgrad_layer: cin=%d cin_real=%d cout=%d cout_pad=%d", c->cin, c->cin_real, c->cout, c->cout_pad);
     if ((flags & RESR_CONV_UPSAMPLE_IN) && ((h | w) & 1)) return fail(RESR_ERR_ARG, "wgrad_layer: upsampled input needs even h,w");
-    return wgrad_layer_launch(*c, n, h, w, flags, splits, partial, stream);
+    return wgrad_layer_launch(*c, n, h, w, flags, splits, dtype == RESR_F16X2 ? wgrad_x2_products() : 1, partial, stream);
 }
 
 int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtype, int flags, int splits,
@@ -1125,8 +1151,10 @@ int wgrad_dispatch(const ResrWgradDesc* d, const void* x0, const void* x1, const
     c.x_chunk_stride = (long)d->x_chunk_stride; c.g_chunk_stride = (long)d->g_chunk_stride;
     c.x_lo_off = (long)d->x_lo_offset; c.g_lo_off = (long)d->g_lo_offset; c.x_s2d_c = 0;
     c.dw = dw; c.db = db; c.scale = d->scale;
-    // more products than one launch's job table holds (or an output wider than 64 channels): the layer mode (f16)
-    if (d->dtype == RESR_F16 && (c.cout_pad > 64 || (c.cin / 32) * (c.cout_pad / 32) > kMaxReduce))
+    // more products than one launch's job table holds (or an output wider than 64 channels): the layer mode (f16, exact16)
+    const int tap_products = (c.cin / 32) * (c.cout_pad / 32) * (d->dtype == RESR_F16X2 ? wgrad_x2_products() : 1);
+    if ((d->dtype == RESR_F16 || d->dtype == RESR_F16X2) &&
+        (c.cout_pad > 64 || (c.cin / 32) * (c.cout_pad / 32) > kMaxReduce || tap_products > kMaxJobs))
         return wgrad_layer(&c, d->n, d->h, d->w, d->dtype, d->flags, d->splits, partial, stream);
     return wgrad_batch(&c, 1, d->n, d->h, d->w, d->dtype, d->flags, d->splits, partial, stream);
 }

@@ -402,6 +402,11 @@ def test_layer_mode_weight_gradients_equal_table_mode():
     for n in layer:
         assert rel(layer[n], table[n]) < 2e-5, (n, rel(layer[n], table[n]))
         assert rel(layer[n], strict[n]) < 0.12, (n, rel(layer[n], strict[n]))
+    # exact16: the same launch pairs on (hi, lo) operands, three tap-products per product
+    layer16, table16 = grads("exact16", False), grads("exact16", True)
+    for n in layer16:
+        assert rel(layer16[n], table16[n]) < 5e-6, (n, rel(layer16[n], table16[n]))
+        assert rel(layer16[n], strict[n]) < 5e-3, (n, rel(layer16[n], strict[n]))   # two fp32-class evaluations of a random-init network (a LeakyReLU flip or two apart): 1.5e-3 at worst, fast mode: 0.1
     assert sum(n.startswith(("down_block2", "down_block3", "up_block1")) for n in layer) == 3      # the three layers that take it
 
 

@@ -322,6 +322,59 @@ def test_wgrad_layer_mode(U, case, diag_dir):
     assert err_w < 2e-3 * scale and err_b < 2e-3 * max(1.0, bs.grad.abs().max().item()), (err_w, err_b, scale)
 
 
+@pytest.mark.parametrize("products", [3, 1])
+@pytest.mark.parametrize("case", LAYER_CASES, ids=[c[0] for c in LAYER_CASES])
+def test_wgrad_layer_mode_exact16(U, case, products, diag_dir):
+    """Layer mode on RESR_F16X2 operands ((hi, lo) f16 pairs, value = hi + lo * 2^-12): the three tap-products (hi, hi), (hi, lo),
+    (lo, hi) of every product as three rounds of quad jobs with their own slab regions, combined by the reduction -- fp32-class
+    gradients against a float64 autograd of the SAME fp32 inputs (1e-3 is the path's tolerance; measured ~1e-6); with
+    RESR_X2_WGRAD_PRODUCTS=1 (hi tensors only) the f16-class error of one rounding per operand."""
+    L = U.L
+    name, cin, cout, up, n, h, w, splits = case
+    g = torch.Generator().manual_seed(12)
+    hs, ws = (h // 2, w // 2) if up else (h, w)
+    x = torch.randn(n, cin, hs, ws, generator=g)
+    gy = torch.randn(n, cout, h, w, generator=g)
+    cin_pad, cout_pad = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+
+    def pair(t, c_pad):          # [2][n,h,w,stride] f16: the hi tensor, directly behind it the lo tensor
+        hi = t.half()
+        lo = ((t - hi.float()) * 4096.0).half()
+        stride = c_pad + 32
+        buf = torch.zeros(2, t.shape[0], t.shape[2], t.shape[3], stride, dtype=torch.float16, device="cuda")
+        buf[0, ..., :t.shape[1]] = hi.permute(0, 2, 3, 1).cuda()
+        buf[1, ..., :t.shape[1]] = lo.permute(0, 2, 3, 1).cuda()
+        value = hi.double() + lo.double() / 4096.0
+        return buf, buf[0].numel(), value
+    xb, x_lo, xv = pair(x, cin_pad)
+    gb, g_lo, gv = pair(gy, cout_pad)
+    d = L.WgradDesc(n, h, w, cin_pad, cin_pad, cin_pad + 32, 0, cin, cout, cout_pad, cout_pad + 32, L.RESR_F16X2,
+                    L.CONV_UPSAMPLE_IN if up else 0, splits, 1.0)
+    d.x_lo_offset, d.g_lo_offset = x_lo, g_lo
+    os.environ["RESR_X2_WGRAD_PRODUCTS"] = str(products)
+    try:
+        partial = torch.empty(L.lib().resr_wgrad_partial_bytes(C.byref(d)) // 4, device="cuda")
+        dw = torch.full((cout, cin, 3, 3), -7.0, device="cuda")
+        db = torch.full((cout,), -7.0, device="cuda")
+        L.check(L.lib().resr_conv3x3_wgrad(C.byref(d), L.ptr(xb), None, L.ptr(gb), L.ptr(partial), L.ptr(dw), L.ptr(db), L.stream_ptr()),
+                "resr_conv3x3_wgrad")
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("RESR_X2_WGRAD_PRODUCTS", None)
+    xin = F.interpolate(xv, scale_factor=2, mode="nearest") if up else xv
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    bs = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(xin, wt, bs, padding=1) * gv).sum().backward()
+    rel_w = ((dw.cpu().double() - wt.grad).norm() / wt.grad.norm()).item()
+    rel_b = ((db.cpu().double() - bs.grad).norm() / bs.grad.norm()).item()
+    with open(os.path.join(diag_dir, f"wgrad_x2_{name}_{products}.json"), "w") as f:
+        json.dump({"rel_w": rel_w, "rel_b": rel_b}, f)
+    if products == 3:
+        assert rel_w < 5e-6 and rel_b < 5e-6, (rel_w, rel_b)
+    else:
+        assert 1e-5 < rel_w < 2e-3 and rel_b < 2e-3, (rel_w, rel_b)    # the hi-only form drops the 2^-12 terms: visibly coarser, still a gradient
+
+
 @pytest.mark.parametrize("knob", ["RESR_WGRAD_PAIR_KERNEL", "RESR_WGRAD_GENERIC_ADDR"])
 def test_wgrad_fallback_kernels(knob):
     """The f16 pair kernel (used when the quad kernel's grouping or 32-bit addressing preconditions fail) and its 64-bit

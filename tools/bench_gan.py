@@ -13,16 +13,17 @@ ap.add_argument("--hr", type=int, default=256)
 ap.add_argument("--tile", type=int, default=400)
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--content", action="store_true")
+ap.add_argument("--precision", default="fast", choices=["fast", "exact16", "strict"])
 ap.add_argument("--graph", action="store_true", help="replay the step from one hipGraph (train.GraphedStep)")
 a = ap.parse_args()
 torch.manual_seed(0)
-g = R.Generator(3, 3, 4).cuda().train()
-d = R.Discriminator().cuda().train()
+g = R.Generator(3, 3, 4, precision=a.precision).cuda().train()
+d = R.Discriminator(precision=a.precision).cuda().train()
 ema = R.EMA(g, 0.999); ema.register()
 ap_flat = not os.environ.get("RESR_PER_TENSOR_ADAM")
 go = torch.optim.Adam([g.flat_parameter()] if ap_flat else g.parameters(), 1e-4, (0.9, 0.99), fused=True, capturable=a.graph)
 do = torch.optim.Adam([d.flat_parameter()] if ap_flat else d.parameters(), 1e-4, (0.9, 0.99), fused=True, capturable=a.graph)
-cl = R.ContentLoss(["features.2", "features.7", "features.16", "features.25", "features.34"], [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]).cuda() if a.content else None
+cl = R.ContentLoss(["features.2", "features.7", "features.16", "features.25", "features.34"], [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], precision=a.precision).cuda() if a.content else None
 deg = Degrader(batch=a.batch, hr_size=a.tile, upscale=4, crop=a.hr, seed=0)
 step = RealESRGANStep(g, d, ema, go, do, torch.amp.GradScaler("cuda"), deg, content_criterion=cl)
 if a.graph:
