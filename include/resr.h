@@ -28,7 +28,11 @@
 extern "C" {
 #endif
 
-#define RESR_VERSION 1
+/* 2: ResrWgradDesc gained x_chunk_stride / g_chunk_stride (round 4), ResrConvDesc.reserved_ became x2_pair_chunks, ResrGeneratorDesc
+ * gained x2_plan.  A caller built against an older header passes shorter structs: compare resr_version() with the RESR_VERSION it was
+ * compiled with and refuse on a mismatch.  New fields are appended (or replace reserved ones) and mean "as before" when zero, so
+ * zero-initialise every descriptor (memset / = {0}) before filling it. */
+#define RESR_VERSION 2
 
 typedef enum {
     RESR_OK = 0,
@@ -61,7 +65,10 @@ enum {
      * pass); the matching backward-data pass reads it instead of re-reading the saved activation (64 B -> 4 B per
      * pixel and 32 channels in f16).  MASK_BITS goes together with RESR_CONV_MASK, without residuals. */
     RESR_CONV_WRITE_SIGNBITS = 1 << 8,
-    RESR_CONV_MASK_BITS = 1 << 9
+    RESR_CONV_MASK_BITS = 1 << 9,
+    /* RESR_F16X2 only: the output is stored as ONE f16 tensor (the hi tensor; no lo tensor is written and out_lo_offset is
+     * ignored).  A later pass reads such a tensor as a "single" chunk (x2_pair_chunks).  Ignored for other dtypes. */
+    RESR_CONV_OUT_SINGLE = 1 << 10
 };
 
 /* One 3x3, stride 1, pad 1 convolution pass (forward conv or backward-data conv):
@@ -102,7 +109,13 @@ typedef struct {
      * elements (how resr_pack_weights lays out consecutive 64-row chunks tables) and writes / reads out, res0, res1, mask,
      * aux 64*g channels further inside the pixel.  The discriminator's 128..512-channel layers at 32^2..128^2 pixels
      * fill the 256 CUs only this way. */
-    int32_t s2d_in_channels, s2d_out_channels, cout_groups, reserved_;
+    int32_t s2d_in_channels, s2d_out_channels, cout_groups;
+    /* RESR_F16X2 only: P > 0 = only the FIRST P 32-channel input chunks are hi/lo pairs (three stages each: x_hi W0 + x_hi W1 +
+     * x_lo W2); the chunks behind them are single f16 tensors -- no lo tensor is read, two stages each (x W0 + x W1: the weights
+     * stay split, the activation carries 11 bits).  0 = every chunk is a pair.  The dense blocks use P = 2: the residual stream
+     * (x0 x1 / g_y) as pairs, the growth planes (o1..o4 at inference, their gradients in backward) as single f16 -- the rungs of
+     * DESIGN section 2 that keep the 1e-3 gate at 50 instead of 60 stages per block. */
+    int32_t x2_pair_chunks;
 } ResrConvDesc;
 
 int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const void* w_packed,
@@ -154,7 +167,8 @@ typedef struct {
     int32_t dtype, flags;                      /* RESR_CONV_UPSAMPLE_IN honoured for X            */
     int32_t splits;                            /* pixel splits (partial slabs)                    */
     float scale;
-    int64_t x_lo_offset, g_lo_offset;          /* RESR_F16X2: hi -> lo element offsets of X and G */
+    int64_t x_lo_offset, g_lo_offset;          /* RESR_F16X2: hi -> lo element offsets of X and G; g_lo_offset = 0: G is a
+                                                * single f16 tensor (RESR_CONV_OUT_SINGLE): dW = X_hi^T G + 2^-12 X_lo^T G     */
     /* elements between consecutive 32-channel chunks of X / G (0 = 32: interleaved NHWC; a chunk-planar tensor
      * [C/32][N,H,W,32] has pixel stride 32 and chunk stride N*H*W*32 -- how the generator keeps its dense-block workspaces) */
     int64_t x_chunk_stride, g_chunk_stride;
@@ -202,7 +216,21 @@ typedef struct {
     int32_t dtype;            /* RESR_F16 fast / RESR_F32 strict                                  */
     int32_t training;         /* keep activations for backward                                    */
     int32_t wgrad_splits;     /* 0 = auto                                                         */
+    /* RESR_F16X2 only, bit set of RESR_X2_PLAN_*: which tensors of the dense blocks are single f16 instead of hi/lo pairs.  0 =
+     * pairs everywhere (three stages per chunk in every pass: forward 1.8e-6, gradients 5.8e-6 vs float64). */
+    int32_t x2_plan;
+    int32_t reserved_;
 } ResrGeneratorDesc;
+enum {
+    /* inference forward (training = 0) only: the growth planes o1..o4 of every dense block are single f16 tensors, the residual
+     * stream and the HR tail stay pairs, weights stay split: 50 instead of 60 stages per block (forward 1e-6 at the reference's
+     * init scale; a TRAINING forward ignores the bit -- a 2^-12 perturbation of a pre-activation flips LeakyReLU mask elements) */
+    RESR_X2_PLAN_GROWTH_F16_INFER = 1,
+    /* backward: the gradients of the growth planes (g_o1..g_o4) are single f16 tensors: their chunks take two stages in the
+     * mirrored backward-data passes and conv1..conv4's weight gradients two tap-products instead of three (worst gradient
+     * tensor 3-5e-4 vs float64) */
+    RESR_X2_PLAN_GROWTH_GRAD_F16 = 2
+};
 
 size_t resr_generator_param_count(const ResrGeneratorDesc* d);
 size_t resr_generator_packed_bytes(const ResrGeneratorDesc* d, int32_t backward);

@@ -17,6 +17,9 @@ CONV_LRELU, CONV_UPSAMPLE_IN, CONV_CLAMP01, CONV_OUT_NCHW_F32, CONV_MASK, CONV_N
 CONV_AUX_BEFORE_MASK, CONV_AUX_BEFORE_RES = 64, 128
 CONV_WRITE_SIGNBITS = 1 << 8
 CONV_MASK_BITS = 1 << 9
+CONV_OUT_SINGLE = 1 << 10
+X2_PLAN_GROWTH_F16_INFER, X2_PLAN_GROWTH_GRAD_F16 = 1, 2
+RESR_VERSION = 2   # include/resr.h: the structures below mirror THIS version of the header
 
 
 class ConvDesc(C.Structure):
@@ -31,7 +34,7 @@ class ConvDesc(C.Structure):
                 ("in0_lo_offset", C.c_int64), ("in1_lo_offset", C.c_int64), ("out_lo_offset", C.c_int64),
                 ("res0_lo_offset", C.c_int64), ("res1_lo_offset", C.c_int64),
                 ("s2d_in_channels", C.c_int32), ("s2d_out_channels", C.c_int32), ("cout_groups", C.c_int32),
-                ("reserved_", C.c_int32)]
+                ("x2_pair_chunks", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -56,7 +59,8 @@ class ProfEntry(C.Structure):
 class GeneratorDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
                 ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("upscale", C.c_int32),
-                ("n_blocks", C.c_int32), ("dtype", C.c_int32), ("training", C.c_int32), ("wgrad_splits", C.c_int32)]
+                ("n_blocks", C.c_int32), ("dtype", C.c_int32), ("training", C.c_int32), ("wgrad_splits", C.c_int32),
+                ("x2_plan", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class DiscriminatorDesc(C.Structure):
@@ -149,6 +153,9 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        if handle.resr_version() != RESR_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {handle.resr_version()}, this package binds version {RESR_VERSION}: "
+                               "rebuild it (python real_esrgan-pytorch_amd/csrc/build.py --force)")
         _lib = handle
     return _lib
 

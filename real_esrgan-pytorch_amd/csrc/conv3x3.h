@@ -27,7 +27,10 @@ struct ConvArgs {
     int tiles_x, tiles_y;
     // RESR_F16X2: byte offsets hi -> lo of the two input segments, element offsets hi -> lo of out / residuals
     size_t in0_lo_b, in1_lo_b;
-    long out_lo, res0_lo, res1_lo;
+    long out_lo, res0_lo, res1_lo;   // out_lo = 0: the output is a single f16 tensor (RESR_CONV_OUT_SINGLE), no lo store
+    // RESR_F16X2: the first pair_chunks 32-channel input chunks are hi/lo pairs (three stages each), the chunks behind them single
+    // f16 tensors (two stages: x W0 + x W1); >= cin / 32 = every chunk a pair (ResrConvDesc.x2_pair_chunks)
+    int pair_chunks, out_single;
     // sparse taps of a 4x4 / stride-2 convolution run over the space-to-depth image (conv3x3_ws.h, SP): channels per
     // sub-position of the input (forward), sub-position of this launch's output group (backward-data)
     int s2d_c, tap_c;
@@ -85,11 +88,13 @@ struct ChainArgs {
 struct ChainNone {};
 
 // Algorithmic HBM bytes of one pass: input channels + output (+ mask, residuals, aux) once per pixel.
+// (es = 4 for RESR_F16X2 pairs: single f16 chunks / a single f16 output count 2 bytes per element)
 inline double conv_algorithmic_bytes(const ConvArgs& a, size_t es) {
     const double px_out = (double)a.n * a.h * a.w_, px_in = (double)a.n * a.hs * a.ws;
-    double b = px_in * a.cin * es;
+    const int pair_ch = (es == 4 && a.pair_chunks > 0 && a.pair_chunks * 32 < a.cin) ? a.pair_chunks * 32 : a.cin;
+    double b = px_in * (pair_ch * (double)es + (a.cin - pair_ch) * 2.0);
     const bool nchw = a.flags & RESR_CONV_OUT_NCHW_F32;
-    b += px_out * a.cout * (nchw ? 4 : es);
+    b += px_out * a.cout * (nchw ? 4 : (es == 4 && a.out_single) ? 2 : es);
     if (a.flags & RESR_CONV_MASK) b += px_out * ((a.flags & RESR_CONV_MASK_BITS) ? ((a.cout + 31) / 32) * 4.0 : a.cout * (double)es);
     if (a.res0) b += px_out * a.cout * es;
     if (a.res1) b += px_out * a.cout * es;

@@ -340,8 +340,19 @@ static int conv3x3_args(const ResrConvDesc* d, const void* in0, const void* in1,
     a.in0_chunk_b = (size_t)chunk(d->in0_chunk_stride) * es; a.in1_chunk_b = (size_t)chunk(d->in1_chunk_stride) * es;
     a.out_chunk = chunk(d->out_chunk_stride); a.res0_chunk = chunk(d->res0_chunk_stride);
     a.res1_chunk = chunk(d->res1_chunk_stride); a.mask_chunk = chunk(d->mask_chunk_stride);
-    a.flags = d->flags; a.s0 = d->s0; a.t0 = d->t0; a.s1 = d->s1; a.t1 = d->t1; a.slope = d->slope;
+    a.flags = d->flags & ~RESR_CONV_OUT_SINGLE; a.s0 = d->s0; a.t0 = d->t0; a.s1 = d->s1; a.t1 = d->t1; a.slope = d->slope;
     a.s2d_c = 0; a.tap_c = 0; a.ngroups = 1; a.w_group_b = 0;
+    // RESR_F16X2: leading pair chunks / a single-f16 output (kept out of a.flags: the kernels and the chain checks never see the bit)
+    a.pair_chunks = d->cin / 32; a.out_single = 0;
+    if (d->dtype == RESR_F16X2) {
+        if (d->x2_pair_chunks < 0 || d->x2_pair_chunks > d->cin / 32)
+            return fail(RESR_ERR_ARG, "conv3x3: x2_pair_chunks=%d of %d chunks", d->x2_pair_chunks, d->cin / 32);
+        if (d->x2_pair_chunks > 0) a.pair_chunks = d->x2_pair_chunks;
+        if (d->flags & RESR_CONV_OUT_SINGLE) {
+            if (d->flags & RESR_CONV_OUT_NCHW_F32) return fail(RESR_ERR_ARG, "conv3x3: OUT_SINGLE is an NHWC f16 output");
+            a.out_single = 1;
+        }
+    }
     const int groups = d->cout_groups > 1 ? d->cout_groups : 1;
     if (groups > 1) {
         const bool biased = bias && !(d->flags & RESR_CONV_NO_BIAS);
@@ -385,11 +396,12 @@ static int conv3x3_route(const ResrConvDesc* d, ConvArgs& a, bool have_bias, boo
         // hi/lo pairs: only the producer/consumer kernel has the mode (an aux tensor of AUX_BEFORE_* has out's shape and out's
         // hi -> lo offset)
         const bool nchw = d->flags & RESR_CONV_OUT_NCHW_F32;
-        if (d->in0_lo_offset == 0 || (in1 && d->cin0 < d->cin && d->in1_lo_offset == 0) || (!nchw && d->out_lo_offset == 0) ||
+        const bool in1_pairs = in1 && d->cin0 < d->cin && a.pair_chunks * 32 > d->cin0;   // does the second segment hold pair chunks?
+        if (d->in0_lo_offset == 0 || (in1_pairs && d->in1_lo_offset == 0) || (!nchw && !a.out_single && d->out_lo_offset == 0) ||
             (res0 && d->res0_lo_offset == 0) || (res1 && d->res1_lo_offset == 0))
-            return fail(RESR_ERR_ARG, "conv3x3: RESR_F16X2 needs the hi -> lo offset of every operand");
+            return fail(RESR_ERR_ARG, "conv3x3: RESR_F16X2 needs the hi -> lo offset of every pair operand");
         a.in0_lo_b = (size_t)d->in0_lo_offset * es; a.in1_lo_b = (size_t)d->in1_lo_offset * es;
-        a.out_lo = (long)d->out_lo_offset; a.res0_lo = (long)d->res0_lo_offset; a.res1_lo = (long)d->res1_lo_offset;
+        a.out_lo = a.out_single ? 0L : (long)d->out_lo_offset; a.res0_lo = (long)d->res0_lo_offset; a.res1_lo = (long)d->res1_lo_offset;
         if (!conv3x3_ws_supported(a))
             return fail(RESR_ERR_ARG, "conv3x3: RESR_F16X2 needs tensors below 4 GB / 2^24 pixels and cout %% 8 == 0");
         return conv3x3_ws_f16(a, mt, true, stream);
@@ -440,9 +452,10 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
     if (ok && x2) {   // hi -> lo offsets as conv3x3_route sets them for single launches
         const size_t es2 = 2;
         for (int j = 0; j < njobs; ++j) {
-            if (d[j].dtype != RESR_F16X2 || d[j].in0_lo_offset == 0 || d[j].out_lo_offset == 0 || (in1 && d[j].cin0 < d[j].cin && d[j].in1_lo_offset == 0)) { ok = false; break; }
+            const bool in1_pairs = in1 && d[j].cin0 < d[j].cin && a[j].pair_chunks * 32 > d[j].cin0;
+            if (d[j].dtype != RESR_F16X2 || d[j].in0_lo_offset == 0 || (d[j].out_lo_offset == 0 && !a[j].out_single) || (in1_pairs && d[j].in1_lo_offset == 0)) { ok = false; break; }
             a[j].in0_lo_b = (size_t)d[j].in0_lo_offset * es2; a[j].in1_lo_b = (size_t)d[j].in1_lo_offset * es2;
-            a[j].out_lo = (long)d[j].out_lo_offset;
+            a[j].out_lo = a[j].out_single ? 0L : (long)d[j].out_lo_offset;
         }
         if (ok && d5) {
             if (d5->dtype != RESR_F16X2 || d5->in0_lo_offset == 0 || d5->out_lo_offset == 0 || (res0_5 && d5->res0_lo_offset == 0) ||
@@ -454,9 +467,13 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
     const int fwd_flags = RESR_CONV_LRELU | RESR_CONV_WRITE_SIGNBITS, inf_flags = RESR_CONV_LRELU;
     const int bwd_flags = RESR_CONV_MASK | RESR_CONV_MASK_BITS | RESR_CONV_NO_BIAS;
     const ConvArgs& b = a[njobs - 1];   // the widest growth job: its in0 / in1 split describes every prefix
+    // exact16: one "leading pair chunks" count for the whole chain (kAllPairs: every chunk of every job is a pair)
+    constexpr int kAllPairs = 1 << 20;
+    auto eff_pairs = [&](const ConvArgs& c) { return c.pair_chunks * 32 < c.cin ? c.pair_chunks : kAllPairs; };
+    const int chain_pairs = eff_pairs(b);
     for (int j = 0; ok && j < njobs; ++j) {
         const ConvArgs& c = a[j];
-        ok = d[j].dtype == d[0].dtype && d[j].cout_pad == 32 && c.cout == 32 && c.in0_lo_b == b.in0_lo_b && c.in1_lo_b == b.in1_lo_b && (c.flags == fwd_flags || c.flags == bwd_flags || c.flags == inf_flags) &&
+        ok = d[j].dtype == d[0].dtype && (!x2 || eff_pairs(c) == chain_pairs || c.cin <= chain_pairs * 32) && c.out_single == b.out_single && d[j].cout_pad == 32 && c.cout == 32 && c.in0_lo_b == b.in0_lo_b && c.in1_lo_b == b.in1_lo_b && (c.flags == fwd_flags || c.flags == bwd_flags || c.flags == inf_flags) &&
              c.flags == b.flags && c.n == b.n && c.h == b.h && c.w_ == b.w_ && c.hs == c.h && c.ws == c.w_ &&
              (c.n % 8) == 0 && (c.w_ % 2) == 0 && c.slope == b.slope &&
              c.in0_stride_b == 64 && c.in0_chunk_b == b.in0_chunk_b && c.out_stride == 32 &&
@@ -486,7 +503,7 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
         const int c0 = c.cin - 32;
         const bool seg1 = c0 >= c.cin0;
         const char* last = seg1 ? c.in1 + (size_t)((c0 - c.cin0) >> 5) * c.in1_chunk_b : c.in0 + (size_t)(c0 >> 5) * c.in0_chunk_b;
-        with5 = with5 && d5->dtype == d[0].dtype && c.in0_lo_b == b.in0_lo_b && c.in1_lo_b == b.in1_lo_b && d5->cout_pad == 64 && c.cout == 64 && c.cin == b.cin + 32 && last == b.out &&
+        with5 = with5 && d5->dtype == d[0].dtype && (!x2 || eff_pairs(c) == chain_pairs) && !c.out_single && c.in0_lo_b == b.in0_lo_b && c.in1_lo_b == b.in1_lo_b && d5->cout_pad == 64 && c.cout == 64 && c.cin == b.cin + 32 && last == b.out &&
                 (c.flags & ~RESR_CONV_NO_BIAS) == 0 && ((c.flags & RESR_CONV_NO_BIAS) != 0) == ((b.flags & RESR_CONV_NO_BIAS) != 0) &&
                 c.n == b.n && c.h == b.h && c.w_ == b.w_ && c.hs == c.h && c.ws == c.w_ &&
                 c.in0_stride_b == 64 && c.in0_chunk_b == b.in0_chunk_b &&
@@ -514,6 +531,7 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
         bytes[j] = conv_algorithmic_bytes(a[j], x2 ? 4 : 2);
     }
     ConvArgs base = b;
+    base.pair_chunks = chain_pairs;
     if (base.cin0 == base.cin) base.cin0 = base.cin;   // single-segment prefix: every chunk of every job lies in in0
     int total = njobs;
     if (with5) {

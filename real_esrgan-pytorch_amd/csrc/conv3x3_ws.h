@@ -270,8 +270,17 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             tile_step = cj.split[pin_job + 1] - cj.split[pin_job];
         }
     }
-    int nchunks = X2 ? 3 * (a.cin >> 5) : a.cin >> 5;   // stages per tile (CH: of the current job)
-    if constexpr (CH) nchunks = (cj.job[CH == 3 ? pin_job : 0].cin >> 5) * (X2 ? 3 : 1);
+    // X2 stage map: the first a.pair_chunks real chunks are hi/lo pairs -- three stages (x_hi W0, x_hi W1, x_lo W2) --, the chunks
+    // behind them single f16 tensors -- two stages (x W0, x W1).  Packed weights keep three blocks per real chunk whatever its
+    // kind (block = chunk * 3 + part; a single chunk never reads its third).
+    const int x2_p = X2 ? a.pair_chunks : 0, x2_p3 = 3 * x2_p;
+    auto stages_of = [&](int cin) { const int c = cin >> 5; return !X2 ? c : (c <= x2_p ? 3 * c : x2_p3 + 2 * (c - x2_p)); };
+    auto st_chunk = [&](int ck) { return !X2 ? ck : (ck < x2_p3 ? ck / 3 : x2_p + ((ck - x2_p3) >> 1)); };      // real chunk of stage ck
+    auto st_part = [&](int ck) { return !X2 ? 0 : (ck < x2_p3 ? ck % 3 : ((ck - x2_p3) & 1)); };               // its part: 0 / 1 on x (hi), 2 on x_lo
+    auto st_wblock = [&](int ck) { return !X2 ? ck : st_chunk(ck) * 3 + st_part(ck); };                        // its packed weight block
+    auto last_stages = [&](int cin) { return !X2 ? 1 : ((cin >> 5) <= x2_p ? 3 : 2); };                        // stages of a job's LAST real chunk
+    int nchunks = stages_of(a.cin);   // stages per tile (CH: of the current job)
+    if constexpr (CH) nchunks = stages_of(cj.job[CH == 3 ? pin_job : 0].cin);
     int tk = 0;
     auto stamp = [&](int role) {
 #ifndef RESR_TRACE   // The timeline hooks are compiled in only by a trace build (python tools/build_variant.py trace -DRESR_TRACE=1; the
@@ -393,11 +402,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             const char* const zero = a.zero;
             const char* poison_src = nullptr;   // CH: set by a poll that gave up, consumed by the halo request that follows it
             auto issue_h = [&](int ck, int hb) {   // halo of (current pix, chunk ck) -> halo buffer hb
-                const int ckr = X2 ? ck / 3 : ck;   // X2: stage ck = (real chunk ck / 3, part ck % 3); part 2 reads the lo tensor
+                const int ckr = st_chunk(ck);   // X2: stage ck = (real chunk, part); part 2 reads the lo tensor
                 const int c0 = ckr * 32;
                 const bool seg1 = c0 >= a.cin0;
                 const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
-                if (X2 && ck - ckr * 3 == 2) base += seg1 ? a.in1_lo_b : a.in0_lo_b;
+                if (X2 && st_part(ck) == 2) base += seg1 ? a.in1_lo_b : a.in0_lo_b;
                 const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
                 if (stride_b != voff_stride) {
 #pragma unroll
@@ -425,8 +434,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     }
                 }
             };
-            auto issue_w = [&](int ck, int par) {   // chunk ck's packed weights, lane-linear = fragment order
-                const char* wbase = a.w + (size_t)ck * C::WBUF;
+            auto issue_w = [&](int ck, int par) {   // stage ck's packed weights, lane-linear = fragment order
+                const char* wbase = a.w + (size_t)st_wblock(ck) * C::WBUF;
 #pragma unroll
                 for (int i = 0; i < C::NWIP; ++i) {
                     const int idx = i * NP + pw;
@@ -442,6 +451,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 // ---- chain: the same pipeline over the stages of ALL jobs; ring weights; the dependent chunk polls first ----
                 const int njobs = cj.njobs;
                 int job = CH == 3 ? pin_job : 0, nch = nchunks;   // job / chunk count of the stage whose halo was requested last
+                int nlast = last_stages(cj.job[job].cin);         // ... and the stages of that job's last (dependent) real chunk
                 int it = first, ick = 0, hb = 0;
                 bool tile_settled = false;   // the current tile's neighbourhood has shown the progress its last chunk needs
                 // job jb's weights of chunk ck: fragment idx of this kernel's 32-channel output tile is fragment idx * w_mt + w_m of
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 auto issue_wj = [&](int jb, int ck, int par) {
                     int wmt = 1, wm = 0;
                     if constexpr (CH == 2) { wmt = cj.job[jb].w_mt; wm = cj.job[jb].w_m; }
-                    const char* wbase = cj.job[jb].w + (size_t)ck * C::WBUF * wmt + (size_t)wm * 1024;
+                    const char* wbase = cj.job[jb].w + (size_t)st_wblock(ck) * C::WBUF * wmt + (size_t)wm * 1024;
 #pragma unroll
                     for (int i = 0; i < C::NWIP; ++i) {
                         const int idx = i * NP + pw;
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         if (it >= tile_end) {
                             it = first;
                             if constexpr (CH == 3) job = njobs;   // pinned: this workgroup's only job is done
-                            else if (++job < njobs) nch = (cj.job[job].cin >> 5) * (X2 ? 3 : 1);
+                            else if (++job < njobs) { nch = stages_of(cj.job[job].cin); nlast = last_stages(cj.job[job].cin); }
                         }
                     }
                     return job < njobs;
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 issue_h(0, 0);
                 __syncthreads();           // the set-up barrier
                 // X2: stage (chunk, part 1) multiplies the x_hi halo of part 0 again with the second weight block: no halo of its own
-                auto needs_hc = [&](int ck) { return !X2 || (ck % 3) != 1; };
+                auto needs_hc = [&](int ck) { return !X2 || st_part(ck) != 1; };
                 bool have_next = advance();   // chunk 1 of the same tile (every job has >= 2 chunks, host-checked)
                 int ck_next = ick, job_next = job;
                 if (have_next && needs_hc(ick)) {
@@ -542,9 +552,9 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             if (ick == 0) tile_settled = false;
                             if (ick == 2 && dep >= 1) tile_settled = poll(it, chain_epoch + (unsigned)dep, chain_epoch + (unsigned)dep + 1u);
                         }
-                        // (X2: the dependent real chunk is the job's last THREE stages; its first halo request -- the hi plane -- polls)
+                        // (X2: the dependent real chunk is the job's last three -- a single f16 plane: two -- stages; its first halo request polls)
                         stamp(0);
-                        if (ick == nch - (X2 ? 3 : 1) && dep >= 0 && !(CH == 3 && tile_settled)) poll(it, chain_epoch + (unsigned)dep + 1u, chain_epoch + (unsigned)dep + 1u);
+                        if (ick == nch - nlast && dep >= 0 && !(CH == 3 && tile_settled)) poll(it, chain_epoch + (unsigned)dep + 1u, chain_epoch + (unsigned)dep + 1u);
                         stamp(0);
                         hb = hb == 2 ? 0 : hb + 1;
 #ifndef RESR_TIMING_NO_H
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             if (first >= ntiles) { __syncthreads(); return; }
             // X2: stage (chunk, part 1) multiplies the SAME x_hi halo as (chunk, part 0) with the second weight block: no new
             // halo is requested for it and the consumers stay on the buffer (one LDS-DMA halo less per three stages)
-            auto needs_h = [&](int ck) { return !X2 || (ck % 3) != 1; };
+            auto needs_h = [&](int ck) { return !X2 || st_part(ck) != 1; };
             const bool wres = nchunks <= C::NWB;
             int it = first, ick = 0;   // the stage whose halo was requested last
             int hb = 0;                // ... and its buffer
@@ -660,8 +670,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             }
         }
         const unsigned wdst0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + C::WOFF);
-        auto stage_weights = [&](int tile, int ck, int par) {   // chunk ck's packed weights of the tile's output group, lane-linear = fragment order
-            const char* wbase = a.w + (size_t)(tile / ntiles_sp) * a.w_group_b + (size_t)ck * C::WBUF;
+        auto stage_weights = [&](int tile, int ck, int par) {   // stage ck's packed weights of the tile's output group, lane-linear = fragment order
+            const char* wbase = a.w + (size_t)(tile / ntiles_sp) * a.w_group_b + (size_t)st_wblock(ck) * C::WBUF;
 #pragma unroll
             for (int i = 0; i < C::NWIP; ++i) {
                 const int idx = i * NP + pw;
@@ -693,14 +703,14 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         for (int tile = first; tile < ntiles; tile += G) {
             stamp(0);
             for (int ck = 0; ck < nchunks; ++ck) {
-                const int ckr = X2 ? ck / 3 : ck;
+                const int ckr = st_chunk(ck), cpart = st_part(ck);
                 const int c0 = ckr * 32;
                 const bool seg1 = c0 >= a.cin0;
                 const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
-                if (X2 && ck - ckr * 3 == 2) base += seg1 ? a.in1_lo_b : a.in0_lo_b;
+                if (X2 && cpart == 2) base += seg1 ? a.in1_lo_b : a.in0_lo_b;
                 const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
                 const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + hpar * BUF);
-                const bool new_halo = !X2 || (ck % 3) != 1;   // X2 part 1: the x_hi halo of part 0 again, second weight block
+                const bool new_halo = !X2 || cpart != 1;   // X2 part 1: the x_hi halo of part 0 again, second weight block
                 if (tile != first || ck != 0) {  // the first stage was requested above
 #pragma unroll
                     for (int i = 0; i < NIP; ++i) {
@@ -717,7 +727,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     else if (nstage < nchunks) stage_weights(tile, ck, ck);    // resident: buffer = chunk, first tile only
                 }
                 par ^= 1;
-                if (!X2 || (ck % 3) != 0) hpar ^= 1;   // X2 part 0: the next stage stays on this buffer
+                if (!X2 || cpart != 0) hpar ^= 1;   // X2 part 0: the next stage stays on this buffer
                 ++nstage;
                 stamp(0);
                 // the next tile's index math runs while this tile's last chunk is in flight
@@ -821,7 +831,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     const int s_ty = s_t2 % a.tiles_y, s_n = s_t2 / a.tiles_y;   // s_n counts images of ALL groups (group = image / a.n)
     // CH 3: only the pinned job
     for (int job = (CH == 3 ? pin_job : 0); job < (CH == 3 ? pin_job + 1 : njobs_c); ++job) {
-    if constexpr (CH) nchunks = (cj.job[job].cin >> 5) * (X2 ? 3 : 1);
+    if constexpr (CH) nchunks = stages_of(cj.job[job].cin);
     for (int tile = first; tile < tile_end; tile += tile_step) {
         if constexpr (FAST) {
             if (tile == first) {
@@ -889,7 +899,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             };
             if constexpr (SP != 0) {
                 // ---- sparse taps: valid dy in {dy0, dy0+1}, valid dx in {dx0, dx0+1}; rows dy0 .. dy0+NT; 2*KS groups ----
-                const int sub = SP == 1 ? ((X2 ? ck / 3 : ck) * 32) / a.s2d_c : ((tile / ntiles_sp) * 64) / a.tap_c;   // wave-uniform
+                const int sub = SP == 1 ? (st_chunk(ck) * 32) / a.s2d_c : ((tile / ntiles_sp) * 64) / a.tap_c;   // wave-uniform
                 auto sparse_stage = [&](auto si_c, auto sj_c) {
                     constexpr int SI = decltype(si_c)::value, SJ = decltype(sj_c)::value;
                     // forward: ky = 2*ty + i - 1 in [0,4)  ->  i = 0: ty in {1,2}, i = 1: ty in {0,1}; backward-data uses the
@@ -937,7 +947,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     default: sparse_stage(I1{}, I1{}); break;
                 }
                 par ^= 1;
-                if (!X2 || (ck % 3) != 0) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
+                if (!X2 || st_part(ck) != 0) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
                 if (wave == 0) stamp(1);
                 continue;
             }
@@ -969,7 +979,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 }
             }
             par ^= 1;
-            if (!X2 || (ck % 3) != 0) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
+            if (!X2 || st_part(ck) != 0) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
             if (wave == 0) stamp(1);
             if constexpr (CH) publish();
         }
@@ -1139,7 +1149,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         for (int k = 0; k < 4; ++k) d[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(q[k], half2v));
                         if (in_img && piece_ok(m, j))
                             *reinterpret_cast<uint4v*>(orow + ((size_t)m * e.out_chunk + j * 16) * 2) = d;
-                        if constexpr (X2) {   // lo = f16((v - hi) * 2^12), behind the hi tensor
+                        if (X2 && e.out_lo != 0) {   // lo = f16((v - hi) * 2^12), behind the hi tensor (out_lo = 0: a single f16 output)
                             uint4v dl;
                             const float2v k4 = {kLoScale, kLoScale};
 #pragma unroll
@@ -1343,7 +1353,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                         for (int r = 0; r < 8; ++r) h[r] = (half_t)v[r];
                         *reinterpret_cast<half8*>(base + idx * 2) = h;
-                        if constexpr (X2) {
+                        if (X2 && e.out_lo != 0) {   // (out_lo = 0: a single f16 output)
                             half8 l;
 #pragma unroll
                             for (int r = 0; r < 8; ++r) l[r] = (half_t)((v[r] - (float)h[r]) * kLoScale);

@@ -3,6 +3,9 @@
 //
 // RESR_F16X2 ("exact16"): every activation / gradient tensor below is a (hi, lo) pair of f16 tensors -- the lo tensor
 // directly follows the hi tensor of the same buffer -- and packed weights take three blocks per chunk (include/resr.h).
+// ResrGeneratorDesc.x2_plan (RESR_X2_PLAN_*) turns the dense blocks' growth planes (inference forward) / their gradients
+// (backward) into single f16 tensors: their chunks then take two stages instead of three and conv1..conv4's weight gradients
+// two tap-products instead of three; the lo halves of those planes stay allocated and unused.
 // HBM plan (T = f16 fast / f32 strict, all tensors pixel-major / NHWC):
 //   x_in              [N,h,w,CI]      input image, pixel-unshuffled, channels padded to 32/64
 //   ws[r], r=0..3B-1  [6][N,h,w,32]   one dense-block workspace per RDB, chunk-planar: planes [x0 x1 | o1 | o2 | o3 | o4]
@@ -223,6 +226,10 @@ void carve(const Plan& p, char* base, Bufs& b) {
         for (int k = 1; k <= wm; k += 2) {          // both weight-gradient settings of RESR_F16X2 (1 or 3 jobs per product)
             const size_t q0 = (size_t)26 * k * splits_for(p, 26 * k, p.h, p.w) * slab;
             if (q0 > pb) pb = q0;
+            if (k == 3) {   // RESR_X2_PLAN_GROWTH_GRAD_F16: conv1..conv4 (14 products) two tap-products each, conv5 (12) three
+                const size_t qg = (size_t)64 * splits_for(p, 64, p.h, p.w) * slab;
+                if (qg > pb) pb = qg;
+            }
             if (78 * k <= kWgradMaxJobs) {
                 const size_t q3 = (size_t)78 * k * splits_for(p, 78 * k, p.h, p.w) * slab;
                 if (q3 > pb) pb = q3;
@@ -399,6 +406,9 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
     const int nws = (int)b.ws.size();
     if ((long)N * h * w * 32 * 16 > 0x7fffffffL) return fail(RESR_ERR_ARG, "generator: batch x resolution too large for 32-bit chunk strides");
     const int plane = N * h * w * 32;  // elements per 32-channel plane of the chunk-planar trunk tensors
+    // exact16 inference with single-f16 growth planes (RESR_X2_PLAN_GROWTH_F16_INFER): o1..o4 are stored without a lo tensor and
+    // read as two-stage chunks; a training forward keeps every pre-activation fp32-class (a rounded input flips LeakyReLU masks)
+    const bool growth_single = x2 && !d->training && (d->x2_plan & RESR_X2_PLAN_GROWTH_F16_INFER);
     // RESR_F16X2: element offset hi -> lo of a buffer holding `planes` 32-channel planes of `pl` elements
     auto LO = [&](long planes, long pl) -> int64_t { return x2 ? planes * pl : 0; };
     const int64_t lo_ws = LO(6, plane), lo_t = LO(2, plane), lo_xin = x2 ? (int64_t)N * h * w * p.ci_pad : 0;
@@ -431,6 +441,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
                 ResrConvDesc cd = conv_desc(p, N, h, w, c.cin, c.cin, 32, 0, 32, 32, 32, RESR_CONV_LRELU);
                 cd.in0_chunk_stride = plane;
                 cd.in0_lo_offset = lo_ws; cd.out_lo_offset = lo_ws;
+                if (growth_single) { cd.x2_pair_chunks = 2; cd.flags |= RESR_CONV_OUT_SINGLE; }
                 char* signs = nullptr;
                 if (d->training) {   // the backward pass reads the 1-bit mask, not the activation
                     cd.flags |= RESR_CONV_WRITE_SIGNBITS;
@@ -447,6 +458,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
             cd.in0_chunk_stride = plane;
             cd.out_chunk_stride = plane;
             cd.in0_lo_offset = lo_ws; cd.out_lo_offset = last ? lo_t : lo_ws;
+            if (growth_single) cd.x2_pair_chunks = 2;
             cd.s0 = 0.2f; cd.t0 = 1.f; cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.res0_lo_offset = lo_ws;  // model.py:95-96
             const char* res1 = nullptr;
             if (r % 3 == 2) {  // model.py:129-130
@@ -524,6 +536,8 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     const bool x2 = d->dtype == RESR_F16X2;
     const size_t wes = es * (x2 ? 3 : 1);
     const int wm = x2 ? wgrad_x2_products() : 1;
+    // exact16 with single-f16 growth-plane gradients (RESR_X2_PLAN_GROWTH_GRAD_F16): g_o1..g_o4 are stored without a lo tensor
+    const bool gg_single = x2 && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_F16);
     const char* pk = (const char*)packed;
     const int N = d->n, h = p.h, w = p.w;
     const int H4 = 4 * h, W4 = 4 * w, H2 = 2 * h, W2 = 2 * w;
@@ -546,9 +560,9 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         return wc;
     };
     auto wgrad_run = [&](const WgradConv* wc, int nconv, int hh, int ww, int flags) -> int {
-        int njobs = 0;
-        for (int i = 0; i < nconv; ++i) njobs += (wc[i].cin / 32) * (wc[i].cout_pad / 32);
-        const int splits = splits_for(p, njobs * wm, hh, ww);
+        int njobs = 0;   // tap-products: wm per product, two of three where G is a single f16 tensor (g_lo_off = 0)
+        for (int i = 0; i < nconv; ++i) njobs += (wc[i].cin / 32) * (wc[i].cout_pad / 32) * ((x2 && wm == 3 && wc[i].g_lo_off == 0) ? 2 : wm);
+        const int splits = splits_for(p, njobs, hh, ww);
         if (wgrad_batch_partial_bytes(wc, nconv, splits, d->dtype) > b.partial_bytes)
             return fail(RESR_ERR_WORKSPACE, "wgrad slab buffer too small");
         return wgrad_batch(wc, nconv, N, hh, ww, d->dtype, flags, splits, b.partial, st);
@@ -643,11 +657,12 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             const int cin = 64 + 32 * ps;
             ResrConvDesc cd = dgrad(h, w, 64, 32, cin, 32, 32, 32, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS, lo_t, lo_gs, lo_gs);
             cd.in0_chunk_stride = plane; cd.in1_chunk_stride = plane;
+            if (gg_single) { cd.x2_pair_chunks = 2; cd.flags |= RESR_CONV_OUT_SINGLE; }   // g_y (in0) pairs, the slab (in1, out) single f16
             char* out = gS + (size_t)ps * plane * es;
             const char* mask = b.bits[r] + (size_t)(k - 1) * N * h * w * sizeof(uint32_t);   // sign plane of o_k
             cds[ps] = cd; ws4[ps] = pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * wes; masks4[ps] = mask; outs4[ps] = out;
             const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
-            wcb[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f, lo_ws, lo_gs);
+            wcb[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f, lo_ws, gg_single ? 0 : lo_gs);
             wcb[k - 1].x_chunk_stride = plane;
         }
         {   // the four mirrored cout-32 passes, then g_x = convT(all) + (skip terms): one chained launch where the kernel supports
@@ -656,6 +671,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             if (nxt == e_idx && pos != 2) nxt = (nxt + 1) & 3;
             ResrConvDesc cd = dgrad(h, w, 64, 32, 192, 32, 64, 64, 32, 0, lo_t, lo_gs, lo_t);
             cd.in0_chunk_stride = plane; cd.in1_chunk_stride = plane; cd.out_chunk_stride = plane;
+            if (gg_single) cd.x2_pair_chunks = 2;
             const char* res0 = gin;
             const char* res1 = nullptr;
             cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.s0 = 1.f; cd.res0_lo_offset = lo_t;

@@ -367,9 +367,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const ReduceArgs
         return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     };
     float s = tree(job.slab_off);
-    if (job.slab_b != ~0u) {   // RESR_F16X2: dW = A + (B + C) * 2^-12, bias sums: only the g_lo product
-        float s2 = tree(job.slab_b);
-        if (e < 9 * 1024) s2 += tree(job.slab_c);
+    if (job.slab_b != ~0u || job.slab_c != ~0u) {   // RESR_F16X2: dW = A + (B + C) * 2^-12, bias sums: only the g_lo product (absent for a single-f16 G)
+        float s2 = job.slab_b != ~0u ? tree(job.slab_b) : 0.f;
+        if (job.slab_c != ~0u && e < 9 * 1024) s2 += tree(job.slab_c);
         s = __builtin_fmaf(s2, kLoInv, s);
     }
     s *= job.scale;
@@ -723,9 +723,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     };
     if (e < kSlab) {
         s = sum_splits(a.partial + job.slab_off + e, 0.f);
-        if (job.slab_b != ~0u) {   // RESR_F16X2: the two cross products (bias sums: only the g_lo one)
-            float s2 = sum_splits(a.partial + job.slab_b + e, 0.f);
-            if (e < 9 * 1024) s2 = sum_splits(a.partial + job.slab_c + e, s2);
+        if (job.slab_b != ~0u || job.slab_c != ~0u) {   // RESR_F16X2: the cross products (bias sums: only the g_lo one; a single-f16 G has none)
+            float s2 = job.slab_b != ~0u ? sum_splits(a.partial + job.slab_b + e, 0.f) : 0.f;
+            if (job.slab_c != ~0u && e < 9 * 1024) s2 = sum_splits(a.partial + job.slab_c + e, s2);
             s = __builtin_fmaf(s2, kLoInv, s);
         }
     }
@@ -954,10 +954,18 @@ int wgrad_x2_products() {
     return kX2WgradProductsDefault;
 }
 
+// tap-products of one algorithmic product: RESR_F16X2 takes wgrad_x2_products() of them -- two of the three where G is a single f16
+// tensor (g_lo_off = 0: no (x_hi, g_lo) product)
+static int wgrad_parts(const WgradConv& c, int dtype) {
+    if (dtype != RESR_F16X2) return 1;
+    const int n = wgrad_x2_products();
+    return (n == 3 && c.g_lo_off == 0) ? 2 : n;
+}
+
 size_t wgrad_batch_partial_bytes(const WgradConv* convs, int nconv, int splits, int dtype) {
     size_t jobs = 0;
-    for (int i = 0; i < nconv; ++i) jobs += (size_t)(convs[i].cin / 32) * (convs[i].cout_pad / 32);
-    return jobs * (dtype == RESR_F16X2 ? wgrad_x2_products() : 1) * splits * kSlab * sizeof(float);
+    for (int i = 0; i < nconv; ++i) jobs += (size_t)(convs[i].cin / 32) * (convs[i].cout_pad / 32) * wgrad_parts(convs[i], dtype);
+    return jobs * splits * kSlab * sizeof(float);
 }
 
 // One convolution with a regular grid of more products than a launch's job table holds (WgradLayer): one launch pair for the
@@ -1052,7 +1060,8 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
     for (int i = 0; i < nconv; ++i) {
         const WgradConv& c = convs[i];
         if (!c.x0 || !c.g || !c.dw) return fail(RESR_ERR_ARG, "wgrad: null tensor");
-        if (x2 && (c.x_lo_off <= 0 || c.g_lo_off <= 0)) return fail(RESR_ERR_ARG, "wgrad: RESR_F16X2 needs the hi -> lo offsets of X and G");
+        if (x2 && (c.x_lo_off <= 0 || c.g_lo_off < 0)) return fail(RESR_ERR_ARG, "wgrad: RESR_F16X2 needs the hi -> lo offsets of X and G (g_lo_offset = 0: G is a single f16 tensor)");
+        const bool g_single = x2 && c.g_lo_off == 0;
         if (c.cin <= 0 || (c.cin & 31) || (c.cout_pad != 32 && c.cout_pad != 64) || c.cout <= 0 || c.cout > c.cout_pad ||
             c.cin_real <= 0 || c.cin_real > c.cin)
             return fail(RESR_ERR_ARG, "wgrad: cin=%d cin_real=%d cout=%d cout_pad=%d", c.cin, c.cin_real, c.cout, c.cout_pad);
@@ -1068,6 +1077,7 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
                 q.cout = c.cout; q.cin_real = c.cin_real; q.scale = c.scale; q.want_bias = (short)want_bias; q.pad_ = 0;
                 // parts: (x_hi, g_hi); RESR_F16X2 adds (x_hi, g_lo) and (x_lo, g_hi)
                 for (int part = 0; part < nparts; ++part) {
+                    if (part == 1 && g_single) continue;   // no g_lo: dW = X_hi^T G + 2^-12 X_lo^T G
                     WgradJob& j = a.jobs[nj++];
                     j.x = xh + (part == 2 ? (size_t)c.x_lo_off * es : 0);
                     j.g = gh + (part == 1 ? (size_t)c.g_lo_off * es : 0);
@@ -1145,6 +1155,14 @@ int wgrad_dispatch(const ResrWgradDesc* d, const void* x0, const void* x1, const
                    float* db, hipStream_t stream) {
     if (!d || !x0 || !g || !partial || !dw) return fail(RESR_ERR_ARG, "wgrad: null argument");
     if (d->cin0 != d->cin || x1) return fail(RESR_ERR_ARG, "wgrad: two-segment X is not supported (cin0 must equal cin)");
+    // (a caller built against the version-1 header passes a shorter struct: whatever lies behind it is read as chunk strides)
+    {
+        const int64_t px = (int64_t)d->n * d->h * d->w;
+        auto bad = [&](int64_t cs) { return cs < 0 || (cs > 0 && (cs < 32 || cs > px * 32 * 64)); };
+        if (bad(d->x_chunk_stride) || bad(d->g_chunk_stride) || d->x_lo_offset < 0 || d->g_lo_offset < 0)
+            return fail(RESR_ERR_ARG, "wgrad: chunk strides %lld / %lld, lo offsets %lld / %lld out of range (zero-initialise ResrWgradDesc; resr_version() = %d)",
+                        (long long)d->x_chunk_stride, (long long)d->g_chunk_stride, (long long)d->x_lo_offset, (long long)d->g_lo_offset, RESR_VERSION);
+    }
     WgradConv c;
     c.x0 = x0; c.cin = d->cin; c.in0_stride = d->in0_stride; c.cin_real = d->cin_real;
     c.g = g; c.cout = d->cout; c.cout_pad = d->cout_pad; c.g_stride = d->g_stride;

@@ -214,19 +214,27 @@ class Generator(nn.Module):
     MFMAs per product, fp32 accumulate: meets the 1e-3 parity tolerance vs the fp32 CPU path at about a third
     of fast mode's throughput), "strict" = f32 operands on v_mfma_f32_32x32x2_f32 (bit-for-bit fp32 FMA chains).
     Default from $RESR_PRECISION, else "fast".
+    `x2_plan` (exact16 only; bit set of _lib.X2_PLAN_*, default from $RESR_X2_PLAN, else both bits): which tensors of the dense
+    blocks are single f16 instead of hi/lo pairs -- bit 0: the growth planes o1..o4 of an INFERENCE forward (50 instead of 60
+    stages per block; forward ~1e-6 at the reference's init scale, gate 2e-4), bit 1: the growth-plane gradients of the backward
+    pass (two stages / two tap-products on their chunks; worst gradient tensor 3-5e-4 vs float64, gate 1e-3).  x2_plan=0 = pairs
+    everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
     forward(x[N,C,H,W] float in [0,1]) -> [N,out,H*s,W*s] clamped to [0,1]; differentiable.
     """
 
     N_BLOCKS = 23
 
     def __init__(self, in_channels: int, out_channels: int, upscale_factor: int,
-                 precision: Optional[str] = None, n_blocks: Optional[int] = None) -> None:
+                 precision: Optional[str] = None, n_blocks: Optional[int] = None, x2_plan: Optional[int] = None) -> None:
         super().__init__()
         if upscale_factor not in (1, 2, 4):
             raise ValueError("upscale_factor must be 1, 2 or 4")
         self.in_channels, self.out_channels, self.upscale_factor = in_channels, out_channels, upscale_factor
         self.precision = precision or os.environ.get("RESR_PRECISION", "fast")
         self._dtype = _precision_to_dtype(self.precision)
+        self.x2_plan = int(os.environ.get("RESR_X2_PLAN", "3")) if x2_plan is None else int(x2_plan)
+        if not 0 <= self.x2_plan <= 3:
+            raise ValueError(f"x2_plan must be a bit set of X2_PLAN_GROWTH_F16_INFER (1) | X2_PLAN_GROWTH_GRAD_F16 (2), got {self.x2_plan}")
         self.n_blocks = n_blocks or self.N_BLOCKS
         if upscale_factor == 2:
             conv_in, downscale_factor = in_channels * 4, 2
@@ -339,7 +347,8 @@ class Generator(nn.Module):
             raise RuntimeError(f"Generator: expected {self.in_channels} input channels, got {c}")
         return _lib.GeneratorDesc(n, h, w, self.in_channels, self.out_channels, self.upscale_factor,
                                   self.n_blocks, self._dtype, 1 if training else 0,
-                                  int(os.environ.get("RESR_WGRAD_SPLITS", "0")))
+                                  int(os.environ.get("RESR_WGRAD_SPLITS", "0")),
+                                  self.x2_plan if self._dtype == _lib.RESR_F16X2 else 0, 0)
 
     def _pack(self, desc: _lib.GeneratorDesc, backward: bool) -> None:
         L = _lib.lib()

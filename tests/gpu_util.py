@@ -45,7 +45,7 @@ def pack_conv(weight, dtype, transposed=False, scale=1.0):
                                  1 if transposed else 0, scale, 0, None)
     table = torch.frombuffer(bytearray(bytes(chunks)), dtype=torch.uint8).cuda()
     arena = weight.reshape(-1).float().cuda()
-    es = 2 if dtype == L.RESR_F16 else 4
+    es = {L.RESR_F16: 2, L.RESR_F32: 4, L.RESR_F16X2: 6}[dtype]   # exact16: three f16 blocks per chunk
     packed = torch.zeros(nck * 9 * mt * 1024 * es + 16384, dtype=torch.uint8, device="cuda")
     L.check(L.lib().resr_pack_weights(L.ptr(table), nck, L.ptr(arena), L.ptr(packed), dtype, L.stream_ptr()),
             "resr_pack_weights")

@@ -8,13 +8,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(upscale, n_blocks, seed, precision):
+def _setup(upscale, n_blocks, seed, precision, x2_plan=0):
+    """exact16 here is the all-pairs plan (x2_plan = 0: three stages per chunk everywhere); the single-f16 growth planes /
+    growth-plane gradients that `Generator(precision="exact16")` takes by default have their own gates in test_gpu_x2_plan.py."""
     import real_esrgan_pytorch_amd as R
     from oracle import model_ref as M
     sd = M.init_generator_state(seed, 3, 3, upscale, bias_noise=0.02)
     sd = {k: v for k, v in sd.items() if not k.startswith("trunk.") or int(k.split(".")[1]) < n_blocks}
     sd["conv4.bias"] = sd["conv4.bias"] + 0.5     # centre the output inside the clamp range
-    g = R.Generator(3, 3, upscale, precision=precision, n_blocks=n_blocks)
+    g = R.Generator(3, 3, upscale, precision=precision, n_blocks=n_blocks, x2_plan=x2_plan)
     g.load_state_dict(sd)
     return g.cuda(), sd, M
 

@@ -1,0 +1,299 @@
+"""-m gpu: exact16 with single-f16 growth planes / growth-plane gradients (ResrConvDesc.x2_pair_chunks, RESR_CONV_OUT_SINGLE,
+ResrGeneratorDesc.x2_plan -- DESIGN.md section 2, round 5).
+
+The residual stream of a dense block stays a (hi, lo) pair; the four growth planes (inference) and their gradients (backward) are
+single f16 tensors: their chunks take two MFMA stages (x W0 + x W1) instead of three, conv1..conv4's weight gradients two
+tap-products instead of three.  Reference arithmetic: /root/reference/model.py:87-98,255-272 (fp32 on the CPU, inference.py:52-53).
+Gates: inference forward <= 2e-4 vs the fp32 oracle at 23 blocks for weights x 1, x 4 and after 60
+training steps; every gradient tensor <= 1e-3 relative L2 vs the float64 evaluation of the oracle (shipped because the emulation
+of tools/precision_ladder_sim.py keeps the worst tensor <= 5e-4 at three geometries and five seeds)."""
+import ctypes as C
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def U():
+    from tests import gpu_util
+    return gpu_util
+
+
+def _pair_planar(t):
+    """[N,C,H,W] fp32 (cpu) -> chunk-planar pair buffer [2][C/32][N,H,W,32] f16 (hi planes, then lo planes) + the pair's value."""
+    n, c, h, w = t.shape
+    hi = t.half()
+    lo = ((t - hi.float()) * 4096.0).half()
+
+    def planar(v):
+        return v.reshape(n, c // 32, 32, h, w).permute(1, 0, 3, 4, 2).contiguous()
+    buf = torch.stack([planar(hi), planar(lo)]).cuda()
+    return buf, hi.double() + lo.double() / 4096.0, hi.double()
+
+
+@pytest.mark.parametrize("name,cin,cout,n,h,w", [("growth_conv4", 160, 32, 3, 40, 36), ("closing_conv5", 192, 64, 2, 36, 70),
+                                                 ("growth_conv2_small", 96, 32, 1, 12, 20)])
+def test_conv_reads_single_chunks_and_writes_single_output(U, name, cin, cout, n, h, w, diag_dir):
+    """One conv pass: chunks 0, 1 of the input are pairs, the chunks behind them single f16 tensors (their lo planes hold
+    garbage that must not be read); a cout-32 pass stores a single f16 output (its lo plane stays untouched), the closing
+    cout-64 pass stores a pair.  Against float64 on the values the kernel is given."""
+    L = U.L
+    g = torch.Generator().manual_seed(len(name))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    xb, xv, xhi = _pair_planar(x)
+    xb[1, 2:] = 777.0                                    # lo planes of the single chunks: poison
+    x_eff = torch.cat([xv[:, :64], xhi[:, 64:]], 1)
+    plane = n * h * w * 32
+    growth = cout == 32
+    out = torch.full((2, cout // 32, n, h, w, 32), -7.0, dtype=torch.float16, device="cuda")
+    d = L.ConvDesc(n, h, w, cin, cin, 32, 0, cout, cout, 32, 0, 0, 0, L.RESR_F16X2, 0, 1.0, 1.0, 1.0, 1.0, 0.2)
+    d.in0_chunk_stride = plane
+    d.out_chunk_stride = plane
+    d.in0_lo_offset = (cin // 32) * plane
+    d.out_lo_offset = (cout // 32) * plane
+    d.x2_pair_chunks = 2
+    ref = F.conv2d(x_eff, wt.double(), bias.double(), padding=1)
+    res0 = None
+    if growth:
+        d.flags = L.CONV_LRELU | L.CONV_OUT_SINGLE
+        ref = F.leaky_relu(ref, 0.2)
+    else:
+        r0 = torch.randn(n, cout, h, w, generator=g)
+        res0, r0v, _ = _pair_planar(r0)
+        d.res0_stride, d.res0_chunk_stride, d.s0, d.t0, d.res0_lo_offset = 32, plane, 0.2, 1.0, (cout // 32) * plane
+        ref = ref * 0.2 + r0v
+    packed = U.pack_conv(wt, L.RESR_F16X2)
+    bias_d = bias.cuda()
+    L.check(L.lib().resr_conv3x3(C.byref(d), L.ptr(xb), None, L.ptr(packed), L.ptr(bias_d), L.ptr(res0), None, None,
+                                 L.ptr(out), None, L.stream_ptr()), "resr_conv3x3")
+    torch.cuda.synchronize()
+
+    def unplanar(t):
+        return t.double().cpu().permute(1, 0, 4, 2, 3).reshape(n, cout, h, w)
+    if growth:
+        assert (out[1] == -7.0).all(), "a single f16 output must leave the lo tensor alone"
+        got = unplanar(out[0])
+        # the stored value is the f16 rounding of an fp32-class result: half an ulp of each element, not of the tensor's maximum
+        bound = ref.abs() * (2.0 ** -11 * 1.01) + 2e-6
+    else:
+        got = unplanar(out[0]) + unplanar(out[1]) / 4096.0
+        bound = torch.full_like(ref, 2e-6 * max(1.0, ref.abs().max().item()))
+    err = (got - ref).abs()
+    with open(os.path.join(diag_dir, f"x2_single_conv_{name}.json"), "w") as f:
+        json.dump({"max_abs_err": err.max().item(), "ref_absmax": ref.abs().max().item(), "worst_over_bound": (err / bound).max().item()}, f)
+    assert (err <= bound).all(), (name, err.max().item(), (err / bound).max().item())
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w,splits", [(96, 32, 2, 40, 36, 4), (64, 64, 1, 24, 64, 2)])
+def test_wgrad_single_g_equals_pair_g_with_zero_lo(U, cin, cout, n, h, w, splits):
+    """g_lo_offset = 0: G is a single f16 tensor -- the (x_hi, g_lo) tap-product is not issued.  Same bits as the three-product
+    launch on a G pair whose lo tensor is zero (the skipped slab only ever added zeros)."""
+    L = U.L
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, cin, h, w, generator=g)
+    gy = torch.randn(n, cout, h, w, generator=g)
+
+    def pair(t, zero_lo=False):
+        hi = t.half()
+        lo = ((t - hi.float()) * 4096.0).half()
+        if zero_lo:
+            lo = torch.zeros_like(lo)
+        buf = torch.stack([hi.permute(0, 2, 3, 1), lo.permute(0, 2, 3, 1)]).contiguous().cuda()
+        return buf, buf[0].numel()
+    xb, x_lo = pair(x)
+    gb, g_lo = pair(gy, zero_lo=True)
+
+    def run(g_lo_offset):
+        d = L.WgradDesc(n, h, w, cin, cin, cin, 0, cin, cout, cout, cout, L.RESR_F16X2, 0, splits, 1.0)
+        d.x_lo_offset, d.g_lo_offset = x_lo, g_lo_offset
+        partial = torch.zeros(L.lib().resr_wgrad_partial_bytes(C.byref(d)) // 4, device="cuda")
+        dw = torch.full((cout, cin, 3, 3), -7.0, device="cuda")
+        db = torch.full((cout,), -7.0, device="cuda")
+        L.check(L.lib().resr_conv3x3_wgrad(C.byref(d), L.ptr(xb), None, L.ptr(gb), L.ptr(partial), L.ptr(dw), L.ptr(db), L.stream_ptr()),
+                "resr_conv3x3_wgrad")
+        torch.cuda.synchronize()
+        return dw, db
+    dw3, db3 = run(g_lo)
+    dw2, db2 = run(0)
+    assert torch.equal(dw3, dw2) and torch.equal(db3, db2)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    bs = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), wt, bs, padding=1) * gy.half().double()).sum().backward()
+    assert ((dw2.cpu().double() - wt.grad).norm() / wt.grad.norm()).item() < 5e-6
+
+
+def _setup(n_blocks, seed, x2_plan, wscale=1.0, upscale=4):
+    import real_esrgan_pytorch_amd as R
+    from oracle import model_ref as M
+    sd = M.init_generator_state(seed, 3, 3, upscale, bias_noise=0.02)
+    sd = {k: v for k, v in sd.items() if not k.startswith("trunk.") or int(k.split(".")[1]) < n_blocks}
+    sd["conv4.bias"] = sd["conv4.bias"] + 0.5
+    if wscale != 1.0:   # off the init scale: the dense branches grow with their weights
+        sd = {k: (v * wscale if k.endswith(".weight") and ".rdb" in k else v) for k, v in sd.items()}
+    g = R.Generator(3, 3, upscale, precision="exact16", n_blocks=n_blocks, x2_plan=x2_plan)
+    g.load_state_dict(sd)
+    return g.cuda(), sd, M
+
+
+@pytest.mark.parametrize("wscale", [1.0, 4.0])
+@pytest.mark.parametrize("n,h,w", [(1, 24, 24), (2, 40, 36), (8, 32, 32)])
+def test_inference_plan_forward_vs_oracle(n, h, w, wscale, diag_dir):
+    """23 blocks, eval: growth planes single f16 (50 stages per block) against the fp32 CPU oracle and against the all-pairs plan;
+    weights at the reference's init scale and dense-block weights x 4 (activations grow, the dense branch is no longer small);
+    8 x 32^2 runs the dense blocks as chained launches."""
+    from real_esrgan_pytorch_amd import _lib as L
+    g1, sd, M = _setup(23, 11, 1, wscale)
+    g0, _, _ = _setup(23, 11, 0, wscale)
+    x = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        y1 = g1.eval()(x.cuda()).cpu()
+        y0 = g0.eval()(x.cuda()).cpu()
+    yo = M.generator_forward(x, sd, 4, 23)
+    yo64 = M.generator_forward(x.double(), {k: v.double() for k, v in sd.items()}, 4, 23)
+    rep = {"plan1_vs_f32_oracle": (y1 - yo).abs().max().item(), "plan0_vs_f32_oracle": (y0 - yo).abs().max().item(),
+           "plan1_vs_f64": (y1.double() - yo64).abs().max().item(), "plan0_vs_f64": (y0.double() - yo64).abs().max().item(),
+           "frac_unclamped": ((yo > 0) & (yo < 1)).float().mean().item()}
+    with open(os.path.join(diag_dir, f"x2_plan_infer_{n}x{h}x{w}_w{wscale}.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    assert rep["plan1_vs_f32_oracle"] < 2e-4 and rep["plan1_vs_f64"] < 2e-4, rep
+    assert rep["plan0_vs_f64"] < 5e-5, rep
+    assert int(L.lib().resr_debug_chain_errors()) == 0
+
+
+def test_inference_plan_after_training_steps(diag_dir):
+    """The same gate on weights that have left the init: 60 RealESRNet steps (fast mode, as the train scripts run) on one fixed
+    batch, then exact16 inference of the trained weights, plan 1 against plan 0 and the fp32 oracle."""
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd.train import RealESRNetStep
+    from oracle import model_ref as M
+    torch.manual_seed(0)
+    g = R.Generator(3, 3, 4, precision="fast").cuda().train()
+    opt = torch.optim.Adam(g.parameters(), 2e-4, (0.9, 0.99), fused=True)
+    step = RealESRNetStep(g, None, opt, torch.amp.GradScaler("cuda"), None)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    hr = F.interpolate(torch.rand(4, 3, 32, 32, device="cuda", generator=gen), size=(256, 256), mode="bicubic").clamp(0, 1)
+    lr = F.interpolate(hr, scale_factor=0.25, mode="area")
+    losses = [step(hr, lr).item() for _ in range(60)]
+    assert losses[-1] < 0.5 * losses[0]
+    sd = {k: v.detach().float().cpu().clone() for k, v in g.state_dict().items()}
+    ys = {}
+    for plan in (0, 1):
+        ge = R.Generator(3, 3, 4, precision="exact16", x2_plan=plan)
+        ge.load_state_dict(sd)
+        with torch.no_grad():
+            ys[plan] = ge.cuda().eval()(lr[:1]).cpu()
+    yo = M.generator_forward(lr[:1].cpu(), sd, 4, 23)
+    rep = {"plan1_vs_f32_oracle": (ys[1] - yo).abs().max().item(), "plan0_vs_f32_oracle": (ys[0] - yo).abs().max().item(),
+           "plan1_vs_plan0": (ys[1] - ys[0]).abs().max().item()}
+    with open(os.path.join(diag_dir, "x2_plan_infer_trained.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    assert rep["plan1_vs_f32_oracle"] < 2e-4, rep
+
+
+@pytest.mark.parametrize("n,h,w,n_blocks,seed", [(1, 24, 24, 23, 11), (1, 24, 24, 23, 12), (8, 32, 32, 3, 11), (2, 33, 17, 2, 13)])
+def test_training_plan_gradients_vs_float64_oracle(n, h, w, n_blocks, seed, diag_dir):
+    """Backward with single-f16 growth-plane gradients (x2_plan bit 1; the forward pass keeps every pair): all gradient tensors
+    against the float64 evaluation of the oracle.  Gate 1e-3 relative L2 per tensor (emulation: worst 3-5e-4); the forward pass
+    and the input gradient stay at the all-pairs level."""
+    g, sd, M = _setup(n_blocks, seed, 3)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(n, 3, h, w, generator=gen)
+    gw = torch.randn(n, 3, 4 * h, 4 * w, generator=gen)
+    sdo = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+    xo = x.double().clone().requires_grad_(True)
+    yo = M.generator_forward(xo, sdo, 4, n_blocks)
+    (yo * gw.double()).sum().backward()
+    xd = x.cuda().requires_grad_(True)
+    y = g.train()(xd)
+    (y * gw.cuda()).sum().mul(1024.0).backward()
+    torch.cuda.synchronize()
+
+    def rel(got, ref):
+        return ((got.double() - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+    errs = {name: rel(p.grad.cpu() / 1024.0, sdo[name].grad) for name, p in g.named_parameters()}
+    worst = max(errs, key=errs.get)
+    vals = sorted(errs.values())
+    rep = {"fwd_vs_f64": (y.detach().cpu().double() - yo.detach()).abs().max().item(), "worst": errs[worst], "worst_tensor": worst,
+           "median": vals[len(vals) // 2], "gx": rel(xd.grad.cpu() / 1024.0, xo.grad)}
+    with open(os.path.join(diag_dir, f"x2_plan_train_{n}x{h}x{w}_{n_blocks}_{seed}.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    assert rep["fwd_vs_f64"] < 5e-5, rep
+    assert rep["worst"] < 1e-3 and rep["gx"] < 1e-4, rep
+    assert rep["median"] > 2e-5, "the plan does not seem to be active (gradients at the all-pairs level)"
+
+
+def test_plan_bits_are_honoured_and_ignored_outside_exact16():
+    """x2_plan = 0 reproduces the all-pairs results bit for bit whatever $RESR_X2_PLAN says; a training forward ignores bit 0;
+    fast mode ignores the plan."""
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(2)
+    ref = R.Generator(3, 3, 4, precision="exact16", n_blocks=2, x2_plan=0).cuda()
+    sd = ref.state_dict()
+    x = torch.rand(8, 3, 24, 32, device="cuda")
+    outs = {}
+    for plan in (0, 1, 2, 3):
+        g = R.Generator(3, 3, 4, precision="exact16", n_blocks=2, x2_plan=plan).cuda()
+        g.load_state_dict(sd)
+        with torch.no_grad():
+            ye = g.eval()(x)
+        xt = x.clone().requires_grad_(True)
+        yt = g.train()(xt)
+        yt.square().sum().mul(256.0).backward()
+        outs[plan] = (ye, yt.detach(), xt.grad.clone(), g.trunk[0].rdb1.conv2.weight.grad.clone())
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][1], outs[3][1]), "a training forward keeps every pair"
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[1][0], outs[3][0])
+    assert not torch.equal(outs[0][0], outs[1][0]), "bit 0 changes the inference forward"
+    assert torch.equal(outs[0][3], outs[1][3]) and not torch.equal(outs[0][3], outs[2][3]), "bit 1 changes the backward pass"
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-4
+    f0 = R.Generator(3, 3, 4, precision="fast", n_blocks=2, x2_plan=0).cuda()
+    f3 = R.Generator(3, 3, 4, precision="fast", n_blocks=2, x2_plan=3).cuda()
+    f0.load_state_dict(sd)
+    f3.load_state_dict(sd)
+    with torch.no_grad():
+        assert torch.equal(f0(x), f3(x))
+    with pytest.raises(ValueError):
+        R.Generator(3, 3, 4, precision="exact16", x2_plan=7)
+
+
+@pytest.mark.parametrize("n,h,w", [(8, 24, 40), (16, 64, 64), (16, 128, 128)])
+def test_single_plane_chains_equal_separate_launches(n, h, w):
+    """Chained dense-block launches with two-stage chunks (the dependent chunk of a job is its last TWO stages): inference forward
+    (x2_plan bit 0, conv5 inside the chain on the small launches) and training backward (bit 1) bit-equal to one launch per pass."""
+    import real_esrgan_pytorch_amd as R
+    L = R._lib
+    torch.manual_seed(3)
+    g = R.Generator(3, 3, 4, precision="exact16", n_blocks=1, x2_plan=3).cuda()
+    with torch.no_grad():
+        g.conv4.bias.add_(0.5)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.rand(n, 3, h, w, device="cuda", generator=gen)
+    gw = torch.randn(n, 3, 4 * h, 4 * w, device="cuda", generator=gen)
+
+    def run(no_chain):
+        if no_chain:
+            os.environ["RESR_CONV_NO_CHAIN"] = "1"
+        try:
+            with torch.no_grad():
+                ye = g.eval()(x).clone()
+            g.zero_grad(set_to_none=True)
+            xt = x.clone().requires_grad_(True)
+            (g.train()(xt) * gw).sum().mul(256.0).backward()
+            torch.cuda.synchronize()
+            return ye, xt.grad.clone(), [p.grad.clone() for p in g.parameters()]
+        finally:
+            os.environ.pop("RESR_CONV_NO_CHAIN", None)
+    y0, gx0, g0 = run(True)
+    for rep in range(2):
+        y1, gx1, g1 = run(False)
+        assert torch.equal(y0, y1), (rep, (y0 - y1).abs().max().item())
+        assert torch.equal(gx0, gx1), rep
+        for i, (a, b) in enumerate(zip(g0, g1)):
+            assert torch.equal(a, b), (rep, i, (a - b).abs().max().item())
+    assert int(L.lib().resr_debug_chain_errors()) == 0

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built):
             assert hasattr(lib, name), f"{name} declared in include/{h} but not exported"
         declared += names
     assert set(built._lib.exported_symbols()) <= set(declared)
-    assert lib.resr_version() == 1
+    assert lib.resr_version() == built._lib.RESR_VERSION == 2
 
 
 def test_struct_layouts_match_header(built):
@@ -42,7 +42,7 @@ def test_struct_layouts_match_header(built):
     assert ctypes.sizeof(L.ConvDesc) == 26 * 4 + 5 * 8 + 4 * 4   # 20 original fields + 6 chunk strides + 5 hi->lo offsets (RESR_F16X2) + sparse-tap / group fields
     assert ctypes.sizeof(L.WgradDesc) == 16 * 4 + 4 * 8   # 15 fields + padding + 2 hi->lo offsets + 2 chunk strides
     assert ctypes.sizeof(L.PackChunk) == 64
-    assert ctypes.sizeof(L.GeneratorDesc) == 10 * 4
+    assert ctypes.sizeof(L.GeneratorDesc) == 12 * 4   # + x2_plan, reserved_ (ABI version 2)
 
 
 def test_host_planning_calls_need_no_gpu(built):

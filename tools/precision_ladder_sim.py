@@ -9,7 +9,7 @@ HIP path stores a tensor, forward and backward, and reports the two numbers the 
 
 so that only rungs that can pass are built as kernels.  Test infrastructure only (imports oracle/).
 
-    python tools/precision_ladder_sim.py [--blocks 23] [--size 24] [--seeds 11,12,13]
+    python tools/precision_ladder_sim.py [--blocks 23] [--size 24] [--seeds 11,12,13] [--batch 1] [--wscale 1] [--set round5]
 """
 import argparse
 import itertools
@@ -26,6 +26,56 @@ from oracle import model_ref as M  # noqa: E402
 
 def q16(t):
     return t.to(torch.float16).to(t.dtype)
+
+
+def q8(t, dim):
+    """MX-style fp8: e4m3 values with one shared power-of-two scale per block of 32 elements along `dim` (the K dimension of
+    the product the operand enters: input channels for conv / backward-data, pixels of a row for the weight gradients)."""
+    t = t.movedim(dim, -1)
+    shp = t.shape
+    pad = (-shp[-1]) % 32
+    tp = F.pad(t, (0, pad)) if pad else t
+    b = tp.reshape(*tp.shape[:-1], -1, 32)
+    amax = b.abs().amax(-1, keepdim=True).clamp_min(1e-300)
+    sc = torch.exp2(torch.floor(torch.log2(amax)) - 7.0)          # block maximum lands in [128, 256) of e4m3's 448
+    q = (b / sc).to(torch.float32).to(torch.float8_e4m3fn).to(t.dtype) * sc
+    q = q.reshape(tp.shape)[..., :shp[-1]]
+    return q.movedim(-1, dim)
+
+
+def split16(t):
+    hi = q16(t)
+    return hi, t - hi
+
+
+class Conv8(torch.autograd.Function):
+    """3x3 conv on split operands whose two 2^-12-weighted correction products take fp8 (MX e4m3) operands:
+    x w ~ x_hi w_hi + q8(x_hi) q8(w_lo) + q8(x_lo) q8(w_hi), per pass selected by `where` ("f" forward, "d" backward-data,
+    "w" weight gradients); passes not selected multiply the exact (pair) operands."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, where):
+        ctx.save_for_backward(x, w)
+        ctx.where = where
+        if "f" not in where:
+            return F.conv2d(x, w, b, padding=1)
+        xh, xl = split16(x)
+        wh, wl = split16(w)
+        return F.conv2d(xh, wh, b, padding=1) + F.conv2d(q8(xh, 1), q8(wl, 1), None, padding=1) + F.conv2d(q8(xl, 1), q8(wh, 1), None, padding=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gh, gl = split16(g)
+        wh, wl = split16(w)
+        xh, xl = split16(x)
+        ci = lambda gg, ww: torch.nn.grad.conv2d_input(x.shape, ww, gg, padding=1)    # noqa: E731
+        cw = lambda xx, gg: torch.nn.grad.conv2d_weight(xx, w.shape, gg, padding=1)   # noqa: E731
+        # backward-data contracts over the OUTPUT channels (dim 1 of g, dim 0 of w)
+        gx = ci(gh, wh) + ci(q8(gh, 1), q8(wl, 0)) + ci(q8(gl, 1), q8(wh, 0)) if "d" in ctx.where else ci(g, w)
+        # the weight gradients contract over pixels: blocks of 32 along a row
+        gw = cw(xh, gh) + cw(q8(xh, 3), q8(gl, 3)) + cw(q8(xl, 3), q8(gh, 3)) if "w" in ctx.where else cw(x, g)
+        return gx, gw, g.sum((0, 2, 3)), None
 
 
 class Store(torch.autograd.Function):
@@ -66,7 +116,11 @@ def generator(x, sd, cfg, upscale=4, n_blocks=23):
     S = lambda t, cls: Store.apply(t, cfg["a_" + cls], cfg["g_" + cls])   # noqa: E731
 
     def conv(t, key):
-        return Conv.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["w"], cfg["wg"], cfg.get("wb", cfg["w"]))
+        if cfg.get("fp8"):
+            return Conv8.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["fp8"])
+        growth = ".rdb" in key and not key.endswith("conv5")      # conv1..4 of a dense block: their G operand is a growth-plane gradient
+        wg = cfg.get("wg_growth", cfg["wg"]) if growth else cfg["wg"]
+        return Conv.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["w"], wg, cfg.get("wb", cfg["w"]))
 
     x = S(x, "in")
     out1 = S(conv(x, "conv1"), "stream")
@@ -112,13 +166,35 @@ RUNGS = {
 }
 
 
-def run(seed, n_blocks, size, upscale=4, only=None):
+def _with(cfg, **kw):
+    c = dict(cfg)
+    c.update(kw)
+    return c
+
+
+_EXACT = mk("pair", "pair", "pair", "split", "pair")
+# round 5: the two rungs that get built, as they are built, + fp8 (MX e4m3) operands for the 2^-12-weighted correction products
+RUNGS5 = {
+    "INFER: stream+tail pair, growth planes f16, W split":           mk("pair", "f16", "pair", "split", "pair"),
+    "TRAIN: fwd exact; growth-plane gradients f16 (bwd-data 2 stages, wgrad conv1-4 2 products)": mk("pair", "pair", "pair", "split", "pair", g_dense="f16"),
+    "TRAIN + hi-only wgrad on conv1-4 only":                         _with(mk("pair", "pair", "pair", "split", "pair", g_dense="f16"), wg_growth="f16"),
+    "fp8 corrections: weight gradients only":                        _with(_EXACT, fp8="w"),
+    "fp8 corrections: backward-data + weight gradients":             _with(_EXACT, fp8="dw"),
+    "fp8 corrections: forward + backward-data + weight gradients":   _with(_EXACT, fp8="fdw"),
+    "fp8 corrections: forward only":                                 _with(_EXACT, fp8="f"),
+    "exact16x3 (all pair, W split, wgrad pairs)":                    _EXACT,
+}
+
+
+def run(seed, n_blocks, size, upscale=4, only=None, batch=1, wscale=1.0, rungs=None):
     sd = M.init_generator_state(seed, 3, 3, upscale, bias_noise=0.02)
     sd = {k: v for k, v in sd.items() if not k.startswith("trunk.") or int(k.split(".")[1]) < n_blocks}
     sd["conv4.bias"] = sd["conv4.bias"] + 0.5
+    if wscale != 1.0:   # off the init scale: every convolution weight times `wscale` (the dense branches grow with it)
+        sd = {k: (v * wscale if k.endswith(".weight") and ".rdb" in k else v) for k, v in sd.items()}
     gen = torch.Generator().manual_seed(5)
-    x = torch.rand(1, 3, size, size, generator=gen).double()
-    gw = torch.randn(1, 3, size * upscale, size * upscale, generator=gen).double()
+    x = torch.rand(batch, 3, size, size, generator=gen).double()
+    gw = torch.randn(batch, 3, size * upscale, size * upscale, generator=gen).double()
     exact = mk("pair", "pair", "pair", "split", "pair")
 
     def one(cfg, scale):
@@ -129,14 +205,14 @@ def run(seed, n_blocks, size, upscale=4, only=None):
         return y.detach(), {k: v.grad / scale for k, v in p.items()}, xi.grad / scale
     y0, g0, gx0 = one(exact, 1.0)
     rows = {}
-    for name, cfg in RUNGS.items():
+    for name, cfg in (rungs or RUNGS).items():
         if only and not any(o in name for o in only):
             continue
         y, g, gx = one(cfg, 1024.0)
         rel = {k: ((g[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)).item() for k in g0}
         worst_k = max(rel, key=rel.get)
         vals = sorted(rel.values())
-        rows[name] = {"fwd_max_abs": (y - y0).abs().max().item(), "grad_worst": rel[worst_k], "grad_worst_tensor": worst_k,
+        rows[name] = {"fwd_max_abs": (y - y0).abs().max().item(), "act_max": float(y0.abs().max()), "grad_worst": rel[worst_k], "grad_worst_tensor": worst_k,
                       "grad_median": vals[len(vals) // 2], "gx": ((gx - gx0).norm() / gx0.norm()).item()}
     return rows
 
@@ -148,13 +224,18 @@ if __name__ == "__main__":
     ap.add_argument("--seeds", type=str, default="11")
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--json", type=str, default="")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--wscale", type=float, default=1.0, help="dense-block weights times this (off the init scale)")
+    ap.add_argument("--set", type=str, default="ladder", choices=["ladder", "round5"])
+    ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
-    torch.set_num_threads(8)
+    torch.set_num_threads(a.threads)
     allrows = {}
     for seed in [int(s) for s in a.seeds.split(",")]:
-        rows = run(seed, a.blocks, a.size, only=[o for o in a.only.split(",") if o])
+        rows = run(seed, a.blocks, a.size, only=[o for o in a.only.split(",") if o], batch=a.batch, wscale=a.wscale,
+                   rungs=RUNGS5 if a.set == "round5" else RUNGS)
         allrows[seed] = rows
-        print(f"== seed {seed}, {a.blocks} blocks, {a.size}^2 LR")
+        print(f"== seed {seed}, {a.blocks} blocks, {a.batch} x {a.size}^2 LR, dense weights x {a.wscale}", flush=True)
         for name, r in rows.items():
             print(f"{name:58s} fwd {r['fwd_max_abs']:.2e}  grad worst {r['grad_worst']:.2e} ({r['grad_worst_tensor']})  median {r['grad_median']:.2e}  gx {r['gx']:.2e}")
     if a.json:
