@@ -68,6 +68,9 @@ def _parser():
                     help="conv4.bias + 0.5 before the run (what the config-3 probe does): at LR 64^2 a random init whose first Adam step overshoots the "
                          "training-time clamp leaves a step with zero gradients, which draws less power and times ~8 %% faster than a real one")
     ap.add_argument("--isolated-probe", action="store_true", help="also time every conv shape back-to-back in isolation")
+    ap.add_argument("--single-policy", action="store_true",
+                    help="N > 1: time only the exchange policy the environment selects (default: BOTH -- sequential, then RESR_DP_OVERLAP=1 + "
+                         "RESR_CHAIN_CUS_PER_XCD=31 -- K timed steps each, the better one is `value`, both under dist.policies)")
     return ap
 
 
@@ -509,6 +512,102 @@ def cpu_baseline(probe_path="", timeout_s=240.0):
     return rec, d.get("probe")
 
 
+def timed_region(fn, steps, world, sampler=None):
+    """EXACTLY `steps` calls of fn bracketed by barrier + synchronize on both sides; seconds, the MAX over ranks."""
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    out = None
+    t0 = time.perf_counter()
+    if sampler is not None:
+        with sampler:
+            for _ in range(steps):
+                out = fn()
+            torch.cuda.synchronize()
+    else:
+        for _ in range(steps):
+            out = fn()
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    return dt, out
+
+
+def host_record(fn, world, reps=3):
+    """What a step costs the HOST: wall time of issuing one step onto an idle device, no synchronisation inside (the launches
+    are asynchronous, so this is Python + ctypes + runtime enqueue time, collectives' enqueue included).  A step whose enqueue
+    time approaches ms_per_step is host-bound -- the first suspect when N ranks share a pod's CPUs.  Max / mean over ranks."""
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
+    mine = sorted(ts)[len(ts) // 2]
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 0)
+    rec = {"enqueue_ms_per_step": round(mine, 2), "cpus_in_affinity": cpus, "cpus_online": os.cpu_count(),
+           "how": f"median of {reps} steps issued onto an idle device, timed without a synchronisation"}
+    try:
+        rec["loadavg_1min"] = round(os.getloadavg()[0], 1)
+    except OSError:
+        pass
+    if world > 1:
+        t = torch.tensor([mine, -mine, float(cpus), -float(cpus)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        s = torch.tensor([mine], device="cuda", dtype=torch.float64)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        rec.update(enqueue_ms_per_step=round(t[0].item(), 2), enqueue_ms_min_rank=round(-t[1].item(), 2),
+                   enqueue_ms_mean_rank=round(s.item() / world, 2), cpus_in_affinity=int(-t[3].item()),
+                   cpus_in_affinity_max_rank=int(t[2].item()), note="enqueue_ms_per_step = MAX over ranks, cpus_in_affinity = MIN over ranks")
+    return rec
+
+
+def time_policies(args, steps, warmup, world, one, dp, model, dt_seq):
+    """N > 1 (or a forced world-1 RCCL group): the gradient exchange has two policies and which one wins is a question only a
+    multi-GPU box answers -- so the bench times BOTH in one process, K steps each on the same state:
+      sequential    one all-reduce per arena, issued behind the backward pass (overlaps the next batch's degradation only);
+      overlap_31cu  RESR_DP_OVERLAP=1: bucketed all-reduces on a communication stream behind the backward pass's range events,
+                    with RESR_CHAIN_CUS_PER_XCD=31 (the chained launches leave one CU of every XCD to the collective).
+    Returns (dt of the better policy, record); the model is left attached to the better policy."""
+    if not dp.active:          # one rank, no process group: nothing is exchanged
+        return dt_seq, None
+    timed = {"ms_per_step": round(dt_seq / steps * 1e3, 2)}
+    if getattr(dp, "overlap", False):   # the environment already selected the overlapped form: what was timed is not `sequential`
+        return dt_seq, {"overlap_env": timed, "chosen": "overlap_env", "note": "RESR_DP_OVERLAP=1 in the environment: only that policy timed"}
+    if args.single_policy:
+        return dt_seq, {"sequential": timed, "chosen": "sequential", "note": "--single-policy: only the default policy timed"}
+    rec = {"sequential": timed}
+    prev_cus = os.environ.get("RESR_CHAIN_CUS_PER_XCD")
+    os.environ["RESR_CHAIN_CUS_PER_XCD"] = "31"
+    model.grad_hook = None
+    dp.attach(model, overlap=True)
+    for _ in range(max(1, min(warmup, 2))):
+        one()
+    dt_ov, _ = timed_region(one, steps, world)
+    rec["overlap_31cu"] = {"ms_per_step": round(dt_ov / steps * 1e3, 2)}
+    if dt_ov < dt_seq:
+        rec["chosen"] = "overlap_31cu"
+        return dt_ov, rec
+    rec["chosen"] = "sequential"
+    if prev_cus is None:
+        os.environ.pop("RESR_CHAIN_CUS_PER_XCD", None)
+    else:
+        os.environ["RESR_CHAIN_CUS_PER_XCD"] = prev_cus
+    model.grad_ready_hook = None
+    dp.attach(model, overlap=False)
+    return dt_seq, rec
+
+
 def make_hr_tiles(args, B, hr_edge, rank):
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
     hr = torch.round(torch.rand(B, 3, hr_edge, hr_edge, device="cuda", generator=g) * 255.0) / 255.0
@@ -562,26 +661,11 @@ def run_mode(args, precision, steps, warmup, world, rank, probe=True, centre_out
 
     for _ in range(warmup):
         one()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     sampler = PowerSampler()
-    t0 = time.perf_counter()
-    with sampler:
-        for _ in range(steps):
-            loss = one()
-        torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+    dt, loss = timed_region(one, steps, world, sampler)
+    dt, policies = time_policies(args, steps, warmup, world, one, dp, model, dt)
     res = {"precision": precision, "dt": dt, "steps": steps, "warmup": warmup, "loss": float(loss), "degradation": degradation,
-           "power": sampler.summary()}
+           "power": sampler.summary(), "policies": policies, "host": host_record(one, world)}
 
     # The in-situ roofline probe is one more (untimed) train step.  With several ranks that step contains the gradient
     # all-reduce, so every rank runs it; only rank 0 brackets its launches with events and reports.  A failure on any rank
@@ -651,23 +735,10 @@ def run_gan(args, world, rank):
     step = RealESRGANStep(g, d, ema, g_opt, d_opt, scaler, degrade, content_criterion=content, dp=dp)
     for _ in range(args.warmup):
         out = step(hr)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(hr)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
-    res = {"dt": dt, "losses": {k: round(float(v), 6) for k, v in out.items()}, "tile": tile, "crop": crop}
+    dt, out = timed_region(lambda: step(hr), args.steps, world)
+    dt, policies = time_policies(args, args.steps, args.warmup, world, lambda: step(hr), dp, g, dt)
+    res = {"dt": dt, "losses": {k: round(float(v), 6) for k, v in out.items()}, "tile": tile, "crop": crop, "policies": policies,
+           "host": host_record(lambda: step(hr), world)}
     if not args.no_probe:
         err = None
         try:
@@ -691,6 +762,7 @@ def run_gan(args, world, rank):
 
 def gan_main(args, world, rank):
     res = run_gan(args, world, rank)
+    res["devices"] = gather_devices(world, rank)     # a collective: every rank
     if rank != 0:
         return
     B, crop = args.batch, res["crop"]
@@ -712,7 +784,8 @@ def gan_main(args, world, rank):
         "algorithmic_tflops_per_gpu": round(value / world * (flop_g + flop_d) / 1e12, 2),
         "losses": res["losses"],
         "chain_errors": int(__import__("real_esrgan_pytorch_amd")._lib.lib().resr_debug_chain_errors()),
-        "dist": dist_record(world),
+        "dist": dist_record(world, res.get("devices"), res.get("policies")),
+        "host": res.get("host"),
     }
     if "roofline" in res:
         out["roofline"] = res["roofline"]
@@ -728,11 +801,36 @@ def compact_roofline(r):
             "per_instance": {k: {"tflops": v["tflops"], "ms_per_step": v["ms_per_step"], "launches": v["launches"]} for k, v in r["per_instance"].items()}}
 
 
-def dist_record(world):
-    """What the collective layer saw: a SCALE line must show that RCCL ran with N ranks."""
+def gather_devices(world, rank):
+    """Which GPU every rank drives (a collective when world > 1: call it on every rank).  `distinct` < world means ranks share
+    a device -- the single-GPU control-flow tests do, a SCALE run must not."""
+    dev = torch.cuda.current_device()
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "local_index": dev, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+            "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+            "cus": props.multi_processor_count, "hbm_gb": round(props.total_memory / 2 ** 30, 1),
+            "visible": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")}
+    allv = [mine]
+    if world > 1:
+        allv = [None] * world
+        dist.all_gather_object(allv, mine)
+    ids = {(d["uuid"], d["pci"]) if (d["uuid"] or d["pci"] != "0000:00:00") else ("rank-local", d["local_index"], d["visible"]) for d in allv}
+    return {"count": len(allv), "distinct": len(ids), "per_rank": allv}
+
+
+def dist_record(world, devices=None, policies=None):
+    """What the collective layer saw: a SCALE line must show that RCCL ran with N ranks on N distinct GPUs."""
     rec = {"world": world, "backend": dist.get_backend() if dist.is_initialized() else None,
+           "nranks": dist.get_world_size() if dist.is_initialized() else 1,
            "overlap_with_backward": os.environ.get("RESR_DP_OVERLAP", "0") == "1",
            "forced_collectives": os.environ.get("RESR_DP_FORCE", "0") == "1"}
+    if devices is not None:
+        rec["devices"] = devices["distinct"]
+        rec["device_list"] = devices["per_rank"]
+        if devices["distinct"] < world:
+            rec["warning"] = f"{world} ranks on {devices['distinct']} distinct device(s): ranks SHARE a GPU (control-flow test, not a scaling measurement)"
+    if policies is not None:
+        rec["policies"] = policies
     try:
         v = torch.cuda.nccl.version()
         rec["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
@@ -916,6 +1014,7 @@ def main():
     B, lr_edge = args.batch, args.lr_size
     hr_edge = lr_edge * 4
     main_res = run_mode(args, args.precision, args.steps, args.warmup, world, rank, centre_output=args.centre_output)
+    devices = gather_devices(world, rank)      # a collective: every rank
     # the mode that meets north_star's 1e-3 tolerance, timed on the same workload (fewer steps: it is ~2.5x slower)
     parity_res = parity_hi = None
     if args.precision == "fast" and not args.no_parity_mode:
@@ -952,7 +1051,9 @@ def main():
             "chain_errors": int(__import__("real_esrgan_pytorch_amd")._lib.lib().resr_debug_chain_errors()),
             # rank 0's board power / shader clock over the timed steps (the step runs at the power cap: DESIGN section 5)
             "power": main_res.get("power"),
-            "dist": dist_record(world),
+            "dist": dist_record(world, devices, main_res.get("policies")),
+            # host side of a step (enqueue time without a sync, CPUs this process may run on): max over ranks
+            "host": main_res.get("host"),
         }
         if "roofline" in main_res:
             out["roofline"] = main_res["roofline"]

@@ -33,49 +33,58 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     if (idx >= (unsigned)wo * pieces) return;
     const int xo = (int)(idx / pieces);
     const int piece = (int)(idx - (unsigned)xo * pieces);
-    const int yo = (int)blockIdx.y, b = (int)blockIdx.z;
-    const long p = ((long)b * ho + yo) * wo + xo;
     const int creal = c * r * r;
-    uint4 out, outl;
-    T* o = reinterpret_cast<T*>(&out);
-    T* ol = reinterpret_cast<T*>(&outl);
+    // rows / images from the grid, strided: a grid dimension holds 65535 at most (taller images, larger batches loop)
+    for (int b = (int)blockIdx.z; b < n; b += (int)gridDim.z)
+    for (int yo = (int)blockIdx.y; yo < ho; yo += (int)gridDim.y) {
+        const long p = ((long)b * ho + yo) * wo + xo;
+        uint4 out, outl;
+        T* o = reinterpret_cast<T*>(&out);
+        T* ol = reinterpret_cast<T*>(&outl);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int co = piece * E + e;
-        float v = 0.f;
-        if (co < creal) {
-            const int ch = co / (r * r), ij = co % (r * r), i = ij / r, j = ij % r;
-            const size_t q = (((size_t)b * c + ch) * h + (yo * r + i)) * w + (xo * r + j);
-            v = src[q];
-            if (mask) v = mask[q] ? v : 0.f;
+        for (int e = 0; e < E; ++e) {
+            const int co = piece * E + e;
+            float v = 0.f;
+            if (co < creal) {
+                const int ch = co / (r * r), ij = co % (r * r), i = ij / r, j = ij % r;
+                const size_t q = (((size_t)b * c + ch) * h + (yo * r + i)) * w + (xo * r + j);
+                v = src[q];
+                if (mask) v = mask[q] ? v : 0.f;
+            }
+            if constexpr (sizeof(T) == 2) {
+                if (lo_off) split_f16(v, o[e], ol[e]);
+                else o[e] = (T)v;
+            } else {
+                o[e] = (T)v;
+            }
         }
-        if constexpr (sizeof(T) == 2) {
-            if (lo_off) split_f16(v, o[e], ol[e]);
-            else o[e] = (T)v;
-        } else {
-            o[e] = (T)v;
-        }
+        *reinterpret_cast<uint4*>(dst + p * c_pad + piece * E) = out;
+        if (sizeof(T) == 2 && lo_off) *reinterpret_cast<uint4*>(dst + lo_off + p * c_pad + piece * E) = outl;
     }
-    *reinterpret_cast<uint4*>(dst + p * c_pad + piece * E) = out;
-    if (sizeof(T) == 2 && lo_off) *reinterpret_cast<uint4*>(dst + lo_off + p * c_pad + piece * E) = outl;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst,
-                                                           int n, int c, int h, int w, int r, int src_stride, long lo_off) {
+                                                           int n, int c, int h, int w, int r, int src_stride, long lo_off, int wsh) {
     // src pixel grid (h/r) x (w/r) with c*r*r channels; dst [n,c,h,w]
-    // x from the thread, row from blockIdx.y, (image, channel) from blockIdx.z: no 64-bit divisions per element
-    const int x = (int)(blockIdx.x * 256u + threadIdx.x);
+    // x from the thread, row from blockIdx.y, (image, channel) from blockIdx.z: no 64-bit divisions per element.  A workgroup
+    // covers 2^wsh columns x 256 >> wsh rows (narrow images -- the discriminator's coarse levels -- would leave most of a
+    // 256-column workgroup idle); rows and (image, channel) pairs beyond the grid's 65535 loop.
+    const int x = (int)(blockIdx.x << wsh) + (int)(threadIdx.x & ((1u << wsh) - 1u));
     if (x >= w) return;
-    const int y = (int)blockIdx.y;
-    const int b = (int)(blockIdx.z / (unsigned)c), ch = (int)(blockIdx.z - (unsigned)b * (unsigned)c);
-    const size_t q = (((size_t)b * c + ch) * h + y) * w + x;
+    const int rows_pb = 256 >> wsh, ysub = (int)(threadIdx.x >> wsh);
     const int ho = h / r, wo = w / r;
-    const int co = ch * r * r + (y % r) * r + (x % r);
-    const size_t p = ((size_t)b * ho + y / r) * wo + x / r;
-    float v = (float)src[p * src_stride + co];
-    if (sizeof(T) == 2 && lo_off) v = __builtin_fmaf((float)src[lo_off + p * src_stride + co], kLoInv, v);
-    dst[q] = v;
+    for (unsigned z = blockIdx.z; z < (unsigned)n * (unsigned)c; z += gridDim.z) {
+        const int b = (int)(z / (unsigned)c), ch = (int)(z - (unsigned)b * (unsigned)c);
+        for (int y = (int)blockIdx.y * rows_pb + ysub; y < h; y += (int)gridDim.y * rows_pb) {
+            const size_t q = (((size_t)b * c + ch) * h + y) * w + x;
+            const int co = ch * r * r + (y % r) * r + (x % r);
+            const size_t p = ((size_t)b * ho + y / r) * wo + x / r;
+            float v = (float)src[p * src_stride + co];
+            if (sizeof(T) == 2 && lo_off) v = __builtin_fmaf((float)src[lo_off + p * src_stride + co], kLoInv, v);
+            dst[q] = v;
+        }
+    }
 }
 
 template <typename T>
@@ -87,9 +96,10 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ s
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;      // (x, group) inside the output row; row / image from the grid
     if (idx >= (unsigned)wo * groups) return;
     const int x = (int)(idx / groups), g = (int)(idx - (unsigned)x * groups);
-    const int y = (int)blockIdx.y, b = (int)blockIdx.z;
-    const long p = ((long)b * ho + y) * wo + x;
     const int wi = wo * 2;
+    for (int b = (int)blockIdx.z; b < n; b += (int)gridDim.z)          // (grid dimensions hold 65535 at most: the rest loops)
+    for (int y = (int)blockIdx.y; y < ho; y += (int)gridDim.y) {
+    const long p = ((long)b * ho + y) * wo + x;
     const T* s = src + (((size_t)b * ho * 2 + y * 2) * wi + x * 2) * c + g * E;
     float acc[E];
 #pragma unroll
@@ -129,6 +139,7 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ s
     }
     *reinterpret_cast<uint4*>(dst + p * c + g * E) = outv;
     if (sizeof(T) == 2 && dst_lo) *reinterpret_cast<uint4*>(dst + dst_lo + p * c + g * E) = outl;
+    }
 }
 
 template <typename T>
@@ -169,8 +180,7 @@ int nchw_to_nhwc_dispatch(const float* src, void* dst, int n, int c, int h, int 
                           const uint8_t* mask, hipStream_t stream, long lo_off) {
     if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || r <= 0 || (h % r) || (w % r) || c * r * r > c_pad || (c_pad & 7))
         return fail(RESR_ERR_ARG, "nchw_to_nhwc: bad argument (c=%d r=%d c_pad=%d h=%d w=%d)", c, r, c_pad, h, w);
-    if (h / r > 65535 || n > 65535) return fail(RESR_ERR_ARG, "nchw_to_nhwc: image too large");
-    const dim3 grid(blocks_for((long)(w / r) * (c_pad / (dtype != RESR_F32 ? 8 : 4))), (unsigned)(h / r), (unsigned)n);
+    const dim3 grid(blocks_for((long)(w / r) * (c_pad / (dtype != RESR_F32 ? 8 : 4))), (unsigned)(h / r > 65535 ? 65535 : h / r), (unsigned)(n > 65535 ? 65535 : n));
     if (dtype == RESR_F16X2 && lo_off < 0) lo_off = (long)n * (h / r) * (w / r) * c_pad;
     if (dtype != RESR_F16X2) lo_off = 0;
     if (dtype != RESR_F32)
@@ -185,14 +195,17 @@ int nhwc_to_nchw_dispatch(const void* src, float* dst, int n, int c, int h, int 
                           hipStream_t stream, long lo_off) {
     if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || r <= 0 || (h % r) || (w % r))
         return fail(RESR_ERR_ARG, "nhwc_to_nchw: bad argument");
-    if (h > 65535 || (long)n * c > 65535) return fail(RESR_ERR_ARG, "nhwc_to_nchw: image too large");
-    const dim3 grid(blocks_for(w), (unsigned)h, (unsigned)(n * c));
+    if ((long)n * c > 0x7fffffffL) return fail(RESR_ERR_ARG, "nhwc_to_nchw: n * c beyond 2^31");
+    int wsh = 8;                                   // columns per workgroup = 2^wsh >= w (at least a wavefront's half), rows = 256 >> wsh
+    while (wsh > 5 && (1 << (wsh - 1)) >= w) --wsh;
+    const long rowblocks = ((long)h + (256 >> wsh) - 1) / (256 >> wsh);
+    const dim3 grid((unsigned)((w + (1 << wsh) - 1) >> wsh), (unsigned)(rowblocks > 65535 ? 65535 : rowblocks), (unsigned)((long)n * c > 65535 ? 65535 : n * c));
     if (dtype == RESR_F16X2 && lo_off < 0) lo_off = (long)n * (h / r) * (w / r) * src_stride;
     if (dtype != RESR_F16X2) lo_off = 0;
     if (dtype != RESR_F32)
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, grid, dim3(256), 0, stream, (const half_t*)src, dst, n, c, h, w, r, src_stride, lo_off);
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, grid, dim3(256), 0, stream, (const half_t*)src, dst, n, c, h, w, r, src_stride, lo_off, wsh);
     else
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, stream, (const float*)src, dst, n, c, h, w, r, src_stride, 0L);
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, stream, (const float*)src, dst, n, c, h, w, r, src_stride, 0L, wsh);
     RESR_CHECK_LAUNCH("nhwc_to_nchw_kernel");
     return RESR_OK;
 }
@@ -205,8 +218,7 @@ int sumpool2x2_dispatch(const void* src, void* dst, const void* mask, int n, int
     if (dtype != RESR_F16X2) src_lo = dst_lo = 0;
     if (!src || !dst || n <= 0 || ho <= 0 || wo <= 0 || c <= 0 || (c % E))
         return fail(RESR_ERR_ARG, "sumpool2x2: bad argument");
-    if (ho > 65535 || n > 65535) return fail(RESR_ERR_ARG, "sumpool2x2: image too large");
-    const dim3 grid(blocks_for((long)wo * (c / E)), (unsigned)ho, (unsigned)n);
+    const dim3 grid(blocks_for((long)wo * (c / E)), (unsigned)(ho > 65535 ? 65535 : ho), (unsigned)(n > 65535 ? 65535 : n));
     if (dtype != RESR_F32)
         hipLaunchKernelGGL(sumpool2x2_kernel<half_t>, grid, dim3(256), 0, stream, (const half_t*)src, (half_t*)dst, (const half_t*)mask, n, ho, wo, c, slope, src_lo, dst_lo);
     else

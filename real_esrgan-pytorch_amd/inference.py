@@ -3,7 +3,8 @@
     python -m real_esrgan_pytorch_amd.inference --inputs_path lr.png --output_path sr.png --weights_path g.pth.tar
 
 Same flow as the reference: build `Generator`, load `checkpoint["state_dict"]` with the "model." prefix
-stripped, read the image as RGB float in [0,1], run the model under no_grad on the whole image, write
+stripped, read the image as RGB float in [0,1], run the model under no_grad on the whole image (frames beyond the conv
+kernels' 2^24-pixel tensors -- a 1080p LR input of the x4 model -- are cut into haloed tiles and stitched: tiling.super_resolve), write
 `tensor_to_image` (truncating uint8 conversion, imgproc.py:1594).  Image I/O uses PIL (cv2 is not part of
 this environment); the BGR<->RGB swaps of the reference cancel out and are therefore absent.
 """
@@ -14,6 +15,7 @@ import torch
 
 from . import _lib, config, imgproc
 from .model import Generator
+from .tiling import super_resolve
 
 
 def main(args) -> None:
@@ -31,7 +33,7 @@ def main(args) -> None:
     lr_tensor = imgproc.image_to_tensor(lr_image, False, False).unsqueeze_(0)
     lr_tensor = lr_tensor.to(device=config.device, memory_format=torch.channels_last, non_blocking=True)
     with torch.no_grad():
-        sr_tensor = model(lr_tensor)                                                   # inference.py:53
+        sr_tensor = super_resolve(model, lr_tensor)                                    # inference.py:53 (any frame size)
     sr_image = imgproc.tensor_to_image(sr_tensor, False, False)
     _lib.chain_health()             # (the image is on the host: every launch has reported) a broken chained launch must not reach the file
     Image.fromarray(sr_image).save(args.output_path)

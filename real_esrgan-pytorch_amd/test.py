@@ -17,6 +17,7 @@ import torch
 from . import _lib, config, imgproc
 from .image_quality_assessment import NIQE
 from .model import Generator
+from .tiling import super_resolve
 
 
 def natural_sorted(names: List[str]) -> List[str]:
@@ -48,7 +49,7 @@ def main() -> float:
         lr_tensor = imgproc.image_to_tensor(imgproc.read_image_rgb(lr_image_path), False, False).unsqueeze_(0)
         lr_tensor = lr_tensor.to(device=config.device, memory_format=torch.channels_last, non_blocking=True)
         with torch.no_grad():
-            sr_tensor = model(lr_tensor)                                                   # test.py:79
+            sr_tensor = super_resolve(model, lr_tensor)                                    # test.py:79 (any frame size)
         Image.fromarray(imgproc.tensor_to_image(sr_tensor, False, False)).save(os.path.join(config.sr_dir, name))
         niqe_metrics += niqe(sr_tensor).item()
     _lib.chain_health()             # fail loudly if a chained conv launch ever gave up on a neighbouring tile

@@ -31,6 +31,31 @@ import torch
 from .model import Generator
 
 _MAX_OUT_PIXELS = 1 << 24        # conv3x3_ws.hip: per-tensor pixel limit of the 32-bit lane offsets
+# Halo (LR pixels) of the tiles `super_resolve` cuts when a frame exceeds that limit.  The 23-block trunk's receptive field is
+# ~350 LR pixels, but what a far pixel contributes decays fast (every dense block and every RRDB adds its branch times 0.2):
+# measured seam error against a whole-image pass on a 512^2 frame, 23 blocks (tools/tile_halo_error.py) --
+# the default keeps it below the entry points' uint8 output step at the reference's init scale AND at dense weights x 4.
+DEFAULT_HALO = int(__import__("os").environ.get("RESR_TILE_HALO", "64"))
+
+
+def fits_whole(model: Generator, n: int, H: int, W: int) -> bool:
+    """Can `model` take an [n, c, H, W] batch as ONE launch sequence?  The producer/consumer conv kernels address a tensor with
+    24 x 24-bit offsets: at most 2^24 pixels per tensor, i.e. of the HR-resolution tail (csrc/conv3x3_ws.hip,
+    conv3x3_ws_supported; csrc/generator.hip additionally wants n * h * w * 512 < 2^31 elements per plane stack)."""
+    s = model.upscale_factor
+    r = {4: 1, 2: 2, 1: 4}[s]
+    return n * H * s * W * s <= _MAX_OUT_PIXELS and n * (H // r) * (W // r) * 512 <= 0x7fffffff
+
+
+@torch.no_grad()
+def super_resolve(model: Generator, x: torch.Tensor, halo: Optional[int] = None) -> torch.Tensor:
+    """`model(x)` for a frame of ANY size (the reference's whole-image call sites, inference.py:52-53 and test.py:79-80, run
+    whatever memory allows): one pass when the frame fits the kernels' per-tensor limit, else equal tiles of the fewest pixels
+    with `halo` LR pixels of context (TiledGenerator, no graph: one frame per call) stitched into the full image."""
+    n, _, H, W = x.shape
+    if fits_whole(model, n, H, W):
+        return model(x)
+    return TiledGenerator(model, tile=None, halo=DEFAULT_HALO if halo is None else halo, use_graph=False)(x.contiguous())
 
 
 class TiledGenerator:

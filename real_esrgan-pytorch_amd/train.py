@@ -341,7 +341,10 @@ class RealESRGANStep:
         hr_out = self.d(hr)                                                                # :499
         d_loss_hr = losses.bce_with_logits_const(self.adv, hr_out, 1.0, 1.0, "d_hr")
         self._backward(d_loss_hr)                                                          # :503
-        sr_out = self.d(sr.detach())                                                       # :507 (the module copies its input: no clone needed)
+        # :507 `sr.detach().clone()`: no clone here.  Discriminator._run_forward ALIASES a contiguous fp32 input (it copies nothing);
+        # what makes that safe is that the native forward consumes x into its NHWC workspace before it returns and the backward
+        # pass never re-reads x -- and that nothing below mutates `sr` in place.  An in-place op on `sr` added later needs the clone back.
+        sr_out = self.d(sr.detach())
         d_loss_sr = losses.bce_with_logits_const(self.adv, sr_out, 0.0, 1.0, "d_sr")
         self._backward(d_loss_sr)                                                          # :513
         if self.dp is not None:                                                            # one exchange for both backwards
@@ -365,10 +368,14 @@ class GraphedStep:
     replayed: ~600 dependent launches per RealESRGAN step leave the host in one call.  The degradation keeps running eagerly on its
     side stream (its plan changes per batch); its LR / HR outputs are copied into the graph's static inputs.
 
-    Requirements (checked): optimisers built with `capturable=True` (the step counter lives on the device; `fused=True` as
-    usual), no data-parallel exchange inside the step (`dp` inactive), the same shapes on every call.  The first `warmup` calls
-    run eagerly (one-time allocations, kernel attributes, optimizer state); a change of shape or of any optimiser's learning rate
-    (a scheduler stepped) re-captures.  Returns what the wrapped step returns -- tensors that the NEXT replay overwrites.
+    Requirements (checked): optimisers built with `capturable=True` (the step counter lives on the device) and, next to a
+    GradScaler, `fused=True` (the scaler's step of a non-fused optimiser reads found_inf on the host: a sync inside the capture);
+    no data-parallel exchange inside the step (`dp` inactive); the same shapes on every call.  The first `warmup` calls
+    run eagerly (one-time allocations, kernel attributes, optimizer state); a change of shape or of a FLOAT learning rate
+    re-captures -- a scheduler that moves the rate every iteration would therefore never let a graph replay (a warning says so):
+    give such optimisers a TENSOR learning rate (`lr=torch.tensor(2e-4, device=...)`: capturable Adam reads it on the device, the
+    scheduler updates it in place, and it is not part of the capture key).  Returns what the wrapped step returns -- tensors that
+    the NEXT replay overwrites.
     Chained dense-block launches are captured like any other (csrc/conv3x3_ws.hip): do not replay while ANOTHER stream runs
     chained launches on the same device (include/resr.h)."""
 
@@ -378,9 +385,13 @@ class GraphedStep:
         self._key = None
         self._calls = 0
         self._hr = self._lr = self._out = None
+        self._recaptures = 0
         for opt in self._optimizers():
             if not opt.defaults.get("capturable", False):
                 raise ValueError("GraphedStep: build the optimisers with capturable=True (their step counters must live on the device)")
+            if getattr(step, "scaler", None) is not None and not opt.defaults.get("fused", False):
+                raise ValueError("GraphedStep: next to a GradScaler the optimisers must be fused=True (scaler.step() of a non-fused "
+                                 "optimiser calls .item() on found_inf, which aborts a stream capture)")
         dp = getattr(step, "dp", None)
         if dp is not None and getattr(dp, "active", False):
             raise ValueError("GraphedStep: a data-parallel exchange inside the step is not captured; run the step eagerly")
@@ -389,7 +400,9 @@ class GraphedStep:
         return [o for o in (getattr(self.step, n, None) for n in ("optimizer", "g_opt", "d_opt")) if o is not None]
 
     def _lrs(self):
-        return tuple(float(g["lr"]) for o in self._optimizers() for g in o.param_groups)
+        # float rates are baked into the captured launches: part of the key.  Tensor rates live on the device (capturable Adam
+        # reads them there) and are updated in place: not part of the key, and never read back (float() would be a sync per call)
+        return tuple(float(g["lr"]) for o in self._optimizers() for g in o.param_groups if not torch.is_tensor(g["lr"]))
 
     def __call__(self, hr: torch.Tensor, lr: Optional[torch.Tensor] = None):
         if lr is None:
@@ -397,6 +410,12 @@ class GraphedStep:
         key = (tuple(hr.shape), tuple(lr.shape), str(hr.device), self._lrs())
         if self._graph is None or key != self._key:
             if key != self._key:
+                if self._key is not None:
+                    self._recaptures += 1
+                    if self._recaptures in (8, 64, 512):
+                        import warnings
+                        warnings.warn(f"GraphedStep: capture key changed {self._recaptures} times (shape or a float learning rate): the step "
+                                      "keeps running eagerly; use tensor learning rates with a per-iteration scheduler", RuntimeWarning)
                 self._graph, self._calls, self._key = None, 0, key
             if self._calls < self.warmup:
                 self._calls += 1
@@ -404,8 +423,12 @@ class GraphedStep:
             self._hr, self._lr = hr.clone(), lr.clone()
             torch.cuda.synchronize(hr.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._out = self.step(self._hr, self._lr)
+            try:
+                with torch.cuda.graph(g):
+                    self._out = self.step(self._hr, self._lr)
+            except Exception:
+                self._graph, self._key, self._calls = None, None, 0      # a failed capture leaves nothing half-set
+                raise
             self._graph = g
             g.replay()                  # the capture itself executes nothing: this call's step is the first replay
             return self._out

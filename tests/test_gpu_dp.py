@@ -201,6 +201,13 @@ def test_bench_two_ranks_prints_one_line():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and out["scaling"] == "weak" and "roofline" in out and "cpu_baseline" not in out
     assert "error" not in out["roofline"], out["roofline"]
+    # self-diagnosing line: which devices the ranks drove, what a step costs the host, both exchange policies timed
+    d = out["dist"]
+    assert d["nranks"] == 2 and d["devices"] == 1 and len(d["device_list"]) == 2 and "SHARE" in d["warning"]
+    assert set(d["policies"]) >= {"sequential", "overlap_31cu", "chosen"} and d["policies"]["chosen"] in ("sequential", "overlap_31cu")
+    best = min(d["policies"]["sequential"]["ms_per_step"], d["policies"]["overlap_31cu"]["ms_per_step"])
+    assert abs(out["ms_per_step"] - best) < 0.02, (out["ms_per_step"], d["policies"])
+    assert out["host"]["enqueue_ms_per_step"] > 0 and out["host"]["cpus_in_affinity"] >= 1
 
 
 def test_bench_gan_two_ranks_prints_one_line():
@@ -221,6 +228,32 @@ def test_bench_gan_two_ranks_prints_one_line():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and "GAN" in out["metric"] and set(out["losses"]) >= {"pixel_loss", "adversarial_loss", "d_loss_hr", "d_loss_sr", "content_loss"}
     assert "roofline" in out and "error" not in out["roofline"], out.get("roofline")
+
+
+def test_bench_gan_eight_ranks_on_one_gpu():
+    """The SCALE run's widest launch line (`--nproc-per-node 8 ... bench.py --gpus 8 --gan`, BASELINE config 4: global batch
+    8 x per-GPU batch) at a tiny size with the eight ranks sharing the test box's one GPU (gloo; LOCAL_RANK % device_count):
+    ports, seeds, both exchange policies, the roofline step and the teardown complete; ONE JSON line whose `dist` record says
+    that eight ranks ran on ONE distinct device."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RESR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--batch", "1", "--lr-size", "16", "--gan", "--no-sustained"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp8"
+    d = out["dist"]
+    assert d["world"] == d["nranks"] == 8 and d["devices"] == 1 and [x["rank"] for x in d["device_list"]] == list(range(8))
+    assert d["policies"]["chosen"] in ("sequential", "overlap_31cu") and "overlap_31cu" in d["policies"]
+    assert out["host"]["enqueue_ms_per_step"] >= out["host"]["enqueue_ms_min_rank"] > 0
+    assert out["chain_errors"] == 0
 
 
 def test_train_script_two_ranks(tmp_path):

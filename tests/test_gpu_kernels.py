@@ -416,6 +416,24 @@ def test_layout_and_pool(U):
         assert (U.from_nhwc(out, 64) - ref).abs().max().item() < (2e-2 if dtype == L.RESR_F16 else 1e-5)
 
 
+@pytest.mark.parametrize("n,c,h,w", [(128, 512, 4, 6), (2, 40, 70, 64), (1, 3, 300, 33), (1, 8, 66000, 2)])
+def test_layout_helpers_beyond_the_grid_limits(U, n, c, h, w):
+    """resr_nhwc_to_nchw with n * c > 65535 (128 x 512-channel feature maps), narrow images (several rows per workgroup) and
+    h > 65535: rows / (image, channel) pairs beyond a grid dimension loop instead of failing."""
+    L = U.L
+    g = torch.Generator().manual_seed(7)
+    src = torch.randn(n, h, w, c, generator=g).half().cuda()
+    out = torch.full((n, c, h, w), -7.0, device="cuda")
+    L.check(L.lib().resr_nhwc_to_nchw(L.ptr(src), L.ptr(out), n, c, h, w, 1, c, L.RESR_F16, L.stream_ptr()), "resr_nhwc_to_nchw")
+    torch.cuda.synchronize()
+    assert torch.equal(out, src.float().permute(0, 3, 1, 2))
+    if c <= 32:   # and back (rows from the grid, strided)
+        back = torch.full((n, h, w, 32), -1.0, dtype=torch.float16, device="cuda")
+        L.check(L.lib().resr_nchw_to_nhwc(L.ptr(out), L.ptr(back), n, c, h, w, 1, 32, L.RESR_F16, None, L.stream_ptr()), "resr_nchw_to_nhwc")
+        torch.cuda.synchronize()
+        assert torch.equal(back[..., :c], src) and (back[..., c:] == 0).all()
+
+
 def test_ema_bit_exact(U):
     L = U.L
     g = torch.Generator().manual_seed(5)

@@ -199,3 +199,95 @@ def test_graphed_step_equals_eager_step(gan):
     with pytest.raises(ValueError):          # the step counter must live on the device
         g = R.Generator(3, 3, 4, n_blocks=1).cuda()
         GraphedStep(RealESRNetStep(g, None, torch.optim.Adam([g.flat_parameter()], 1e-4, fused=True), None, None))
+
+
+@pytest.mark.parametrize("flat", [True, False])
+def test_gradscaler_overflow_skips_the_realesrnet_step(flat):
+    """A forced overflow (reference train_realesrnet.py:388-391: scaler.scale(loss).backward(); scaler.step(); scaler.update()): the
+    loss scale starts far beyond what the f16 activation gradients can carry, so the gradient arena fills with inf / NaN.  Every
+    such step must be SKIPPED -- weights, Adam moments and step count untouched, the scale halved -- until a scale fits and the
+    step proceeds; the EMA update runs every step on whatever the weights are (train_realesrnet.py:394).  Flat-arena Adam (one
+    Parameter, bench.py's default) and the per-tensor form."""
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd.train import RealESRNetStep
+    torch.manual_seed(4)
+    g = R.Generator(3, 3, 4, n_blocks=2).cuda().train()
+    with torch.no_grad():
+        g.conv4.bias.add_(0.5)
+    ema = R.EMA(g, 0.9)
+    ema.register()
+    opt = torch.optim.Adam([g.flat_parameter()] if flat else g.parameters(), 2e-4, (0.9, 0.99), fused=True)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 40, growth_interval=10 ** 9)
+    step = RealESRNetStep(g, ema, opt, scaler, None)
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    lr = torch.rand(8, 3, 32, 32, device="cuda", generator=gen)
+    hr = torch.rand(8, 3, 128, 128, device="cuda", generator=gen)
+    w0 = g.flat_parameters().clone()
+    skipped = 0
+    for it in range(16):
+        before, scale_before = g.flat_parameters().clone(), scaler.get_scale()
+        shadow_before = ema._flat_shadow.clone()
+        loss = step(hr, lr)
+        after, scale_after = g.flat_parameters(), scaler.get_scale()
+        assert torch.isfinite(after).all() and torch.isfinite(ema._flat_shadow).all(), it
+        assert torch.equal(ema._flat_shadow, (1.0 - 0.9) * after + 0.9 * shadow_before) or \
+            torch.allclose(ema._flat_shadow, 0.1 * after + 0.9 * shadow_before, rtol=1e-6, atol=1e-9), "EMA runs every step on the current weights"
+        if torch.equal(before, after):
+            skipped += 1
+            assert scale_after == 0.5 * scale_before, (it, scale_before, scale_after)
+            assert torch.equal(after, w0)
+            states = [s for s in opt.state.values() if s]
+            assert all(float(s["step"]) == 0 for s in states) and all(torch.isfinite(s["exp_avg"]).all() for s in states), "a skipped step must not touch Adam's state"
+        else:
+            assert scale_after == scale_before and torch.isfinite(loss), (it, scale_before, scale_after)
+            break
+    else:
+        raise AssertionError("no step ever proceeded")
+    assert skipped >= 2, skipped                     # the first scales did overflow
+    states = [s for s in opt.state.values() if s]
+    assert states and all(float(s["step"]) == 1 for s in states)
+    assert not torch.equal(g.flat_parameters(), w0)
+    R._lib.chain_health(sync=True)
+
+
+def test_gradscaler_overflow_in_the_gan_step_shared_scaler():
+    """The RealESRGAN step shares ONE GradScaler between the generator and the discriminator update and calls update() after
+    each (reference train_realesrgan.py:485-487, 515-517): with a scale that overflows both, each half-step is skipped on its own
+    and the scale halves once per skipped half; arenas (weights, spectral-norm u / v aside) stay untouched while skipped; the
+    step recovers by itself."""
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd.train import RealESRGANStep
+    torch.manual_seed(6)
+    g = R.Generator(3, 3, 4, n_blocks=1).cuda().train()
+    d = R.Discriminator().cuda().train()
+    with torch.no_grad():
+        g.conv4.bias.add_(0.5)
+    g_opt = torch.optim.Adam([g.flat_parameter()], 1e-4, (0.9, 0.99), fused=True)
+    d_opt = torch.optim.Adam([d.flat_parameter()], 1e-4, (0.9, 0.99), fused=True)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 42, growth_interval=10 ** 9)
+    step = RealESRGANStep(g, d, None, g_opt, d_opt, scaler, None)
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    lr = torch.rand(8, 3, 16, 16, device="cuda", generator=gen)
+    hr = torch.rand(8, 3, 64, 64, device="cuda", generator=gen)
+    g0, d0 = g.flat_parameters().clone(), d.flat_parameters().clone()
+    g_moved = d_moved = False
+    halvings = 0
+    for it in range(24):
+        gb, db, sb = g.flat_parameters().clone(), d.flat_parameters().clone(), scaler.get_scale()
+        out = step(hr, lr)
+        ga, da, sa = g.flat_parameters(), d.flat_parameters(), scaler.get_scale()
+        assert torch.isfinite(ga).all() and torch.isfinite(da).all(), it
+        g_skip, d_skip = torch.equal(gb, ga), torch.equal(db, da)
+        assert sa == sb * 0.5 ** (int(g_skip) + int(d_skip)), (it, sb, sa, g_skip, d_skip)
+        halvings += int(g_skip) + int(d_skip)
+        g_moved, d_moved = g_moved or not g_skip, d_moved or not d_skip
+        if not g_skip and not d_skip:
+            assert all(torch.isfinite(v) for v in out.values()), out
+            break
+    else:
+        raise AssertionError("the step never recovered")
+    assert halvings >= 3 and g_moved and d_moved
+    assert not torch.equal(g.flat_parameters(), g0) and not torch.equal(d.flat_parameters(), d0)
+    for opt in (g_opt, d_opt):
+        states = [s for s in opt.state.values() if s]
+        assert states and all(float(s["step"]) == 1 for s in states)

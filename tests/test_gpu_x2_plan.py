@@ -197,12 +197,18 @@ def test_inference_plan_after_training_steps(diag_dir):
     assert rep["plan1_vs_f32_oracle"] < 2e-4, rep
 
 
-@pytest.mark.parametrize("n,h,w,n_blocks,seed", [(1, 24, 24, 23, 11), (1, 24, 24, 23, 12), (8, 32, 32, 3, 11), (2, 33, 17, 2, 13)])
+@pytest.mark.parametrize("n,h,w,n_blocks,seed", [(1, 24, 24, 23, 11), (1, 24, 24, 23, 12), (1, 24, 24, 23, 13), (8, 32, 32, 3, 11), (2, 33, 17, 2, 13)])
 def test_training_plan_gradients_vs_float64_oracle(n, h, w, n_blocks, seed, diag_dir):
     """Backward with single-f16 growth-plane gradients (x2_plan bit 1; the forward pass keeps every pair): all gradient tensors
-    against the float64 evaluation of the oracle.  Gate 1e-3 relative L2 per tensor (emulation: worst 3-5e-4); the forward pass
-    and the input gradient stay at the all-pairs level."""
+    against the float64 evaluation of the oracle AND against the all-pairs plan on the same device.  Gate 1e-3 relative L2 per
+    tensor (emulation: worst 3-5e-4); the forward pass and the input gradient stay at the all-pairs level.
+    The two plans share their forward pass bit for bit, hence their LeakyReLU masks: the distance between them is the rung's own
+    effect.  Against float64 a pre-activation within rounding of zero may flip a mask element in ANY finite-precision forward (the
+    fp32 CPU path does it on seed 11; exact16 does it on seed 12 -- one element of trunk.6.rdb1.conv3, the
+    very element the emulation's rounded-growth-plane forward flips: 1.011e-2 in both): such a tensor is accepted when the
+    all-pairs plan shows the same distance."""
     g, sd, M = _setup(n_blocks, seed, 3)
+    g0, _, _ = _setup(n_blocks, seed, 0)
     gen = torch.Generator().manual_seed(5)
     x = torch.rand(n, 3, h, w, generator=gen)
     gw = torch.randn(n, 3, 4 * h, 4 * w, generator=gen)
@@ -210,23 +216,35 @@ def test_training_plan_gradients_vs_float64_oracle(n, h, w, n_blocks, seed, diag
     xo = x.double().clone().requires_grad_(True)
     yo = M.generator_forward(xo, sdo, 4, n_blocks)
     (yo * gw.double()).sum().backward()
-    xd = x.cuda().requires_grad_(True)
-    y = g.train()(xd)
-    (y * gw.cuda()).sum().mul(1024.0).backward()
-    torch.cuda.synchronize()
+
+    def run(model):
+        xd = x.cuda().requires_grad_(True)
+        y = model.train()(xd)
+        (y * gw.cuda()).sum().mul(1024.0).backward()
+        torch.cuda.synchronize()
+        return y.detach().cpu(), {name: p.grad.cpu().double() / 1024.0 for name, p in model.named_parameters()}, xd.grad.cpu().double() / 1024.0
+    y, gr, gx = run(g)
+    y0, gr0, gx0 = run(g0)
+    assert torch.equal(y, y0), "the training forward does not depend on the plan"
 
     def rel(got, ref):
-        return ((got.double() - ref).norm() / ref.norm().clamp_min(1e-30)).item()
-    errs = {name: rel(p.grad.cpu() / 1024.0, sdo[name].grad) for name, p in g.named_parameters()}
-    worst = max(errs, key=errs.get)
+        return ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+    errs = {name: rel(gr[name], sdo[name].grad) for name in gr}
+    errs0 = {name: rel(gr0[name], sdo[name].grad) for name in gr}
+    between = {name: rel(gr[name], gr0[name]) for name in gr}
+    worst, worst_b = max(errs, key=errs.get), max(between, key=between.get)
     vals = sorted(errs.values())
-    rep = {"fwd_vs_f64": (y.detach().cpu().double() - yo.detach()).abs().max().item(), "worst": errs[worst], "worst_tensor": worst,
-           "median": vals[len(vals) // 2], "gx": rel(xd.grad.cpu() / 1024.0, xo.grad)}
+    rep = {"fwd_vs_f64": (y.double() - yo.detach()).abs().max().item(), "worst_vs_f64": errs[worst], "worst_tensor": worst,
+           "all_pairs_plan_on_that_tensor": errs0[worst], "worst_all_pairs_vs_f64": max(errs0.values()),
+           "worst_vs_all_pairs_plan": between[worst_b], "worst_vs_all_pairs_tensor": worst_b,
+           "median_vs_f64": vals[len(vals) // 2], "gx_vs_f64": rel(gx, xo.grad), "gx_vs_all_pairs": rel(gx, gx0)}
     with open(os.path.join(diag_dir, f"x2_plan_train_{n}x{h}x{w}_{n_blocks}_{seed}.json"), "w") as f:
         json.dump(rep, f, indent=1)
     assert rep["fwd_vs_f64"] < 5e-5, rep
-    assert rep["worst"] < 1e-3 and rep["gx"] < 1e-4, rep
-    assert rep["median"] > 2e-5, "the plan does not seem to be active (gradients at the all-pairs level)"
+    assert rep["worst_vs_all_pairs_plan"] < 1e-3 and rep["gx_vs_all_pairs"] < 1e-4, rep
+    for name, e in errs.items():     # vs float64: inside the gate, or a mask flip of the (shared) forward pass
+        assert e < 1e-3 or errs0[name] > 0.8 * e, (name, e, errs0[name])
+    assert rep["median_vs_f64"] > 2e-5, "the plan does not seem to be active (gradients at the all-pairs level)"
 
 
 def test_plan_bits_are_honoured_and_ignored_outside_exact16():
