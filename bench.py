@@ -161,6 +161,61 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
+def degrade_sources_sha16():
+    """sha256 over the sources that decide the degradation stage's traffic (its kernels and its launch plan)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in (os.path.join(ROOT, "real_esrgan-pytorch_amd", "csrc", "degrade.hip"), os.path.join(ROOT, "real_esrgan-pytorch_amd", "degrade.py"),
+                 os.path.join(ROOT, "real_esrgan-pytorch_amd", "imgproc.py")):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def degradation_roofline(degrade, hr, batch, step_ms, step_ms_no_degradation):
+    """The degradation stage against the HBM roofline: its kernels alone on their side stream, `ms` per batch by HIP
+    events on THAT stream over five batches (plans differ from batch to batch: random resize factors and noise kinds), HBM bytes
+    per batch from the committed PMC passes of this command (profiles/r*_pmc_traffic_b<batch>.json `degradation_stage`, quoted
+    only while the hash of the degradation sources matches), and what the stage costs the step on this box: the timed step against
+    the same step fed pre-degraded tiles."""
+    import glob
+    st = degrade.stream
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    keep = []
+    reps = 5
+    with torch.cuda.stream(st):
+        e0.record(st)
+    for _ in range(reps):
+        keep.append(degrade._enqueue(hr))
+    with torch.cuda.stream(st):
+        e1.record(st)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del keep
+    rec = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "ms_per_batch_alone": round(ms, 3),
+           "how": f"{reps} batches back to back on the side stream, nothing else running; HIP events on that stream",
+           "step_ms_with": round(step_ms, 2), "step_ms_without": round(step_ms_no_degradation, 2) if step_ms_no_degradation else None,
+           "step_delta_ms": round(step_ms - step_ms_no_degradation, 2) if step_ms_no_degradation else None}
+    sha, stale = degrade_sources_sha16(), None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_b{batch}.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if "degradation_stage" not in d:
+            continue
+        if d.get("degrade_sha16") != sha:
+            stale = stale or f"{os.path.basename(path)} was measured on another build of the degradation stage: not quoted"
+            continue
+        b = d["degradation_stage"]["hbm_bytes_per_batch"]
+        rec.update(traffic=b, traffic_source=os.path.basename(path), achieved=round(b / ms / 1e6, 1), frac=round(b / ms / 1e6 / PEAK_HBM_GBS, 4))
+        break
+    else:
+        rec.update(traffic=None, traffic_note=stale or "no PMC file with a degradation_stage record for this batch size", achieved=None, frac=None)
+    return rec
+
+
 def pmc_traffic(kernel, batch):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
     (profiles/r*_pmc_traffic_b<batch>.json, made by tools/pmc_traffic.py through tools/profile_round.sh: FETCH_SIZE and
@@ -619,7 +674,7 @@ def make_hr_tiles(args, B, hr_edge, rank):
     return hr
 
 
-def run_mode(args, precision, steps, warmup, world, rank, probe=True, centre_output=False):
+def run_mode(args, precision, steps, warmup, world, rank, probe=True, centre_output=False, degradation_record=False):
     """Build the training state in `precision`, run `warmup` untimed + `steps` timed steps (barrier + synchronize on both
     sides, max over ranks) and, optionally, one more step with per-launch events for the roofline record."""
     import real_esrgan_pytorch_amd as R
@@ -688,6 +743,20 @@ def run_mode(args, precision, steps, warmup, world, rank, probe=True, centre_out
                 raise SystemExit(f"roofline probe step failed on a rank: {err}")
         elif err is not None:
             res["roofline"] = {"error": err}
+
+    if degradation_record and rank == 0 and world == 1 and degrade is not None and not args.no_probe:
+        # the degradation stage against its own (HBM) roofline + what it costs the step: a few more steps fed pre-degraded tiles
+        try:
+            lr_pre, hr_pre = degrade(hr)
+            lr_pre, hr_pre = lr_pre.clone(), hr_pre.clone()
+            torch.cuda.synchronize()
+            k = max(3, min(steps, 8))
+            step(hr_pre, lr_pre)
+            dt0, _ = timed_region(lambda: step(hr_pre, lr_pre), k, 1)
+            res["degradation_roofline"] = degradation_roofline(degrade, hr, B, dt / steps * 1e3, dt0 / k * 1e3)
+            del lr_pre, hr_pre
+        except Exception as e:  # pragma: no cover
+            res["degradation_roofline"] = {"error": repr(e)}
 
     if rank == 0:
         with torch.no_grad():
@@ -1013,7 +1082,7 @@ def main():
         return
     B, lr_edge = args.batch, args.lr_size
     hr_edge = lr_edge * 4
-    main_res = run_mode(args, args.precision, args.steps, args.warmup, world, rank, centre_output=args.centre_output)
+    main_res = run_mode(args, args.precision, args.steps, args.warmup, world, rank, centre_output=args.centre_output, degradation_record=True)
     devices = gather_devices(world, rank)      # a collective: every rank
     # the mode that meets north_star's 1e-3 tolerance, timed on the same workload (fewer steps: it is ~2.5x slower)
     parity_res = parity_hi = None
@@ -1057,6 +1126,8 @@ def main():
         }
         if "roofline" in main_res:
             out["roofline"] = main_res["roofline"]
+            if "degradation_roofline" in main_res and isinstance(out["roofline"], dict):
+                out["roofline"]["degradation"] = main_res["degradation_roofline"]
             pw = main_res.get("power")
             if pw and pw.get("sclk_mhz_avg") and precision_is_f16(main_res):
                 # the contract's frac stays priced against the nominal peak (2.4 GHz); next to it, the same rate against what the

@@ -215,10 +215,130 @@ __global__ __launch_bounds__(256) void usm_combine_kernel(const float* __restric
     out[i] = s * sharp + (1.f - s) * xv;
 }
 
+// ---- USMSharp(50, 0).forward as TWO launches (round 5) -----------------------------------------------------------------
+// The six passes above (row blur, column blur, mask, row blur, column blur, combine) move 15 fp32 planes = 60 B per value, and
+// the column pass of a 32 x 32 tile fetches its 82-row window from HBM again for every tile column that lands on another XCD
+// (measured 2.94 x its plane).  Here:
+//   launch A  x tile + 25-pixel halo in LDS -> row pass (LDS) -> column pass -> blur (fp32, kept: combine and backward read it)
+//             + the mask |x - blur| * 255 > threshold as ONE BYTE per value;
+//   launch B  mask bytes + halo in LDS -> row pass -> column pass = soft -> out = soft * clip(x + w (x - blur), 0, 1) + (1 - soft) x,
+//             soft stored for the backward pass.
+// 4 + 4 + 1 and 1 + 4 + 4 + 4 + 4 = 26 B per value.  Same taps in the same order as the separate passes (t = 0 .. 50, fused
+// multiply-adds): within an ulp of them (tests/test_gpu_degrade.py), the goldens do not move.  Work is dealt to the XCDs in contiguous plane-major ranges (workgroup b -> range
+// b % 8): the halo rows and columns a tile shares with its neighbours are then found in THAT XCD's L2 instead of being fetched
+// from HBM once per XCD (a locality hint only: nothing depends on where a workgroup really runs).
+template <typename TIN, int EPI>   // EPI 0: blur + byte mask (TIN = float);  EPI 1: soft mask + combine (TIN = uint8_t)
+__global__ __launch_bounds__(256) void usm51_kernel(const TIN* __restrict__ src, const float* __restrict__ x, float* __restrict__ blur,
+                                                    uint8_t* __restrict__ mask, float* __restrict__ soft, float* __restrict__ out,
+                                                    const float* __restrict__ kern, int planes, int h, int w, int tiles_x, int tiles_y,
+                                                    float threshold, float weight) {
+    constexpr int K = 51, R = 25, TW = 64, TH = 32, IH = TH + 2 * R, IW = TW + 2 * R, IWP = 120;   // 82 x 114 input window, rows padded for float4 windows
+    __shared__ __attribute__((aligned(16))) float in[IH * IWP];      // 39.4 KB
+    __shared__ __attribute__((aligned(16))) float hp[IH * TW];       // 21 KB: the row pass
+    __shared__ __attribute__((aligned(16))) float taps[52];
+    __shared__ __attribute__((aligned(4))) uint8_t mb[EPI == 0 ? TH * TW : 4];
+    const long per_plane = (long)tiles_x * tiles_y, items = per_plane * planes, per_xcd = (items + 7) / 8;
+    const long item = (long)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((long)(blockIdx.x >> 3) >= per_xcd || item >= items) return;
+    const int plane = (int)(item / per_plane), t = (int)(item - (long)plane * per_plane);
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const TIN* sp = src + (size_t)plane * h * w;
+    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+        const int r = i / IW, c = i - r * IW;
+        const int iy = reflect(y0 + r - R, h), ix = reflect(x0 + c - R, w);
+        // (beyond the image's last tile the reflected index may still fall outside: zero, never used by a stored output)
+        in[r * IWP + c] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? (float)sp[(size_t)iy * w + ix] : 0.f;
+    }
+    for (int i = threadIdx.x; i < IH * (IWP - IW); i += 256) in[(i / (IWP - IW)) * IWP + IW + i % (IWP - IW)] = 0.f;
+    if (threadIdx.x < 52) taps[threadIdx.x] = threadIdx.x < K ? kern[threadIdx.x] : 0.f;
+    __syncthreads();
+    float tp[52];
+#pragma unroll
+    for (int q = 0; q < 13; ++q) {
+        const float4 v = reinterpret_cast<const float4*>(taps)[q];
+        tp[q * 4] = v.x; tp[q * 4 + 1] = v.y; tp[q * 4 + 2] = v.z; tp[q * 4 + 3] = v.w;
+    }
+    // row pass: item = (row, group of 4 columns); window of 54 (read as 56) values, 4 x 51 FMAs
+    for (int i = threadIdx.x; i < IH * (TW / 4); i += 256) {
+        const int r = i / (TW / 4), cg = i - r * (TW / 4);
+        float win[56];
+        const float4* wp = reinterpret_cast<const float4*>(in + r * IWP + cg * 4);
+#pragma unroll
+        for (int q = 0; q < 14; ++q) {
+            const float4 v = wp[q];
+            win[q * 4] = v.x; win[q * 4 + 1] = v.y; win[q * 4 + 2] = v.z; win[q * 4 + 3] = v.w;
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += tp[k] * win[j + k];
+        *reinterpret_cast<float4*>(hp + r * TW + cg * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    __syncthreads();
+    // column pass: item = (group of 4 rows, column); lanes walk the columns (conflict-free), window of 54 rows
+    for (int i = threadIdx.x; i < (TH / 4) * TW; i += 256) {
+        const int rg = i / TW, col = i - rg * TW;
+        float win[54];
+#pragma unroll
+        for (int q = 0; q < 54; ++q) win[q] = hp[(rg * 4 + q) * TW + col];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += tp[k] * win[j + k];
+        const int gx = x0 + col;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ly = rg * 4 + j, gy = y0 + ly;
+            const bool ok = gy < h && gx < w;
+            const size_t q = ((size_t)plane * h + gy) * w + gx;
+            if constexpr (EPI == 0) {
+                const float xv = in[(ly + R) * IWP + col + R];
+                mb[ly * TW + col] = (fabsf(xv - acc[j]) * 255.f > threshold) ? 1 : 0;
+                if (ok) blur[q] = acc[j];
+            } else if (ok) {
+                const float xv = x[q], s = acc[j];
+                const float sharp = fminf(fmaxf(xv + weight * (xv - blur[q]), 0.f), 1.f);
+                soft[q] = s;
+                out[q] = s * sharp + (1.f - s) * xv;
+            }
+        }
+    }
+    if constexpr (EPI == 0) {   // the tile's mask bytes leave as 4-byte words where the row allows it
+        __syncthreads();
+        for (int i = threadIdx.x; i < TH * TW / 4; i += 256) {
+            const int ly = i / (TW / 4), c4 = (i - ly * (TW / 4)) * 4;
+            const int gy = y0 + ly, gx = x0 + c4;
+            if (gy >= h || gx >= w) continue;
+            uint8_t* mp = mask + ((size_t)plane * h + gy) * w + gx;
+            if (gx + 3 < w && (((size_t)mp) & 3) == 0) *reinterpret_cast<uint32_t*>(mp) = *reinterpret_cast<const uint32_t*>(mb + ly * TW + c4);
+            else for (int e = 0; e < 4 && gx + e < w; ++e) mp[e] = mb[ly * TW + c4 + e];
+        }
+    }
+}
+
 int usm_dispatch(const float* src, float* dst, float* tmp, const float* k1d, int ksize, float weight, float threshold,
                  int n, int c, int h, int w, hipStream_t st) {
     if (!src || !dst || !tmp || !k1d) return fail(RESR_ERR_ARG, "usm_sharp: null argument");
     const long count = (long)n * c * h * w;
+    const char* six_env = getenv("RESR_USM_SIX_PASSES");   // A/B and test knob (read per call): the separate passes
+    if (ksize == 51 && h > 25 && w > 25 && !six_env && (long)n * c < (1L << 24)) {
+        uint8_t* mask = reinterpret_cast<uint8_t*>(tmp);   // tmp3 = [mask bytes (+ unused) | blur | soft]
+        float* blur = tmp + count;
+        float* soft = tmp + 2 * count;
+        const int tiles_x = (w + 63) / 64, tiles_y = (h + 31) / 32;
+        const long items = (long)tiles_x * tiles_y * n * c;
+        const unsigned grid = (unsigned)(((items + 7) / 8) * 8);
+        hipLaunchKernelGGL((usm51_kernel<float, 0>), dim3(grid), dim3(256), 0, st, src, src, blur, mask, (float*)nullptr, (float*)nullptr, k1d,
+                           n * c, h, w, tiles_x, tiles_y, threshold, weight);
+        RESR_CHECK_LAUNCH("usm51_kernel (blur + mask)");
+        hipLaunchKernelGGL((usm51_kernel<uint8_t, 1>), dim3(grid), dim3(256), 0, st, (const uint8_t*)mask, src, blur, (uint8_t*)nullptr, soft, dst, k1d,
+                           n * c, h, w, tiles_x, tiles_y, threshold, weight);
+        RESR_CHECK_LAUNCH("usm51_kernel (soft + combine)");
+        return RESR_OK;
+    }
     float* t0 = tmp;               // row pass
     float* blur = tmp + count;     // blurred x, later soft mask input
     float* t2 = tmp + 2 * count;   // mask / soft

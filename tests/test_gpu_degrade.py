@@ -40,6 +40,42 @@ def test_usm_and_filter2d_vs_reference_golden(ip):
         ip.filter2d_torch(x, torch.ones(1, 4, 4).cuda())
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 72, 64), (1, 3, 400, 400), (3, 1, 31, 97), (1, 3, 26, 26), (2, 3, 130, 67)])
+def test_usm_two_launches_equal_six_passes(ip, shape):
+    """USMSharp(50, 0).forward as two fused launches (blur + byte mask; soft mask + combine, csrc/degrade.hip usm51_kernel) against
+    the six separate passes (RESR_USM_SIX_PASSES=1): same taps in the same order -> the same values to an ulp, output AND the tensors
+    the backward pass reads (blur, soft); ragged sizes, tiles cut by the image border, the smallest size the reflect padding allows."""
+    from oracle import imgproc_ref as I
+    n, c, h, w = shape
+    gen = torch.Generator().manual_seed(h * w)
+    import torch.nn.functional as F
+    x = F.interpolate(torch.rand(n, c, max(2, h // 8), max(2, w // 8), generator=gen), size=(h, w), mode="bicubic").clamp(0, 1)
+    x = (0.8 * x + 0.2 * torch.rand(n, c, h, w, generator=gen)).clamp(0, 1)
+    usm = ip.USMSharp(50, 0).cuda()
+
+    def run(six):
+        if six:
+            os.environ["RESR_USM_SIX_PASSES"] = "1"
+        try:
+            xd = x.cuda().requires_grad_(True)
+            y = usm(xd, 0.5, 10)
+            gw = torch.ones_like(y)
+            y.backward(gw)
+            torch.cuda.synchronize()
+            return y.detach().clone(), xd.grad.clone()
+        finally:
+            os.environ.pop("RESR_USM_SIX_PASSES", None)
+    y6, g6 = run(True)
+    y2, g2 = run(False)
+    # (one ulp apart where the compiler contracts the two kernels' multiply-adds differently; a flipped mask element would be ~1e-2)
+    assert (y2 - y6).abs().max().item() <= 2.5e-7, (y2 - y6).abs().max().item()
+    assert (g2 - g6).abs().max().item() <= 1e-6 * max(1.0, g6.abs().max().item()), (g2 - g6).abs().max().item()   # the backward pass reads the forward's blur / soft tensors
+    ref = I.usm_sharp(x, I.usm_kernel(50, 0), 0.5, 10)
+    assert err(y2, ref) < 2e-5
+    frac = ((y2.cpu() - x).abs() > 1e-6).float().mean().item()
+    assert frac > 0.01, "the mask never fired: the test image is too smooth to exercise the sharpening branch"
+
+
 def test_resize_vs_reference_golden(ip):
     g = load("imgproc_resize")
     x = g["x"].cuda()

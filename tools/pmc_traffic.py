@@ -47,12 +47,25 @@ def main():
         w = sum(write[k]) / len(write[k]) * 1024
         out[k] = {"launches": len(fetch[k]), "read_bytes_per_launch": round(f), "write_bytes_per_launch": round(w),
                   "hbm_bytes_per_launch": round(f + w)}
+    # the degradation stage as a whole (SURVEY 8d asks for its HBM rate): every resr:: kernel of csrc/degrade.hip, per batch --
+    # one crop_kernel launch closes each batch (train_realesrnet.py:374-377).  Plans differ from batch to batch (random resize
+    # factors, noise kinds): this is the mean over the profiled run's batches.
+    DEG = ("usm", "filter1d", "filter2d", "resize_kernel", "randn_kernel", "gauss_noise", "poisson_noise", "unique_", "jpeg_kernel", "crop_kernel")
+    batches = out.get("resr::crop_kernel", {}).get("launches", 0)
+    if batches:
+        per = {k: v for k, v in out.items() if isinstance(v, dict) and "resr::" in k and any(d in k for d in DEG)}
+        tot_r = sum(v["read_bytes_per_launch"] * v["launches"] for v in per.values())
+        tot_w = sum(v["write_bytes_per_launch"] * v["launches"] for v in per.values())
+        out["degradation_stage"] = {"batches": batches, "read_bytes_per_batch": round(tot_r / batches), "write_bytes_per_batch": round(tot_w / batches),
+                                    "hbm_bytes_per_batch": round((tot_r + tot_w) / batches),
+                                    "kernels": {k: {"launches_per_batch": round(v["launches"] / batches, 2), "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in per.items()}}
     # the build the counters were taken on: bench.py only quotes a traffic figure whose hash matches the current kernel sources
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     try:
         import bench
         out["csrc_sha16"] = bench.kernel_sources_sha16()
+        out["degrade_sha16"] = bench.degrade_sources_sha16()
     except Exception as e:   # pragma: no cover
         out["csrc_sha16"] = None
         out["csrc_sha16_error"] = repr(e)
