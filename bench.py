@@ -943,7 +943,9 @@ def other_configs(args):
         g4x = g4x.cuda().eval()
         with torch.no_grad():
             dtx = timed(lambda: g4x(x), 3)
-        rec2["parity_mode"] = {"precision": "exact16 (the default of inference.py / test.py: fp32 call sites of the reference)",
+        rec2["parity_mode"] = {"precision": "exact16 (the default of inference.py / test.py: fp32 call sites of the reference); inference plan: residual stream "
+                                            "and HR tail as pairs, growth planes single f16 (50 instead of 60 stages per block; forward 2e-6 / 2.4e-5 vs the "
+                                            "fp32 oracle at init scale / dense weights x 4, tests/test_gpu_x2_plan.py)",
                                "images_per_sec": round(16 / dtx, 1), "ms": round(dtx * 1e3, 2), "tflops_algorithmic": round(flop / dtx / 1e12, 1)}
         out["config2_x4_f16_inference_b16_lr256"] = rec2
         del g4x, x, sd2
@@ -1141,10 +1143,13 @@ def main():
             pm = {"precision": "exact16",
                   "what": "the same train step with split-operand f16 MFMA (activations and weights as hi+lo f16 pairs, three MFMAs per "
                           "product, fp32 accumulate): the mode that meets the 1e-3 max-abs parity tolerance vs the fp32 CPU path",
+                  "x2_plan": "default (3): forward all pairs; backward with single-f16 growth-plane gradients -- two stages on their chunks in "
+                             "backward-data, two tap-products in conv1..conv4's weight gradients (worst gradient tensor 2.3-4.0e-4 vs float64 "
+                             "at three geometries x five seeds, DESIGN section 2); x2_plan=0 = pairs everywhere (5.8e-6)",
                   "value": round(pv, 3), "unit": "images/sec", "steps": parity_res["steps"], "warmup": parity_res["warmup"],
                   "ms_per_step": round(parity_res["dt"] / parity_res["steps"] * 1e3, 2),
                   "generator_tflops_per_gpu": round(pv / world * flop_per_image / 1e12, 2), "loss": parity_res["loss"],
-                  "weight_gradients": "three tap-products (X_hi G_hi + 2^-12 (X_hi G_lo + X_lo G_hi)): every tensor within 6e-6 of the float64 evaluation"}
+                  "weight_gradients": "conv5 / tail: three tap-products (X_hi G_hi + 2^-12 (X_hi G_lo + X_lo G_hi)); conv1..conv4: two (G is a single f16 tensor)"}
             if parity_hi is not None:
                 pm["hi_only_weight_gradients"] = {"knob": "RESR_X2_WGRAD_PRODUCTS=1 (opt-in)", "value": round(rate(parity_hi), 3), "unit": "images/sec",
                                                   "ms_per_step": round(parity_hi["dt"] / parity_hi["steps"] * 1e3, 2),

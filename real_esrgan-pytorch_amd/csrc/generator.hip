@@ -43,6 +43,7 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
                            void* out5, void* chain_state, size_t chain_state_bytes, hipStream_t stream);
 size_t conv3x3_chain_state_bytes(int, int, int);
 int wgrad_batch(const WgradConv*, int, int, int, int, int, int, int, float*, hipStream_t);
+int wgrad_batch_quads(const WgradConv*, int, int);
 int wgrad_tile_rows(int dtype);
 int wgrad_x2_products();
 int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long);
@@ -164,10 +165,26 @@ struct Bufs {
 // tiles per workgroup.  strict: one workgroup per product and split, 256 CUs filled about three times over.  fast: the
 // quad kernel runs one 8-wave workgroup per CU on npairs/4 jobs -- two rounds of 256, in whole groups of 8 splits
 // (a split's jobs share one XCD).
-int splits_for(const Plan& p, int npairs, int h, int w) {
+// exact16 (nquads > 0: the launch's real quad-job count, wgrad_batch_quads): its job sets do not fill whole rounds the way fast
+// mode's do -- a dense block with single-f16 growth gradients is 17 quads, and 17 x 32 splits = 544 workgroups is a third,
+// nearly empty residency round (68 workgroups per XCD on 32 CUs).  Splits come in eights (a split's jobs share one XCD: nquads
+// x s / 8 workgroups per XCD); the count minimises   rounds x (tiles / s x t_tile + t_round) + slab traffic,
+// rounds = ceil(nquads x s / 8 / 32), with t_tile ~ 2.9 us per 8 x 32 tile and quad, t_round ~ 8 us of fill / drain, and every
+// (job, split) slab written and read back once (36.9 KB each at ~4 TB/s).
+int splits_for(const Plan& p, int npairs, int h, int w, int nquads = 0) {
     if (p.d.wgrad_splits > 0) return p.d.wgrad_splits;
     const int th = wgrad_tile_rows(p.d.dtype);
     const long tiles = (long)((w + 31) / 32) * ((h + th - 1) / th) * p.d.n;
+    if (p.d.dtype == RESR_F16X2 && nquads > 0 && tiles >= 64 && !getenv("RESR_X2_WGRAD_OLD_SPLITS")) {
+        long best_s = 8;
+        double best = 1e30;
+        for (long s = 8; s <= 256 && s <= tiles / 2; s += 8) {
+            const long rounds = (nquads * (s / 8) + 31) / 32;
+            const double cost = rounds * ((double)tiles / s * 2.9 + 8.0) + (double)npairs * s * 0.0185;
+            if (cost < best) { best = cost; best_s = s; }
+        }
+        return (int)best_s;
+    }
     long s;
     if (p.d.dtype != RESR_F32) {
         s = 512 / ((npairs + 3) / 4);
@@ -223,6 +240,15 @@ void carve(const Plan& p, char* base, Bufs& b) {
         // wgrad slabs: largest batch (an RRDB = 78 products, a dense block = 26 at LR; single 64->64 convs = 4 jobs at 1x/2x/4x)
         const size_t slab = (9 * 1024 + 32) * sizeof(float);
         size_t pb = 0;
+        if (p.d.dtype == RESR_F16X2) {   // exact16 picks its splits per launch (splits_for with the real quad count): size for any choice
+            const int th = wgrad_tile_rows(p.d.dtype);
+            for (int m = 1; m <= 4; m *= 2) {
+                const long tiles = (long)((p.w * m + 31) / 32) * ((p.h * m + th - 1) / th) * p.d.n;
+                const long smax = tiles / 2 < 256 ? (tiles / 2 < 1 ? 1 : tiles / 2) : 256;
+                const size_t q = (size_t)(m == 1 ? 78 : 12) * (size_t)smax * slab;
+                if (q > pb) pb = q;
+            }
+        }
         for (int k = 1; k <= wm; k += 2) {          // both weight-gradient settings of RESR_F16X2 (1 or 3 jobs per product)
             const size_t q0 = (size_t)26 * k * splits_for(p, 26 * k, p.h, p.w) * slab;
             if (q0 > pb) pb = q0;
@@ -562,7 +588,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     auto wgrad_run = [&](const WgradConv* wc, int nconv, int hh, int ww, int flags) -> int {
         int njobs = 0;   // tap-products: wm per product, two of three where G is a single f16 tensor (g_lo_off = 0)
         for (int i = 0; i < nconv; ++i) njobs += (wc[i].cin / 32) * (wc[i].cout_pad / 32) * ((x2 && wm == 3 && wc[i].g_lo_off == 0) ? 2 : wm);
-        const int splits = splits_for(p, njobs, hh, ww);
+        const int splits = splits_for(p, njobs, hh, ww, x2 ? wgrad_batch_quads(wc, nconv, d->dtype) : 0);
         if (wgrad_batch_partial_bytes(wc, nconv, splits, d->dtype) > b.partial_bytes)
             return fail(RESR_ERR_WORKSPACE, "wgrad slab buffer too small");
         return wgrad_batch(wc, nconv, N, hh, ww, d->dtype, flags, splits, b.partial, st);

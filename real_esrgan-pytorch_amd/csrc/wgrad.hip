@@ -962,6 +962,39 @@ static int wgrad_parts(const WgradConv& c, int dtype) {
     return (n == 3 && c.g_lo_off == 0) ? 2 : n;
 }
 
+// Quad jobs (workgroups per pixel split) the batched launch of `convs` will run: the planners size their pixel splits by it --
+// a dense block's 64 exact16 tap-products with single-f16 growth gradients group into 17 quads, not 64 / 4 (the plan is cached
+// per operand pattern, so this costs a map lookup after the first call).  Falls back to ceil(jobs / 4).
+int wgrad_batch_quads(const WgradConv* convs, int nconv, int dtype) {
+    const size_t es = elem_size(dtype);
+    const bool x2 = dtype == RESR_F16X2;
+    const int nparts = x2 ? wgrad_x2_products() : 1;
+    const char* xs[kMaxJobs]; const char* gs[kMaxJobs];
+    int jx[kMaxJobs], jg[kMaxJobs], nx = 0, ng = 0, nj = 0, total = 0;
+    for (int i = 0; i < nconv; ++i) {
+        const WgradConv& c = convs[i];
+        const bool g_single = x2 && c.g_lo_off == 0;
+        for (int ct = 0; ct < c.cout_pad / 32; ++ct)
+            for (int ck = 0; ck < c.cin / 32; ++ck)
+                for (int part = 0; part < nparts; ++part) {
+                    if (part == 1 && g_single) continue;
+                    ++total;
+                    if (nj >= kMaxJobs) continue;
+                    const char* xp = (const char*)c.x0 + (size_t)ck * (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * es + (part == 2 ? (size_t)c.x_lo_off * es : 0);
+                    const char* gp = (const char*)c.g + (size_t)ct * (c.g_chunk_stride > 0 ? c.g_chunk_stride : 32) * es + (part == 1 ? (size_t)c.g_lo_off * es : 0);
+                    int xi = 0, gi = 0;
+                    while (xi < nx && xs[xi] != xp) ++xi;
+                    if (xi == nx) xs[nx++] = xp;
+                    while (gi < ng && gs[gi] != gp) ++gi;
+                    if (gi == ng) gs[ng++] = gp;
+                    jx[nj] = xi; jg[nj] = gi; ++nj;
+                }
+    }
+    if (total > kMaxJobs || dtype == RESR_F32) return (total + 3) / 4;
+    const std::vector<QuadIdx>* plan = plan_quads(jx, jg, nj, nx, ng);
+    return plan ? (int)plan->size() : (total + 3) / 4;
+}
+
 size_t wgrad_batch_partial_bytes(const WgradConv* convs, int nconv, int splits, int dtype) {
     size_t jobs = 0;
     for (int i = 0; i < nconv; ++i) jobs += (size_t)(convs[i].cin / 32) * (convs[i].cout_pad / 32) * wgrad_parts(convs[i], dtype);
