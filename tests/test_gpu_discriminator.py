@@ -66,6 +66,48 @@ def test_three_training_calls_vs_reference_golden(precision, golden, diag_dir):
     assert (ye.cpu() - g["y_eval"]).abs().max().item() < tol_y * max(1.0, g["y_eval"].abs().max().item())
 
 
+@pytest.mark.parametrize("golden", ["discriminator_allgrads_240", "discriminator_allgrads_243"])
+@pytest.mark.parametrize("precision", ["strict", "exact16", "fast"])
+def test_every_gradient_tensor_vs_reference_golden(precision, golden, diag_dir):
+    """The 1e-3 gate of strict / exact16 on seeds that were NOT searched for (most seeds have no pre-activation within fp32
+    rounding of zero) and on EVERY gradient tensor of the three training calls, not a slice of four."""
+    z = np.load(os.path.join(G, golden + ".npz"))
+    g = {k: torch.from_numpy(z[k]) if z[k].dtype.kind == "f" else z[k] for k in z.files}
+    d, sd, M = _make(precision, int(g["seed"]))
+    d.train()
+    names = [str(n) for n in g["names"]]
+    x = g["x"].cuda().requires_grad_(True)
+    scale = 1.0 if precision == "strict" else 256.0
+    tol_y, tol_g = (2e-4, 1e-3) if precision != "fast" else (2e-2, 0.12)
+
+    def sub(t, cap=4096):
+        f = t.reshape(-1)
+        return f if f.numel() <= cap else f[::(f.numel() + cap - 1) // cap]
+    rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+    rep = {}
+    for call in range(3):
+        d.zero_grad()
+        x.grad = None
+        y = d(x)
+        (y * g["gw"].cuda()).sum().mul(scale).backward()
+        torch.cuda.synchronize()
+        named = dict(d.named_parameters())
+        assert list(named) == names
+        r = {"y": (y.detach().cpu() - g[f"y{call}"]).abs().max().item(), "gx": rel(x.grad.cpu() / scale, g[f"gx{call}"])}
+        for i, k in enumerate(names):
+            got = named[k].grad.cpu() / scale
+            r[k] = rel(sub(got), g[f"g{call}_{i}"])
+            r["norm_" + k] = abs(got.double().norm().item() / float(g[f"n{call}_{i}"]) - 1.0)
+        rep[f"call{call}"] = r
+    with open(os.path.join(diag_dir, f"disc_allgrads_{precision}_{golden[-3:]}.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    for call in range(3):
+        r = rep[f"call{call}"]
+        assert r["y"] < tol_y * max(1.0, g[f"y{call}"].abs().max().item()) and r["gx"] < tol_g, (call, r)
+        for k in names:
+            assert r[k] < tol_g and r["norm_" + k] < tol_g, (call, k, r[k], r["norm_" + k])
+
+
 @pytest.mark.parametrize("precision", ["strict", "exact16"])
 def test_all_gradients_vs_oracle_odd_shape(precision):
     d, sd, M = _make(precision, 7)

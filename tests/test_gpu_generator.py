@@ -124,8 +124,8 @@ def test_state_dict_surface_and_channels_last():
         g(x.cpu())
 
 
-@pytest.mark.parametrize("precision", [None, "strict"])
-def test_inference_entry_point(tmp_path, precision):
+@pytest.mark.parametrize("precision,size", [(None, (24, 28)), ("strict", (24, 28)), (None, (128, 128))])
+def test_inference_entry_point(tmp_path, precision, size):
     """reference inference.py flow: checkpoint with 'model.'-prefixed keys -> PNG in -> PNG out, vs the oracle.
     precision None = the entry point's DEFAULT (no --precision): the reference runs this call site in fp32
     (inference.py:52-53, no autocast), so the default must be a mode inside the 1e-3 tolerance (config.inference_precision)."""
@@ -137,7 +137,7 @@ def test_inference_entry_point(tmp_path, precision):
     sd["conv4.bias"] = sd["conv4.bias"] + 0.5
     torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}}, tmp_path / "g.pth.tar")
     rng = np.random.RandomState(0)
-    lr = rng.randint(0, 256, size=(24, 28, 3), dtype=np.uint8)
+    lr = rng.randint(0, 256, size=(size[0], size[1], 3), dtype=np.uint8)      # (128, 128): BASELINE config 1's geometry
     Image.fromarray(lr).save(tmp_path / "lr.png")
 
     class A:
@@ -151,7 +151,7 @@ def test_inference_entry_point(tmp_path, precision):
     got = np.asarray(Image.open(tmp_path / "sr.png")).astype(np.int32)
     x = torch.from_numpy(lr.astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
     ref = M.generator_forward(x, sd, 4).squeeze(0).permute(1, 2, 0).mul(255).clamp(0, 255).numpy().astype("uint8").astype(np.int32)
-    assert got.shape == (96, 112, 3)
+    assert got.shape == (4 * size[0], 4 * size[1], 3)
     d = np.abs(got - ref)
     assert d.max() <= 1 and (d > 0).mean() < 1e-3      # truncating uint8 conversion: ties within 2e-6 may flip a level
 
@@ -196,6 +196,47 @@ def test_directory_test_entry_point_default_precision(tmp_path, monkeypatch):
         ref_scores.append(niqe(yo.cuda()).item())
     assert score == score and 0 < score <= 100, score
     assert abs(score - sum(ref_scores) / len(ref_scores)) < 1e-3 * max(1.0, abs(score)), (score, ref_scores)
+
+
+def test_entry_points_route_large_frames_through_the_tiler(tmp_path):
+    """A frame beyond the conv kernels' 2^24-pixel tensors (here 1100 x 1000 LR -> 17.6 M HR pixels) used to raise in
+    inference.main; tiling.super_resolve cuts it into haloed tiles.  With a 1-block trunk (receptive field ~21 LR px < the
+    default halo) the stitched image equals what two half-frames with a generous overlap give where both cover a pixel; a frame
+    that fits runs as one pass, bit-equal to model(x)."""
+    import numpy as np
+    from PIL import Image
+    import real_esrgan_pytorch_amd as R
+    from real_esrgan_pytorch_amd import inference, tiling
+    torch.manual_seed(3)
+    g = R.Generator(3, 3, 4, precision="fast", n_blocks=1).cuda().eval()
+    with torch.no_grad():
+        g.conv4.bias.add_(0.5)
+    small = torch.rand(1, 3, 40, 56, device="cuda")
+    assert tiling.fits_whole(g, 1, 40, 56) and torch.equal(tiling.super_resolve(g, small), g(small).detach())
+    H, W = 1100, 1000
+    assert not tiling.fits_whole(g, 1, H, W)
+    x = torch.rand(1, 3, H, W, device="cuda")
+    y = tiling.super_resolve(g, x)
+    assert y.shape == (1, 3, 4 * H, 4 * W) and torch.isfinite(y).all()
+    with torch.no_grad():
+        top = g(x[:, :, :640].contiguous())            # fits: 640 x 1000 x 16 = 10.2 M HR pixels
+        bot = g(x[:, :, H - 640:].contiguous())
+    assert torch.equal(y[:, :, :4 * 500], top[:, :, :4 * 500])                 # rows far from the cut of either half
+    assert torch.equal(y[:, :, 4 * 600:], bot[:, :, 4 * (600 - (H - 640)):])
+    # ... and through the CLI entry point (default precision = exact16): no exception, the file has the frame's size
+    torch.save({"state_dict": {"model." + k: v for k, v in g.state_dict().items()}}, tmp_path / "g.pth.tar")
+    Image.fromarray((x[0, :, :1050, :1000].permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)).save(tmp_path / "lr.png")
+
+    class A:
+        inputs_path, output_path, weights_path, precision = str(tmp_path / "lr.png"), str(tmp_path / "sr.png"), str(tmp_path / "g.pth.tar"), "fast"
+    from real_esrgan_pytorch_amd import model as model_mod
+    orig = model_mod.Generator.N_BLOCKS
+    model_mod.Generator.N_BLOCKS = 1
+    try:
+        inference.main(A)
+    finally:
+        model_mod.Generator.N_BLOCKS = orig
+    assert Image.open(tmp_path / "sr.png").size == (4000, 4200)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

@@ -272,6 +272,7 @@ def test_gradscaler_overflow_in_the_gan_step_shared_scaler():
     g0, d0 = g.flat_parameters().clone(), d.flat_parameters().clone()
     g_moved = d_moved = False
     halvings = 0
+    g_steps = d_steps = 0
     for it in range(24):
         gb, db, sb = g.flat_parameters().clone(), d.flat_parameters().clone(), scaler.get_scale()
         out = step(hr, lr)
@@ -280,6 +281,7 @@ def test_gradscaler_overflow_in_the_gan_step_shared_scaler():
         g_skip, d_skip = torch.equal(gb, ga), torch.equal(db, da)
         assert sa == sb * 0.5 ** (int(g_skip) + int(d_skip)), (it, sb, sa, g_skip, d_skip)
         halvings += int(g_skip) + int(d_skip)
+        g_steps, d_steps = g_steps + int(not g_skip), d_steps + int(not d_skip)
         g_moved, d_moved = g_moved or not g_skip, d_moved or not d_skip
         if not g_skip and not d_skip:
             assert all(torch.isfinite(v) for v in out.values()), out
@@ -288,6 +290,7 @@ def test_gradscaler_overflow_in_the_gan_step_shared_scaler():
         raise AssertionError("the step never recovered")
     assert halvings >= 3 and g_moved and d_moved
     assert not torch.equal(g.flat_parameters(), g0) and not torch.equal(d.flat_parameters(), d0)
-    for opt in (g_opt, d_opt):
+    # Adam counted exactly the half-steps that were not skipped (the discriminator's gradients are larger: it may recover a step later)
+    for opt, n_steps in ((g_opt, g_steps), (d_opt, d_steps)):
         states = [s for s in opt.state.values() if s]
-        assert states and all(float(s["step"]) == 1 for s in states)
+        assert states and n_steps >= 1 and all(float(s["step"]) == n_steps for s in states), (n_steps, [float(s["step"]) for s in states])

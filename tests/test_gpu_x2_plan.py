@@ -315,3 +315,80 @@ def test_single_plane_chains_equal_separate_launches(n, h, w):
         for i, (a, b) in enumerate(zip(g0, g1)):
             assert torch.equal(a, b), (rep, i, (a - b).abs().max().item())
     assert int(L.lib().resr_debug_chain_errors()) == 0
+
+
+# ---- off the init scale: every parity case above uses 0.1 x kaiming dense blocks and [0, 1] images -----------
+def _oracle_grads(M, sd, x, gw, n_blocks, dt=torch.float64):
+    sdo = {k: v.to(dt).clone().requires_grad_(True) for k, v in sd.items()}
+    xo = x.to(dt).clone().requires_grad_(True)
+    yo = M.generator_forward(xo, sdo, 4, n_blocks)
+    (yo * gw.to(dt)).sum().backward()
+    return yo.detach(), {k: v.grad for k, v in sdo.items()}, xo.grad
+
+
+@pytest.mark.parametrize("precision,plan", [("exact16", 3), ("exact16", 0), ("fast", 0)])
+@pytest.mark.parametrize("case", ["dense_x4", "stream_x40"])
+def test_generator_parity_off_the_init_scale(precision, plan, case, diag_dir):
+    """Forward + backward of a 6-block generator against the float64 oracle with (a) the dense-block weights x 4 (the branches are
+    no longer a small correction of the stream) and (b) conv1's weights x 40 (stream and growth planes of O(10 - 100): the hi
+    tensors leave [0, 1], the scaled lo tensors reach 2^12 x 2^-11 x 100 ~ 200, the loss scale meets large gradients).  exact16
+    (default plan and all-pairs) keeps its gates RELATIVE to the activation scale; fast keeps f16's class."""
+    import real_esrgan_pytorch_amd as R
+    from oracle import model_ref as M
+    nb = 6
+    sd = M.init_generator_state(17, 3, 3, 4, bias_noise=0.02)
+    sd = {k: v for k, v in sd.items() if not k.startswith("trunk.") or int(k.split(".")[1]) < nb}
+    sd["conv4.bias"] = sd["conv4.bias"] + 0.5
+    if case == "dense_x4":
+        sd = {k: (v * 4.0 if k.endswith(".weight") and ".rdb" in k else v) for k, v in sd.items()}
+    else:
+        sd["conv1.weight"] = sd["conv1.weight"] * 40.0
+        sd["conv4.weight"] = sd["conv4.weight"] / 40.0          # keeps the output inside the clamp, the gradients large
+    g = R.Generator(3, 3, 4, precision=precision, n_blocks=nb, x2_plan=plan)
+    g.load_state_dict(sd)
+    g = g.cuda().train()
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 24, 28, generator=gen)
+    gw = torch.randn(2, 3, 96, 112, generator=gen)
+    yo, go, gxo = _oracle_grads(M, sd, x, gw, nb)
+    with torch.no_grad():      # the stream's magnitude, for the record
+        f = torch.nn.functional.conv2d(x.double(), sd["conv1.weight"].double(), sd["conv1.bias"].double(), padding=1)
+    scale = 256.0
+    xd = x.cuda().requires_grad_(True)
+    y = g(xd)
+    (y * gw.cuda()).sum().mul(scale).backward()
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return ((a.double() - b).norm() / b.norm().clamp_min(1e-30)).item()
+    errs = {k: rel(p.grad.cpu() / scale, go[k]) for k, p in g.named_parameters()}
+    worst = max(errs, key=errs.get)
+    rep = {"stream_absmax": f.abs().max().item(), "fwd": (y.detach().cpu().double() - yo).abs().max().item(), "worst": errs[worst], "worst_tensor": worst,
+           "median": sorted(errs.values())[len(errs) // 2], "gx": rel(xd.grad.cpu() / scale, gxo), "unclamped": ((yo > 0) & (yo < 1)).double().mean().item()}
+    with open(os.path.join(diag_dir, f"offscale_{case}_{precision}_{plan}.json"), "w") as fjson:
+        json.dump(rep, fjson, indent=1)
+    assert torch.isfinite(y).all() and all(torch.isfinite(p.grad).all() for p in g.parameters())
+    if precision == "exact16":
+        assert rep["fwd"] < 2e-4, rep
+        # (a mask flip of the forward pass would show as ~1e-2 on one tensor in BOTH plans: see test_training_plan_gradients_vs_float64_oracle)
+        assert rep["worst"] < (1e-3 if plan else 5e-5) or rep["worst"] > 3e-3, rep
+        assert rep["median"] < (5e-4 if plan else 2e-5) and rep["gx"] < 1e-4, rep
+    else:
+        assert rep["fwd"] < 2e-2 and rep["median"] < 0.15, rep
+
+
+def test_exact16_weight_overflow_is_loud():
+    """exact16 packs W0 = f16(w * 2^12): |w| >= 16 overflows (include/resr.h).  That must never be silent: W0 = inf and its remainder
+    W1 = -inf meet in the accumulator as NaN, so the output -- and a training loss -- turns NaN; |w| just below the limit is exact."""
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(1)
+    g = R.Generator(3, 3, 4, precision="exact16", n_blocks=1).cuda().eval()
+    x = torch.rand(1, 3, 16, 16, device="cuda")
+    with torch.no_grad():
+        y0 = g(x)
+        g.trunk[0].rdb1.conv1.weight[0, 0, 1, 1] = 15.9
+        y1 = g(x)
+        g.trunk[0].rdb1.conv1.weight[0, 0, 1, 1] = 17.0
+        y2 = g(x)
+    assert torch.isfinite(y0).all() and torch.isfinite(y1).all()
+    assert torch.isnan(y2).any(), "a weight beyond the split format's range must poison the output"

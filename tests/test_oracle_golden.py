@@ -84,6 +84,33 @@ def test_discriminator_three_training_calls_and_eval():
         assert close(M.discriminator_forward(g["x"], sd, training=False), g["y_eval"], 1e-5)
 
 
+def _sub(t, cap=4096):      # tests/golden/gen_golden.py _subsample
+    f = t.reshape(-1)
+    return f if f.numel() <= cap else f[::(f.numel() + cap - 1) // cap]
+
+
+@pytest.mark.parametrize("name", ["discriminator_allgrads_240", "discriminator_allgrads_243"])
+def test_discriminator_every_gradient_tensor(name):
+    """Two more seeds without a LeakyReLU pre-activation near zero, EVERY gradient tensor of the three training calls (stored
+    subsampled + its norm): the oracle pinned to the reference's own autograd on all of them."""
+    g = load(name)
+    sd = M.init_discriminator_state(int(g["seed"]))
+    names = [str(n) for n in g["names"]]
+    for k in names:
+        sd[k].requires_grad_(True)
+    x = g["x"].clone().requires_grad_(True)
+    for call in range(3):
+        for v in sd.values():
+            v.grad = None
+        x.grad = None
+        y = M.discriminator_forward(x, sd, training=True)
+        (y * g["gw"]).sum().backward()
+        assert close(y.detach(), g[f"y{call}"], 1e-5) and close(x.grad, g[f"gx{call}"], 1e-5), call
+        for i, k in enumerate(names):
+            assert close(_sub(sd[k].grad), g[f"g{call}_{i}"], 1e-5), (call, k)
+            assert abs(sd[k].grad.double().norm().item() - float(g[f"n{call}_{i}"])) <= 1e-5 * max(1.0, float(g[f"n{call}_{i}"])), (call, k)
+
+
 def test_ema_three_updates_bit_exact():
     g = load("ema")
     shadow = {i: g[f"p0_{i}"].clone() for i in range(4)}
