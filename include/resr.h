@@ -265,9 +265,14 @@ int resr_generator_backward(const ResrGeneratorDesc* d, const float* gy_nchw, co
 int resr_filter2d(const float* src, float* dst, const float* kernel, int32_t n, int32_t c, int32_t h, int32_t w,
                   int32_t kh, int32_t kw, int32_t per_sample, void* stream);
 /* USMSharp.forward (imgproc.py:1526-1537) with the Gaussian given as its 1-D factor k1d[ksize];
- * tmp3 = 3*n*c*h*w floats of scratch. */
+ * tmp3 = 3*n*c*h*w floats of scratch, kept by a caller that will run resr_usm_sharp_bwd: [mask bytes / row pass | blur | soft].
+ * ksize = 51 (USMSharp(50, 0), the only configuration the reference builds) runs as two fused launches -- blur + byte mask, soft
+ * mask + combine: 26 B per value instead of the 60 B of six separate passes. */
 int resr_usm_sharp(const float* src, float* dst, float* tmp3, const float* k1d, int32_t ksize, float weight,
                    float threshold, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+/* the same without the soft-mask store the backward pass needs (the degradation path, train_realesrnet.py:268: no graph) */
+int resr_usm_sharp_forward_only(const float* src, float* dst, float* tmp3, const float* k1d, int32_t ksize, float weight,
+                                float threshold, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 /* backward of resr_usm_sharp wrt its input (the GAN step differentiates through usm_sharpener(sr),
  * train_realesrgan.py:476): saved_tmp3 = the forward's tmp3 (kept), tmp2 = 2*n*c*h*w floats of scratch. */
 int resr_usm_sharp_bwd(const float* x, const float* saved_tmp3, const float* g, float* gx, float* tmp2, const float* k1d,
@@ -291,7 +296,8 @@ int resr_noise_poisson(const float* src, float* dst, const float* scale, const f
  * coeffs (optional) receives the rounded coefficients [n][Y blocks | Cb blocks | Cr blocks][64]. */
 int resr_jpeg(const float* src, float* dst, const float* quality, float* coeffs, int32_t n, int32_t h, int32_t w,
               int32_t flags /* bit0: clamp the input to [0,1] first (train_realesrnet.py:308) */, void* stream);
-/* clamp(round(x*255))/255 on lr + random_crop of both (train_realesrnet.py:374-377, imgproc.py:1894-1934) */
+/* clamp(round(x*255))/255 on lr + random_crop of both (train_realesrnet.py:374-377, imgproc.py:1894-1934).  hr_out = NULL is
+ * allowed when the HR window is the whole image (hr_size == hr_h == hr_w): the caller keeps using `hr` instead of a copy of it. */
 int resr_quantize_crop(const float* lr, const float* hr, float* lr_out, float* hr_out, int32_t n, int32_t c, int32_t lr_h,
                        int32_t lr_w, int32_t hr_h, int32_t hr_w, int32_t hr_size, int32_t upscale, int32_t hr_top,
                        int32_t hr_left, void* stream);

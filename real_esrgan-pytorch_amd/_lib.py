@@ -124,6 +124,7 @@ _PROTOS = {
     "resr_fold4x4": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
     "resr_filter2d": (C.c_int, [_P, _P, _P] + [C.c_int32] * 7 + [_P]),
     "resr_usm_sharp": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_float, C.c_float] + [C.c_int32] * 4 + [_P]),
+    "resr_usm_sharp_forward_only": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_float, C.c_float] + [C.c_int32] * 4 + [_P]),
     "resr_usm_sharp_bwd": (C.c_int, [_P] * 6 + [C.c_int32, C.c_float] + [C.c_int32] * 4 + [_P]),
     "resr_resize": (C.c_int, [_P, _P] + [C.c_int32] * 7 + [C.c_double, C.c_double, _P]),
     "resr_randn_fill": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),

@@ -104,7 +104,7 @@ int discriminator_forward(const ResrDiscriminatorDesc*, const float*, const floa
 int discriminator_backward(const ResrDiscriminatorDesc*, const float*, const float*, void*, size_t, float*, float*, hipStream_t);
 
 int filter2d_dispatch(const float*, float*, const float*, int, int, int, int, int, int, int, hipStream_t);
-int usm_dispatch(const float*, float*, float*, const float*, int, float, float, int, int, int, int, hipStream_t);
+int usm_dispatch(const float*, float*, float*, const float*, int, float, float, int, int, int, int, hipStream_t, int);
 int resize_dispatch(const float*, float*, int, int, int, int, int, int, int, double, double, hipStream_t);
 int usm_bwd_dispatch(const float*, const float*, const float*, float*, float*, const float*, int, float, int, int, int, int, hipStream_t);
 int randn_dispatch(float*, long, uint64_t, uint64_t, hipStream_t);
@@ -275,7 +275,13 @@ int resr_filter2d(const float* src, float* dst, const float* kernel, int32_t n, 
 int resr_usm_sharp(const float* src, float* dst, float* tmp3, const float* k1d, int32_t ksize, float weight, float threshold,
                    int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
     RESR_DEVICE_SCOPE(stream);
-    return usm_dispatch(src, dst, tmp3, k1d, ksize, weight, threshold, n, c, h, w, (hipStream_t)stream);
+    return usm_dispatch(src, dst, tmp3, k1d, ksize, weight, threshold, n, c, h, w, (hipStream_t)stream, 1);
+}
+
+int resr_usm_sharp_forward_only(const float* src, float* dst, float* tmp3, const float* k1d, int32_t ksize, float weight, float threshold,
+                                int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return usm_dispatch(src, dst, tmp3, k1d, ksize, weight, threshold, n, c, h, w, (hipStream_t)stream, 0);
 }
 
 int resr_usm_sharp_bwd(const float* x, const float* saved_tmp3, const float* g, float* gx, float* tmp2, const float* k1d,

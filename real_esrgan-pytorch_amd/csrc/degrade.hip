@@ -231,7 +231,7 @@ template <typename TIN, int EPI>   // EPI 0: blur + byte mask (TIN = float);  EP
 __global__ __launch_bounds__(256) void usm51_kernel(const TIN* __restrict__ src, const float* __restrict__ x, float* __restrict__ blur,
                                                     uint8_t* __restrict__ mask, float* __restrict__ soft, float* __restrict__ out,
                                                     const float* __restrict__ kern, int planes, int h, int w, int tiles_x, int tiles_y,
-                                                    float threshold, float weight) {
+                                                    float threshold, float weight, int keep_soft) {
     constexpr int K = 51, R = 25, TW = 64, TH = 32, IH = TH + 2 * R, IW = TW + 2 * R, IWP = 120;   // 82 x 114 input window, rows padded for float4 windows
     __shared__ __attribute__((aligned(16))) float in[IH * IWP];      // 39.4 KB
     __shared__ __attribute__((aligned(16))) float hp[IH * TW];       // 21 KB: the row pass
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void usm51_kernel(const TIN* __restrict__ src,
             } else if (ok) {
                 const float xv = x[q], s = acc[j];
                 const float sharp = fminf(fmaxf(xv + weight * (xv - blur[q]), 0.f), 1.f);
-                soft[q] = s;
+                if (keep_soft) soft[q] = s;          // only the backward pass reads it (the degradation path runs without a graph)
                 out[q] = s * sharp + (1.f - s) * xv;
             }
         }
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void usm51_kernel(const TIN* __restrict__ src,
 }
 
 int usm_dispatch(const float* src, float* dst, float* tmp, const float* k1d, int ksize, float weight, float threshold,
-                 int n, int c, int h, int w, hipStream_t st) {
+                 int n, int c, int h, int w, hipStream_t st, int keep_for_backward) {
     if (!src || !dst || !tmp || !k1d) return fail(RESR_ERR_ARG, "usm_sharp: null argument");
     const long count = (long)n * c * h * w;
     const char* six_env = getenv("RESR_USM_SIX_PASSES");   // A/B and test knob (read per call): the separate passes
@@ -332,10 +332,10 @@ int usm_dispatch(const float* src, float* dst, float* tmp, const float* k1d, int
         const long items = (long)tiles_x * tiles_y * n * c;
         const unsigned grid = (unsigned)(((items + 7) / 8) * 8);
         hipLaunchKernelGGL((usm51_kernel<float, 0>), dim3(grid), dim3(256), 0, st, src, src, blur, mask, (float*)nullptr, (float*)nullptr, k1d,
-                           n * c, h, w, tiles_x, tiles_y, threshold, weight);
+                           n * c, h, w, tiles_x, tiles_y, threshold, weight, 0);
         RESR_CHECK_LAUNCH("usm51_kernel (blur + mask)");
         hipLaunchKernelGGL((usm51_kernel<uint8_t, 1>), dim3(grid), dim3(256), 0, st, (const uint8_t*)mask, src, blur, (uint8_t*)nullptr, soft, dst, k1d,
-                           n * c, h, w, tiles_x, tiles_y, threshold, weight);
+                           n * c, h, w, tiles_x, tiles_y, threshold, weight, keep_for_backward);
         RESR_CHECK_LAUNCH("usm51_kernel (soft + combine)");
         return RESR_OK;
     }
@@ -833,7 +833,9 @@ __global__ __launch_bounds__(256) void crop_kernel(const float* __restrict__ src
 
 int quantize_crop_dispatch(const float* lr, const float* hr, float* lr_out, float* hr_out, int n, int c, int lr_h, int lr_w,
                            int hr_h, int hr_w, int hr_size, int upscale, int hr_top, int hr_left, hipStream_t st) {
-    if (!lr || !hr || !lr_out || !hr_out || upscale <= 0) return fail(RESR_ERR_ARG, "quantize_crop: bad argument");
+    if (!lr || !hr || !lr_out || upscale <= 0) return fail(RESR_ERR_ARG, "quantize_crop: bad argument");
+    if (!hr_out && (hr_top != 0 || hr_left != 0 || hr_size != hr_h || hr_size != hr_w))
+        return fail(RESR_ERR_ARG, "quantize_crop: hr_out may only be NULL when the HR window is the whole image (the caller keeps using hr)");
     const int lr_size = hr_size / upscale, lr_top = hr_top / upscale, lr_left = hr_left / upscale;     // imgproc.py:1917-1919
     if (hr_top < 0 || hr_left < 0 || hr_top + hr_size > hr_h || hr_left + hr_size > hr_w || lr_top + lr_size > lr_h ||
         lr_left + lr_size > lr_w)
@@ -842,9 +844,11 @@ int quantize_crop_dispatch(const float* lr, const float* hr, float* lr_out, floa
     hipLaunchKernelGGL(crop_kernel, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, st, lr, lr_out, n * c, lr_h, lr_w, lr_size,
                        lr_top, lr_left, 1);
     RESR_CHECK_LAUNCH("crop_kernel");
-    hipLaunchKernelGGL(crop_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, hr, hr_out, n * c, hr_h, hr_w, hr_size,
-                       hr_top, hr_left, 0);
-    RESR_CHECK_LAUNCH("crop_kernel");
+    if (hr_out) {   // (NULL: the window is the whole image and the caller aliases hr instead of copying it)
+        hipLaunchKernelGGL(crop_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, st, hr, hr_out, n * c, hr_h, hr_w, hr_size,
+                           hr_top, hr_left, 0);
+        RESR_CHECK_LAUNCH("crop_kernel");
+    }
     return RESR_OK;
 }
 

@@ -92,8 +92,10 @@ class _USMFn(torch.autograd.Function):
         b, c, h, w = xi.shape
         out = torch.empty_like(xi)
         tmp = torch.empty(3 * xi.numel(), dtype=torch.float32, device=xi.device)
-        _lib.check(_lib.lib().resr_usm_sharp(_lib.ptr(xi), _lib.ptr(out), _lib.ptr(tmp), _lib.ptr(k1d), radius, weight,
-                                             threshold, b, c, h, w, _lib.stream_ptr(x)), "resr_usm_sharp")
+        # (the soft mask is stored only for a backward pass: the degradation path sharpens without a graph)
+        fn = _lib.lib().resr_usm_sharp if x.requires_grad else _lib.lib().resr_usm_sharp_forward_only
+        _lib.check(fn(_lib.ptr(xi), _lib.ptr(out), _lib.ptr(tmp), _lib.ptr(k1d), radius, weight,
+                      threshold, b, c, h, w, _lib.stream_ptr(x)), "resr_usm_sharp")
         if x.requires_grad:
             ctx.save_for_backward(xi, tmp, k1d)
             ctx.radius, ctx.weight = radius, weight
@@ -351,8 +353,11 @@ def quantize_crop(lr_images, hr_images, hr_image_size, upscale_factor, hr_top, h
     b, c = lr.shape[:2]
     ls = hr_image_size // upscale_factor
     plr = torch.empty((b, c, ls, ls), dtype=torch.float32, device=lr.device)
-    phr = torch.empty((b, c, hr_image_size, hr_image_size), dtype=torch.float32, device=lr.device)
-    _lib.check(_lib.lib().resr_quantize_crop(_lib.ptr(lr), _lib.ptr(hr), _lib.ptr(plr), _lib.ptr(phr), b, c, lr.shape[2],
+    # an HR window that is the whole tile needs no copy: the target is only ever read (the reference's per-sample copy loop,
+    # imgproc.py:1921-1932, exists to cut a window out)
+    whole = hr_top == 0 and hr_left == 0 and hr_image_size == hr.shape[2] == hr.shape[3]
+    phr = hr if whole else torch.empty((b, c, hr_image_size, hr_image_size), dtype=torch.float32, device=lr.device)
+    _lib.check(_lib.lib().resr_quantize_crop(_lib.ptr(lr), _lib.ptr(hr), _lib.ptr(plr), None if whole else _lib.ptr(phr), b, c, lr.shape[2],
                                              lr.shape[3], hr.shape[2], hr.shape[3], hr_image_size, upscale_factor,
                                              hr_top, hr_left, _lib.stream_ptr(lr)), "resr_quantize_crop")
     return plr, phr

@@ -28,7 +28,7 @@ def q16(t):
     return t.to(torch.float16).to(t.dtype)
 
 
-def q8(t, dim):
+def q8_mx(t, dim):
     """MX-style fp8: e4m3 values with one shared power-of-two scale per block of 32 elements along `dim` (the K dimension of
     the product the operand enters: input channels for conv / backward-data, pixels of a row for the weight gradients)."""
     t = t.movedim(dim, -1)
@@ -41,6 +41,12 @@ def q8(t, dim):
     q = (b / sc).to(torch.float32).to(torch.float8_e4m3fn).to(t.dtype) * sc
     q = q.reshape(tp.shape)[..., :shp[-1]]
     return q.movedim(-1, dim)
+
+
+def q8_e5m2(t, dim=None):
+    """bf8 (e5m2) WITHOUT block scales: f16's exponent range in one byte -- what an epilogue can emit next to the f16 value with one
+    v_cvt_pk_bf8_f32 per two values, and what v_mfma_scale_f32_32x32x64_f8f6f4 multiplies with unit scales."""
+    return t.to(torch.float32).to(torch.float8_e5m2).to(t.dtype)
 
 
 def split16(t):
@@ -57,6 +63,7 @@ class Conv8(torch.autograd.Function):
     def forward(ctx, x, w, b, where):
         ctx.save_for_backward(x, w)
         ctx.where = where
+        q8 = q8_e5m2 if "5" in where else q8_mx
         if "f" not in where:
             return F.conv2d(x, w, b, padding=1)
         xh, xl = split16(x)
@@ -66,6 +73,7 @@ class Conv8(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
+        q8 = q8_e5m2 if "5" in ctx.where else q8_mx
         gh, gl = split16(g)
         wh, wl = split16(w)
         xh, xl = split16(x)
@@ -182,6 +190,9 @@ RUNGS5 = {
     "fp8 corrections: backward-data + weight gradients":             _with(_EXACT, fp8="dw"),
     "fp8 corrections: forward + backward-data + weight gradients":   _with(_EXACT, fp8="fdw"),
     "fp8 corrections: forward only":                                 _with(_EXACT, fp8="f"),
+    "bf8 (e5m2, unit scales) corrections: weight gradients only":    _with(_EXACT, fp8="w5"),
+    "bf8 (e5m2, unit scales) corrections: backward-data only":       _with(_EXACT, fp8="d5"),
+    "bf8 (e5m2, unit scales) corrections: backward-data + weight gradients": _with(_EXACT, fp8="dw5"),
     "exact16x3 (all pair, W split, wgrad pairs)":                    _EXACT,
 }
 
