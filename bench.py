@@ -1170,8 +1170,16 @@ def main():
                 probe_err = repr(e)
                 pm["probe"] = {"error": probe_err}
             out["parity_mode"] = pm
+        # a fixed, kernel-independent figure of THIS box (the power-cap frontier measured before the timed steps): lets a reader tell
+        # box-to-box spread (+-5 % for one build) from a regression when the records of two rounds are compared
+        fr = _LIVE_FRONTIER       # only the live measurement: the committed fallback of sustained_frontier() is another box
+        if fr:
+            out["box_reference"] = {"matrix_alone_tflops": round(fr[0] * 1e3, 1), "stream_tbs": fr[1], "matrix_next_to_stream_tflops": round(fr[2] * 1e3, 1),
+                                    "source": fr[3], "how": "resr_debug_sustained: 256 workgroups of MFMA waves (alone / next to an LDS-DMA stream), 1.5 s per arm"}
         if world == 1 and not args.no_other_configs:
             out["other_configs"] = other_configs(args)
+            if fr:
+                out["other_configs"]["box_reference"] = out["box_reference"]
         if args.isolated_probe:
             rows = probe_conv_kernels(B, lr_edge, args.precision)
             out["conv_probe_isolated"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "flop"}
