@@ -426,17 +426,27 @@ def test_rccl_world1_collectives_next_to_chained_launches(overlap):
         assert res["comm_stream"] and res["buckets"] and all(b >= 2 for b in res["buckets"]), res   # several buckets behind range events
 
 
-def test_bench_force_nccl_one_gpu():
-    """RESR_BENCH_FORCE_NCCL=1 python bench.py --gpus 1: the bench's own steps with a world-1 RCCL group (dist.backend "nccl")."""
+@pytest.mark.parametrize("overlap_env", ["1", "0"])
+def test_bench_force_nccl_one_gpu(overlap_env):
+    """RESR_BENCH_FORCE_NCCL=1 python bench.py --gpus 1: the bench's own steps with a world-1 RCCL group (dist.backend "nccl").
+    overlap_env "0": the default environment of a SCALE run -- BOTH exchange policies are timed in one process with real RCCL
+    kernels (sequential, then overlapped with 31 CUs per XCD left to the chained launches), the better one is `value`."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RESR_BENCH_FORCE_NCCL="1", RESR_DP_OVERLAP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, RESR_BENCH_FORCE_NCCL="1", RESR_DP_OVERLAP=overlap_env, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
            "--lr-size", "64", "--no-other-configs", "--no-cpu-baseline", "--no-parity-mode"]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert out["dist"]["backend"] == "nccl" and out["dist"]["forced_collectives"] and out["dist"]["overlap_with_backward"]
+    assert out["dist"]["backend"] == "nccl" and out["dist"]["forced_collectives"] and out["dist"]["overlap_with_backward"] == (overlap_env == "1")
     assert out["chain_errors"] == 0 and out["value"] > 0
+    pol = out["dist"]["policies"]
+    if overlap_env == "1":
+        assert pol["chosen"] == "overlap_env"
+    else:
+        assert set(pol) >= {"sequential", "overlap_31cu"} and pol["chosen"] in ("sequential", "overlap_31cu")
+        assert abs(out["ms_per_step"] - min(pol["sequential"]["ms_per_step"], pol["overlap_31cu"]["ms_per_step"])) < 0.02
+    assert out["dist"]["devices"] == 1 and out["dist"]["nranks"] == 1 and out["host"]["enqueue_ms_per_step"] > 0
