@@ -219,39 +219,39 @@ __global__ __launch_bounds__(256) void usm_combine_kernel(const float* __restric
 // The six passes above (row blur, column blur, mask, row blur, column blur, combine) move 15 fp32 planes = 60 B per value, and
 // the column pass of a 32 x 32 tile fetches its 82-row window from HBM again for every tile column that lands on another XCD
 // (measured 2.94 x its plane).  Here:
-//   launch A  x tile + 25-pixel halo in LDS -> row pass (LDS) -> column pass -> blur (fp32, kept: combine and backward read it)
-//             + the mask |x - blur| * 255 > threshold as ONE BYTE per value;
-//   launch B  mask bytes + halo in LDS -> row pass -> column pass = soft -> out = soft * clip(x + w (x - blur), 0, 1) + (1 - soft) x,
-//             soft stored for the backward pass.
-// 4 + 4 + 1 and 1 + 4 + 4 + 4 + 4 = 26 B per value.  Same taps in the same order as the separate passes (t = 0 .. 50, fused
-// multiply-adds): within an ulp of them (tests/test_gpu_degrade.py), the goldens do not move.  Work is dealt to the XCDs in contiguous plane-major ranges (workgroup b -> range
-// b % 8): the halo rows and columns a tile shares with its neighbours are then found in THAT XCD's L2 instead of being fetched
+//   launch A  row pass -> column pass -> blur (fp32, kept: combine and backward read it) + the mask |x - blur| * 255 > threshold
+//             as ONE BYTE per value;
+//   launch B  the same two passes over the mask bytes = soft -> out = soft * clip(x + w (x - blur), 0, 1) + (1 - soft) x
+//             (soft stored only when a backward pass will read it).
+// 4 + 4 + 1 and 1 + 4 + 4 (+ 4) + 4 = 22 (26) B per value.  A workgroup owns a 64-column STRIP of one plane (or a vertical
+// segment of it) and walks it downwards 32 rows at a time: every input row is loaded and row-passed ONCE into a ring of 128 rows in
+// LDS, and a tile of 32 output rows is column-passed as soon as the 25 rows below it are in the ring -- 51 + 51 multiply-adds per
+// value instead of the 2.56 x 51 + 51 of independent 32-row tiles (the kernel is bound by its vector and LDS work, not by HBM).
+// Same taps in the same order as the separate passes (t = 0 .. 50, fused multiply-adds): within an ulp of them
+// (tests/test_gpu_degrade.py), the goldens do not move.  Work is dealt to the XCDs in contiguous plane-major ranges (workgroup b ->
+// range b % 8): the 50 halo columns a strip shares with its neighbours are then found in THAT XCD's L2 instead of being fetched
 // from HBM once per XCD (a locality hint only: nothing depends on where a workgroup really runs).
 template <typename TIN, int EPI>   // EPI 0: blur + byte mask (TIN = float);  EPI 1: soft mask + combine (TIN = uint8_t)
 __global__ __launch_bounds__(256) void usm51_kernel(const TIN* __restrict__ src, const float* __restrict__ x, float* __restrict__ blur,
                                                     uint8_t* __restrict__ mask, float* __restrict__ soft, float* __restrict__ out,
-                                                    const float* __restrict__ kern, int planes, int h, int w, int tiles_x, int tiles_y,
+                                                    const float* __restrict__ kern, int planes, int h, int w, int strips, int segs,
                                                     float threshold, float weight, int keep_soft) {
-    constexpr int K = 51, R = 25, TW = 64, TH = 32, IH = TH + 2 * R, IW = TW + 2 * R, IWP = 120;   // 82 x 114 input window, rows padded for float4 windows
-    __shared__ __attribute__((aligned(16))) float in[IH * IWP];      // 39.4 KB
-    __shared__ __attribute__((aligned(16))) float hp[IH * TW];       // 21 KB: the row pass
+    constexpr int K = 51, R = 25, SW = 64, CH = 32, IW = SW + 2 * R, IWP = 120, RING = 128;   // 114-column input rows, padded for float4 windows
+    __shared__ __attribute__((aligned(16))) float in[CH * IWP];      // 15 KB: the newest 32 input rows
+    __shared__ __attribute__((aligned(16))) float ring[RING * SW];   // 32 KB: row-passed rows, slot = (row + 32) & 127
     __shared__ __attribute__((aligned(16))) float taps[52];
-    __shared__ __attribute__((aligned(4))) uint8_t mb[EPI == 0 ? TH * TW : 4];
-    const long per_plane = (long)tiles_x * tiles_y, items = per_plane * planes, per_xcd = (items + 7) / 8;
+    __shared__ __attribute__((aligned(4))) uint8_t mb[EPI == 0 ? CH * SW : 4];
+    const long items = (long)planes * segs * strips, per_xcd = (items + 7) / 8;
     const long item = (long)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((long)(blockIdx.x >> 3) >= per_xcd || item >= items) return;
-    const int plane = (int)(item / per_plane), t = (int)(item - (long)plane * per_plane);
-    const int ty = t / tiles_x, tx = t - ty * tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH;
+    const int plane = (int)(item / ((long)segs * strips)), rem = (int)(item - (long)plane * segs * strips);
+    const int seg = rem / strips, strip = rem - seg * strips;
+    const int tiles_y = (h + CH - 1) / CH;
+    const int t_begin = (int)((long)tiles_y * seg / segs), t_end = (int)((long)tiles_y * (seg + 1) / segs);   // this segment's output tiles
+    const int x0 = strip * SW;
     const TIN* sp = src + (size_t)plane * h * w;
-    for (int i = threadIdx.x; i < IH * IW; i += 256) {
-        const int r = i / IW, c = i - r * IW;
-        const int iy = reflect(y0 + r - R, h), ix = reflect(x0 + c - R, w);
-        // (beyond the image's last tile the reflected index may still fall outside: zero, never used by a stored output)
-        in[r * IWP + c] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? (float)sp[(size_t)iy * w + ix] : 0.f;
-    }
-    for (int i = threadIdx.x; i < IH * (IWP - IW); i += 256) in[(i / (IWP - IW)) * IWP + IW + i % (IWP - IW)] = 0.f;
     if (threadIdx.x < 52) taps[threadIdx.x] = threadIdx.x < K ? kern[threadIdx.x] : 0.f;
+    for (int i = threadIdx.x; i < CH * (IWP - IW); i += 256) in[(i / (IWP - IW)) * IWP + IW + i % (IWP - IW)] = 0.f;
     __syncthreads();
     float tp[52];
 #pragma unroll
@@ -259,63 +259,81 @@ __global__ __launch_bounds__(256) void usm51_kernel(const TIN* __restrict__ src,
         const float4 v = reinterpret_cast<const float4*>(taps)[q];
         tp[q * 4] = v.x; tp[q * 4 + 1] = v.y; tp[q * 4 + 2] = v.z; tp[q * 4 + 3] = v.w;
     }
-    // row pass: item = (row, group of 4 columns); window of 54 (read as 56) values, 4 x 51 FMAs
-    for (int i = threadIdx.x; i < IH * (TW / 4); i += 256) {
-        const int r = i / (TW / 4), cg = i - r * (TW / 4);
-        float win[56];
-        const float4* wp = reinterpret_cast<const float4*>(in + r * IWP + cg * 4);
-#pragma unroll
-        for (int q = 0; q < 14; ++q) {
-            const float4 v = wp[q];
-            win[q * 4] = v.x; win[q * 4 + 1] = v.y; win[q * 4 + 2] = v.z; win[q * 4 + 3] = v.w;
+    // Output tile t (rows 32 t .. 32 t + 31) needs input rows 32 t - 25 .. 32 t + 56.  Chunk k = input rows 32 k - 25 .. 32 k + 6,
+    // so tile t is complete after chunk t + 2 (rows up to 32 t + 70), and the ring's 128 slots hold tile t's 82 rows next to the
+    // 32 rows of the chunk being written (rows 128 apart share a slot: the row a new one replaces is older than 32 t - 25).
+    for (int k = t_begin; k < t_end + 2; ++k) {
+        const int r0 = 32 * k - R;
+        for (int i = threadIdx.x; i < CH * IW; i += 256) {
+            const int rr = i / IW, c = i - rr * IW;
+            const int iy = reflect(r0 + rr, h), ix = reflect(x0 + c - R, w);
+            // (rows / columns whose reflection still falls outside only feed outputs beyond the image, which are never stored)
+            in[rr * IWP + c] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? (float)sp[(size_t)iy * w + ix] : 0.f;
         }
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        // row pass of the 32 new rows: item = (row, group of 4 columns); window of 54 (read as 56) values, 4 x 51 FMAs
+        for (int i = threadIdx.x; i < CH * (SW / 4); i += 256) {
+            const int rr = i / (SW / 4), cg = i - rr * (SW / 4);
+            float win[56];
+            const float4* wp = reinterpret_cast<const float4*>(in + rr * IWP + cg * 4);
 #pragma unroll
-        for (int k = 0; k < K; ++k)
+            for (int q = 0; q < 14; ++q) {
+                const float4 v = wp[q];
+                win[q * 4] = v.x; win[q * 4 + 1] = v.y; win[q * 4 + 2] = v.z; win[q * 4 + 3] = v.w;
+            }
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += tp[k] * win[j + k];
-        *reinterpret_cast<float4*>(hp + r * TW + cg * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    }
-    __syncthreads();
-    // column pass: item = (group of 4 rows, column); lanes walk the columns (conflict-free), window of 54 rows
-    for (int i = threadIdx.x; i < (TH / 4) * TW; i += 256) {
-        const int rg = i / TW, col = i - rg * TW;
-        float win[54];
+            for (int t = 0; t < K; ++t)
 #pragma unroll
-        for (int q = 0; q < 54; ++q) win[q] = hp[(rg * 4 + q) * TW + col];
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) acc[j] += tp[t] * win[j + t];
+            *reinterpret_cast<float4*>(ring + ((r0 + rr + 32) & (RING - 1)) * SW + cg * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        __syncthreads();
+        const int t = k - 2;                    // the tile whose last rows have just arrived
+        if (t < t_begin) continue;              // (uniform: the segment's first two chunks only fill the ring)
+        const int y0 = t * CH;
+        // column pass: item = (group of 4 rows, column); lanes walk the columns (conflict-free), window of 54 ring rows
+        for (int i = threadIdx.x; i < (CH / 4) * SW; i += 256) {
+            const int rg = i / SW, col = i - rg * SW;
+            float win[54];
 #pragma unroll
-        for (int k = 0; k < K; ++k)
+            for (int q = 0; q < 54; ++q) win[q] = ring[((y0 + rg * 4 + q - R + 32) & (RING - 1)) * SW + col];
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += tp[k] * win[j + k];
-        const int gx = x0 + col;
+            for (int tt = 0; tt < K; ++tt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ly = rg * 4 + j, gy = y0 + ly;
-            const bool ok = gy < h && gx < w;
-            const size_t q = ((size_t)plane * h + gy) * w + gx;
-            if constexpr (EPI == 0) {
-                const float xv = in[(ly + R) * IWP + col + R];
-                mb[ly * TW + col] = (fabsf(xv - acc[j]) * 255.f > threshold) ? 1 : 0;
-                if (ok) blur[q] = acc[j];
-            } else if (ok) {
-                const float xv = x[q], s = acc[j];
-                const float sharp = fminf(fmaxf(xv + weight * (xv - blur[q]), 0.f), 1.f);
-                if (keep_soft) soft[q] = s;          // only the backward pass reads it (the degradation path runs without a graph)
-                out[q] = s * sharp + (1.f - s) * xv;
+                for (int j = 0; j < 4; ++j) acc[j] += tp[tt] * win[j + tt];
+            const int gx = x0 + col;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ly = rg * 4 + j, gy = y0 + ly;
+                const bool ok = gy < h && gx < w;
+                const size_t q = ((size_t)plane * h + gy) * w + gx;
+                if constexpr (EPI == 0) {
+                    const float xv = ok ? x[q] : 0.f;
+                    mb[ly * SW + col] = (fabsf(xv - acc[j]) * 255.f > threshold) ? 1 : 0;
+                    if (ok) blur[q] = acc[j];
+                } else if (ok) {
+                    const float xv = x[q], sv = acc[j];
+                    const float sharp = fminf(fmaxf(xv + weight * (xv - blur[q]), 0.f), 1.f);
+                    if (keep_soft) soft[q] = sv;          // only the backward pass reads it (the degradation path runs without a graph)
+                    out[q] = sv * sharp + (1.f - sv) * xv;
+                }
             }
         }
-    }
-    if constexpr (EPI == 0) {   // the tile's mask bytes leave as 4-byte words where the row allows it
-        __syncthreads();
-        for (int i = threadIdx.x; i < TH * TW / 4; i += 256) {
-            const int ly = i / (TW / 4), c4 = (i - ly * (TW / 4)) * 4;
-            const int gy = y0 + ly, gx = x0 + c4;
-            if (gy >= h || gx >= w) continue;
-            uint8_t* mp = mask + ((size_t)plane * h + gy) * w + gx;
-            if (gx + 3 < w && (((size_t)mp) & 3) == 0) *reinterpret_cast<uint32_t*>(mp) = *reinterpret_cast<const uint32_t*>(mb + ly * TW + c4);
-            else for (int e = 0; e < 4 && gx + e < w; ++e) mp[e] = mb[ly * TW + c4 + e];
+        if constexpr (EPI == 0) {   // the tile's mask bytes leave as 4-byte words where the row allows it
+            __syncthreads();
+            for (int i = threadIdx.x; i < CH * SW / 4; i += 256) {
+                const int ly = i / (SW / 4), c4 = (i - ly * (SW / 4)) * 4;
+                const int gy = y0 + ly, gx = x0 + c4;
+                if (gy >= h || gx >= w) continue;
+                uint8_t* mp = mask + ((size_t)plane * h + gy) * w + gx;
+                if (gx + 3 < w && (((size_t)mp) & 3) == 0) *reinterpret_cast<uint32_t*>(mp) = *reinterpret_cast<const uint32_t*>(mb + ly * SW + c4);
+                else for (int e = 0; e < 4 && gx + e < w; ++e) mp[e] = mb[ly * SW + c4 + e];
+            }
         }
+        // (the next chunk's loads overwrite `in`, its row pass writes ring slots no pending column pass reads, and the barrier
+        // behind the loads orders both against this tile's reads of `ring` / `mb`)
     }
 }
 
@@ -328,14 +346,18 @@ int usm_dispatch(const float* src, float* dst, float* tmp, const float* k1d, int
         uint8_t* mask = reinterpret_cast<uint8_t*>(tmp);   // tmp3 = [mask bytes (+ unused) | blur | soft]
         float* blur = tmp + count;
         float* soft = tmp + 2 * count;
-        const int tiles_x = (w + 63) / 64, tiles_y = (h + 31) / 32;
-        const long items = (long)tiles_x * tiles_y * n * c;
+        // workgroups: planes x vertical segments x 64-column strips; a segment pays two extra 32-row chunks of row pass to fill its
+        // ring, so segments are only cut until the launch has ~2 workgroups per CU (three fit a CU's LDS)
+        const int strips = (w + 63) / 64, tiles_y = (h + 31) / 32;
+        int segs = 1;
+        while (segs < 8 && (long)n * c * strips * segs < 512 && tiles_y / (segs * 2) >= 4) segs *= 2;
+        const long items = (long)n * c * strips * segs;
         const unsigned grid = (unsigned)(((items + 7) / 8) * 8);
         hipLaunchKernelGGL((usm51_kernel<float, 0>), dim3(grid), dim3(256), 0, st, src, src, blur, mask, (float*)nullptr, (float*)nullptr, k1d,
-                           n * c, h, w, tiles_x, tiles_y, threshold, weight, 0);
+                           n * c, h, w, strips, segs, threshold, weight, 0);
         RESR_CHECK_LAUNCH("usm51_kernel (blur + mask)");
         hipLaunchKernelGGL((usm51_kernel<uint8_t, 1>), dim3(grid), dim3(256), 0, st, (const uint8_t*)mask, src, blur, (uint8_t*)nullptr, soft, dst, k1d,
-                           n * c, h, w, tiles_x, tiles_y, threshold, weight, keep_for_backward);
+                           n * c, h, w, strips, segs, threshold, weight, keep_for_backward);
         RESR_CHECK_LAUNCH("usm51_kernel (soft + combine)");
         return RESR_OK;
     }
