@@ -239,7 +239,6 @@ __global__ __launch_bounds__(256) void usm51_kernel(const TIN* __restrict__ src,
     constexpr int K = 51, R = 25, SW = 64, CH = 32, IW = SW + 2 * R, IWP = 120, RING = 128;   // 114-column input rows, padded for float4 windows
     __shared__ __attribute__((aligned(16))) float in[CH * IWP];      // 15 KB: the newest 32 input rows
     __shared__ __attribute__((aligned(16))) float ring[RING * SW];   // 32 KB: row-passed rows, slot = (row + 32) & 127
-    __shared__ __attribute__((aligned(16))) float taps[52];
     __shared__ __attribute__((aligned(4))) uint8_t mb[EPI == 0 ? CH * SW : 4];
     const long items = (long)planes * segs * strips, per_xcd = (items + 7) / 8;
     const long item = (long)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
@@ -250,26 +249,41 @@ __global__ __launch_bounds__(256) void usm51_kernel(const TIN* __restrict__ src,
     const int t_begin = (int)((long)tiles_y * seg / segs), t_end = (int)((long)tiles_y * (seg + 1) / segs);   // this segment's output tiles
     const int x0 = strip * SW;
     const TIN* sp = src + (size_t)plane * h * w;
-    if (threadIdx.x < 52) taps[threadIdx.x] = threadIdx.x < K ? kern[threadIdx.x] : 0.f;
     for (int i = threadIdx.x; i < CH * (IWP - IW); i += 256) in[(i / (IWP - IW)) * IWP + IW + i % (IWP - IW)] = 0.f;
-    __syncthreads();
-    float tp[52];
+    // the 51 taps are wave-uniform: read through the scalar cache they live in SGPRs (an FMA takes one scalar operand) and leave
+    // the vector registers to the windows and to the next chunk's prefetch
+    float tp[K];
 #pragma unroll
-    for (int q = 0; q < 13; ++q) {
-        const float4 v = reinterpret_cast<const float4*>(taps)[q];
-        tp[q * 4] = v.x; tp[q * 4 + 1] = v.y; tp[q * 4 + 2] = v.z; tp[q * 4 + 3] = v.w;
-    }
+    for (int q = 0; q < K; ++q) tp[q] = kern[q];
+    // the next chunk's input elements of this thread (global loads in flight under the column pass of the current tile)
+    constexpr int NL = (CH * IW + 255) / 256;
+    float pre[NL];
+    auto fetch = [&](int k) {
+        const int r0 = 32 * k - R;
+#pragma unroll
+        for (int jj = 0; jj < NL; ++jj) {
+            const int i = threadIdx.x + 256 * jj;
+            const int rr = i / IW, c = i - rr * IW;
+            const int iy = reflect(r0 + rr, h), ix = reflect(x0 + c - R, w);
+            // (rows / columns whose reflection still falls outside only feed outputs beyond the image, which are never stored)
+            pre[jj] = (i < CH * IW && iy >= 0 && iy < h && ix >= 0 && ix < w) ? (float)sp[(size_t)iy * w + ix] : 0.f;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int jj = 0; jj < NL; ++jj) {
+            const int i = threadIdx.x + 256 * jj;
+            const int rr = i / IW, c = i - rr * IW;
+            if (i < CH * IW) in[rr * IWP + c] = pre[jj];
+        }
+    };
+    fetch(t_begin);
     // Output tile t (rows 32 t .. 32 t + 31) needs input rows 32 t - 25 .. 32 t + 56.  Chunk k = input rows 32 k - 25 .. 32 k + 6,
     // so tile t is complete after chunk t + 2 (rows up to 32 t + 70), and the ring's 128 slots hold tile t's 82 rows next to the
     // 32 rows of the chunk being written (rows 128 apart share a slot: the row a new one replaces is older than 32 t - 25).
     for (int k = t_begin; k < t_end + 2; ++k) {
         const int r0 = 32 * k - R;
-        for (int i = threadIdx.x; i < CH * IW; i += 256) {
-            const int rr = i / IW, c = i - rr * IW;
-            const int iy = reflect(r0 + rr, h), ix = reflect(x0 + c - R, w);
-            // (rows / columns whose reflection still falls outside only feed outputs beyond the image, which are never stored)
-            in[rr * IWP + c] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? (float)sp[(size_t)iy * w + ix] : 0.f;
-        }
+        commit();                              // (`in` was last read by the previous chunk's row pass, two barriers ago)
         __syncthreads();
         // row pass of the 32 new rows: item = (row, group of 4 columns); window of 54 (read as 56) values, 4 x 51 FMAs
         for (int i = threadIdx.x; i < CH * (SW / 4); i += 256) {
@@ -288,6 +302,7 @@ __global__ __launch_bounds__(256) void usm51_kernel(const TIN* __restrict__ src,
                 for (int j = 0; j < 4; ++j) acc[j] += tp[t] * win[j + t];
             *reinterpret_cast<float4*>(ring + ((r0 + rr + 32) & (RING - 1)) * SW + cg * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
+        if (k + 1 < t_end + 2) fetch(k + 1);
         __syncthreads();
         const int t = k - 2;                    // the tile whose last rows have just arrived
         if (t < t_begin) continue;              // (uniform: the segment's first two chunks only fill the ring)
@@ -295,6 +310,16 @@ __global__ __launch_bounds__(256) void usm51_kernel(const TIN* __restrict__ src,
         // column pass: item = (group of 4 rows, column); lanes walk the columns (conflict-free), window of 54 ring rows
         for (int i = threadIdx.x; i < (CH / 4) * SW; i += 256) {
             const int rg = i / SW, col = i - rg * SW;
+            // the epilogue's global operands first: their round trip runs under the window reads and the 204 multiply-adds
+            float xg[4], bg[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gy = y0 + rg * 4 + j;
+                const bool ok = gy < h && x0 + col < w;
+                const size_t q = ((size_t)plane * h + gy) * w + x0 + col;
+                xg[j] = ok ? x[q] : 0.f;
+                bg[j] = (EPI == 1 && ok) ? blur[q] : 0.f;
+            }
             float win[54];
 #pragma unroll
             for (int q = 0; q < 54; ++q) win[q] = ring[((y0 + rg * 4 + q - R + 32) & (RING - 1)) * SW + col];
@@ -310,12 +335,12 @@ __global__ __launch_bounds__(256) void usm51_kernel(const TIN* __restrict__ src,
                 const bool ok = gy < h && gx < w;
                 const size_t q = ((size_t)plane * h + gy) * w + gx;
                 if constexpr (EPI == 0) {
-                    const float xv = ok ? x[q] : 0.f;
+                    const float xv = xg[j];
                     mb[ly * SW + col] = (fabsf(xv - acc[j]) * 255.f > threshold) ? 1 : 0;
                     if (ok) blur[q] = acc[j];
                 } else if (ok) {
-                    const float xv = x[q], sv = acc[j];
-                    const float sharp = fminf(fmaxf(xv + weight * (xv - blur[q]), 0.f), 1.f);
+                    const float xv = xg[j], sv = acc[j];
+                    const float sharp = fminf(fmaxf(xv + weight * (xv - bg[j]), 0.f), 1.f);
                     if (keep_soft) soft[q] = sv;          // only the backward pass reads it (the degradation path runs without a graph)
                     out[q] = sv * sharp + (1.f - sv) * xv;
                 }
