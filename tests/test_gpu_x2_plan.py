@@ -143,7 +143,7 @@ def _setup(n_blocks, seed, x2_plan, wscale=1.0, upscale=4):
 
 
 @pytest.mark.parametrize("wscale", [1.0, 4.0])
-@pytest.mark.parametrize("n,h,w", [(1, 24, 24), (2, 40, 36), (8, 32, 32)])
+@pytest.mark.parametrize("n,h,w", [(1, 24, 24), (8, 32, 32)])
 def test_inference_plan_forward_vs_oracle(n, h, w, wscale, diag_dir):
     """23 blocks, eval: growth planes single f16 (50 stages per block) against the fp32 CPU oracle and against the all-pairs plan;
     weights at the reference's init scale and dense-block weights x 4 (activations grow, the dense branch is no longer small);
