@@ -327,7 +327,7 @@ def _oracle_grads(M, sd, x, gw, n_blocks, dt=torch.float64):
 
 
 @pytest.mark.parametrize("precision,plan", [("exact16", 3), ("exact16", 0), ("fast", 0)])
-@pytest.mark.parametrize("case", ["dense_x4", "stream_x40"])
+@pytest.mark.parametrize("case", ["dense_x4", "stream_x40", "stream_x0p01"])
 def test_generator_parity_off_the_init_scale(precision, plan, case, diag_dir):
     """Forward + backward of a 6-block generator against the float64 oracle with (a) the dense-block weights x 4 (the branches are
     no longer a small correction of the stream) and (b) conv1's weights x 40 (stream and growth planes of O(10 - 100): the hi
@@ -341,9 +341,14 @@ def test_generator_parity_off_the_init_scale(precision, plan, case, diag_dir):
     sd["conv4.bias"] = sd["conv4.bias"] + 0.5
     if case == "dense_x4":
         sd = {k: (v * 4.0 if k.endswith(".weight") and ".rdb" in k else v) for k, v in sd.items()}
-    else:
+    elif case == "stream_x40":
         sd["conv1.weight"] = sd["conv1.weight"] * 40.0
         sd["conv4.weight"] = sd["conv4.weight"] / 40.0          # keeps the output inside the clamp, the gradients large
+    else:
+        # a stream of O(1e-3): hi tensors near / inside f16's subnormal range (6e-5), lo tensors (scaled by 2^12) still normal --
+        # the pair keeps ~1e-11 absolute whatever the magnitude; a single f16 (fast) does not
+        for k in ("conv1.weight", "conv1.bias"):
+            sd[k] = sd[k] * 0.002
     g = R.Generator(3, 3, 4, precision=precision, n_blocks=nb, x2_plan=plan)
     g.load_state_dict(sd)
     g = g.cuda().train()
@@ -373,8 +378,9 @@ def test_generator_parity_off_the_init_scale(precision, plan, case, diag_dir):
         # (a mask flip of the forward pass would show as ~1e-2 on one tensor in BOTH plans: see test_training_plan_gradients_vs_float64_oracle)
         assert rep["worst"] < (1e-3 if plan else 5e-5) or rep["worst"] > 3e-3, rep
         assert rep["median"] < (5e-4 if plan else 2e-5) and rep["gx"] < 1e-4, rep
-    else:
+    elif case != "stream_x0p01":
         assert rep["fwd"] < 2e-2 and rep["median"] < 0.15, rep
+    # (fast mode on a 1e-3 stream: single f16 activations below 6e-5 keep fewer than 11 bits -- recorded, not gated)
 
 
 def test_exact16_weight_overflow_is_loud():
