@@ -627,6 +627,25 @@ def host_record(fn, world, reps=3):
     return rec
 
 
+def _emergency_line(args, world, steps, dt_seq, why):
+    """The contract's JSON line from the SEQUENTIAL policy's timed steps alone -- printed by the watchdog of time_policies when the
+    second policy (collectives overlapped with chained launches: a pairing no multi-GPU box has run before the first SCALE run)
+    does not come back.  Minimal but valid: the driver gets its measurement whatever the experiment does."""
+    B = args.batch
+    lr_edge = args.lr_size
+    value = B * world * steps / dt_seq
+    gan = bool(args.gan)
+    return {"metric": "x4 SR GAN train images/sec (RealESRGAN step, BASELINE config 4)" if gan else "x4 SR train images/sec (256->1024)",
+            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_seq / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fast": "f16", "exact16": "f16x2", "strict": "f32"}[args.precision], "data": "synthetic",
+            "config": {"workload": ("RealESRGAN x4 GAN train step" if gan else "RealESRNet x4 L1 train step") + f", RRDBNet 23 blocks, LR {lr_edge}^2 -> HR {4 * lr_edge}^2, "
+                                   f"batch {B}/GPU, degradation=hip", "global_batch": B * world, "parallelism": f"dp{world}"},
+            "dist": {"world": world, "backend": dist.get_backend() if dist.is_initialized() else None,
+                     "policies": {"sequential": {"ms_per_step": round(dt_seq / steps * 1e3, 2)}, "overlap_31cu": {"error": why}, "chosen": "sequential"}},
+            "note": "emergency line: " + why}
+
+
 def time_policies(args, steps, warmup, world, one, dp, model, dt_seq):
     """N > 1 (or a forced world-1 RCCL group): the gradient exchange has two policies and which one wins is a question only a
     multi-GPU box answers -- so the bench times BOTH in one process, K steps each on the same state:
@@ -644,11 +663,28 @@ def time_policies(args, steps, warmup, world, one, dp, model, dt_seq):
     rec = {"sequential": timed}
     prev_cus = os.environ.get("RESR_CHAIN_CUS_PER_XCD")
     os.environ["RESR_CHAIN_CUS_PER_XCD"] = "31"
-    model.grad_hook = None
-    dp.attach(model, overlap=True)
-    for _ in range(max(1, min(warmup, 2))):
-        one()
-    dt_ov, _ = timed_region(one, steps, world)
+    # Watchdog (every rank): the overlapped policy is an experiment; if it has not finished within 20 x what the sequential policy
+    # took for the same steps (+ 60 s), rank 0 prints the sequential measurement as the contract's line and every rank leaves.
+    import threading
+    limit = 60.0 + 20.0 * dt_seq * (1 + max(1, min(warmup, 2)) / max(1, steps))
+    rank = dist.get_rank() if dist.is_initialized() else 0
+
+    def fire():
+        why = f"the overlapped exchange policy did not finish within {limit:.0f} s: sequential policy reported"
+        if rank == 0:
+            print(json.dumps(_emergency_line(args, world, steps, dt_seq, why)), flush=True)
+        os._exit(0 if rank == 0 else 0)
+    wd = threading.Timer(limit, fire)
+    wd.daemon = True
+    wd.start()
+    try:
+        model.grad_hook = None
+        dp.attach(model, overlap=True)
+        for _ in range(max(1, min(warmup, 2))):
+            one()
+        dt_ov, _ = timed_region(one, steps, world)
+    finally:
+        wd.cancel()
     rec["overlap_31cu"] = {"ms_per_step": round(dt_ov / steps * 1e3, 2)}
     if dt_ov < dt_seq:
         rec["chosen"] = "overlap_31cu"
