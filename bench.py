@@ -677,6 +677,8 @@ def time_policies(args, steps, warmup, world, one, dp, model, dt_seq):
     wd = threading.Timer(limit, fire)
     wd.daemon = True
     wd.start()
+    import real_esrgan_pytorch_amd as _R
+    errs_before = int(_R._lib.lib().resr_debug_chain_errors())
     try:
         model.grad_hook = None
         dp.attach(model, overlap=True)
@@ -686,6 +688,11 @@ def time_policies(args, steps, warmup, world, one, dp, model, dt_seq):
     finally:
         wd.cancel()
     rec["overlap_31cu"] = {"ms_per_step": round(dt_ov / steps * 1e3, 2)}
+    errs_after = int(_R._lib.lib().resr_debug_chain_errors())
+    if errs_after != errs_before:    # a chained launch gave up on a neighbour next to the collective: never the policy to report
+        rec["overlap_31cu"]["chain_errors"] = errs_after - errs_before
+        rec["overlap_31cu"]["note"] = "chained launches timed out next to the overlapped collectives (their outputs are NaN-poisoned): policy rejected"
+        dt_ov = float("inf")
     if dt_ov < dt_seq:
         rec["chosen"] = "overlap_31cu"
         return dt_ov, rec
