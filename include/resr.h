@@ -226,9 +226,10 @@ enum {
      * stream and the HR tail stay pairs, weights stay split: 50 instead of 60 stages per block (forward 1e-6 at the reference's
      * init scale; a TRAINING forward ignores the bit -- a 2^-12 perturbation of a pre-activation flips LeakyReLU mask elements) */
     RESR_X2_PLAN_GROWTH_F16_INFER = 1,
-    /* backward: the gradients of the growth planes (g_o1..g_o4) are single f16 tensors: their chunks take two stages in the
-     * mirrored backward-data passes and conv1..conv4's weight gradients two tap-products instead of three (worst gradient
-     * tensor 3-5e-4 vs float64) */
+    /* backward: the gradients of the growth planes (g_o1..g_o4) are READ as single f16 tensors (their hi tensor): their chunks
+     * take two stages in the mirrored backward-data passes and conv1..conv4's weight gradients two tap-products instead of
+     * three; they are still stored as pairs, and the BIAS gradients sum hi + lo (one extra tap-product per convolution).  Worst
+     * gradient tensor 3-5e-4 vs float64 */
     RESR_X2_PLAN_GROWTH_GRAD_F16 = 2
 };
 

@@ -421,7 +421,7 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
             c.x0 = x; c.cin = cin_pad; c.in0_stride = xs; c.cin_real = cin_v;
             c.g = g; c.cout = l.cout; c.cout_pad = r32(l.cout); c.g_stride = gs;
             c.x_chunk_stride = c.g_chunk_stride = 0; c.x_lo_off = x2 ? lo_xw : 0; c.g_lo_off = x2 ? lo_gw : 0;
-            c.x_s2d_c = l.k4 ? l.cin : 0;
+            c.x_s2d_c = l.k4 ? l.cin : 0; c.g_lo_bias_only = 0;
             c.dw = raw; c.db = (l.bias ? grad + p.b_off[li] : nullptr); c.scale = 1.f;
             const int splits = layer_splits(chunks * (c.cout_pad / 32), N, h, w, parts);
             if (wgrad_layer_partial_bytes(cin_pad, c.cout_pad, splits, dt) > b.partial_bytes) return fail(RESR_ERR_WORKSPACE, "discriminator: wgrad slabs (layer mode)");
@@ -442,6 +442,7 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
                 c.x0 = x; c.cin = cin_pad; c.in0_stride = xs; c.cin_real = cin_v;
                 c.g = g + (size_t)q0 * es; c.cout = co; c.cout_pad = r32(co); c.g_stride = gs;
                 c.x_chunk_stride = c.g_chunk_stride = 0; c.x_lo_off = lo_xw; c.g_lo_off = lo_gw;
+                c.g_lo_bias_only = 0;
                 c.x_s2d_c = l.k4 ? l.cin : 0;      // 4x4 / stride-2 layers: X is the space-to-depth image, skip the virtual kernel's zero taps
                 c.dw = raw + (size_t)q0 * cin_v * 9; c.db = (l.bias ? grad + p.b_off[li] + q0 : nullptr); c.scale = 1.f;
                 jobs += chunks * (c.cout_pad / 32);

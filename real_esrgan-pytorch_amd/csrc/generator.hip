@@ -252,8 +252,8 @@ void carve(const Plan& p, char* base, Bufs& b) {
         for (int k = 1; k <= wm; k += 2) {          // both weight-gradient settings of RESR_F16X2 (1 or 3 jobs per product)
             const size_t q0 = (size_t)26 * k * splits_for(p, 26 * k, p.h, p.w) * slab;
             if (q0 > pb) pb = q0;
-            if (k == 3) {   // RESR_X2_PLAN_GROWTH_GRAD_F16: conv1..conv4 (14 products) two tap-products each, conv5 (12) three
-                const size_t qg = (size_t)64 * splits_for(p, 64, p.h, p.w) * slab;
+            if (k == 3) {   // RESR_X2_PLAN_GROWTH_GRAD_F16: conv1..conv4 (14 products) two tap-products each + 4 bias jobs, conv5 (12) three
+                const size_t qg = (size_t)68 * splits_for(p, 68, p.h, p.w) * slab;
                 if (qg > pb) pb = qg;
             }
             if (78 * k <= kWgradMaxJobs) {
@@ -562,7 +562,11 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     const bool x2 = d->dtype == RESR_F16X2;
     const size_t wes = es * (x2 ? 3 : 1);
     const int wm = x2 ? wgrad_x2_products() : 1;
-    // exact16 with single-f16 growth-plane gradients (RESR_X2_PLAN_GROWTH_GRAD_F16): g_o1..g_o4 are stored without a lo tensor
+    // exact16, RESR_X2_PLAN_GROWTH_GRAD_F16: the growth-plane gradients g_o1..g_o4 are READ as single f16 tensors -- two stages on
+    // their chunks in every backward-data pass, two tap-products in conv1..conv4's weight gradients.  They are still STORED as
+    // pairs: the bias gradient (a plain sum of G, which cancels where the weight products do not) takes hi + lo through the one
+    // (x_hi chunk 0, g_lo) job per convolution that carries the bias sum -- with a single-f16 G the worst bias tensor of the
+    // emulation reached 6.7e-4 at 1 x 128^2.
     const bool gg_single = x2 && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_F16);
     const char* pk = (const char*)packed;
     const int N = d->n, h = p.h, w = p.w;
@@ -581,13 +585,16 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         wc.x0 = x0; wc.cin = cin; wc.in0_stride = s0; wc.cin_real = c.cin;
         wc.g = g; wc.cout = c.cout; wc.cout_pad = c.cout_pad; wc.g_stride = gstride;
         wc.x_chunk_stride = wc.g_chunk_stride = 0;
-        wc.x_lo_off = x_lo; wc.g_lo_off = g_lo; wc.x_s2d_c = 0;
+        wc.x_lo_off = x_lo; wc.g_lo_off = g_lo; wc.x_s2d_c = 0; wc.g_lo_bias_only = 0;
         wc.dw = grad + c.w_off; wc.db = grad + c.b_off; wc.scale = scale;
         return wc;
     };
     auto wgrad_run = [&](const WgradConv* wc, int nconv, int hh, int ww, int flags) -> int {
         int njobs = 0;   // tap-products: wm per product, two of three where G is a single f16 tensor (g_lo_off = 0)
-        for (int i = 0; i < nconv; ++i) njobs += (wc[i].cin / 32) * (wc[i].cout_pad / 32) * ((x2 && wm == 3 && wc[i].g_lo_off == 0) ? 2 : wm);
+        for (int i = 0; i < nconv; ++i) {
+            const int prod = (wc[i].cin / 32) * (wc[i].cout_pad / 32);
+            njobs += (x2 && wm == 3 && wc[i].g_lo_off == 0) ? prod * 2 : (x2 && wm == 3 && wc[i].g_lo_bias_only) ? prod * 2 + wc[i].cout_pad / 32 : prod * wm;
+        }
         const int splits = splits_for(p, njobs, hh, ww, x2 ? wgrad_batch_quads(wc, nconv, d->dtype) : 0);
         if (wgrad_batch_partial_bytes(wc, nconv, splits, d->dtype) > b.partial_bytes)
             return fail(RESR_ERR_WORKSPACE, "wgrad slab buffer too small");
@@ -683,13 +690,14 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             const int cin = 64 + 32 * ps;
             ResrConvDesc cd = dgrad(h, w, 64, 32, cin, 32, 32, 32, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS, lo_t, lo_gs, lo_gs);
             cd.in0_chunk_stride = plane; cd.in1_chunk_stride = plane;
-            if (gg_single) { cd.x2_pair_chunks = 2; cd.flags |= RESR_CONV_OUT_SINGLE; }   // g_y (in0) pairs, the slab (in1, out) single f16
+            if (gg_single) cd.x2_pair_chunks = 2;   // g_y (in0): pairs; the slab (in1) is read as single f16 chunks, written as a pair
             char* out = gS + (size_t)ps * plane * es;
             const char* mask = b.bits[r] + (size_t)(k - 1) * N * h * w * sizeof(uint32_t);   // sign plane of o_k
             cds[ps] = cd; ws4[ps] = pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * wes; masks4[ps] = mask; outs4[ps] = out;
             const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
-            wcb[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f, lo_ws, gg_single ? 0 : lo_gs);
+            wcb[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f, lo_ws, lo_gs);
             wcb[k - 1].x_chunk_stride = plane;
+            wcb[k - 1].g_lo_bias_only = gg_single ? 1 : 0;
         }
         {   // the four mirrored cout-32 passes, then g_x = convT(all) + (skip terms): one chained launch where the kernel supports
             // it (g_x joins on small launches), else one launch per pass

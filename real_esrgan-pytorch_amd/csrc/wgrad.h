@@ -8,7 +8,9 @@ struct WgradConv {
     const void* x0; int cin, in0_stride, cin_real;     // X: channel prefix [0,cin) of x0
     const void* g; int cout, cout_pad, g_stride;       // G: channels [0,cout_pad) of g
     long x_chunk_stride, g_chunk_stride;               // elements between 32-channel chunks of X / G (0 = 32: interleaved)
-    long x_lo_off, g_lo_off;                           // RESR_F16X2: element offsets hi -> lo tensor of X / G (else 0)
+    long x_lo_off, g_lo_off;                           // RESR_F16X2: element offsets hi -> lo tensor of X / G (else 0; g_lo_off = 0: G is single f16)
+    int g_lo_bias_only;                                // RESR_F16X2: the (x_hi, g_lo) tap-product only for X chunk 0 -- the job that also sums
+                                                       // the bias: dW takes G's hi tensor, db takes hi + lo (generator.hip, x2_plan bit 1)
     int x_s2d_c;                                       // > 0: X is a space-to-depth image with this many channels per sub-position
                                                        // (virtual kernel of a 4x4 / stride-2 conv): the zero taps are skipped
     float* dw; float* db; float scale;

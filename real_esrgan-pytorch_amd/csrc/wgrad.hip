@@ -956,10 +956,13 @@ int wgrad_x2_products() {
 
 // tap-products of one algorithmic product: RESR_F16X2 takes wgrad_x2_products() of them -- two of the three where G is a single f16
 // tensor (g_lo_off = 0: no (x_hi, g_lo) product)
-static int wgrad_parts(const WgradConv& c, int dtype) {
-    if (dtype != RESR_F16X2) return 1;
+static size_t wgrad_conv_jobs(const WgradConv& c, int dtype) {
+    const size_t prod = (size_t)(c.cin / 32) * (c.cout_pad / 32);
+    if (dtype != RESR_F16X2) return prod;
     const int n = wgrad_x2_products();
-    return (n == 3 && c.g_lo_off == 0) ? 2 : n;
+    if (n == 3 && c.g_lo_off == 0) return prod * 2;
+    if (n == 3 && c.g_lo_bias_only) return prod * 2 + (size_t)(c.cout_pad / 32);    // + the (x_hi chunk 0, g_lo) job of every G tile
+    return prod * n;
 }
 
 // Quad jobs (workgroups per pixel split) the batched launch of `convs` will run: the planners size their pixel splits by it --
@@ -977,7 +980,7 @@ int wgrad_batch_quads(const WgradConv* convs, int nconv, int dtype) {
         for (int ct = 0; ct < c.cout_pad / 32; ++ct)
             for (int ck = 0; ck < c.cin / 32; ++ck)
                 for (int part = 0; part < nparts; ++part) {
-                    if (part == 1 && g_single) continue;
+                    if (part == 1 && (g_single || (c.g_lo_bias_only && ck != 0))) continue;
                     ++total;
                     if (nj >= kMaxJobs) continue;
                     const char* xp = (const char*)c.x0 + (size_t)ck * (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * es + (part == 2 ? (size_t)c.x_lo_off * es : 0);
@@ -997,7 +1000,7 @@ int wgrad_batch_quads(const WgradConv* convs, int nconv, int dtype) {
 
 size_t wgrad_batch_partial_bytes(const WgradConv* convs, int nconv, int splits, int dtype) {
     size_t jobs = 0;
-    for (int i = 0; i < nconv; ++i) jobs += (size_t)(convs[i].cin / 32) * (convs[i].cout_pad / 32) * wgrad_parts(convs[i], dtype);
+    for (int i = 0; i < nconv; ++i) jobs += wgrad_conv_jobs(convs[i], dtype);
     return jobs * splits * kSlab * sizeof(float);
 }
 
@@ -1111,6 +1114,7 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
                 // parts: (x_hi, g_hi); RESR_F16X2 adds (x_hi, g_lo) and (x_lo, g_hi)
                 for (int part = 0; part < nparts; ++part) {
                     if (part == 1 && g_single) continue;   // no g_lo: dW = X_hi^T G + 2^-12 X_lo^T G
+                    if (part == 1 && c.g_lo_bias_only && ck != 0) continue;   // g_lo only where the bias is summed (X chunk 0)
                     WgradJob& j = a.jobs[nj++];
                     j.x = xh + (part == 2 ? (size_t)c.x_lo_off * es : 0);
                     j.g = gh + (part == 1 ? (size_t)c.g_lo_off * es : 0);
@@ -1171,7 +1175,7 @@ int wgrad_debug_dense_blocks(int nblocks, const void* const* x, const void* cons
             const int cin = 64 + 32 * (k - 1), cout = k < 5 ? 32 : 64;
             c.x0 = x[b]; c.cin = cin; c.in0_stride = 32; c.cin_real = cin;
             c.g = (const char*)g[b] + (k < 5 ? (size_t)(1 + k) * plane * 2 : 0); c.cout = cout; c.cout_pad = cout; c.g_stride = 32;
-            c.x_chunk_stride = plane; c.g_chunk_stride = plane; c.x_lo_off = c.g_lo_off = 0; c.x_s2d_c = 0;
+            c.x_chunk_stride = plane; c.g_chunk_stride = plane; c.x_lo_off = c.g_lo_off = 0; c.x_s2d_c = 0; c.g_lo_bias_only = 0;
             c.dw = out; c.db = nullptr; c.scale = 1.f;
             out += (size_t)cout * cin * 9;
         }
@@ -1200,7 +1204,7 @@ int wgrad_dispatch(const ResrWgradDesc* d, const void* x0, const void* x1, const
     c.x0 = x0; c.cin = d->cin; c.in0_stride = d->in0_stride; c.cin_real = d->cin_real;
     c.g = g; c.cout = d->cout; c.cout_pad = d->cout_pad; c.g_stride = d->g_stride;
     c.x_chunk_stride = (long)d->x_chunk_stride; c.g_chunk_stride = (long)d->g_chunk_stride;
-    c.x_lo_off = (long)d->x_lo_offset; c.g_lo_off = (long)d->g_lo_offset; c.x_s2d_c = 0;
+    c.x_lo_off = (long)d->x_lo_offset; c.g_lo_off = (long)d->g_lo_offset; c.x_s2d_c = 0; c.g_lo_bias_only = 0;
     c.dw = dw; c.db = db; c.scale = d->scale;
     // more products than one launch's job table holds (or an output wider than 64 channels): the layer mode (f16, exact16)
     const int tap_products = (c.cin / 32) * (c.cout_pad / 32) * (d->dtype == RESR_F16X2 ? wgrad_x2_products() : 1);

@@ -104,19 +104,22 @@ class Conv(torch.autograd.Function):
     f16 separately from the data path (exact16's hi-only weight gradients)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, fw, fwg, fwb):
+    def forward(ctx, x, w, b, fw, fwg, fwb, gread="pair"):
         wq = q16(w) if fw == "f16" else w
         ctx.save_for_backward(x, w)
-        ctx.fwg, ctx.fwb = fwg, fwb
+        ctx.fwg, ctx.fwb, ctx.gread = fwg, fwb, gread
         return F.conv2d(x, wq, b, padding=1)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        gx = torch.nn.grad.conv2d_input(x.shape, q16(w) if ctx.fwb == "f16" else w, g, padding=1)
+        # gread = "hi": the stored gradient plane is a PAIR, but backward-data and the weight products read its hi tensor only;
+        # the bias sum (and nothing else) takes hi + lo
+        gr = q16(g) if ctx.gread == "hi" else g
+        gx = torch.nn.grad.conv2d_input(x.shape, q16(w) if ctx.fwb == "f16" else w, gr, padding=1)
         fx, fg = ctx.fwg if isinstance(ctx.fwg, tuple) else (ctx.fwg, ctx.fwg)
-        gw = torch.nn.grad.conv2d_weight(q16(x) if fx == "f16" else x, w.shape, q16(g) if fg == "f16" else g, padding=1)
-        return gx, gw, g.sum((0, 2, 3)), None, None, None
+        gw = torch.nn.grad.conv2d_weight(q16(x) if fx == "f16" else x, w.shape, q16(gr) if fg == "f16" else gr, padding=1)
+        return gx, gw, g.sum((0, 2, 3)), None, None, None, None
 
 
 def generator(x, sd, cfg, upscale=4, n_blocks=23):
@@ -128,7 +131,8 @@ def generator(x, sd, cfg, upscale=4, n_blocks=23):
             return Conv8.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["fp8"])
         growth = ".rdb" in key and not key.endswith("conv5")      # conv1..4 of a dense block: their G operand is a growth-plane gradient
         wg = cfg.get("wg_growth", cfg["wg"]) if growth else cfg["wg"]
-        return Conv.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["w"], wg, cfg.get("wb", cfg["w"]))
+        return Conv.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["w"], wg, cfg.get("wb", cfg["w"]),
+                          cfg.get("gread_growth", "pair") if growth else "pair")
 
     x = S(x, "in")
     out1 = S(conv(x, "conv1"), "stream")
@@ -185,6 +189,7 @@ _EXACT = mk("pair", "pair", "pair", "split", "pair")
 RUNGS5 = {
     "INFER: stream+tail pair, growth planes f16, W split":           mk("pair", "f16", "pair", "split", "pair"),
     "TRAIN: fwd exact; growth-plane gradients f16 (bwd-data 2 stages, wgrad conv1-4 2 products)": mk("pair", "pair", "pair", "split", "pair", g_dense="f16"),
+    "TRAIN2: growth-plane gradients stored as pairs, READ as hi only by backward-data and the weight products; bias sums from hi + lo": _with(_EXACT, gread_growth="hi"),
     "TRAIN + hi-only wgrad on conv1-4 only":                         _with(mk("pair", "pair", "pair", "split", "pair", g_dense="f16"), wg_growth="f16"),
     "fp8 corrections: weight gradients only":                        _with(_EXACT, fp8="w"),
     "fp8 corrections: backward-data + weight gradients":             _with(_EXACT, fp8="dw"),
@@ -223,7 +228,10 @@ def run(seed, n_blocks, size, upscale=4, only=None, batch=1, wscale=1.0, rungs=N
         rel = {k: ((g[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)).item() for k in g0}
         worst_k = max(rel, key=rel.get)
         vals = sorted(rel.values())
-        rows[name] = {"fwd_max_abs": (y - y0).abs().max().item(), "act_max": float(y0.abs().max()), "grad_worst": rel[worst_k], "grad_worst_tensor": worst_k,
+        wrel = {k: v for k, v in rel.items() if k.endswith(".weight")}
+        worst_w = max(wrel, key=wrel.get)
+        rows[name] = {"fwd_max_abs": (y - y0).abs().max().item(), "act_max": float(y0.abs().max()), "grad_worst_weight": wrel[worst_w],
+                      "grad_worst_weight_tensor": worst_w, "grad_worst": rel[worst_k], "grad_worst_tensor": worst_k,
                       "grad_median": vals[len(vals) // 2], "gx": ((gx - gx0).norm() / gx0.norm()).item()}
     return rows
 
@@ -248,7 +256,7 @@ if __name__ == "__main__":
         allrows[seed] = rows
         print(f"== seed {seed}, {a.blocks} blocks, {a.batch} x {a.size}^2 LR, dense weights x {a.wscale}", flush=True)
         for name, r in rows.items():
-            print(f"{name:58s} fwd {r['fwd_max_abs']:.2e}  grad worst {r['grad_worst']:.2e} ({r['grad_worst_tensor']})  median {r['grad_median']:.2e}  gx {r['gx']:.2e}")
+            print(f"{name:58s} fwd {r['fwd_max_abs']:.2e}  grad worst {r['grad_worst']:.2e} ({r['grad_worst_tensor']})  worst weight {r['grad_worst_weight']:.2e}  median {r['grad_median']:.2e}  gx {r['gx']:.2e}")
     if a.json:
         with open(a.json, "w") as f:
             json.dump(allrows, f, indent=1)
