@@ -230,7 +230,12 @@ enum {
      * take two stages in the mirrored backward-data passes and conv1..conv4's weight gradients two tap-products instead of
      * three; they are still stored as pairs, and the BIAS gradients sum hi + lo (one extra tap-product per convolution).  Worst
      * gradient tensor 3-5e-4 vs float64 */
-    RESR_X2_PLAN_GROWTH_GRAD_F16 = 2
+    RESR_X2_PLAN_GROWTH_GRAD_F16 = 2,
+    /* with GROWTH_GRAD_F16: store the growth-plane gradients as single f16 tensors too (no lo store in the mirrored passes, no
+     * bias job: 64 instead of 68 tap-products per block, ~4 % of an exact16 step).  The bias gradients of conv1..conv4 are then
+     * sums of ROUNDED values: the emulation's worst bias tensor reaches 6.7e-4 at 1 x 128^2 (inside the 1e-3 gate, outside the
+     * 5e-4 rule the default plan keeps): opt-in. */
+    RESR_X2_PLAN_GROWTH_GRAD_STORE_F16 = 4
 };
 
 size_t resr_generator_param_count(const ResrGeneratorDesc* d);

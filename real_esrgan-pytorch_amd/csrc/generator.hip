@@ -568,6 +568,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     // (x_hi chunk 0, g_lo) job per convolution that carries the bias sum -- with a single-f16 G the worst bias tensor of the
     // emulation reached 6.7e-4 at 1 x 128^2.
     const bool gg_single = x2 && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_F16);
+    const bool gg_store_single = gg_single && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_STORE_F16);   // opt-in: no lo store, biases from hi alone
     const char* pk = (const char*)packed;
     const int N = d->n, h = p.h, w = p.w;
     const int H4 = 4 * h, W4 = 4 * w, H2 = 2 * h, W2 = 2 * w;
@@ -691,13 +692,14 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             ResrConvDesc cd = dgrad(h, w, 64, 32, cin, 32, 32, 32, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS, lo_t, lo_gs, lo_gs);
             cd.in0_chunk_stride = plane; cd.in1_chunk_stride = plane;
             if (gg_single) cd.x2_pair_chunks = 2;   // g_y (in0): pairs; the slab (in1) is read as single f16 chunks, written as a pair
+            if (gg_store_single) cd.flags |= RESR_CONV_OUT_SINGLE;
             char* out = gS + (size_t)ps * plane * es;
             const char* mask = b.bits[r] + (size_t)(k - 1) * N * h * w * sizeof(uint32_t);   // sign plane of o_k
             cds[ps] = cd; ws4[ps] = pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * wes; masks4[ps] = mask; outs4[ps] = out;
             const ConvSpec& c = p.convs[p.i_trunk0 + r * 5 + k - 1];
-            wcb[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f, lo_ws, lo_gs);
+            wcb[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f, lo_ws, gg_store_single ? 0 : lo_gs);
             wcb[k - 1].x_chunk_stride = plane;
-            wcb[k - 1].g_lo_bias_only = gg_single ? 1 : 0;
+            wcb[k - 1].g_lo_bias_only = (gg_single && !gg_store_single) ? 1 : 0;
         }
         {   // the four mirrored cout-32 passes, then g_x = convT(all) + (skip terms): one chained launch where the kernel supports
             // it (g_x joins on small launches), else one launch per pass

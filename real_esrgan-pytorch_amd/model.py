@@ -217,8 +217,9 @@ class Generator(nn.Module):
     `x2_plan` (exact16 only; bit set of _lib.X2_PLAN_*, default from $RESR_X2_PLAN, else both bits): which tensors of the dense
     blocks are single f16 instead of hi/lo pairs -- bit 0: the growth planes o1..o4 of an INFERENCE forward (50 instead of 60
     stages per block; forward ~1e-6 at the reference's init scale, gate 2e-4), bit 1: the growth-plane gradients of the backward
-    pass (two stages / two tap-products on their chunks; worst gradient tensor 3-5e-4 vs float64, gate 1e-3).  x2_plan=0 = pairs
-    everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
+    pass are READ as single f16 (two stages / two tap-products on their chunks; the bias sums still take hi + lo; worst gradient
+    tensor 3-5e-4 vs float64, gate 1e-3), bit 2 (opt-in, with bit 1): they are stored single as well (~4 % faster, worst bias tensor
+    6.7e-4).  x2_plan=0 = pairs everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
     forward(x[N,C,H,W] float in [0,1]) -> [N,out,H*s,W*s] clamped to [0,1]; differentiable.
     """
 
@@ -233,8 +234,9 @@ class Generator(nn.Module):
         self.precision = precision or os.environ.get("RESR_PRECISION", "fast")
         self._dtype = _precision_to_dtype(self.precision)
         self.x2_plan = int(os.environ.get("RESR_X2_PLAN", "3")) if x2_plan is None else int(x2_plan)
-        if not 0 <= self.x2_plan <= 3:
-            raise ValueError(f"x2_plan must be a bit set of X2_PLAN_GROWTH_F16_INFER (1) | X2_PLAN_GROWTH_GRAD_F16 (2), got {self.x2_plan}")
+        if not 0 <= self.x2_plan <= 7:
+            raise ValueError(f"x2_plan must be a bit set of X2_PLAN_GROWTH_F16_INFER (1) | X2_PLAN_GROWTH_GRAD_F16 (2) | "
+                             f"X2_PLAN_GROWTH_GRAD_STORE_F16 (4), got {self.x2_plan}")
         self.n_blocks = n_blocks or self.N_BLOCKS
         if upscale_factor == 2:
             conv_in, downscale_factor = in_channels * 4, 2

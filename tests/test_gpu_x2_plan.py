@@ -244,7 +244,11 @@ def test_training_plan_gradients_vs_float64_oracle(n, h, w, n_blocks, seed, diag
     assert rep["worst_vs_all_pairs_plan"] < 1e-3 and rep["gx_vs_all_pairs"] < 1e-4, rep
     for name, e in errs.items():     # vs float64: inside the gate, or a mask flip of the (shared) forward pass
         assert e < 1e-3 or errs0[name] > 0.8 * e, (name, e, errs0[name])
-    assert rep["median_vs_f64"] > 2e-5, "the plan does not seem to be active (gradients at the all-pairs level)"
+    assert rep["worst_vs_all_pairs_plan"] > 5e-5, "the plan does not seem to be active (gradients at the all-pairs level)"
+    # the bias gradients sum hi + lo of the growth-plane gradients: they stay at the level of the propagated error alone
+    worst_bias = max(e for name, e in between.items() if name.endswith(".bias"))
+    rep["worst_bias_vs_all_pairs"] = worst_bias
+    assert worst_bias < 2e-4, rep
 
 
 def test_plan_bits_are_honoured_and_ignored_outside_exact16():
@@ -277,7 +281,16 @@ def test_plan_bits_are_honoured_and_ignored_outside_exact16():
     with torch.no_grad():
         assert torch.equal(f0(x), f3(x))
     with pytest.raises(ValueError):
-        R.Generator(3, 3, 4, precision="exact16", x2_plan=7)
+        R.Generator(3, 3, 4, precision="exact16", x2_plan=8)
+    # bit 2 (opt-in): the growth-plane gradients stored single as well -- another backward pass, the same forward
+    g7 = R.Generator(3, 3, 4, precision="exact16", n_blocks=2, x2_plan=7).cuda()
+    g7.load_state_dict(sd)
+    xt = x.clone().requires_grad_(True)
+    y7 = g7.train()(xt)
+    y7.square().sum().mul(256.0).backward()
+    w7 = g7.trunk[0].rdb1.conv2.weight.grad
+    assert torch.equal(y7.detach(), outs[3][1]) and not torch.equal(w7, outs[3][3])
+    assert ((w7 - outs[0][3]).norm() / outs[0][3].norm()).item() < 1e-3
 
 
 @pytest.mark.parametrize("n,h,w", [(8, 24, 40), (16, 64, 64), (16, 128, 128)])
