@@ -387,11 +387,16 @@ def test_generator_parity_off_the_init_scale(precision, plan, case, diag_dir):
         json.dump(rep, fjson, indent=1)
     assert torch.isfinite(y).all() and all(torch.isfinite(p.grad).all() for p in g.parameters())
     if case == "stream_x0p01":
-        # The pair format is ABSOLUTE, not relative: hi = f16(x) is subnormal below 6.1e-5 and the matrix pipe does not keep f16
-        # subnormals (test_exact16_subnormal_operands_are_flushed), so an element of a 1e-3 stream loses up to 6e-5 of its value
-        # (measured here: every gradient tensor at 1.5-3e-3 in BOTH exact16 plans, forward 1e-6 because the trunk's whole share of
-        # this output is ~1e-3).  Real activations are O(0.1 - 10): recorded, gated only on the forward pass and on finiteness.
+        # A stream of O(1e-3) costs the pair format nothing (f16 subnormals are multiplied exactly:
+        # test_exact16_subnormal_operands_are_exact).  What this case shows instead, in BOTH exact16 plans and whatever the loss
+        # scale (tools/diag_smallscale.py): one LeakyReLU mask element of `upsampling1` flips against float64 -- every tensor BELOW
+        # that layer sits at 1.3-3e-3, upsampling2 / conv3 / conv4 at 1e-6, the forward pass at 1e-6.  With 1344 LR pixels one element
+        # is 1e-3 of a tensor; the flip-aware gates of test_training_plan_gradients_vs_float64_oracle apply: here the tensors above
+        # every trunk LeakyReLU stay at rounding level and nothing exceeds the signature of a single flip.
         assert rep["fwd"] < 2e-4, rep
+        if precision == "exact16":
+            assert max(errs[k] for k in errs if k.startswith(("conv3", "conv4"))) < 1e-5, rep
+            assert rep["worst"] < 1e-2, rep
         return
     if precision == "exact16":
         assert rep["fwd"] < 2e-4, rep
@@ -419,12 +424,11 @@ def test_exact16_weight_overflow_is_loud():
     assert torch.isnan(y2).any(), "a weight beyond the split format's range must poison the output"
 
 
-def test_exact16_subnormal_operands_are_flushed(U, diag_dir):
-    """What bounds exact16 at tiny magnitudes, measured: one 64 -> 32 convolution on pair operands whose values sit (a) in f16's
-    normal range, (b) mostly below 6.1e-5 (hi tensors subnormal, lo tensors -- scaled by 2^12 -- normal).  If `v_mfma_f32_32x32x16_f16`
-    kept subnormal operands, (b) would be as exact as (a); it flushes them, so the hi part of such elements is lost and the result
-    carries an ABSOLUTE error of up to 6.1e-5 x sum |w| per output (relative error O(1) at that magnitude, invisible at O(1)
-    activations).  Characterisation, not a gate on the flush itself: asserts (a) at 2e-6 relative and records (b)."""
+def test_exact16_subnormal_operands_are_exact(U, diag_dir):
+    """A question the small-scale case raised, answered by measurement: does `v_mfma_f32_32x32x16_f16` keep f16 SUBNORMAL operands?
+    One 64 -> 32 convolution on pair operands whose values sit (a) in f16's normal range, (b) 99.8 % below 6.1e-5 (hi tensors
+    subnormal; lo tensors, scaled by 2^12, normal).  It does: (b) is as exact as (a) -- relative L2 3.9e-7 against float64 (3.1e-7
+    for (a)) -- so the pair format's accuracy is relative down to f16's smallest subnormal, not absolute."""
     L = U.L
     g = torch.Generator().manual_seed(9)
     n, cin, cout, h, w = 1, 64, 32, 24, 32
@@ -447,5 +451,4 @@ def test_exact16_subnormal_operands_are_flushed(U, diag_dir):
                     "share_of_hi_below_6e-5": (xv.abs() < 6.1e-5).double().mean().item()}
     with open(os.path.join(diag_dir, "x2_subnormal_probe.json"), "w") as f:
         json.dump(rep, f, indent=1)
-    assert rep["normal"]["rel_l2"] < 2e-6, rep
-    assert rep["tiny"]["max_abs"] < 6.2e-5 * wt.abs().sum(dim=(1, 2, 3)).max().item(), rep      # never worse than dropping every such element
+    assert rep["normal"]["rel_l2"] < 2e-6 and rep["tiny"]["rel_l2"] < 2e-6, rep
