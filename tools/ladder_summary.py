@@ -11,9 +11,11 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 out = {}
-for path in sorted(glob.glob(os.path.join(src, "r5_*x*_w*.json")) + glob.glob(os.path.join(src, "r5_bf8_*.json"))):
-    tag = os.path.basename(path)[3:-5]
-    out[tag] = json.load(open(path))
+for path in sorted(glob.glob(os.path.join(src, "r5_*x*_w*.json")) + glob.glob(os.path.join(src, "r5_bf8_*.json")) + glob.glob(os.path.join(src, "r5t2_*x*_w*.json"))):
+    base = os.path.basename(path)
+    tag = base[5:-5] if base.startswith("r5t2_") else base[3:-5]      # r5t2_*: the TRAIN2 rung, run separately, merged into its geometry
+    for seed, rows in json.load(open(path)).items():
+        out.setdefault(tag, {}).setdefault(seed, {}).update(rows)
 json.dump({"tool": "tools/precision_ladder_sim.py --set round5 (23 blocks, float64 emulation of the storage roundings)", "runs": out}, open(dst, "w"), indent=1)
 rungs = {}
 for tag, seeds in out.items():
