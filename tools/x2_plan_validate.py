@@ -1,0 +1,79 @@
+"""exact16's backward plans against the all-pairs plan ON THE GPU, at the geometries training runs at (the emulation of
+tools/precision_ladder_sim.py stops at 1 x 128^2: a float64 evaluation of 16 x 256^2 is hours of CPU).
+
+The plans share their forward pass bit for bit (hence every LeakyReLU mask), so the distance between their gradients is the
+rung's own effect, free of mask flips: per-tensor relative L2 of all 702 gradient tensors (23 blocks) for
+  plan 3 (default: growth-plane gradients stored as pairs, read as their hi tensor, bias sums from hi + lo) and
+  plan 7 (opt-in: stored single)
+against plan 0, under the L1 loss of the train step on image-like input and under a dense random cotangent.
+
+    python tools/x2_plan_validate.py [--out gpurun_out/x2_plan_validate.json] [--cases 16x256,2x256,...] [--seeds 5,6,7]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import real_esrgan_pytorch_amd as R  # noqa: E402
+
+
+def grads(g, plan, x, loss_of):
+    g.x2_plan = plan
+    g.zero_grad(set_to_none=True)
+    y = g(x)
+    loss_of(y).mul(1024.0).backward()
+    torch.cuda.synchronize()
+    return y.detach().clone(), {n: p.grad.detach().double().cpu() / 1024.0 for n, p in g.named_parameters()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/x2_plan_validate.json")
+    ap.add_argument("--cases", default="16x256,2x256,32x64,1x128,1x24")
+    ap.add_argument("--seeds", default="5,6,7")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    g = R.Generator(3, 3, 4, precision="exact16").cuda().train()
+    with torch.no_grad():
+        g.conv4.bias.add_(0.5)
+    rep = {}
+    for case in a.cases.split(","):
+        n, s = (int(v) for v in case.split("x"))
+        for seed in (int(v) for v in a.seeds.split(",")):
+            gen = torch.Generator(device="cuda").manual_seed(seed)
+            # image-like input: smooth field + grain (the regime training runs in)
+            x = torch.nn.functional.interpolate(torch.rand(n, 3, s // 8, s // 8, device="cuda", generator=gen), size=(s, s), mode="bicubic").clamp(0, 1)
+            x = (0.9 * x + 0.1 * torch.rand(n, 3, s, s, device="cuda", generator=gen)).clamp(0, 1)
+            target = torch.rand(n, 3, 4 * s, 4 * s, device="cuda", generator=gen)
+            gw = torch.randn(n, 3, 4 * s, 4 * s, device="cuda", generator=gen) / (4 * s)
+            for lname, loss_of in (("l1", lambda y: (y - target).abs().mean()), ("dense", lambda y: (y * gw).sum())):
+                y0, g0 = grads(g, 0, x, loss_of)
+                row = {}
+                for plan in (3, 7):
+                    yp, gp = grads(g, plan, x, loss_of)
+                    rel = {k: ((gp[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)).item() for k in g0}
+                    worst = max(rel, key=rel.get)
+                    vals = sorted(rel.values())
+                    row[f"plan{plan}"] = {"forward_equal": bool(torch.equal(yp, y0)), "worst_tensor": worst, "worst_rel_l2": rel[worst],
+                                          "median_rel_l2": vals[len(vals) // 2], "p99_rel_l2": vals[int(len(vals) * 0.99)], "tensors": len(vals),
+                                          "weights_worst": max(v for k, v in rel.items() if k.endswith("weight")),
+                                          "bias_worst": max(v for k, v in rel.items() if k.endswith("bias"))}
+                rep[f"{case}_s{seed}_{lname}"] = row
+                print(case, seed, lname, json.dumps(row), flush=True)
+    summary = {}
+    for plan in ("plan3", "plan7"):
+        for case in a.cases.split(","):
+            rows = [v[plan] for k, v in rep.items() if k.startswith(case + "_")]
+            summary[f"{plan}_{case}"] = {"worst_rel_l2": max(r["worst_rel_l2"] for r in rows), "weights_worst": max(r["weights_worst"] for r in rows),
+                                         "bias_worst": max(r["bias_worst"] for r in rows), "median_max": max(r["median_rel_l2"] for r in rows), "runs": len(rows)}
+    rep["summary"] = summary
+    print(json.dumps(summary, indent=1))
+    os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+    json.dump(rep, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
