@@ -1199,7 +1199,10 @@ def main():
                           "product, fp32 accumulate): the mode that meets the 1e-3 max-abs parity tolerance vs the fp32 CPU path",
                   "x2_plan": "default (3): forward all pairs; backward READS the growth-plane gradients as single f16 -- two stages on their chunks in "
                              "backward-data, two tap-products in conv1..conv4's weight gradients, bias sums from hi + lo (worst gradient tensor "
-                             "2.3-4.9e-4 vs float64 at three geometries x five seeds, DESIGN section 2); x2_plan=0 = pairs everywhere (5.8e-6)",
+                             "2.2-4.6e-4 vs float64 in the emulation at three geometries x five seeds; against the all-pairs plan on the GPU at 16 x 256^2 .. "
+                             "1 x 24^2: 1.7-5.1e-4 under a dense random cotangent, 5e-7 .. 2e-5 under this step's L1 loss -- profiles/r05_x2_plan_validate.json, "
+                             "DESIGN section 2); the backward pass lifts small incoming gradients by a power of two, so the numbers hold at any loss scale; "
+                             "x2_plan=0 = pairs everywhere (5.8e-6)",
                   "value": round(pv, 3), "unit": "images/sec", "steps": parity_res["steps"], "warmup": parity_res["warmup"],
                   "ms_per_step": round(parity_res["dt"] / parity_res["steps"] * 1e3, 2),
                   "generator_tflops_per_gpu": round(pv / world * flop_per_image / 1e12, 2), "loss": parity_res["loss"],

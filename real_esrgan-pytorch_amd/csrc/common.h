@@ -40,6 +40,18 @@ constexpr float kLoScale = 4096.f, kLoInv = 1.f / 4096.f;
 constexpr int kMaxDevices = 16;   // per-device caches (occupancy, zero pages, CU counts) are indexed by hipGetDevice()
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Power-of-two gradient pre-scale of a backward pass (generator.hip, RESR_F16X2).  absmax_dispatch (layout.hip) leaves the bits of
+// m = max |g_y| * 2^-t; when m < 1 the pass runs on g_y * s with s = 2^-floor(log2 m) -- max |g_y * s| in [2^t, 2^(t+1)): f16's
+// normal range however small the caller's loss scale is -- and every result leaves through * 1/s.  Both factors are exact.  Gradients
+// that are large enough already (m >= 1) are left alone (s = 1): a GradScaler that keeps doubling its scale still meets f16's
+// overflow and settles below it, as it does without the pre-scale.  Zero, denormal or non-finite maxima give s = 1.
+__host__ __device__ __forceinline__ float grad_prescale(unsigned amax_bits, bool inverse) {
+    const unsigned e = (amax_bits >> 23) & 0xffu;          // biased exponent of m
+    if (e == 0u || e >= 127u) return 1.f;
+    const unsigned f = (inverse ? e : 254u - e) << 23;     // 2^(e - 127) or 2^(127 - e)
+    return __builtin_bit_cast(float, f);
+}
+
 // MI355X: blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8).  Give every XCD a
 // contiguous range of tiles so neighbouring tiles (shared halo rows, same weights) meet in one L2.
 // Bijective for any grid size.

@@ -35,6 +35,9 @@ int wgrad_x2_products();
 int pack_dispatch(const ResrPackChunk*, int, const float*, void*, int, hipStream_t);
 int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long);
 int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t, long);
+int absmax_dispatch(const float*, long, unsigned*, int, hipStream_t);
+int nchw_to_nhwc_scaled_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long, const unsigned*);
+int nhwc_to_nchw_scaled_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t, long, const unsigned*);
 int s2d_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t);
 int bilinear_up_dispatch(const void*, void*, int, int, int, int, int, int, hipStream_t, long, long);
 int d2s_add_mask_dispatch(const void*, const void*, const void*, void*, int, int, int, int, int, float, hipStream_t, long, long, long);
@@ -113,6 +116,7 @@ struct DBufs {
     char *g4, *G8, *G7, *G6, *g_u3, *g_b3, *g_u2, *G5, *g_b2, *g_u1, *G4, *g_b1, *g_d3, *G3, *g_s3, *G2, *g_s2, *G1, *g_s1,
         *G0, *gxin;
     float *raw, *folded, *tmp1, *partial;
+    unsigned* gscale;           // exact16: bits of max |g_y| of the running backward pass (common.h: grad_prescale)
     float* raw_l[kLayers];      // per normalised layer: the gradient wrt W = W_orig / sigma (virtual 3x3 form for the 4x4 layers) ...
     float* fold_l[kLayers];     // ... and its [cout][C][4][4] form (4x4 layers): all layers' folds and spectral-norm backward steps
                                 // run as three batched launches at the end of the pass
@@ -188,6 +192,7 @@ void carve(const DPlan& p, char* base, DBufs& b) {
         b.G2 = take(px / 16 * 256 * es); b.g_s2 = take(px / 16 * 512 * es);
         b.G1 = take(px / 4 * 128 * es); b.g_s1 = take(px / 4 * 256 * es);
         b.G0 = take(px * 64 * es); b.gxin = take(px * 32 * es);
+        b.gscale = (unsigned*)take(256);
         b.raw = (float*)take((size_t)512 * 1024 * 9 * sizeof(float));
         b.folded = (float*)take((size_t)512 * 256 * 16 * sizeof(float));
         b.tmp1 = (float*)take(8 * 512 * sizeof(float));   // block partials of the spectral-norm backward's <G, W>, all layers
@@ -405,6 +410,11 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
     const long lo_h1_128 = LO(px / 4 * 128), lo_h1_256 = LO(px / 4 * 256), lo_h2_256 = LO(px / 16 * 256), lo_h2_512 = LO(px / 16 * 512);
     const long lo_h3_512 = LO(px / 64 * 512), lo_h3_1024 = LO(px / 64 * 1024);
 
+    // exact16: a small incoming gradient is lifted into f16's normal range by a power of two and every result handed out unscaled
+    // (generator.hip has the measurements; common.h grad_prescale).  The spectral-norm backward at the end of the pass reads the
+    // raw weight gradients the reducers have already unscaled.
+    const char* pre_t = getenv("RESR_X2_GRAD_PRESCALE_LOG2");
+    const unsigned* gsc = (x2 && !getenv("RESR_X2_NO_GRAD_PRESCALE")) ? b.gscale : nullptr;
     // weight (and bias) gradient of layer li: X = first cin_pad channels of x (pixel stride xs), G = first cout channels of g
     auto wgrad_layer = [&](int li, const char* x, int xs, const char* g, int gs, int h, int w, long lo_xw, long lo_gw) -> int {
         if (!need_w) return RESR_OK;
@@ -423,6 +433,7 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
             c.x_chunk_stride = c.g_chunk_stride = 0; c.x_lo_off = x2 ? lo_xw : 0; c.g_lo_off = x2 ? lo_gw : 0;
             c.x_s2d_c = l.k4 ? l.cin : 0; c.g_lo_bias_only = 0;
             c.dw = raw; c.db = (l.bias ? grad + p.b_off[li] : nullptr); c.scale = 1.f;
+            c.unscale = gsc;
             const int splits = layer_splits(chunks * (c.cout_pad / 32), N, h, w, parts);
             if (wgrad_layer_partial_bytes(cin_pad, c.cout_pad, splits, dt) > b.partial_bytes) return fail(RESR_ERR_WORKSPACE, "discriminator: wgrad slabs (layer mode)");
             DRUN(resr::wgrad_layer(&c, N, h, w, dt, 0, splits, b.partial, st));
@@ -445,6 +456,7 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
                 c.g_lo_bias_only = 0;
                 c.x_s2d_c = l.k4 ? l.cin : 0;      // 4x4 / stride-2 layers: X is the space-to-depth image, skip the virtual kernel's zero taps
                 c.dw = raw + (size_t)q0 * cin_v * 9; c.db = (l.bias ? grad + p.b_off[li] + q0 : nullptr); c.scale = 1.f;
+                c.unscale = gsc;
                 jobs += chunks * (c.cout_pad / 32);
             }
             if (!nc) continue;
@@ -482,7 +494,8 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
                           lo_g, lo_o, 0);
     };
 
-    DRUN(nchw_to_nhwc_dispatch(gy, b.g4, N, 1, S, W, 1, 32, dt, nullptr, st, lo_in));
+    if (gsc) DRUN(absmax_dispatch(gy, (long)N * S * W, b.gscale, pre_t ? atoi(pre_t) : 6, st));
+    DRUN(nchw_to_nhwc_scaled_dispatch(gy, b.g4, N, 1, S, W, 1, 32, dt, nullptr, st, lo_in, gsc));
     DRUN(wgrad_layer(CONV4, b.c3, 64, b.g4, 32, S, W, lo64, lo_in));
     DRUN(dconv(CONV4, b.g4, 32, S, W, b.G8, 64, MK, b.c3, 64, nullptr, 0, lo_in, lo64));
     DRUN(wgrad_layer(CONV3, b.c2, 64, b.G8, 64, S, W, lo64, lo64));
@@ -511,7 +524,7 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
     DRUN(finish_sn());
     if (gx) {
         DRUN(dconv(CONV1, b.G0, 64, S, W, b.gxin, 32, 0, nullptr, 0, nullptr, 0, lo64, lo_in));
-        DRUN(nhwc_to_nchw_dispatch(b.gxin, gx, N, 3, S, W, 1, 32, dt, st, lo_in));
+        DRUN(nhwc_to_nchw_scaled_dispatch(b.gxin, gx, N, 3, S, W, 1, 32, dt, st, lo_in, gsc));
     }
     return RESR_OK;
 }

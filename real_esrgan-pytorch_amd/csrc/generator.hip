@@ -48,6 +48,9 @@ int wgrad_tile_rows(int dtype);
 int wgrad_x2_products();
 int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long);
 int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t, long);
+int absmax_dispatch(const float*, long, unsigned*, int, hipStream_t);
+int nchw_to_nhwc_scaled_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long, const unsigned*);
+int nhwc_to_nchw_scaled_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t, long, const unsigned*);
 int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int, float, hipStream_t, long, long);
 int add_inplace_dispatch(void*, const void*, long, int, hipStream_t, long, long);
 
@@ -158,6 +161,7 @@ struct Bufs {
     char *g4, *gA, *gB, *gM1, *gF, *gT[4], *gS[3], *gxin;   // gS: one slab per dense block of an RRDB (their weight gradients run as one batch)
     float* partial;
     size_t partial_bytes;
+    unsigned* gscale;         // exact16: bits of max |g_y| of the running backward pass (common.h: grad_prescale)
     size_t total;
 };
 
@@ -209,6 +213,7 @@ void carve(const Plan& p, char* base, Bufs& b) {
         off += align_up(bytes, 256);
         return ptr;
     };
+    b.gscale = nullptr;
     b.chain_bytes = conv3x3_chain_state_bytes(p.d.n, p.h, p.w);
     b.chain = take(b.chain_bytes);
     b.x_in = take(px * p.ci_pad * es);
@@ -237,6 +242,7 @@ void carve(const Plan& p, char* base, Bufs& b) {
         for (int i = 0; i < 4; ++i) b.gT[i] = take(px * 64 * es);
         for (int i = 0; i < 3; ++i) b.gS[i] = take(px * 128 * es);
         b.gxin = take(px * p.ci_pad * es);
+        b.gscale = (unsigned*)take(256);
         // wgrad slabs: largest batch (an RRDB = 78 products, a dense block = 26 at LR; single 64->64 convs = 4 jobs at 1x/2x/4x)
         const size_t slab = (9 * 1024 + 32) * sizeof(float);
         size_t pb = 0;
@@ -567,6 +573,17 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     // pairs: the bias gradient (a plain sum of G, which cancels where the weight products do not) takes hi + lo through the one
     // (x_hi chunk 0, g_lo) job per convolution that carries the bias sum -- with a single-f16 G the worst bias tensor of the
     // emulation reached 6.7e-4 at 1 x 128^2.
+    // exact16 lifts a small incoming gradient into f16's normal range: when max |g_y| < 2^6 the pass runs on g_y * 2^k with
+    // max |g_y * 2^k| in [2^6, 2^7) and hands every result out times 2^-k (both exact; common.h grad_prescale).  The pass is linear in
+    // g_y, and its f16 tensors -- the hi halves that the plan below reads alone most of all -- keep their 11 bits whatever loss scale
+    // the caller works at.  Measured without it (tools/x2_plan_validate.py, L1 mean loss at 16 x 256^2: g_y = scale x 2e-8 per
+    // element): worst gradient tensor of the default plan against the all-pairs plan 0.82 at loss scale 2^10, 3.3e-3 at a GradScaler's
+    // initial 2^16, 1.2e-5 at 2^20 -- hi halves below 6e-5 are f16 subnormals.  The target leaves 2^9 of headroom to f16's maximum for
+    // gradients that grow on their way back; $RESR_X2_GRAD_PRESCALE_LOG2 moves it, RESR_X2_NO_GRAD_PRESCALE=1 turns the lift off.
+    const char* no_prescale = getenv("RESR_X2_NO_GRAD_PRESCALE");   // (read per call: A/B knobs)
+    const char* pre_t = getenv("RESR_X2_GRAD_PRESCALE_LOG2");
+    const int pre_log2 = pre_t ? atoi(pre_t) : 6;
+    const unsigned* gsc = (x2 && !no_prescale) ? b.gscale : nullptr;
     const bool gg_single = x2 && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_F16);
     const bool gg_store_single = gg_single && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_STORE_F16);   // opt-in: no lo store, biases from hi alone
     const char* pk = (const char*)packed;
@@ -588,6 +605,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         wc.x_chunk_stride = wc.g_chunk_stride = 0;
         wc.x_lo_off = x_lo; wc.g_lo_off = g_lo; wc.x_s2d_c = 0; wc.g_lo_bias_only = 0;
         wc.dw = grad + c.w_off; wc.db = grad + c.b_off; wc.scale = scale;
+        wc.unscale = gsc;
         return wc;
     };
     auto wgrad_run = [&](const WgradConv* wc, int nconv, int hh, int ww, int flags) -> int {
@@ -616,7 +634,8 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     };
 
     // clamp_ backward + layout                                              model.py:270
-    RUN(nchw_to_nhwc_dispatch(gy, b.g4, N, d->out_channels, H4, W4, 1, 32, d->dtype, b.ymask, st, lo_g4));
+    if (gsc) RUN(absmax_dispatch(gy, (long)N * d->out_channels * H4 * W4, b.gscale, pre_log2, st));
+    RUN(nchw_to_nhwc_scaled_dispatch(gy, b.g4, N, d->out_channels, H4, W4, 1, 32, d->dtype, b.ymask, st, lo_g4, gsc));
     {   // conv4                                                            model.py:268
         const ConvSpec& c = p.convs[p.i_conv4];
         RUN(wgrad(c, H4, W4, b.c3, 64, 32, b.g4, 32, 0, 1.f, pl4, 0, lo_4, lo_g4));
@@ -732,7 +751,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             ResrConvDesc cd = dgrad(h, w, 64, 32, 64, 0, p.ci_pad, p.ci_pad, p.ci_pad, 0, lo_t, 0, lo_xin);
             cd.in0_chunk_stride = plane;
             RUN(conv3x3_dispatch(&cd, b.gT[cur], nullptr, pk + p.pk_bwd_conv1 * wes, nullptr, nullptr, nullptr, nullptr, b.gxin, nullptr, st));
-            RUN(nhwc_to_nchw_dispatch(b.gxin, gx, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, st, lo_xin));
+            RUN(nhwc_to_nchw_scaled_dispatch(b.gxin, gx, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, st, lo_xin, gsc));
         }
     }
     return RESR_OK;

@@ -6,7 +6,10 @@
 //   sumpool2x2   : backward of F.interpolate(scale_factor=2, mode="nearest") (model.py:264-265)
 //                  fused with the LeakyReLU backward of the producer
 //   add_inplace  : skip-connection gradient merge (model.py:262)
+//   absmax       : bits of max |g_y| of a backward pass's incoming gradient (common.h: grad_prescale)
 // All are one-pass, 16-byte vectorised where the layout allows; each thread owns one pixel.
+#include <math.h>
+
 #include "common.h"
 
 namespace resr {
@@ -21,7 +24,8 @@ __device__ __forceinline__ void split_f16(float v, half_t& hi, half_t& lo) {
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
                                                            int n, int c, int h, int w, int r, int c_pad,
-                                                           const uint8_t* __restrict__ mask, long lo_off) {
+                                                           const uint8_t* __restrict__ mask, long lo_off,
+                                                           const unsigned* __restrict__ amax) {
     // output pixel grid is (h/r) x (w/r); output channel = ch*r*r + i*r + j  (torch pixel_unshuffle).
     // One thread per 16-byte piece of an output pixel: consecutive threads write consecutive 16 bytes.
     // Rows and images come from blockIdx.y / blockIdx.z, (pixel, piece) inside the row from one 32-bit division: decoded from one flat
@@ -34,6 +38,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     const int xo = (int)(idx / pieces);
     const int piece = (int)(idx - (unsigned)xo * pieces);
     const int creal = c * r * r;
+    const float pre = amax ? grad_prescale(*amax, false) : 1.f;   // (exact: a power of two)
     // rows / images from the grid, strided: a grid dimension holds 65535 at most (taller images, larger batches loop)
     for (int b = (int)blockIdx.z; b < n; b += (int)gridDim.z)
     for (int yo = (int)blockIdx.y; yo < ho; yo += (int)gridDim.y) {
@@ -48,7 +53,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
             if (co < creal) {
                 const int ch = co / (r * r), ij = co % (r * r), i = ij / r, j = ij % r;
                 const size_t q = (((size_t)b * c + ch) * h + (yo * r + i)) * w + (xo * r + j);
-                v = src[q];
+                v = src[q] * pre;
                 if (mask) v = mask[q] ? v : 0.f;
             }
             if constexpr (sizeof(T) == 2) {
@@ -65,7 +70,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst,
-                                                           int n, int c, int h, int w, int r, int src_stride, long lo_off, int wsh) {
+                                                           int n, int c, int h, int w, int r, int src_stride, long lo_off, int wsh,
+                                                           const unsigned* __restrict__ amax) {
     // src pixel grid (h/r) x (w/r) with c*r*r channels; dst [n,c,h,w]
     // x from the thread, row from blockIdx.y, (image, channel) from blockIdx.z: no 64-bit divisions per element.  A workgroup
     // covers 2^wsh columns x 256 >> wsh rows (narrow images -- the discriminator's coarse levels -- would leave most of a
@@ -74,6 +80,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
     if (x >= w) return;
     const int rows_pb = 256 >> wsh, ysub = (int)(threadIdx.x >> wsh);
     const int ho = h / r, wo = w / r;
+    const float post = amax ? grad_prescale(*amax, true) : 1.f;
     for (unsigned z = blockIdx.z; z < (unsigned)n * (unsigned)c; z += gridDim.z) {
         const int b = (int)(z / (unsigned)c), ch = (int)(z - (unsigned)b * (unsigned)c);
         for (int y = (int)blockIdx.y * rows_pb + ysub; y < h; y += (int)gridDim.y * rows_pb) {
@@ -82,8 +89,42 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
             const size_t p = ((size_t)b * ho + y / r) * wo + x / r;
             float v = (float)src[p * src_stride + co];
             if (sizeof(T) == 2 && lo_off) v = __builtin_fmaf((float)src[lo_off + p * src_stride + co], kLoInv, v);
-            dst[q] = v;
+            dst[q] = v * post;
         }
+    }
+}
+
+// bits of max |src| * 2^-t (positive floats order like their bit patterns; a NaN beats every number, so a non-finite gradient stays
+// visible to grad_prescale).  *slot is zeroed by the dispatcher; the maximum is order-independent, hence deterministic.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ src, long count, unsigned* __restrict__ slot, int vec, float down) {
+    unsigned m = 0u;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < count; i += stride) {
+        if (vec && i + 4 <= count) {
+            const uint4 v = *reinterpret_cast<const uint4*>(src + i);
+            const unsigned a = v.x & 0x7fffffffu, b = v.y & 0x7fffffffu, c = v.z & 0x7fffffffu, d = v.w & 0x7fffffffu;
+            const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+            const unsigned q = ab > cd ? ab : cd;
+            m = m > q ? m : q;
+        } else {
+            for (long k = i; k < count && k < i + 4; ++k) {
+                const unsigned a = __float_as_uint(src[k]) & 0x7fffffffu;
+                m = m > a ? m : a;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)m, o);
+        m = m > other ? m : other;
+    }
+    __shared__ unsigned wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a = wm[0] > wm[1] ? wm[0] : wm[1], b = wm[2] > wm[3] ? wm[2] : wm[3];
+        // times 2^-t (exact; an inf or NaN stays one): the slot holds the bits of max |src| * 2^-t
+        atomicMax(slot, __float_as_uint(__uint_as_float(a > b ? a : b) * down) & 0x7fffffffu);
     }
 }
 
@@ -176,23 +217,49 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ dst, c
 static unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
 
 // RESR_F16X2: lo_off < 0 selects the C-ABI default -- the lo tensor directly follows the hi tensor
+int absmax_dispatch(const float* src, long count, unsigned* slot, int target_log2, hipStream_t stream) {
+    if (!src || !slot || count <= 0 || target_log2 < -64 || target_log2 > 64) return fail(RESR_ERR_ARG, "absmax: bad argument");
+    if (hipMemsetAsync(slot, 0, sizeof(unsigned), stream) != hipSuccess) return fail(RESR_ERR_LAUNCH, "absmax: memset");
+    const long want = (count / 4 + 255) / 256;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(want < 1 ? 1 : want > 2048 ? 2048 : want)), dim3(256), 0, stream, src, count, slot,
+                       ((size_t)src & 15) ? 0 : 1, ldexpf(1.f, -target_log2));
+    RESR_CHECK_LAUNCH("absmax_kernel");
+    return RESR_OK;
+}
+
+int nchw_to_nhwc_scaled_dispatch(const float* src, void* dst, int n, int c, int h, int w, int r, int c_pad, int dtype,
+                                 const uint8_t* mask, hipStream_t stream, long lo_off, const unsigned* amax);
 int nchw_to_nhwc_dispatch(const float* src, void* dst, int n, int c, int h, int w, int r, int c_pad, int dtype,
                           const uint8_t* mask, hipStream_t stream, long lo_off) {
+    return nchw_to_nhwc_scaled_dispatch(src, dst, n, c, h, w, r, c_pad, dtype, mask, stream, lo_off, nullptr);
+}
+
+// amax: device pointer to the bits of max |src| (absmax_dispatch) -- src is read times grad_prescale(*amax) -- or nullptr
+int nchw_to_nhwc_scaled_dispatch(const float* src, void* dst, int n, int c, int h, int w, int r, int c_pad, int dtype,
+                                 const uint8_t* mask, hipStream_t stream, long lo_off, const unsigned* amax) {
     if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || r <= 0 || (h % r) || (w % r) || c * r * r > c_pad || (c_pad & 7))
         return fail(RESR_ERR_ARG, "nchw_to_nhwc: bad argument (c=%d r=%d c_pad=%d h=%d w=%d)", c, r, c_pad, h, w);
     const dim3 grid(blocks_for((long)(w / r) * (c_pad / (dtype != RESR_F32 ? 8 : 4))), (unsigned)(h / r > 65535 ? 65535 : h / r), (unsigned)(n > 65535 ? 65535 : n));
     if (dtype == RESR_F16X2 && lo_off < 0) lo_off = (long)n * (h / r) * (w / r) * c_pad;
     if (dtype != RESR_F16X2) lo_off = 0;
     if (dtype != RESR_F32)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, grid, dim3(256), 0, stream, src, (half_t*)dst, n, c, h, w, r, c_pad, mask, lo_off);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, grid, dim3(256), 0, stream, src, (half_t*)dst, n, c, h, w, r, c_pad, mask, lo_off, amax);
     else
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, stream, src, (float*)dst, n, c, h, w, r, c_pad, mask, 0L);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, stream, src, (float*)dst, n, c, h, w, r, c_pad, mask, 0L, amax);
     RESR_CHECK_LAUNCH("nchw_to_nhwc_kernel");
     return RESR_OK;
 }
 
+int nhwc_to_nchw_scaled_dispatch(const void* src, float* dst, int n, int c, int h, int w, int r, int src_stride, int dtype,
+                                 hipStream_t stream, long lo_off, const unsigned* amax);
 int nhwc_to_nchw_dispatch(const void* src, float* dst, int n, int c, int h, int w, int r, int src_stride, int dtype,
                           hipStream_t stream, long lo_off) {
+    return nhwc_to_nchw_scaled_dispatch(src, dst, n, c, h, w, r, src_stride, dtype, stream, lo_off, nullptr);
+}
+
+// amax: the result leaves times 1 / grad_prescale(*amax) (the inverse of what nchw_to_nhwc_scaled_dispatch applied), or nullptr
+int nhwc_to_nchw_scaled_dispatch(const void* src, float* dst, int n, int c, int h, int w, int r, int src_stride, int dtype,
+                                 hipStream_t stream, long lo_off, const unsigned* amax) {
     if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || r <= 0 || (h % r) || (w % r))
         return fail(RESR_ERR_ARG, "nhwc_to_nchw: bad argument");
     if ((long)n * c > 0x7fffffffL) return fail(RESR_ERR_ARG, "nhwc_to_nchw: n * c beyond 2^31");
@@ -203,9 +270,9 @@ int nhwc_to_nchw_dispatch(const void* src, float* dst, int n, int c, int h, int 
     if (dtype == RESR_F16X2 && lo_off < 0) lo_off = (long)n * (h / r) * (w / r) * src_stride;
     if (dtype != RESR_F16X2) lo_off = 0;
     if (dtype != RESR_F32)
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, grid, dim3(256), 0, stream, (const half_t*)src, dst, n, c, h, w, r, src_stride, lo_off, wsh);
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, grid, dim3(256), 0, stream, (const half_t*)src, dst, n, c, h, w, r, src_stride, lo_off, wsh, amax);
     else
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, stream, (const float*)src, dst, n, c, h, w, r, src_stride, 0L, wsh);
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, stream, (const float*)src, dst, n, c, h, w, r, src_stride, 0L, wsh, amax);
     RESR_CHECK_LAUNCH("nhwc_to_nchw_kernel");
     return RESR_OK;
 }

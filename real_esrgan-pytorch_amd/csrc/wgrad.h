@@ -14,6 +14,8 @@ struct WgradConv {
     int x_s2d_c;                                       // > 0: X is a space-to-depth image with this many channels per sub-position
                                                        // (virtual kernel of a 4x4 / stride-2 conv): the zero taps are skipped
     float* dw; float* db; float scale;
+    const unsigned* unscale = nullptr;                 // device pointer to the bits of max |g_y| of a pre-scaled backward pass (common.h:
+                                                       // grad_prescale): dw / db leave times its inverse; one per launch (convs[0]'s)
 };
 
 constexpr int kWgradMaxJobs = 96;   // (X chunk, G tile) tap-products per weight-gradient launch (kernel arguments: 96 x 40 B + header < 4 KB)

@@ -81,6 +81,7 @@ struct ReduceArgs {
     int splits;
     int layer_nck;   // > 0: layer mode (WgradLayer) -- workgroup row b reduces product (b / nck, b % nck) of the convolution jobs[0] describes
     unsigned layer_part_stride;   // layer mode, RESR_F16X2 with three tap-products: floats from a product's (hi, hi) slabs to its (hi, lo) and on to its (lo, hi) slabs; else 0
+    const unsigned* unscale;      // pre-scaled backward pass (common.h: grad_prescale): results leave times the inverse factor; else nullptr
 };
 
 static_assert(sizeof(ReduceArgs) <= 4096, "kernel arguments");
@@ -373,6 +374,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const ReduceArgs
         s = __builtin_fmaf(s2, kLoInv, s);
     }
     s *= job.scale;
+    if (a.unscale) s *= grad_prescale(*a.unscale, true);
     if (e < 9 * 1024) {
         const int tap = e >> 10, co = job.co_base + ((e >> 5) & 31), ci = job.ci_base + (e & 31);
         if (co < job.cout && ci < job.cin_real) job.dw[((size_t)co * job.cin_real + ci) * 9 + tap] = s;
@@ -733,6 +735,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     __syncthreads();
     if (g != 0 || e >= kSlab) return;
     s = (((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) + ((red[4][lane] + red[5][lane]) + (red[6][lane] + red[7][lane]))) * job.scale;
+    if (a.unscale) s *= grad_prescale(*a.unscale, true);
     if (e < 9 * 1024) {
         const int tap = e >> 10, co = job.co_base + ((e >> 5) & 31), ci = job.ci_base + (e & 31);
         if (co < job.cout && ci < job.cin_real) job.dw[((size_t)co * job.cin_real + ci) * 9 + tap] = s;
@@ -1055,6 +1058,7 @@ static int wgrad_layer_launch(const WgradConv& c, int n, int h, int w, int flags
     j.dw = c.dw; j.db = c.db; j.slab_off = 0; j.slab_b = j.slab_c = ~0u; j.co_base = j.ci_base = 0;
     j.cout = c.cout; j.cin_real = c.cin_real; j.scale = c.scale; j.want_bias = 0; j.pad_ = 0;
     r.partial = partial; r.splits = splits; r.layer_nck = nck; r.layer_part_stride = nparts > 1 ? L.part_slabs : 0u;
+    r.unscale = c.unscale;
     if (splits <= 8) hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(nck * nct, (kSlab + 255) / 256), dim3(256), 0, stream, r);
     else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nck * nct, (kSlab + 31) / 32), dim3(256), 0, stream, r);
     RESR_CHECK_LAUNCH("wgrad_reduce_kernel (layer mode)");
@@ -1130,6 +1134,9 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
             }
     }
     a.partial = partial; r.partial = partial; r.splits = splits;
+    r.unscale = convs[0].unscale;
+    for (int i = 1; i < nconv; ++i)
+        if (convs[i].unscale != convs[0].unscale) return fail(RESR_ERR_ARG, "wgrad: one pre-scale per launch");
     {   // 32-bit lane offsets are enough when every operand stays below 2^24 pixels and 4 GB
         const size_t px = (size_t)n * h * w;
         size_t smax = 0;

@@ -355,6 +355,40 @@ def test_content_loss_gradient_vs_oracle_autograd(precision, tol, aliasing):
     assert not any(t.requires_grad for t in cl(sr.cuda().requires_grad_(True), hr.cuda()))
 
 
+def test_exact16_backward_does_not_depend_on_the_loss_scale(monkeypatch):
+    """The discriminator's native exact16 backward lifts a small incoming gradient by a power of two and unscales its results, like
+    the generator's (csrc/disc_native.hip, common.h grad_prescale): under the BCE mean loss of the GAN step (g_y = (sigmoid - label)
+    x scale / numel) weight gradients -- spectral-norm backward included -- and the input gradient at loss scales 1 and 2^16 are the
+    same numbers times the scale bit for bit; without the lift the tiny-scale pass differs."""
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(6)
+    d = R.Discriminator(precision="exact16").cuda().train()
+    x = torch.rand(2, 3, 64, 64, device="cuda")
+
+    def run(scale):
+        d.zero_grad(set_to_none=True)
+        xt = x.clone().requires_grad_(True)
+        torch.manual_seed(1)      # (the power iteration draws nothing, but keep every call on the same footing)
+        out = d(xt)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(out, torch.ones_like(out)) * scale
+        loss.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in d.named_parameters() if p.grad is not None}, xt.grad.detach().clone()
+    sd = {k: v.clone() for k, v in d.state_dict().items()}
+    g1, x1 = run(1.0)
+    d.load_state_dict(sd)         # the same u vectors for the second call
+    g2, x2 = run(65536.0)
+    assert len(g1) > 10
+    assert all(torch.equal(g2[k], g1[k] * 65536.0) for k in g1)
+    assert torch.equal(x2, x1 * 65536.0)
+    monkeypatch.setenv("RESR_X2_NO_GRAD_PRESCALE", "1")
+    d.load_state_dict(sd)
+    g3, _ = run(1.0)
+    monkeypatch.delenv("RESR_X2_NO_GRAD_PRESCALE")
+    worst = max(((g3[k] - g1[k]).norm() / g1[k].norm().clamp_min(1e-30)).item() for k in g1)
+    assert 0 < worst < 5e-2, worst      # pairs degrade gently (the lo halves carry 2^12 more range): visible, not catastrophic
+
+
 def test_unknown_precision_raises():
     """An unsupported precision is an error, never a silent downgrade (round 2's exact16 -> fast)."""
     import real_esrgan_pytorch_amd as R

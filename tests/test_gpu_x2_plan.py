@@ -293,6 +293,79 @@ def test_plan_bits_are_honoured_and_ignored_outside_exact16():
     assert ((w7 - outs[0][3]).norm() / outs[0][3].norm()).item() < 1e-3
 
 
+def _l1_grads(g, plan, x, target, scale, poison=None):
+    g.x2_plan = plan
+    g.zero_grad(set_to_none=True)
+    xt = x.clone().requires_grad_(True)
+    y = g(xt)
+    loss = (y - target).abs().mean() * scale
+    if poison is None:
+        loss.backward()
+    else:
+        gy = torch.autograd.grad(loss, y)[0]
+        gy.view(-1)[poison[0]] = poison[1]
+        y.backward(gy)
+    torch.cuda.synchronize()
+    return {n: p.grad.detach().clone() for n, p in g.named_parameters()}, xt.grad.detach().clone()
+
+
+def test_exact16_backward_does_not_depend_on_the_loss_scale(diag_dir, monkeypatch):
+    """exact16 runs its backward pass on g_y * 2^k (max |.| in [1, 2)) and unscales every result (generator.hip, common.h
+    grad_prescale): under the train step's L1 mean loss (g_y = scale / numel per element: 4e-6 here at scale 1, 2e-8 at the headline
+    geometry) the gradients at loss scales 1, 2^10 and 2^20 are the same numbers times the scale, BIT FOR BIT, and the default plan
+    (growth-plane gradients read as their f16 hi halves) stays at its usual distance from the all-pairs plan.  Without the
+    pre-scale those hi halves are f16 subnormals at small scales: the same comparison is off by percents
+    (tools/x2_plan_validate.py: 0.82 at 16 x 256^2 and loss scale 2^10, 3.3e-3 at a GradScaler's initial 2^16)."""
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(4)
+    g = R.Generator(3, 3, 4, precision="exact16", n_blocks=23).cuda().train()
+    with torch.no_grad():
+        g.conv4.bias.add_(0.5)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    n, s = 4, 32
+    x = torch.rand(n, 3, s, s, device="cuda", generator=gen)
+    target = torch.rand(n, 3, 4 * s, 4 * s, device="cuda", generator=gen)
+    base, gx_base = _l1_grads(g, 3, x, target, 1.0)
+    for scale in (2.0 ** 10, 2.0 ** 20):
+        gr, gx = _l1_grads(g, 3, x, target, scale)
+        assert all(torch.equal(gr[k], base[k] * scale) for k in base), f"loss scale {scale}"
+        assert torch.equal(gx, gx_base * scale)
+    ref, gx_ref = _l1_grads(g, 0, x, target, 1.0)
+
+    def worst(a, b):
+        return max(((a[k].double() - b[k].double()).norm() / b[k].double().norm().clamp_min(1e-300)).item() for k in b)
+    rep = {"plan3_vs_plan0_loss_scale_1": worst(base, ref), "gx": ((gx_base - gx_ref).norm() / gx_ref.norm()).item()}
+    monkeypatch.setenv("RESR_X2_NO_GRAD_PRESCALE", "1")
+    raw, _ = _l1_grads(g, 3, x, target, 1.0)
+    raw0, _ = _l1_grads(g, 0, x, target, 1.0)
+    monkeypatch.delenv("RESR_X2_NO_GRAD_PRESCALE")
+    rep["without_prescale_plan3_vs_plan0"] = worst(raw, raw0)
+    rep["without_prescale_plan0_vs_prescaled_plan0"] = worst(raw0, ref)
+    with open(os.path.join(diag_dir, "x2_prescale.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    assert rep["plan3_vs_plan0_loss_scale_1"] < 2e-4 and rep["gx"] < 1e-5, rep
+    assert rep["without_prescale_plan3_vs_plan0"] > 1e-2, ("the case does not exercise f16 subnormals", rep)
+
+
+def test_exact16_backward_keeps_a_non_finite_gradient_visible():
+    """The pre-scale takes its factor from the bits of max |g_y|: an inf or NaN element wins the maximum, the factor falls back to 1
+    and the non-finite value reaches the weight gradients -- a GradScaler's inf check still skips the step."""
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(4)
+    g = R.Generator(3, 3, 4, precision="exact16", n_blocks=2).cuda().train()
+    with torch.no_grad():
+        g.conv4.bias.add_(0.5)      # keep the outputs inside the clamp: its backward mask would drop the poisoned element otherwise
+    x = torch.rand(2, 3, 24, 24, device="cuda")
+    target = torch.rand(2, 3, 96, 96, device="cuda")
+    clean, _ = _l1_grads(g, 3, x, target, 1024.0)
+    assert all(torch.isfinite(v).all() for v in clean.values())
+    for bad in (float("inf"), float("nan")):
+        gr, _ = _l1_grads(g, 3, x, target, 1024.0, poison=(5000, bad))
+        assert not torch.isfinite(gr["conv4.weight"]).all(), bad
+    again, _ = _l1_grads(g, 3, x, target, 1024.0)
+    assert all(torch.equal(again[k], clean[k]) for k in clean), "the next pass is clean again"
+
+
 @pytest.mark.parametrize("n,h,w", [(8, 24, 40), (16, 64, 64), (16, 128, 128)])
 def test_single_plane_chains_equal_separate_launches(n, h, w):
     """Chained dense-block launches with two-stage chunks (the dependent chunk of a job is its last TWO stages): inference forward

@@ -20,13 +20,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import real_esrgan_pytorch_amd as R  # noqa: E402
 
 
-def grads(g, plan, x, loss_of):
+def grads(g, plan, x, loss_of, scale=1024.0):
     g.x2_plan = plan
     g.zero_grad(set_to_none=True)
     y = g(x)
-    loss_of(y).mul(1024.0).backward()
+    loss_of(y).mul(scale).backward()
     torch.cuda.synchronize()
-    return y.detach().clone(), {n: p.grad.detach().double().cpu() / 1024.0 for n, p in g.named_parameters()}
+    return y.detach().clone(), {n: p.grad.detach().double().cpu() / scale for n, p in g.named_parameters()}
 
 
 def main():
@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--out", default="gpurun_out/x2_plan_validate.json")
     ap.add_argument("--cases", default="16x256,2x256,32x64,1x128,1x24")
     ap.add_argument("--seeds", default="5,6,7")
+    ap.add_argument("--l1-scales", default="1024", help="loss scales of the L1 runs (a GradScaler starts at 65536 and doubles every 2000 clean steps)")
+    ap.add_argument("--prescale-targets", default="", help="e.g. 0,3,6,9,12: the dense-cotangent runs at amplitude 2^-20 (always lifted) "
+                                                            "under each $RESR_X2_GRAD_PRESCALE_LOG2 -- how high must the lift go")
     a = ap.parse_args()
     torch.manual_seed(0)
     g = R.Generator(3, 3, 4, precision="exact16").cuda().train()
@@ -49,11 +52,18 @@ def main():
             x = (0.9 * x + 0.1 * torch.rand(n, 3, s, s, device="cuda", generator=gen)).clamp(0, 1)
             target = torch.rand(n, 3, 4 * s, 4 * s, device="cuda", generator=gen)
             gw = torch.randn(n, 3, 4 * s, 4 * s, device="cuda", generator=gen) / (4 * s)
-            for lname, loss_of in (("l1", lambda y: (y - target).abs().mean()), ("dense", lambda y: (y * gw).sum())):
-                y0, g0 = grads(g, 0, x, loss_of)
+            runs = [(f"l1_x{int(sc)}", lambda y: (y - target).abs().mean(), sc) for sc in (float(v) for v in a.l1_scales.split(","))]
+            runs.append(("dense", lambda y: (y * gw).sum(), 1024.0))
+            for t in (int(v) for v in a.prescale_targets.split(",") if v):
+                runs.append((f"dense_tiny_target{t}", lambda y: (y * gw).sum(), 2.0 ** -20))
+            for lname, loss_of, sc in runs:
+                os.environ.pop("RESR_X2_GRAD_PRESCALE_LOG2", None)
+                if "_target" in lname:
+                    os.environ["RESR_X2_GRAD_PRESCALE_LOG2"] = lname.split("_target")[1]
+                y0, g0 = grads(g, 0, x, loss_of, sc)
                 row = {}
                 for plan in (3, 7):
-                    yp, gp = grads(g, plan, x, loss_of)
+                    yp, gp = grads(g, plan, x, loss_of, sc)
                     rel = {k: ((gp[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)).item() for k in g0}
                     worst = max(rel, key=rel.get)
                     vals = sorted(rel.values())
@@ -64,10 +74,12 @@ def main():
                 rep[f"{case}_s{seed}_{lname}"] = row
                 print(case, seed, lname, json.dumps(row), flush=True)
     summary = {}
+    lnames = sorted({k.split("_", 2)[2] for k in rep})
     for plan in ("plan3", "plan7"):
         for case in a.cases.split(","):
-            rows = [v[plan] for k, v in rep.items() if k.startswith(case + "_")]
-            summary[f"{plan}_{case}"] = {"worst_rel_l2": max(r["worst_rel_l2"] for r in rows), "weights_worst": max(r["weights_worst"] for r in rows),
+          for ln in lnames:
+            rows = [v[plan] for k, v in rep.items() if k.startswith(case + "_") and k.endswith("_" + ln)]
+            summary[f"{plan}_{case}_{ln}"] = {"worst_rel_l2": max(r["worst_rel_l2"] for r in rows), "weights_worst": max(r["weights_worst"] for r in rows),
                                          "bias_worst": max(r["bias_worst"] for r in rows), "median_max": max(r["median_rel_l2"] for r in rows), "runs": len(rows)}
     rep["summary"] = summary
     print(json.dumps(summary, indent=1))
