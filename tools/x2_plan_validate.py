@@ -20,8 +20,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import real_esrgan_pytorch_amd as R  # noqa: E402
 
 
-def grads(g, plan, x, loss_of, scale=1024.0):
+def grads(g, plan, x, loss_of, scale=1024.0, products=None):
     g.x2_plan = plan
+    os.environ.pop("RESR_X2_WGRAD_PRODUCTS", None)
+    if products:
+        os.environ["RESR_X2_WGRAD_PRODUCTS"] = str(products)
     g.zero_grad(set_to_none=True)
     y = g(x)
     loss_of(y).mul(scale).backward()
@@ -37,6 +40,7 @@ def main():
     ap.add_argument("--l1-scales", default="1024", help="loss scales of the L1 runs (a GradScaler starts at 65536 and doubles every 2000 clean steps)")
     ap.add_argument("--prescale-targets", default="", help="e.g. 0,3,6,9,12: the dense-cotangent runs at amplitude 2^-20 (always lifted) "
                                                             "under each $RESR_X2_GRAD_PRESCALE_LOG2 -- how high must the lift go")
+    ap.add_argument("--hi-only", action="store_true", help="also the opt-in hi-only weight gradients (RESR_X2_WGRAD_PRODUCTS=1) on top of plan 3")
     a = ap.parse_args()
     torch.manual_seed(0)
     g = R.Generator(3, 3, 4, precision="exact16").cuda().train()
@@ -62,8 +66,13 @@ def main():
                     os.environ["RESR_X2_GRAD_PRESCALE_LOG2"] = lname.split("_target")[1]
                 y0, g0 = grads(g, 0, x, loss_of, sc)
                 row = {}
-                for plan in (3, 7):
-                    yp, gp = grads(g, plan, x, loss_of, sc)
+                for plan in (3, 7, "3_hi_only_wgrad"):
+                    if plan == "3_hi_only_wgrad":
+                        if not a.hi_only:
+                            continue
+                        yp, gp = grads(g, 3, x, loss_of, sc, products=1)
+                    else:
+                        yp, gp = grads(g, plan, x, loss_of, sc)
                     rel = {k: ((gp[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)).item() for k in g0}
                     worst = max(rel, key=rel.get)
                     vals = sorted(rel.values())
@@ -75,7 +84,7 @@ def main():
                 print(case, seed, lname, json.dumps(row), flush=True)
     summary = {}
     lnames = sorted({k.split("_", 2)[2] for k in rep})
-    for plan in ("plan3", "plan7"):
+    for plan in ("plan3", "plan7") + (("plan3_hi_only_wgrad",) if a.hi_only else ()):
         for case in a.cases.split(","):
           for ln in lnames:
             rows = [v[plan] for k, v in rep.items() if k.startswith(case + "_") and k.endswith("_" + ln)]
