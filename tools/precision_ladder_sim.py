@@ -12,6 +12,7 @@ so that only rungs that can pass are built as kernels.  Test infrastructure only
     python tools/precision_ladder_sim.py [--blocks 23] [--size 24] [--seeds 11,12,13] [--batch 1] [--wscale 1] [--set round5]
 """
 import argparse
+import math
 import itertools
 import json
 import os
@@ -202,7 +203,7 @@ RUNGS5 = {
 }
 
 
-def run(seed, n_blocks, size, upscale=4, only=None, batch=1, wscale=1.0, rungs=None):
+def run(seed, n_blocks, size, upscale=4, only=None, batch=1, wscale=1.0, rungs=None, loss="dense"):
     sd = M.init_generator_state(seed, 3, 3, upscale, bias_noise=0.02)
     sd = {k: v for k, v in sd.items() if not k.startswith("trunk.") or int(k.split(".")[1]) < n_blocks}
     sd["conv4.bias"] = sd["conv4.bias"] + 0.5
@@ -212,19 +213,23 @@ def run(seed, n_blocks, size, upscale=4, only=None, batch=1, wscale=1.0, rungs=N
     x = torch.rand(batch, 3, size, size, generator=gen).double()
     gw = torch.randn(batch, 3, size * upscale, size * upscale, generator=gen).double()
     exact = mk("pair", "pair", "pair", "split", "pair")
+    # loss = "l1": the train step's own loss, mean |y - target| (its gradient has ONE magnitude, 1 / numel, and pulls coherently); the
+    # rungs then run at the loss scale the product's power-of-two lift would put them at (max |g_y| in [2^6, 2^7): generator.hip)
+    target = torch.rand(batch, 3, size * upscale, size * upscale, generator=gen).double()
+    rung_scale = 1024.0 if loss == "dense" else 2.0 ** math.ceil(math.log2(64.0 * gw.numel()))
 
     def one(cfg, scale):
         p = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
         xi = x.clone().requires_grad_(True)
         y = generator(xi, p, cfg, upscale, n_blocks)
-        (y * gw).sum().mul(scale).backward()
+        ((y * gw).sum() if loss == "dense" else (y - target).abs().mean()).mul(scale).backward()
         return y.detach(), {k: v.grad / scale for k, v in p.items()}, xi.grad / scale
     y0, g0, gx0 = one(exact, 1.0)
     rows = {}
     for name, cfg in (rungs or RUNGS).items():
         if only and not any(o in name for o in only):
             continue
-        y, g, gx = one(cfg, 1024.0)
+        y, g, gx = one(cfg, rung_scale)
         rel = {k: ((g[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)).item() for k in g0}
         worst_k = max(rel, key=rel.get)
         vals = sorted(rel.values())
@@ -247,12 +252,13 @@ if __name__ == "__main__":
     ap.add_argument("--wscale", type=float, default=1.0, help="dense-block weights times this (off the init scale)")
     ap.add_argument("--set", type=str, default="ladder", choices=["ladder", "round5"])
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--loss", type=str, default="dense", choices=["dense", "l1"], help="dense: a random cotangent (the worst case); l1: the train step's mean |y - target|")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     allrows = {}
     for seed in [int(s) for s in a.seeds.split(",")]:
         rows = run(seed, a.blocks, a.size, only=[o for o in a.only.split(",") if o], batch=a.batch, wscale=a.wscale,
-                   rungs=RUNGS5 if a.set == "round5" else RUNGS)
+                   rungs=RUNGS5 if a.set == "round5" else RUNGS, loss=a.loss)
         allrows[seed] = rows
         print(f"== seed {seed}, {a.blocks} blocks, {a.batch} x {a.size}^2 LR, dense weights x {a.wscale}", flush=True)
         for name, r in rows.items():
