@@ -56,7 +56,9 @@ enum {
     RESR_CONV_UPSAMPLE_IN = 1 << 1,  /* input is nearest-upsampled x2 on load (model.py:264-265)            */
     RESR_CONV_CLAMP01 = 1 << 2,      /* v = min(max(v,0),1)                   (model.py:270)                */
     RESR_CONV_OUT_NCHW_F32 = 1 << 3, /* write planar fp32 [N,cout,H,W] (+ pass-mask bytes to aux)           */
-    RESR_CONV_MASK = 1 << 4,         /* v *= (mask[p,c] > 0 ? 1 : slope): LeakyReLU backward                */
+    RESR_CONV_MASK = 1 << 4,         /* v *= (mask[p,c] > 0 ? 1 : slope): LeakyReLU backward.  RESR_F16X2: the mask is a saved
+                                      * activation of out's shape, i.e. a (hi, lo) pair with out_lo_offset; hi decides, the lo half
+                                      * only where hi rounded to zero (|value| < 2^-25)                        */
     RESR_CONV_NO_BIAS = 1 << 5,
     RESR_CONV_AUX_BEFORE_MASK = 1 << 6, /* aux_out (NHWC, out_stride) also receives v after bias, before the mask     */
     RESR_CONV_AUX_BEFORE_RES = 1 << 7,  /* aux_out (NHWC, out_stride) also receives v after LeakyReLU, before residuals */

@@ -52,6 +52,12 @@ __host__ __device__ __forceinline__ float grad_prescale(unsigned amax_bits, bool
     return __builtin_bit_cast(float, f);
 }
 
+// RESR_F16X2: "is this saved activation positive" for a LeakyReLU-backward mask read from a (hi, lo) pair.  hi decides unless it
+// rounded to zero (|v| < 2^-25, below f16's subnormals); then the lo tensor (v * 2^12) carries the sign.
+__device__ __forceinline__ bool pair_positive(half_t hi, half_t lo) {
+    return (float)hi > 0.f || ((float)hi == 0.f && (float)lo > 0.f);
+}
+
 // MI355X: blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8).  Give every XCD a
 // contiguous range of tiles so neighbouring tiles (shared halo rows, same weights) meet in one L2.
 // Bijective for any grid size.

@@ -1230,13 +1230,13 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             int h, w_, cout, out_stride, res0_stride, res1_stride, mask_stride, flags;
             int out_chunk, res0_chunk, res1_chunk, mask_chunk;
             float s0, t0, s1, t1, slope;
-            long out_lo, res0_lo, res1_lo;
+            long out_lo, res0_lo, res1_lo, mask_lo;
         } e;
         e.res0 = ep->res0; e.res1 = ep->res1; e.mask = ep->mask; e.out = ep->out; e.aux = ep->aux;
         e.h = ep->h; e.w_ = ep->w_; e.cout = ep->cout; e.out_stride = ep->out_stride;
         e.res0_stride = ep->res0_stride; e.res1_stride = ep->res1_stride; e.mask_stride = ep->mask_stride;
         e.out_chunk = ep->out_chunk; e.res0_chunk = ep->res0_chunk; e.res1_chunk = ep->res1_chunk; e.mask_chunk = ep->mask_chunk;
-        if constexpr (X2) { e.out_lo = ep->out_lo; e.res0_lo = ep->res0_lo; e.res1_lo = ep->res1_lo; }
+        if constexpr (X2) { e.out_lo = ep->out_lo; e.res0_lo = ep->res0_lo; e.res1_lo = ep->res1_lo; e.mask_lo = ep->mask_lo; }
         e.flags = ep->flags; e.s0 = ep->s0; e.t0 = ep->t0; e.s1 = ep->s1; e.t1 = ep->t1; e.slope = ep->slope;
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
@@ -1366,8 +1366,21 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] *= ((byte >> r) & 1u) ? 1.f : e.slope;
                     } else if (f_mask) {
+                        half8 mk = rmask[b][m % MA][j];
+                        if constexpr (X2) {
+                            // the mask is a saved activation (a pair): a hi value that rounded to zero (|v| < 2^-25) defers to the lo tensor,
+                            // which is read only then (common.h pair_positive)
+                            bool anyz = false;
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] *= ((float)rmask[b][m % MA][j][r] > 0.f ? 1.f : e.slope);
+                            for (int r = 0; r < 8; ++r) anyz = anyz || (float)mk[r] == 0.f;
+                            if (anyz && e.mask_lo != 0) {
+                                const half8 ml = *reinterpret_cast<const half8*>(e.mask + (p * e.mask_stride + poff(m, j, e.mask_chunk) + e.mask_lo) * 2);
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) mk[r] = (float)mk[r] == 0.f ? ml[r] : mk[r];
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] *= ((float)mk[r] > 0.f ? 1.f : e.slope);
                     }
                     if (f_lrelu) {
 #pragma unroll

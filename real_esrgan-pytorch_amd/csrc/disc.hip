@@ -48,6 +48,29 @@ __device__ __forceinline__ void st_vals(T* p, long lo, const float* v) {
     }
 }
 
+// LeakyReLU-backward multipliers from a saved activation `pm` (8 / 4 values at `at`); RESR_F16X2 (lo != 0): a hi value that rounded to
+// zero defers to the lo tensor, read only then (common.h pair_positive)
+template <typename T>
+__device__ __forceinline__ void mask_mult(const T* at, long lo, float slope, float* v) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const uint4 rm = *reinterpret_cast<const uint4*>(at);
+    const T* pm = reinterpret_cast<const T*>(&rm);
+    bool pos[E];
+    bool anyz = false;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { pos[e] = (float)pm[e] > 0.f; anyz = anyz || (float)pm[e] == 0.f; }
+    if constexpr (sizeof(T) == 2) {
+        if (lo && anyz) {
+            const uint4 rl = *reinterpret_cast<const uint4*>(at + lo);
+            const T* pl = reinterpret_cast<const T*>(&rl);
+#pragma unroll
+            for (int e = 0; e < E; ++e) pos[e] = pair_positive(pm[e], pl[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] *= pos[e] ? 1.f : slope;
+}
+
 // dst[Y][X][(i*2+j)*C + c] = src[2Y+i][2X+j][c]   (inverse: the other way round).  A pure permutation: RESR_F16X2 callers run it
 // over hi and lo at once as a batch of 2n (the lo tensor directly follows the hi tensor in both operands).
 template <typename T>
@@ -68,7 +91,7 @@ __global__ __launch_bounds__(256) void s2d_kernel(const T* __restrict__ src, T* 
 // depth-to-space fused with the skip-gradient merge and the LeakyReLU backward that follow it in the discriminator's backward
 // pass: out[full] = (src[packed] + add[full]) * (mask[full] > 0 ? 1 : slope)   (add, mask optional) -- the same roundings as
 // s2d(inverse) followed by add_mask, one pass instead of two.  lo_* : RESR_F16X2 hi -> lo offsets of src / add / out (the mask is
-// an activation: its sign is its hi tensor's).
+// an activation of out's shape: its sign is its hi tensor's, or its lo tensor's where hi rounded to zero).
 template <typename T>
 __global__ __launch_bounds__(256) void d2s_add_mask_kernel(const T* __restrict__ src, const T* __restrict__ add, const T* __restrict__ mask,
                                                            T* __restrict__ out, int n, int h, int w, int c, float slope, long lo_src,
@@ -89,14 +112,11 @@ __global__ __launch_bounds__(256) void d2s_add_mask_kernel(const T* __restrict__
         for (int e = 0; e < E; ++e) v[e] += va[e];
     }
     if (mask) {
-        const uint4 rm = *reinterpret_cast<const uint4*>(mask + full);
-        const T* pm = reinterpret_cast<const T*>(&rm);
         if (lo_out == 0) {   // plain tensors: the sum is rounded to T before the mask multiplies it (two passes' roundings)
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = (float)(T)v[e];
         }
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] *= ((float)pm[e] > 0.f ? 1.f : slope);
+        mask_mult(mask + full, lo_out, slope, v);   // the mask has out's shape, hence its hi -> lo offset
     }
     st_vals(out + full, lo_out, v);
 }
@@ -281,11 +301,10 @@ __global__ __launch_bounds__(256) void bilinear_up_bwd_kernel(const T* __restric
     const size_t po = (((size_t)b * h + y) * w + x) * c + gi * E;
     st_vals(gin + po, lo_gin, acc);
     if (gmasked) {
-        const uint4 rm = *reinterpret_cast<const uint4*>(mask + po);
-        const T* pm = reinterpret_cast<const T*>(&rm);
         float m[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) m[e] = (lo_gin ? acc[e] : (float)(T)acc[e]) * ((float)pm[e] > 0.f ? 1.f : slope);
+        for (int e = 0; e < E; ++e) m[e] = lo_gin ? acc[e] : (float)(T)acc[e];
+        mask_mult(mask + po, lo_gin, slope, m);
         st_vals(gmasked + po, lo_gin, m);   // the same shape as gin: the same hi -> lo offset
     }
 }
@@ -340,12 +359,7 @@ __global__ __launch_bounds__(256) void add_mask_kernel(const T* __restrict__ a, 
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] += vb[e];
     }
-    if (mask) {
-        const uint4 rm = *reinterpret_cast<const uint4*>(mask + i);
-        const T* pm = reinterpret_cast<const T*>(&rm);
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] *= ((float)pm[e] > 0.f ? 1.f : slope);
-    }
+    if (mask) mask_mult(mask + i, lo, slope, v);
     st_vals(out + i, lo, v);
 }
 

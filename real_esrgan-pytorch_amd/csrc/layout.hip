@@ -160,11 +160,23 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ s
                 for (int e = 0; e < E; ++e) acc[e] = __builtin_fmaf((float)vl[e], kLoInv, acc[e]);
             }
         }
-    if (mask) {
+    if (mask) {   // a saved activation of dst's shape (RESR_F16X2: a pair with dst's hi -> lo offset; common.h pair_positive)
         const uint4 raw = *reinterpret_cast<const uint4*>(mask + p * c + g * E);
         const T* v = reinterpret_cast<const T*>(&raw);
+        bool pos[E];
+        bool anyz = false;
 #pragma unroll
-        for (int e = 0; e < E; ++e) acc[e] *= ((float)v[e] > 0.f ? 1.f : slope);
+        for (int e = 0; e < E; ++e) { pos[e] = (float)v[e] > 0.f; anyz = anyz || (float)v[e] == 0.f; }
+        if constexpr (sizeof(T) == 2) {
+            if (dst_lo && anyz) {
+                const uint4 rawl = *reinterpret_cast<const uint4*>(mask + dst_lo + p * c + g * E);
+                const T* vl = reinterpret_cast<const T*>(&rawl);
+#pragma unroll
+                for (int e = 0; e < E; ++e) pos[e] = pair_positive(v[e], vl[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] *= pos[e] ? 1.f : slope;
     }
     uint4 outv, outl;
     T* o = reinterpret_cast<T*>(&outv);

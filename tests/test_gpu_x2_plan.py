@@ -91,6 +91,43 @@ def test_conv_reads_single_chunks_and_writes_single_output(U, name, cin, cout, n
     assert (err <= bound).all(), (name, err.max().item(), (err / bound).max().item())
 
 
+def test_conv_mask_from_a_saved_activation_whose_hi_half_is_zero(U):
+    """RESR_CONV_MASK without _BITS on RESR_F16X2 (the discriminator's backward-data passes): the mask is a saved activation, a
+    (hi, lo) pair of out's shape.  Values below 2^-25 round their hi half to zero; their sign is then the lo half's (common.h
+    pair_positive) -- a third of the mask elements here are +-1e-9.  Against float64."""
+    L = U.L
+    g = torch.Generator().manual_seed(3)
+    n, cin, cout, h, w = 2, 64, 64, 20, 36
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    act = torch.randn(n, cout, h, w, generator=g)
+    tiny = torch.rand(n, cout, h, w, generator=g) < 0.33
+    act = torch.where(tiny, act.sign() * 1e-9, act)
+    xb, xv, _ = _pair_planar(x)
+    mb, mv, mhi = _pair_planar(act)
+    assert (mhi[tiny] == 0).all() and (mb[1].cpu().float() != 0).any()
+    plane = n * h * w * 32
+    out = torch.full((2, cout // 32, n, h, w, 32), -7.0, dtype=torch.float16, device="cuda")
+    d = L.ConvDesc(n, h, w, cin, cin, 32, 0, cout, cout, 32, 0, 0, 32, L.RESR_F16X2, L.CONV_MASK | L.CONV_NO_BIAS, 1.0, 1.0, 1.0, 1.0, 0.2)
+    d.in0_chunk_stride = plane
+    d.out_chunk_stride = plane
+    d.mask_chunk_stride = plane
+    d.in0_lo_offset = (cin // 32) * plane
+    d.out_lo_offset = (cout // 32) * plane
+    packed = U.pack_conv(wt, L.RESR_F16X2)
+    L.check(L.lib().resr_conv3x3(C.byref(d), L.ptr(xb), None, L.ptr(packed), None, None, None, L.ptr(mb), L.ptr(out), None,
+                                 L.stream_ptr()), "resr_conv3x3")
+    torch.cuda.synchronize()
+
+    def unplanar(t):
+        return t.double().cpu().permute(1, 0, 4, 2, 3).reshape(n, cout, h, w)
+    got = unplanar(out[0]) + unplanar(out[1]) / 4096.0
+    ref = F.conv2d(xv, wt.double(), None, padding=1) * torch.where(act.double() > 0, 1.0, 0.2)
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-6
+    wrong = F.conv2d(xv, wt.double(), None, padding=1) * torch.where(mhi > 0, 1.0, 0.2)      # what the hi halves alone would give
+    assert ((wrong - ref).abs().max() / ref.abs().max()).item() > 0.1
+
+
 @pytest.mark.parametrize("cin,cout,n,h,w,splits", [(96, 32, 2, 40, 36, 4), (64, 64, 1, 24, 64, 2)])
 def test_wgrad_single_g_equals_pair_g_with_zero_lo(U, cin, cout, n, h, w, splits):
     """g_lo_offset = 0: G is a single f16 tensor -- the (x_hi, g_lo) tap-product is not issued.  Same bits as the three-product

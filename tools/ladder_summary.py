@@ -16,6 +16,10 @@ for path in sorted(glob.glob(os.path.join(src, "r5_*x*_w*.json")) + glob.glob(os
     tag = base[5:-5] if base.startswith("r5t2_") else base[3:-5]      # r5t2_*: the TRAIN2 rung, run separately, merged into its geometry
     for seed, rows in json.load(open(path)).items():
         out.setdefault(tag, {}).setdefault(seed, {}).update(rows)
+for path in sorted(glob.glob(os.path.join(src, "r5l1_*x*_w*.json"))):   # --loss l1: the train step's own loss, kept as separate geometries
+    tag = os.path.basename(path)[5:-5] + "_l1loss"
+    for seed, rows in json.load(open(path)).items():
+        out.setdefault(tag, {}).setdefault(seed, {}).update({name + " [L1 loss]": r for name, r in rows.items()})
 json.dump({"tool": "tools/precision_ladder_sim.py --set round5 (23 blocks, float64 emulation of the storage roundings)", "runs": out}, open(dst, "w"), indent=1)
 rungs = {}
 for tag, seeds in out.items():
