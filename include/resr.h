@@ -28,8 +28,8 @@
 extern "C" {
 #endif
 
-/* 2: ResrWgradDesc gained x_chunk_stride / g_chunk_stride (round 4), ResrConvDesc.reserved_ became x2_pair_chunks, ResrGeneratorDesc
- * gained x2_plan.  A caller built against an older header passes shorter structs: compare resr_version() with the RESR_VERSION it was
+/* 2: ResrWgradDesc gained x_chunk_stride / g_chunk_stride (round 4), ResrConvDesc.reserved_ became x2_pair_chunks and the struct gained mask_lo_offset,
+ * ResrGeneratorDesc gained x2_plan.  A caller built against an older header passes shorter structs: compare resr_version() with the RESR_VERSION it was
  * compiled with and refuse on a mismatch.  New fields are appended (or replace reserved ones) and mean "as before" when zero, so
  * zero-initialise every descriptor (memset / = {0}) before filling it. */
 #define RESR_VERSION 2
@@ -56,9 +56,7 @@ enum {
     RESR_CONV_UPSAMPLE_IN = 1 << 1,  /* input is nearest-upsampled x2 on load (model.py:264-265)            */
     RESR_CONV_CLAMP01 = 1 << 2,      /* v = min(max(v,0),1)                   (model.py:270)                */
     RESR_CONV_OUT_NCHW_F32 = 1 << 3, /* write planar fp32 [N,cout,H,W] (+ pass-mask bytes to aux)           */
-    RESR_CONV_MASK = 1 << 4,         /* v *= (mask[p,c] > 0 ? 1 : slope): LeakyReLU backward.  RESR_F16X2: the mask is a saved
-                                      * activation of out's shape, i.e. a (hi, lo) pair with out_lo_offset; hi decides, the lo half
-                                      * only where hi rounded to zero (|value| < 2^-25)                        */
+    RESR_CONV_MASK = 1 << 4,         /* v *= (mask[p,c] > 0 ? 1 : slope): LeakyReLU backward (RESR_F16X2: mask_lo_offset) */
     RESR_CONV_NO_BIAS = 1 << 5,
     RESR_CONV_AUX_BEFORE_MASK = 1 << 6, /* aux_out (NHWC, out_stride) also receives v after bias, before the mask     */
     RESR_CONV_AUX_BEFORE_RES = 1 << 7,  /* aux_out (NHWC, out_stride) also receives v after LeakyReLU, before residuals */
@@ -98,7 +96,7 @@ typedef struct {
     int32_t in0_chunk_stride, in1_chunk_stride, out_chunk_stride;
     int32_t res0_chunk_stride, res1_chunk_stride, mask_chunk_stride;
     /* RESR_F16X2 only: element offset from the hi tensor of an operand to its lo tensor (a mask given as an f16
-     * activation is read from its hi tensor alone; the aux tensor of AUX_BEFORE_* uses out's offset). */
+     * activation: mask_lo_offset below; the aux tensor of AUX_BEFORE_* uses out's offset). */
     int64_t in0_lo_offset, in1_lo_offset, out_lo_offset, res0_lo_offset, res1_lo_offset;
     /* 4x4 / stride-2 convolutions (model.py:140-152) run as 3x3 convolutions over the 2x2 space-to-depth image with the
      * "virtual" kernel of ResrPackChunk.virtual4x4; 20 of its 36 (tap, sub-position) blocks are zero.  These two hints let
@@ -118,6 +116,12 @@ typedef struct {
      * (x0 x1 / g_y) as pairs, the growth planes (o1..o4 at inference, their gradients in backward) as single f16 -- the rungs of
      * DESIGN section 2 that keep the 1e-3 gate at 50 instead of 60 stages per block. */
     int32_t x2_pair_chunks;
+    /* RESR_F16X2, RESR_CONV_MASK without _BITS: element offset from the mask's hi tensor to its lo tensor when the saved activation
+     * is a pair of out's layout.  hi decides; the lo half is read only where hi rounded to zero (|value| < 2^-25: below f16's
+     * subnormals), so that a LeakyReLU mask survives activations of any scale.  0 = the hi tensor alone (such values count as
+     * "not positive"; the mask may then be any f16 tensor, e.g. a view of a larger batch). */
+    int32_t reserved2_;
+    int64_t mask_lo_offset;
 } ResrConvDesc;
 
 int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const void* w_packed,

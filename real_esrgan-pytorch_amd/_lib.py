@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
                 ("in0_lo_offset", C.c_int64), ("in1_lo_offset", C.c_int64), ("out_lo_offset", C.c_int64),
                 ("res0_lo_offset", C.c_int64), ("res1_lo_offset", C.c_int64),
                 ("s2d_in_channels", C.c_int32), ("s2d_out_channels", C.c_int32), ("cout_groups", C.c_int32),
-                ("x2_pair_chunks", C.c_int32)]
+                ("x2_pair_chunks", C.c_int32), ("reserved2_", C.c_int32), ("mask_lo_offset", C.c_int64)]
 
 
 class WgradDesc(C.Structure):

@@ -28,8 +28,8 @@ struct ConvArgs {
     // RESR_F16X2: byte offsets hi -> lo of the two input segments, element offsets hi -> lo of out / residuals
     size_t in0_lo_b, in1_lo_b;
     long out_lo, res0_lo, res1_lo;   // out_lo = 0: the output is a single f16 tensor (RESR_CONV_OUT_SINGLE), no lo store
-    long mask_lo;                    // a mask given as a saved activation (RESR_CONV_MASK without _BITS) has out's shape: its hi -> lo offset
-                                     // is ResrConvDesc.out_lo_offset; read only where a hi value is zero (common.h pair_positive); 0 = no lo tensor
+    long mask_lo;                    // a mask given as a saved activation (RESR_CONV_MASK without _BITS): its hi -> lo offset
+                                     // (ResrConvDesc.mask_lo_offset); read only where a hi value is zero (common.h pair_positive); 0 = no lo tensor
     // RESR_F16X2: the first pair_chunks 32-channel input chunks are hi/lo pairs (three stages each), the chunks behind them single
     // f16 tensors (two stages: x W0 + x W1); >= cin / 32 = every chunk a pair (ResrConvDesc.x2_pair_chunks)
     int pair_chunks, out_single;

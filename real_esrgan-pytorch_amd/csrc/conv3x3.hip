@@ -344,7 +344,8 @@ static int conv3x3_args(const ResrConvDesc* d, const void* in0, const void* in1,
     a.s2d_c = 0; a.tap_c = 0; a.ngroups = 1; a.w_group_b = 0;
     // RESR_F16X2: leading pair chunks / a single-f16 output (kept out of a.flags: the kernels and the chain checks never see the bit)
     a.pair_chunks = d->cin / 32; a.out_single = 0;
-    a.mask_lo = (d->dtype == RESR_F16X2 && mask && (d->flags & RESR_CONV_MASK) && !(d->flags & RESR_CONV_MASK_BITS)) ? (long)d->out_lo_offset : 0L;
+    a.mask_lo = (d->dtype == RESR_F16X2 && mask && (d->flags & RESR_CONV_MASK) && !(d->flags & RESR_CONV_MASK_BITS)) ? (long)d->mask_lo_offset : 0L;
+    if (a.mask_lo < 0) return fail(RESR_ERR_ARG, "conv3x3: mask_lo_offset=%ld", a.mask_lo);
     if (d->dtype == RESR_F16X2) {
         if (d->x2_pair_chunks < 0 || d->x2_pair_chunks > d->cin / 32)
             return fail(RESR_ERR_ARG, "conv3x3: x2_pair_chunks=%d of %d chunks", d->x2_pair_chunks, d->cin / 32);

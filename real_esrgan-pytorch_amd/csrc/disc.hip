@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void add_mask_kernel(const T* __restrict__ a, 
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] += vb[e];
     }
-    if (mask) mask_mult(mask + i, lo, slope, v);
+    if (mask) mask_mult(mask + i, 0L, slope, v);   // hi tensor only: the C-ABI gives no lo offset for the mask (it may be a view of a larger batch)
     st_vals(out + i, lo, v);
 }
 

@@ -263,6 +263,7 @@ int conv_layer(const DPlan& p, const DBufs& b, int li, bool backward, const char
         c.res0_stride = res0_stride; c.mask_stride = mask_stride;
         c.cout_groups = ngroups; c.s2d_in_channels = s2d_in; c.s2d_out_channels = s2d_out;
         c.in0_lo_offset = lo_x; c.out_lo_offset = lo_out; c.res0_lo_offset = lo_res0;
+        c.mask_lo_offset = mask ? lo_out : 0;   // the mask is a saved activation of out's shape
         return conv3x3_dispatch(&c, x, nullptr, b.packed + pk0 * wes, nullptr, res0, nullptr, mask, out, aux, st);
     }
     size_t pk = pk0;
@@ -274,6 +275,7 @@ int conv_layer(const DPlan& p, const DBufs& b, int li, bool backward, const char
             c.res0_stride = res0_stride; c.mask_stride = mask_stride;
             c.s2d_in_channels = (ngroups == 1 ? s2d_in : 0);
             c.in0_lo_offset = lo_x; c.out_lo_offset = lo_out; c.res0_lo_offset = lo_res0;
+        c.mask_lo_offset = mask ? lo_out : 0;   // the mask is a saved activation of out's shape
             auto sh = [&](const char* q) { return q ? q + (size_t)g0 * es : nullptr; };
             DRUN(conv3x3_dispatch(&c, x, nullptr, b.packed + pk * wes, bias ? bias + g0 : nullptr, sh(res0), nullptr, sh(mask),
                                   nchw ? (void*)out_nchw : (void*)(out + (size_t)g0 * es), aux ? aux + (size_t)g0 * es : nullptr, st));

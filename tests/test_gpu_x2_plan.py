@@ -114,18 +114,27 @@ def test_conv_mask_from_a_saved_activation_whose_hi_half_is_zero(U):
     d.mask_chunk_stride = plane
     d.in0_lo_offset = (cin // 32) * plane
     d.out_lo_offset = (cout // 32) * plane
+    d.mask_lo_offset = (cout // 32) * plane
     packed = U.pack_conv(wt, L.RESR_F16X2)
-    L.check(L.lib().resr_conv3x3(C.byref(d), L.ptr(xb), None, L.ptr(packed), None, None, None, L.ptr(mb), L.ptr(out), None,
-                                 L.stream_ptr()), "resr_conv3x3")
-    torch.cuda.synchronize()
+
+    def run():
+        out.fill_(-7.0)
+        L.check(L.lib().resr_conv3x3(C.byref(d), L.ptr(xb), None, L.ptr(packed), None, None, None, L.ptr(mb), L.ptr(out), None,
+                                     L.stream_ptr()), "resr_conv3x3")
+        torch.cuda.synchronize()
+    run()
 
     def unplanar(t):
         return t.double().cpu().permute(1, 0, 4, 2, 3).reshape(n, cout, h, w)
     got = unplanar(out[0]) + unplanar(out[1]) / 4096.0
     ref = F.conv2d(xv, wt.double(), None, padding=1) * torch.where(act.double() > 0, 1.0, 0.2)
     assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-6
-    wrong = F.conv2d(xv, wt.double(), None, padding=1) * torch.where(mhi > 0, 1.0, 0.2)      # what the hi halves alone would give
-    assert ((wrong - ref).abs().max() / ref.abs().max()).item() > 0.1
+    hi_only = F.conv2d(xv, wt.double(), None, padding=1) * torch.where(mhi > 0, 1.0, 0.2)      # what the hi halves alone give
+    assert ((hi_only - ref).abs().max() / ref.abs().max()).item() > 0.1
+    d.mask_lo_offset = 0          # the documented default: the mask's hi tensor alone (it may then be any f16 tensor)
+    run()
+    got0 = unplanar(out[0]) + unplanar(out[1]) / 4096.0
+    assert ((got0 - hi_only).abs().max() / ref.abs().max()).item() < 2e-6
 
 
 @pytest.mark.parametrize("cin,cout,n,h,w,splits", [(96, 32, 2, 40, 36, 4), (64, 64, 1, 24, 64, 2)])

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(built):
 
 def test_struct_layouts_match_header(built):
     L = built._lib
-    assert ctypes.sizeof(L.ConvDesc) == 26 * 4 + 5 * 8 + 4 * 4   # 20 original fields + 6 chunk strides + 5 hi->lo offsets (RESR_F16X2) + sparse-tap / group fields
+    assert ctypes.sizeof(L.ConvDesc) == 26 * 4 + 5 * 8 + 4 * 4 + 4 + 4 + 8   # 20 original fields + 6 chunk strides + 5 hi->lo offsets (RESR_F16X2) + sparse-tap / group fields + x2_pair_chunks slot, padding, mask_lo_offset
     assert ctypes.sizeof(L.WgradDesc) == 16 * 4 + 4 * 8   # 15 fields + padding + 2 hi->lo offsets + 2 chunk strides
     assert ctypes.sizeof(L.PackChunk) == 64
     assert ctypes.sizeof(L.GeneratorDesc) == 12 * 4   # + x2_plan, reserved_ (ABI version 2)
