@@ -1081,6 +1081,38 @@ def parity_probe(sd, edge=24):
     return x.cpu(), ys
 
 
+def gradient_probe(sd, batch, lr_edge):
+    """What training consumes: every gradient tensor of the benchmarked f16 mode (and of exact16's default plan) against exact16's
+    all-pairs plan (5.8e-6 from float64 where the emulation reaches) -- same weights (the timed model's, after its steps), same image-like
+    batch at the benchmark's geometry, the train step's L1 mean loss at a GradScaler's initial scale.  Per-tensor relative L2."""
+    import real_esrgan_pytorch_amd as R
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    hr_edge = 4 * lr_edge
+    base = torch.rand(batch, 3, hr_edge // 16, hr_edge // 16, device="cuda", generator=gen)
+    hr = torch.nn.functional.interpolate(base, size=(hr_edge, hr_edge), mode="bicubic").clamp(0, 1)
+    hr = (0.9 * hr + 0.1 * torch.rand(batch, 3, hr_edge, hr_edge, device="cuda", generator=gen)).clamp(0, 1)
+    lr = torch.nn.functional.interpolate(hr, size=(lr_edge, lr_edge), mode="area")
+
+    def grads(precision, plan):
+        g = R.Generator(3, 3, 4, precision=precision, x2_plan=plan)
+        g.load_state_dict(sd)
+        g = g.cuda().train()
+        ((g(lr) - hr).abs().mean() * 65536.0).backward()
+        torch.cuda.synchronize()
+        out = {n: p.grad.detach().double() / 65536.0 for n, p in g.named_parameters()}
+        del g
+        torch.cuda.empty_cache()
+        return out
+    ref = grads("exact16", 0)
+    rec = {"loss": "mean |G(lr) - hr| x 65536 (a GradScaler's initial scale)", "geometry": f"{batch} x 3 x {lr_edge}^2 -> {hr_edge}^2, image-like tiles",
+           "reference": "exact16, all-pairs plan (x2_plan = 0), same weights and batch", "metric": "relative L2 per gradient tensor (702 tensors)"}
+    for name, (precision, plan) in {"fast_f16": ("fast", 0), "exact16_default_plan": ("exact16", None)}.items():
+        got = grads(precision, plan)
+        rel = sorted(((got[k] - ref[k]).norm() / ref[k].norm().clamp_min(1e-300)).item() for k in ref)
+        rec[name] = {"median": float(f"{rel[len(rel) // 2]:.3e}"), "p90": float(f"{rel[int(len(rel) * 0.9)]:.3e}"), "worst": float(f"{rel[-1]:.3e}")}
+    return rec
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1230,6 +1262,11 @@ def main():
             except Exception as e:  # pragma: no cover
                 probe_err = repr(e)
                 pm["probe"] = {"error": probe_err}
+            if world == 1:
+                try:
+                    pm["gradient_probe"] = gradient_probe(main_res["state_dict"], B, lr_edge)
+                except Exception as e:  # pragma: no cover
+                    pm["gradient_probe"] = {"error": repr(e)}
             out["parity_mode"] = pm
         # a fixed, kernel-independent figure of THIS box (the power-cap frontier measured before the timed steps): lets a reader tell
         # box-to-box spread (+-5 % for one build) from a regression when the records of two rounds are compared

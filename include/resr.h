@@ -264,7 +264,7 @@ int resr_generator_forward(const ResrGeneratorDesc* d, const float* x_nchw, cons
  * range of the gradient arena is final, in backward order -- [0] the tail (conv2, upsampling1/2, conv3, conv4: the END of the
  * arena), [1 + j] RRDB n_blocks-1-j, [n_blocks + 1] conv1 (everything).  A data-parallel caller makes its communication
  * stream wait on them and all-reduces each range while the rest of the backward pass still runs.
- * RESR_F16X2: the pass does not depend on the scale of gy -- when max |gy| < 2^6 it runs on gy * 2^k (max in [2^6, 2^7)) and hands
+ * RESR_F16 / RESR_F16X2: the pass does not depend on the scale of gy -- when max |gy| < 2^6 it runs on gy * 2^k (max in [2^6, 2^7)) and hands
  * grad / gx out times 2^-k, both exact, so its f16 tensors never see subnormals at small loss scales; an inf / NaN in gy turns the
  * lift off and reaches grad (resr_discriminator_backward does the same).  $RESR_X2_GRAD_PRESCALE_LOG2, RESR_X2_NO_GRAD_PRESCALE=1. */
 int resr_generator_backward(const ResrGeneratorDesc* d, const float* gy_nchw, const float* params,

@@ -412,11 +412,11 @@ int discriminator_backward(const ResrDiscriminatorDesc* d, const float* gy, cons
     const long lo_h1_128 = LO(px / 4 * 128), lo_h1_256 = LO(px / 4 * 256), lo_h2_256 = LO(px / 16 * 256), lo_h2_512 = LO(px / 16 * 512);
     const long lo_h3_512 = LO(px / 64 * 512), lo_h3_1024 = LO(px / 64 * 1024);
 
-    // exact16: a small incoming gradient is lifted into f16's normal range by a power of two and every result handed out unscaled
+    // exact16 and fast: a small incoming gradient is lifted into f16's normal range by a power of two and every result handed out unscaled
     // (generator.hip has the measurements; common.h grad_prescale).  The spectral-norm backward at the end of the pass reads the
     // raw weight gradients the reducers have already unscaled.
     const char* pre_t = getenv("RESR_X2_GRAD_PRESCALE_LOG2");
-    const unsigned* gsc = (x2 && !getenv("RESR_X2_NO_GRAD_PRESCALE")) ? b.gscale : nullptr;
+    const unsigned* gsc = (dt != RESR_F32 && !getenv("RESR_X2_NO_GRAD_PRESCALE")) ? b.gscale : nullptr;
     // weight (and bias) gradient of layer li: X = first cin_pad channels of x (pixel stride xs), G = first cout channels of g
     auto wgrad_layer = [&](int li, const char* x, int xs, const char* g, int gs, int h, int w, long lo_xw, long lo_gw) -> int {
         if (!need_w) return RESR_OK;

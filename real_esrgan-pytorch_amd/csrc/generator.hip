@@ -573,7 +573,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     // pairs: the bias gradient (a plain sum of G, which cancels where the weight products do not) takes hi + lo through the one
     // (x_hi chunk 0, g_lo) job per convolution that carries the bias sum -- with a single-f16 G the worst bias tensor of the
     // emulation reached 6.7e-4 at 1 x 128^2.
-    // exact16 lifts a small incoming gradient into f16's normal range: when max |g_y| < 2^6 the pass runs on g_y * 2^k with
+    // The 16-bit modes lift a small incoming gradient into f16's normal range: when max |g_y| < 2^6 the pass runs on g_y * 2^k with
     // max |g_y * 2^k| in [2^6, 2^7) and hands every result out times 2^-k (both exact; common.h grad_prescale).  The pass is linear in
     // g_y, and its f16 tensors -- the hi halves that the plan below reads alone most of all -- keep their 11 bits whatever loss scale
     // the caller works at.  Measured without it (tools/x2_plan_validate.py, L1 mean loss at 16 x 256^2: g_y = scale x 2e-8 per
@@ -583,7 +583,10 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     const char* no_prescale = getenv("RESR_X2_NO_GRAD_PRESCALE");   // (read per call: A/B knobs)
     const char* pre_t = getenv("RESR_X2_GRAD_PRESCALE_LOG2");
     const int pre_log2 = pre_t ? atoi(pre_t) : 6;
-    const unsigned* gsc = (x2 && !no_prescale) ? b.gscale : nullptr;
+    // fast mode (plain f16) takes the same lift: under the L1 loss at 16 x 256^2 its worst gradient tensor against exact16's all-pairs plan
+    // reads 4.3e-3 at a GradScaler's initial 2^16 and 1.4e-3 from 2^20 on (median 7.7e-4 throughout; garbage at 2^10) -- the difference is
+    // f16 underflow, not f16 arithmetic (tools/fast_loss_scale_probe.py).  strict (f32) needs none.
+    const unsigned* gsc = (d->dtype != RESR_F32 && !no_prescale) ? b.gscale : nullptr;
     const bool gg_single = x2 && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_F16);
     const bool gg_store_single = gg_single && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_STORE_F16);   // opt-in: no lo store, biases from hi alone
     const char* pk = (const char*)packed;

@@ -220,7 +220,7 @@ class Generator(nn.Module):
     pass are READ as single f16 (two stages / two tap-products on their chunks; the bias sums still take hi + lo; worst gradient
     tensor 3-5e-4 vs float64, gate 1e-3), bit 2 (opt-in, with bit 1): they are stored single as well (~4 % faster, worst bias tensor
     6.7e-4).  x2_plan=0 = pairs everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
-    exact16's backward pass does not depend on the caller's loss scale: an incoming gradient whose largest element is below 2^6 is
+    The backward pass of the 16-bit modes (exact16, fast) does not depend on the caller's loss scale: an incoming gradient whose largest element is below 2^6 is
     lifted by a power of two inside the native pass and the results are handed back unscaled (bit-identical gradients at loss scale
     1 and 2^20; csrc/generator.hip, $RESR_X2_GRAD_PRESCALE_LOG2 / RESR_X2_NO_GRAD_PRESCALE=1).
     forward(x[N,C,H,W] float in [0,1]) -> [N,out,H*s,W*s] clamped to [0,1]; differentiable.

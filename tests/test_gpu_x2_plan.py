@@ -393,6 +393,23 @@ def test_exact16_backward_does_not_depend_on_the_loss_scale(diag_dir, monkeypatc
     assert rep["without_prescale_plan3_vs_plan0"] > 1e-2, ("the case does not exercise f16 subnormals", rep)
 
 
+def test_fast_backward_does_not_depend_on_the_loss_scale_either():
+    """The lift applies to both 16-bit modes: fast mode's gradients under the L1 mean loss at loss scales 1 and 2^20 are the same
+    numbers times the scale bit for bit (without it the scale-1 pass is f16 underflow: tools/fast_loss_scale_probe.py)."""
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(4)
+    g = R.Generator(3, 3, 4, precision="fast", n_blocks=4).cuda().train()
+    with torch.no_grad():
+        g.conv4.bias.add_(0.5)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.rand(8, 3, 32, 32, device="cuda", generator=gen)
+    target = torch.rand(8, 3, 128, 128, device="cuda", generator=gen)
+    base, gx_base = _l1_grads(g, 0, x, target, 1.0)
+    gr, gx = _l1_grads(g, 0, x, target, 2.0 ** 20)
+    assert all(torch.equal(gr[k], base[k] * 2.0 ** 20) for k in base) and torch.equal(gx, gx_base * 2.0 ** 20)
+    assert all(v.abs().max() > 0 for v in base.values())
+
+
 def test_exact16_backward_keeps_a_non_finite_gradient_visible():
     """The pre-scale takes its factor from the bits of max |g_y|: an inf or NaN element wins the maximum, the factor falls back to 1
     and the non-finite value reaches the weight gradients -- a GradScaler's inf check still skips the step."""
