@@ -241,7 +241,13 @@ enum {
      * bias job: 64 instead of 68 tap-products per block, ~4 % of an exact16 step).  The bias gradients of conv1..conv4 are then
      * sums of ROUNDED values: the emulation's worst bias tensor reaches 6.7e-4 at 1 x 128^2 (inside the 1e-3 gate, outside the
      * 5e-4 rule the default plan keeps): opt-in. */
-    RESR_X2_PLAN_GROWTH_GRAD_STORE_F16 = 4
+    RESR_X2_PLAN_GROWTH_GRAD_STORE_F16 = 4,
+    /* backward: the weight products read the growth planes o1..o4 (the X chunks behind the residual stream of conv2..conv5) as their
+     * hi tensor: no (x_lo, g_hi) tap-product for them -- 14 fewer tap-products per dense block (54 instead of 68 next to
+     * GROWTH_GRAD_F16).  The forward pass and backward-data still see the pairs.  What is dropped is a zero-mean residue of the
+     * SMALL operand of conv5's products (the growth planes next to the stream): the worst gradient tensor does not move (emulation:
+     * 3.0e-4 -> 3.0e-4 at the reference's init, 3.9e-4 -> 4.0e-4 with the dense weights x 4; conv5's own tensors 7e-7 -> 2.6e-5 / 1e-4) */
+    RESR_X2_PLAN_GROWTH_ACT_F16_WGRAD = 8
 };
 
 size_t resr_generator_param_count(const ResrGeneratorDesc* d);

@@ -18,7 +18,7 @@ CONV_AUX_BEFORE_MASK, CONV_AUX_BEFORE_RES = 64, 128
 CONV_WRITE_SIGNBITS = 1 << 8
 CONV_MASK_BITS = 1 << 9
 CONV_OUT_SINGLE = 1 << 10
-X2_PLAN_GROWTH_F16_INFER, X2_PLAN_GROWTH_GRAD_F16, X2_PLAN_GROWTH_GRAD_STORE_F16 = 1, 2, 4
+X2_PLAN_GROWTH_F16_INFER, X2_PLAN_GROWTH_GRAD_F16, X2_PLAN_GROWTH_GRAD_STORE_F16, X2_PLAN_GROWTH_ACT_F16_WGRAD = 1, 2, 4, 8
 RESR_VERSION = 2   # include/resr.h: the structures below mirror THIS version of the header
 
 

@@ -43,6 +43,7 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
                            void* out5, void* chain_state, size_t chain_state_bytes, hipStream_t stream);
 size_t conv3x3_chain_state_bytes(int, int, int);
 int wgrad_batch(const WgradConv*, int, int, int, int, int, int, int, float*, hipStream_t);
+int wgrad_batch_jobs(const WgradConv*, int, int);
 int wgrad_batch_quads(const WgradConv*, int, int);
 int wgrad_tile_rows(int dtype);
 int wgrad_x2_products();
@@ -589,6 +590,8 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     const unsigned* gsc = (d->dtype != RESR_F32 && !no_prescale) ? b.gscale : nullptr;
     const bool gg_single = x2 && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_F16);
     const bool gg_store_single = gg_single && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_STORE_F16);   // opt-in: no lo store, biases from hi alone
+    // RESR_X2_PLAN_GROWTH_ACT_F16_WGRAD: the weight products of conv2..conv5 read the growth planes (X chunks 2..) as their hi tensor
+    const int wx_pairs = (x2 && (d->x2_plan & RESR_X2_PLAN_GROWTH_ACT_F16_WGRAD)) ? 2 : 0;
     const char* pk = (const char*)packed;
     const int N = d->n, h = p.h, w = p.w;
     const int H4 = 4 * h, W4 = 4 * w, H2 = 2 * h, W2 = 2 * w;
@@ -612,11 +615,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         return wc;
     };
     auto wgrad_run = [&](const WgradConv* wc, int nconv, int hh, int ww, int flags) -> int {
-        int njobs = 0;   // tap-products: wm per product, two of three where G is a single f16 tensor (g_lo_off = 0)
-        for (int i = 0; i < nconv; ++i) {
-            const int prod = (wc[i].cin / 32) * (wc[i].cout_pad / 32);
-            njobs += (x2 && wm == 3 && wc[i].g_lo_off == 0) ? prod * 2 : (x2 && wm == 3 && wc[i].g_lo_bias_only) ? prod * 2 + wc[i].cout_pad / 32 : prod * wm;
-        }
+        const int njobs = wgrad_batch_jobs(wc, nconv, d->dtype);   // tap-products: fewer than wm per product where G or an X chunk is read single
         const int splits = splits_for(p, njobs, hh, ww, x2 ? wgrad_batch_quads(wc, nconv, d->dtype) : 0);
         if (wgrad_batch_partial_bytes(wc, nconv, splits, d->dtype) > b.partial_bytes)
             return fail(RESR_ERR_WORKSPACE, "wgrad slab buffer too small");
@@ -704,6 +703,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         WgradConv* wcb = wc + (batch_rrdb ? 5 * pos : 0);
         wcb[4] = wconv(p.convs[p.i_trunk0 + r * 5 + 4], act, 192, 32, gin, 32, fold, lo_ws, lo_t);   // conv5: G = fold * gin
         wcb[4].x_chunk_stride = plane; wcb[4].g_chunk_stride = plane;
+        wcb[4].x_pair_chunks = wx_pairs;
         ResrConvDesc cds[4];
         const void* ws4[4];
         const void* masks4[4];
@@ -722,6 +722,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             wcb[k - 1] = wconv(c, act, c.cin, 32, out, 32, 1.f, lo_ws, gg_store_single ? 0 : lo_gs);
             wcb[k - 1].x_chunk_stride = plane;
             wcb[k - 1].g_lo_bias_only = (gg_single && !gg_store_single) ? 1 : 0;
+            wcb[k - 1].x_pair_chunks = wx_pairs;
         }
         {   // the four mirrored cout-32 passes, then g_x = convT(all) + (skip terms): one chained launch where the kernel supports
             // it (g_x joins on small launches), else one launch per pass

@@ -11,6 +11,9 @@ struct WgradConv {
     long x_lo_off, g_lo_off;                           // RESR_F16X2: element offsets hi -> lo tensor of X / G (else 0; g_lo_off = 0: G is single f16)
     int g_lo_bias_only;                                // RESR_F16X2: the (x_hi, g_lo) tap-product only for X chunk 0 -- the job that also sums
                                                        // the bias: dW takes G's hi tensor, db takes hi + lo (generator.hip, x2_plan bit 1)
+    int x_pair_chunks = 0;                             // RESR_F16X2: > 0 = only the first P X chunks are read as pairs; the chunks behind them (a dense
+                                                       // block's growth planes) enter the weight products as their hi tensor: no (x_lo, g_hi) tap-product
+                                                       // for them (generator.hip, x2_plan bit 3).  0 = every chunk a pair
     int x_s2d_c;                                       // > 0: X is a space-to-depth image with this many channels per sub-position
                                                        // (virtual kernel of a 4x4 / stride-2 conv): the zero taps are skipped
     float* dw; float* db; float scale;

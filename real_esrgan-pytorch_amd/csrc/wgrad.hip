@@ -963,9 +963,12 @@ static size_t wgrad_conv_jobs(const WgradConv& c, int dtype) {
     const size_t prod = (size_t)(c.cin / 32) * (c.cout_pad / 32);
     if (dtype != RESR_F16X2) return prod;
     const int n = wgrad_x2_products();
-    if (n == 3 && c.g_lo_off == 0) return prod * 2;
-    if (n == 3 && c.g_lo_bias_only) return prod * 2 + (size_t)(c.cout_pad / 32);    // + the (x_hi chunk 0, g_lo) job of every G tile
-    return prod * n;
+    if (n != 3) return prod * n;
+    // per (G tile, X chunk): (x_hi, g_hi); (x_hi, g_lo) unless G is single / only for chunk 0 (the bias job); (x_lo, g_hi) unless the chunk is read single
+    const size_t nck = (size_t)(c.cin / 32), nct = (size_t)(c.cout_pad / 32);
+    const size_t xpairs = (c.x_pair_chunks > 0 && (size_t)c.x_pair_chunks < nck) ? (size_t)c.x_pair_chunks : nck;
+    const size_t part1 = c.g_lo_off == 0 ? 0 : (c.g_lo_bias_only ? 1 : nck);
+    return nct * (nck + part1 + xpairs);
 }
 
 // Quad jobs (workgroups per pixel split) the batched launch of `convs` will run: the planners size their pixel splits by it --
@@ -984,6 +987,7 @@ int wgrad_batch_quads(const WgradConv* convs, int nconv, int dtype) {
             for (int ck = 0; ck < c.cin / 32; ++ck)
                 for (int part = 0; part < nparts; ++part) {
                     if (part == 1 && (g_single || (c.g_lo_bias_only && ck != 0))) continue;
+                    if (part == 2 && c.x_pair_chunks > 0 && ck >= c.x_pair_chunks) continue;
                     ++total;
                     if (nj >= kMaxJobs) continue;
                     const char* xp = (const char*)c.x0 + (size_t)ck * (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * es + (part == 2 ? (size_t)c.x_lo_off * es : 0);
@@ -999,6 +1003,13 @@ int wgrad_batch_quads(const WgradConv* convs, int nconv, int dtype) {
     if (total > kMaxJobs || dtype == RESR_F32) return (total + 3) / 4;
     const std::vector<QuadIdx>* plan = plan_quads(jx, jg, nj, nx, ng);
     return plan ? (int)plan->size() : (total + 3) / 4;
+}
+
+// tap-products (= slab regions, kernel jobs) of a batched launch
+int wgrad_batch_jobs(const WgradConv* convs, int nconv, int dtype) {
+    size_t jobs = 0;
+    for (int i = 0; i < nconv; ++i) jobs += wgrad_conv_jobs(convs[i], dtype);
+    return (int)jobs;
 }
 
 size_t wgrad_batch_partial_bytes(const WgradConv* convs, int nconv, int splits, int dtype) {
@@ -1119,6 +1130,7 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
                 for (int part = 0; part < nparts; ++part) {
                     if (part == 1 && g_single) continue;   // no g_lo: dW = X_hi^T G + 2^-12 X_lo^T G
                     if (part == 1 && c.g_lo_bias_only && ck != 0) continue;   // g_lo only where the bias is summed (X chunk 0)
+                    if (part == 2 && c.x_pair_chunks > 0 && ck >= c.x_pair_chunks) continue;   // this X chunk enters as its hi tensor: dW = X_hi^T G
                     WgradJob& j = a.jobs[nj++];
                     j.x = xh + (part == 2 ? (size_t)c.x_lo_off * es : 0);
                     j.g = gh + (part == 1 ? (size_t)c.g_lo_off * es : 0);

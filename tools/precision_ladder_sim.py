@@ -105,10 +105,10 @@ class Conv(torch.autograd.Function):
     f16 separately from the data path (exact16's hi-only weight gradients)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, fw, fwg, fwb, gread="pair"):
+    def forward(ctx, x, w, b, fw, fwg, fwb, gread="pair", wx_from=None):
         wq = q16(w) if fw == "f16" else w
         ctx.save_for_backward(x, w)
-        ctx.fwg, ctx.fwb, ctx.gread = fwg, fwb, gread
+        ctx.fwg, ctx.fwb, ctx.gread, ctx.wx_from = fwg, fwb, gread, wx_from
         return F.conv2d(x, wq, b, padding=1)
 
     @staticmethod
@@ -119,8 +119,11 @@ class Conv(torch.autograd.Function):
         gr = q16(g) if ctx.gread == "hi" else g
         gx = torch.nn.grad.conv2d_input(x.shape, q16(w) if ctx.fwb == "f16" else w, gr, padding=1)
         fx, fg = ctx.fwg if isinstance(ctx.fwg, tuple) else (ctx.fwg, ctx.fwg)
-        gw = torch.nn.grad.conv2d_weight(q16(x) if fx == "f16" else x, w.shape, q16(gr) if fg == "f16" else gr, padding=1)
-        return gx, gw, g.sum((0, 2, 3)), None, None, None, None
+        xw = q16(x) if fx == "f16" else x
+        if ctx.wx_from is not None:      # the weight products read the input channels from wx_from on (the growth planes) as their hi tensor only
+            xw = torch.cat([xw[:, :ctx.wx_from], q16(xw[:, ctx.wx_from:])], 1)
+        gw = torch.nn.grad.conv2d_weight(xw, w.shape, q16(gr) if fg == "f16" else gr, padding=1)
+        return gx, gw, g.sum((0, 2, 3)), None, None, None, None, None
 
 
 def generator(x, sd, cfg, upscale=4, n_blocks=23):
@@ -132,8 +135,10 @@ def generator(x, sd, cfg, upscale=4, n_blocks=23):
             return Conv8.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["fp8"])
         growth = ".rdb" in key and not key.endswith("conv5")      # conv1..4 of a dense block: their G operand is a growth-plane gradient
         wg = cfg.get("wg_growth", cfg["wg"]) if growth else cfg["wg"]
+        wx_from = 64 if (".rdb" in key and ((cfg.get("wx5_growth") == "hi" and key.endswith("conv5")) or
+                                             (cfg.get("wx_growth") == "hi" and not key.endswith("conv1")))) else None
         return Conv.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["w"], wg, cfg.get("wb", cfg["w"]),
-                          cfg.get("gread_growth", "pair") if growth else "pair")
+                          cfg.get("gread_growth", "pair") if growth else "pair", wx_from)
 
     x = S(x, "in")
     out1 = S(conv(x, "conv1"), "stream")
@@ -191,6 +196,8 @@ RUNGS5 = {
     "INFER: stream+tail pair, growth planes f16, W split":           mk("pair", "f16", "pair", "split", "pair"),
     "TRAIN: fwd exact; growth-plane gradients f16 (bwd-data 2 stages, wgrad conv1-4 2 products)": mk("pair", "pair", "pair", "split", "pair", g_dense="f16"),
     "TRAIN2: growth-plane gradients stored as pairs, READ as hi only by backward-data and the weight products; bias sums from hi + lo": _with(_EXACT, gread_growth="hi"),
+    "TRAIN3: TRAIN2 + conv5's weight products read the growth planes o1..o4 as their hi tensor": _with(_EXACT, gread_growth="hi", wx5_growth="hi"),
+    "TRAIN4: TRAIN2 + EVERY weight product reads the growth planes o1..o4 as their hi tensor (conv2..conv5)": _with(_EXACT, gread_growth="hi", wx_growth="hi"),
     "TRAIN + hi-only wgrad on conv1-4 only":                         _with(mk("pair", "pair", "pair", "split", "pair", g_dense="f16"), wg_growth="f16"),
     "fp8 corrections: weight gradients only":                        _with(_EXACT, fp8="w"),
     "fp8 corrections: backward-data + weight gradients":             _with(_EXACT, fp8="dw"),
@@ -237,7 +244,8 @@ def run(seed, n_blocks, size, upscale=4, only=None, batch=1, wscale=1.0, rungs=N
         worst_w = max(wrel, key=wrel.get)
         rows[name] = {"fwd_max_abs": (y - y0).abs().max().item(), "act_max": float(y0.abs().max()), "grad_worst_weight": wrel[worst_w],
                       "grad_worst_weight_tensor": worst_w, "grad_worst": rel[worst_k], "grad_worst_tensor": worst_k,
-                      "grad_median": vals[len(vals) // 2], "gx": ((gx - gx0).norm() / gx0.norm()).item()}
+                      "grad_median": vals[len(vals) // 2], "gx": ((gx - gx0).norm() / gx0.norm()).item(),
+                      "grad_worst_conv5": max(v for k, v in rel.items() if ".conv5." in k)}
     return rows
 
 
@@ -262,7 +270,7 @@ if __name__ == "__main__":
         allrows[seed] = rows
         print(f"== seed {seed}, {a.blocks} blocks, {a.batch} x {a.size}^2 LR, dense weights x {a.wscale}", flush=True)
         for name, r in rows.items():
-            print(f"{name:58s} fwd {r['fwd_max_abs']:.2e}  grad worst {r['grad_worst']:.2e} ({r['grad_worst_tensor']})  worst weight {r['grad_worst_weight']:.2e}  median {r['grad_median']:.2e}  gx {r['gx']:.2e}")
+            print(f"{name:58s} fwd {r['fwd_max_abs']:.2e}  grad worst {r['grad_worst']:.2e} ({r['grad_worst_tensor']})  worst weight {r['grad_worst_weight']:.2e}  worst conv5 {r['grad_worst_conv5']:.2e}  median {r['grad_median']:.2e}  gx {r['gx']:.2e}")
     if a.json:
         with open(a.json, "w") as f:
             json.dump(allrows, f, indent=1)

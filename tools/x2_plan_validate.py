@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--l1-scales", default="1024", help="loss scales of the L1 runs (a GradScaler starts at 65536 and doubles every 2000 clean steps)")
     ap.add_argument("--prescale-targets", default="", help="e.g. 0,3,6,9,12: the dense-cotangent runs at amplitude 2^-20 (always lifted) "
                                                             "under each $RESR_X2_GRAD_PRESCALE_LOG2 -- how high must the lift go")
+    ap.add_argument("--plans", default="3,7", help="plans compared with plan 0 (11 = 3 + the weight products read the growth planes as hi)")
     ap.add_argument("--hi-only", action="store_true", help="also the opt-in hi-only weight gradients (RESR_X2_WGRAD_PRODUCTS=1) on top of plan 3")
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -66,7 +67,7 @@ def main():
                     os.environ["RESR_X2_GRAD_PRESCALE_LOG2"] = lname.split("_target")[1]
                 y0, g0 = grads(g, 0, x, loss_of, sc)
                 row = {}
-                for plan in (3, 7, "3_hi_only_wgrad"):
+                for plan in [int(v) for v in a.plans.split(",")] + ["3_hi_only_wgrad"]:
                     if plan == "3_hi_only_wgrad":
                         if not a.hi_only:
                             continue
@@ -84,7 +85,7 @@ def main():
                 print(case, seed, lname, json.dumps(row), flush=True)
     summary = {}
     lnames = sorted({k.split("_", 2)[2] for k in rep})
-    for plan in ("plan3", "plan7") + (("plan3_hi_only_wgrad",) if a.hi_only else ()):
+    for plan in tuple(f"plan{v}" for v in a.plans.split(",")) + (("plan3_hi_only_wgrad",) if a.hi_only else ()):
         for case in a.cases.split(","):
           for ln in lnames:
             rows = [v[plan] for k, v in rep.items() if k.startswith(case + "_") and k.endswith("_" + ln)]
