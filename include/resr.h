@@ -247,7 +247,11 @@ enum {
      * GROWTH_GRAD_F16).  The forward pass and backward-data still see the pairs.  What is dropped is a zero-mean residue of the
      * SMALL operand of conv5's products (the growth planes next to the stream): the worst gradient tensor does not move (emulation:
      * 3.0e-4 -> 3.0e-4 at the reference's init, 3.9e-4 -> 4.0e-4 with the dense weights x 4; conv5's own tensors 7e-7 -> 2.6e-5 / 1e-4) */
-    RESR_X2_PLAN_GROWTH_ACT_F16_WGRAD = 8
+    RESR_X2_PLAN_GROWTH_ACT_F16_WGRAD = 8,
+    /* with GROWTH_ACT_F16_WGRAD: conv5's products of the growth planes also take g_y's hi tensor alone -- one tap-product
+     * (x_hi, g_hi) per growth chunk, 46 per dense block.  Both dropped residues belong to the small operand block of conv5's weight
+     * tensor (emulation: conv5's tensors 2.6e-5 -> 3.8e-5, 1.0e-4 -> 1.5e-4 with the dense weights x 4; the worst tensor does not move) */
+    RESR_X2_PLAN_GROWTH_ACT_G_HI_WGRAD = 16
 };
 
 size_t resr_generator_param_count(const ResrGeneratorDesc* d);

@@ -704,6 +704,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         wcb[4] = wconv(p.convs[p.i_trunk0 + r * 5 + 4], act, 192, 32, gin, 32, fold, lo_ws, lo_t);   // conv5: G = fold * gin
         wcb[4].x_chunk_stride = plane; wcb[4].g_chunk_stride = plane;
         wcb[4].x_pair_chunks = wx_pairs;
+        wcb[4].x_single_g_hi = (wx_pairs && (d->x2_plan & RESR_X2_PLAN_GROWTH_ACT_G_HI_WGRAD)) ? 1 : 0;
         ResrConvDesc cds[4];
         const void* ws4[4];
         const void* masks4[4];

@@ -14,6 +14,8 @@ struct WgradConv {
     int x_pair_chunks = 0;                             // RESR_F16X2: > 0 = only the first P X chunks are read as pairs; the chunks behind them (a dense
                                                        // block's growth planes) enter the weight products as their hi tensor: no (x_lo, g_hi) tap-product
                                                        // for them (generator.hip, x2_plan bit 3).  0 = every chunk a pair
+    int x_single_g_hi = 0;                             // with x_pair_chunks: the products of those single X chunks also take G's hi tensor alone -- no (x_hi, g_lo)
+                                                       // tap-product for them either (conv5 of a dense block, x2_plan bit 4)
     int x_s2d_c;                                       // > 0: X is a space-to-depth image with this many channels per sub-position
                                                        // (virtual kernel of a 4x4 / stride-2 conv): the zero taps are skipped
     float* dw; float* db; float scale;

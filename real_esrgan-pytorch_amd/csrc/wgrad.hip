@@ -967,7 +967,7 @@ static size_t wgrad_conv_jobs(const WgradConv& c, int dtype) {
     // per (G tile, X chunk): (x_hi, g_hi); (x_hi, g_lo) unless G is single / only for chunk 0 (the bias job); (x_lo, g_hi) unless the chunk is read single
     const size_t nck = (size_t)(c.cin / 32), nct = (size_t)(c.cout_pad / 32);
     const size_t xpairs = (c.x_pair_chunks > 0 && (size_t)c.x_pair_chunks < nck) ? (size_t)c.x_pair_chunks : nck;
-    const size_t part1 = c.g_lo_off == 0 ? 0 : (c.g_lo_bias_only ? 1 : nck);
+    const size_t part1 = c.g_lo_off == 0 ? 0 : (c.g_lo_bias_only ? 1 : (c.x_single_g_hi ? xpairs : nck));
     return nct * (nck + part1 + xpairs);
 }
 
@@ -987,7 +987,7 @@ int wgrad_batch_quads(const WgradConv* convs, int nconv, int dtype) {
             for (int ck = 0; ck < c.cin / 32; ++ck)
                 for (int part = 0; part < nparts; ++part) {
                     if (part == 1 && (g_single || (c.g_lo_bias_only && ck != 0))) continue;
-                    if (part == 2 && c.x_pair_chunks > 0 && ck >= c.x_pair_chunks) continue;
+                    if (part != 0 && c.x_pair_chunks > 0 && ck >= c.x_pair_chunks && (part == 2 || c.x_single_g_hi)) continue;
                     ++total;
                     if (nj >= kMaxJobs) continue;
                     const char* xp = (const char*)c.x0 + (size_t)ck * (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * es + (part == 2 ? (size_t)c.x_lo_off * es : 0);
@@ -1130,7 +1130,7 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
                 for (int part = 0; part < nparts; ++part) {
                     if (part == 1 && g_single) continue;   // no g_lo: dW = X_hi^T G + 2^-12 X_lo^T G
                     if (part == 1 && c.g_lo_bias_only && ck != 0) continue;   // g_lo only where the bias is summed (X chunk 0)
-                    if (part == 2 && c.x_pair_chunks > 0 && ck >= c.x_pair_chunks) continue;   // this X chunk enters as its hi tensor: dW = X_hi^T G
+                    if (part != 0 && c.x_pair_chunks > 0 && ck >= c.x_pair_chunks && (part == 2 || c.x_single_g_hi)) continue;   // this X chunk enters as its hi tensor: dW = X_hi^T G (x_single_g_hi: X_hi^T G_hi)
                     WgradJob& j = a.jobs[nj++];
                     j.x = xh + (part == 2 ? (size_t)c.x_lo_off * es : 0);
                     j.g = gh + (part == 1 ? (size_t)c.g_lo_off * es : 0);

@@ -246,7 +246,7 @@ def test_inference_plan_after_training_steps(diag_dir):
 @pytest.mark.parametrize("n,h,w,n_blocks,seed", [(1, 24, 24, 23, 11), (1, 24, 24, 23, 12), (1, 24, 24, 23, 13), (8, 32, 32, 3, 11), (2, 33, 17, 2, 13)])
 def test_training_plan_gradients_vs_float64_oracle(n, h, w, n_blocks, seed, diag_dir):
     """Backward with single-f16 growth-plane gradients (x2_plan bit 1) and weight products that read the growth planes as their hi
-    tensor (bit 3) -- the default plan, 11; the forward pass keeps every pair: all gradient tensors
+    tensor (bits 3, 4) -- the default plan, 27; the forward pass keeps every pair: all gradient tensors
     against the float64 evaluation of the oracle AND against the all-pairs plan on the same device.  Gate 1e-3 relative L2 per
     tensor (emulation: worst 3-5e-4); the forward pass and the input gradient stay at the all-pairs level.
     The two plans share their forward pass bit for bit, hence their LeakyReLU masks: the distance between them is the rung's own
@@ -254,7 +254,7 @@ def test_training_plan_gradients_vs_float64_oracle(n, h, w, n_blocks, seed, diag
     fp32 CPU path does it on seed 11; exact16 does it on seed 12 -- one element of trunk.6.rdb1.conv3, the
     very element the emulation's rounded-growth-plane forward flips: 1.011e-2 in both): such a tensor is accepted when the
     all-pairs plan shows the same distance."""
-    g, sd, M = _setup(n_blocks, seed, 3 if (n, seed) == (8, 11) else 11)     # the default plan (one case: without bit 3)
+    g, sd, M = _setup(n_blocks, seed, 3 if (n, seed) == (8, 11) else 27)     # the default plan (one case: without bits 3, 4)
     g0, _, _ = _setup(n_blocks, seed, 0)
     gen = torch.Generator().manual_seed(5)
     x = torch.rand(n, 3, h, w, generator=gen)
@@ -328,7 +328,7 @@ def test_plan_bits_are_honoured_and_ignored_outside_exact16():
     with torch.no_grad():
         assert torch.equal(f0(x), f3(x))
     with pytest.raises(ValueError):
-        R.Generator(3, 3, 4, precision="exact16", x2_plan=16)
+        R.Generator(3, 3, 4, precision="exact16", x2_plan=32)
     # bit 3: the weight products read the growth planes (X chunks 2..) as their hi tensor -- conv2's gradient changes, conv1's
     # (stream chunks only) and the backward-data path (the input gradient) do not
     g11 = R.Generator(3, 3, 4, precision="exact16", n_blocks=2, x2_plan=11).cuda()
@@ -347,6 +347,16 @@ def test_plan_bits_are_honoured_and_ignored_outside_exact16():
     for name in ("conv2", "conv5"):
         a, b = getattr(g11.trunk[0].rdb1, name).weight.grad, getattr(g3.trunk[0].rdb1, name).weight.grad
         assert not torch.equal(a, b) and ((a - b).norm() / b.norm()).item() < 2e-4, name     # (3e-7 here: the growth planes are the small operand)
+    # bit 4 (with bit 3): conv5's growth-plane products take g_y's hi tensor alone -- conv5's gradient moves again, conv2's does not
+    g27 = R.Generator(3, 3, 4, precision="exact16", n_blocks=2, x2_plan=27).cuda()
+    g27.load_state_dict(sd)
+    xt = x.clone().requires_grad_(True)
+    g27.train()(xt).square().sum().mul(256.0).backward()
+    assert torch.equal(xt.grad, outs[3][2])
+    assert same(g27.trunk[0].rdb1.conv2.weight.grad, g11.trunk[0].rdb1.conv2.weight.grad)
+    a, b = g27.trunk[0].rdb1.conv5.weight.grad, g11.trunk[0].rdb1.conv5.weight.grad
+    assert not torch.equal(a, b) and ((a - b).norm() / b.norm()).item() < 2e-4
+    assert same(g27.trunk[0].rdb1.conv5.bias.grad, g11.trunk[0].rdb1.conv5.bias.grad)
     # bit 2 (opt-in): the growth-plane gradients stored single as well -- another backward pass, the same forward
     g7 = R.Generator(3, 3, 4, precision="exact16", n_blocks=2, x2_plan=7).cuda()
     g7.load_state_dict(sd)
@@ -390,9 +400,9 @@ def test_exact16_backward_does_not_depend_on_the_loss_scale(diag_dir, monkeypatc
     n, s = 4, 32
     x = torch.rand(n, 3, s, s, device="cuda", generator=gen)
     target = torch.rand(n, 3, 4 * s, 4 * s, device="cuda", generator=gen)
-    base, gx_base = _l1_grads(g, 11, x, target, 1.0)
+    base, gx_base = _l1_grads(g, 27, x, target, 1.0)
     for scale in (2.0 ** 10, 2.0 ** 20):
-        gr, gx = _l1_grads(g, 11, x, target, scale)
+        gr, gx = _l1_grads(g, 27, x, target, scale)
         assert all(torch.equal(gr[k], base[k] * scale) for k in base), f"loss scale {scale}"
         assert torch.equal(gx, gx_base * scale)
     ref, gx_ref = _l1_grads(g, 0, x, target, 1.0)
@@ -401,7 +411,7 @@ def test_exact16_backward_does_not_depend_on_the_loss_scale(diag_dir, monkeypatc
         return max(((a[k].double() - b[k].double()).norm() / b[k].double().norm().clamp_min(1e-300)).item() for k in b)
     rep = {"plan3_vs_plan0_loss_scale_1": worst(base, ref), "gx": ((gx_base - gx_ref).norm() / gx_ref.norm()).item()}
     monkeypatch.setenv("RESR_X2_NO_GRAD_PRESCALE", "1")
-    raw, _ = _l1_grads(g, 11, x, target, 1.0)
+    raw, _ = _l1_grads(g, 27, x, target, 1.0)
     raw0, _ = _l1_grads(g, 0, x, target, 1.0)
     monkeypatch.delenv("RESR_X2_NO_GRAD_PRESCALE")
     rep["without_prescale_plan3_vs_plan0"] = worst(raw, raw0)
@@ -439,12 +449,12 @@ def test_exact16_backward_keeps_a_non_finite_gradient_visible():
         g.conv4.bias.add_(0.5)      # keep the outputs inside the clamp: its backward mask would drop the poisoned element otherwise
     x = torch.rand(2, 3, 24, 24, device="cuda")
     target = torch.rand(2, 3, 96, 96, device="cuda")
-    clean, _ = _l1_grads(g, 11, x, target, 1024.0)
+    clean, _ = _l1_grads(g, 27, x, target, 1024.0)
     assert all(torch.isfinite(v).all() for v in clean.values())
     for bad in (float("inf"), float("nan")):
-        gr, _ = _l1_grads(g, 11, x, target, 1024.0, poison=(5000, bad))
+        gr, _ = _l1_grads(g, 27, x, target, 1024.0, poison=(5000, bad))
         assert not torch.isfinite(gr["conv4.weight"]).all(), bad
-    again, _ = _l1_grads(g, 11, x, target, 1024.0)
+    again, _ = _l1_grads(g, 27, x, target, 1024.0)
     assert all(torch.equal(again[k], clean[k]) for k in clean), "the next pass is clean again"
 
 
@@ -494,7 +504,7 @@ def _oracle_grads(M, sd, x, gw, n_blocks, dt=torch.float64):
     return yo.detach(), {k: v.grad for k, v in sdo.items()}, xo.grad
 
 
-@pytest.mark.parametrize("precision,plan", [("exact16", 11), ("exact16", 0), ("fast", 0)])
+@pytest.mark.parametrize("precision,plan", [("exact16", 27), ("exact16", 0), ("fast", 0)])
 @pytest.mark.parametrize("case", ["dense_x4", "stream_x40", "stream_x0p01"])
 def test_generator_parity_off_the_init_scale(precision, plan, case, diag_dir):
     """Forward + backward of a 6-block generator against the float64 oracle with (a) the dense-block weights x 4 (the branches are

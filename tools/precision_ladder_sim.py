@@ -105,10 +105,10 @@ class Conv(torch.autograd.Function):
     f16 separately from the data path (exact16's hi-only weight gradients)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, fw, fwg, fwb, gread="pair", wx_from=None):
+    def forward(ctx, x, w, b, fw, fwg, fwb, gread="pair", wx_from=None, wxg_hi=False):
         wq = q16(w) if fw == "f16" else w
         ctx.save_for_backward(x, w)
-        ctx.fwg, ctx.fwb, ctx.gread, ctx.wx_from = fwg, fwb, gread, wx_from
+        ctx.fwg, ctx.fwb, ctx.gread, ctx.wx_from, ctx.wxg_hi = fwg, fwb, gread, wx_from, wxg_hi
         return F.conv2d(x, wq, b, padding=1)
 
     @staticmethod
@@ -122,8 +122,14 @@ class Conv(torch.autograd.Function):
         xw = q16(x) if fx == "f16" else x
         if ctx.wx_from is not None:      # the weight products read the input channels from wx_from on (the growth planes) as their hi tensor only
             xw = torch.cat([xw[:, :ctx.wx_from], q16(xw[:, ctx.wx_from:])], 1)
-        gw = torch.nn.grad.conv2d_weight(xw, w.shape, q16(gr) if fg == "f16" else gr, padding=1)
-        return gx, gw, g.sum((0, 2, 3)), None, None, None, None, None
+        gq = q16(gr) if fg == "f16" else gr
+        if ctx.wx_from is not None and ctx.wxg_hi:   # ... and those chunks' products take G's hi tensor too: one tap-product, (x_hi, g_hi)
+            k = ctx.wx_from
+            gw = torch.cat([torch.nn.grad.conv2d_weight(xw[:, :k], (w.shape[0], k, 3, 3), gq, padding=1),
+                            torch.nn.grad.conv2d_weight(xw[:, k:], (w.shape[0], w.shape[1] - k, 3, 3), q16(gq), padding=1)], 1)
+        else:
+            gw = torch.nn.grad.conv2d_weight(xw, w.shape, gq, padding=1)
+        return gx, gw, g.sum((0, 2, 3)), None, None, None, None, None, None
 
 
 def generator(x, sd, cfg, upscale=4, n_blocks=23):
@@ -138,7 +144,7 @@ def generator(x, sd, cfg, upscale=4, n_blocks=23):
         wx_from = 64 if (".rdb" in key and ((cfg.get("wx5_growth") == "hi" and key.endswith("conv5")) or
                                              (cfg.get("wx_growth") == "hi" and not key.endswith("conv1")))) else None
         return Conv.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["w"], wg, cfg.get("wb", cfg["w"]),
-                          cfg.get("gread_growth", "pair") if growth else "pair", wx_from)
+                          cfg.get("gread_growth", "pair") if growth else "pair", wx_from, bool(cfg.get("wxg5_hi")) and key.endswith("conv5"))
 
     x = S(x, "in")
     out1 = S(conv(x, "conv1"), "stream")
@@ -198,6 +204,7 @@ RUNGS5 = {
     "TRAIN2: growth-plane gradients stored as pairs, READ as hi only by backward-data and the weight products; bias sums from hi + lo": _with(_EXACT, gread_growth="hi"),
     "TRAIN3: TRAIN2 + conv5's weight products read the growth planes o1..o4 as their hi tensor": _with(_EXACT, gread_growth="hi", wx5_growth="hi"),
     "TRAIN4: TRAIN2 + EVERY weight product reads the growth planes o1..o4 as their hi tensor (conv2..conv5)": _with(_EXACT, gread_growth="hi", wx_growth="hi"),
+    "TRAIN5: TRAIN4 + conv5's growth-plane products take g_y's hi tensor too (one tap-product per growth chunk)": _with(_EXACT, gread_growth="hi", wx_growth="hi", wxg5_hi=True),
     "TRAIN + hi-only wgrad on conv1-4 only":                         _with(mk("pair", "pair", "pair", "split", "pair", g_dense="f16"), wg_growth="f16"),
     "fp8 corrections: weight gradients only":                        _with(_EXACT, fp8="w"),
     "fp8 corrections: backward-data + weight gradients":             _with(_EXACT, fp8="dw"),

@@ -1,7 +1,7 @@
 """What exact16's backward plans mean for TRAINING: the same RealESRNet steps (fixed batches, no degradation draws: lr = area-downsampled
 hr) from the same initial weights under
-    exact16 plan 0 (pairs everywhere: the reference trajectory), plan 11 (default), plan 3 (without bit 3), plan 15 (opt-in single store),
-    exact16 plan 11 + hi-only weight gradients (RESR_X2_WGRAD_PRODUCTS=1), and fast (f16),
+    exact16 plan 0 (pairs everywhere: the reference trajectory), plan 27 (default), plans 11 / 3 (without bit 4 / bits 3, 4), plan 31 (opt-in single store),
+    exact16 plan 27 + hi-only weight gradients (RESR_X2_WGRAD_PRODUCTS=1), and fast (f16),
 and after K Adam steps the distance of every trajectory's weights from plan 0's, relative to the distance plan 0 travelled from
 the initial weights -- Adam divides by the gradient's own magnitude, so what counts is the DIRECTION error of the gradient, summed
 over steps -- plus the loss curves.
@@ -65,9 +65,9 @@ def main():
     sd = {k: v.clone() for k, v in ref.state_dict().items()}
     w0 = torch.cat([p.detach().double().flatten() for p in ref.parameters()]).cpu()
     data = batches(a.steps, a.batch, a.crop, 3)
-    runs = {"exact16_plan0": ("exact16", 0, None), "exact16_plan0_again": ("exact16", 0, None), "exact16_plan11_default": ("exact16", 11, None),
-            "exact16_plan3": ("exact16", 3, None), "exact16_plan15_single_store": ("exact16", 15, None),
-            "exact16_plan11_hi_only_wgrad": ("exact16", 11, 1), "fast_f16": ("fast", 0, None)}
+    runs = {"exact16_plan0": ("exact16", 0, None), "exact16_plan0_again": ("exact16", 0, None), "exact16_plan27_default": ("exact16", 27, None),
+            "exact16_plan11": ("exact16", 11, None), "exact16_plan3": ("exact16", 3, None), "exact16_plan31_single_store": ("exact16", 31, None),
+            "exact16_plan27_hi_only_wgrad": ("exact16", 27, 1), "fast_f16": ("fast", 0, None)}
     res = {}
     for name, (prec, plan, prod) in runs.items():
         res[name] = run(prec, plan, prod, sd, data, a.lr)
