@@ -68,7 +68,11 @@ enum {
     RESR_CONV_MASK_BITS = 1 << 9,
     /* RESR_F16X2 only: the output is stored as ONE f16 tensor (the hi tensor; no lo tensor is written and out_lo_offset is
      * ignored).  A later pass reads such a tensor as a "single" chunk (x2_pair_chunks).  Ignored for other dtypes. */
-    RESR_CONV_OUT_SINGLE = 1 << 10
+    RESR_CONV_OUT_SINGLE = 1 << 10,
+    /* RESR_F16X2 with x2_pair_chunks: the single chunks meet the f16 weights W0 alone -- ONE stage (x W0) instead of two (x W0 + x W1).
+     * For operands that are the small ones of the sum (the growth planes of an inference forward next to the residual stream: forward
+     * 1.4-2.1e-6 instead of 1.0-1.4e-6 at the reference's init, 2.4-2.9e-5 instead of 1.6-2.9e-5 with the dense weights x 4). */
+    RESR_CONV_SINGLE_W16 = 1 << 11
 };
 
 /* One 3x3, stride 1, pad 1 convolution pass (forward conv or backward-data conv):
@@ -251,7 +255,10 @@ enum {
     /* with GROWTH_ACT_F16_WGRAD: conv5's products of the growth planes also take g_y's hi tensor alone -- one tap-product
      * (x_hi, g_hi) per growth chunk, 46 per dense block.  Both dropped residues belong to the small operand block of conv5's weight
      * tensor (emulation: conv5's tensors 2.6e-5 -> 3.8e-5, 1.0e-4 -> 1.5e-4 with the dense weights x 4; the worst tensor does not move) */
-    RESR_X2_PLAN_GROWTH_ACT_G_HI_WGRAD = 16
+    RESR_X2_PLAN_GROWTH_ACT_G_HI_WGRAD = 16,
+    /* with GROWTH_F16_INFER: the growth chunks of an inference forward take ONE stage (RESR_CONV_SINGLE_W16): 40 instead of 50 stages per
+     * dense block */
+    RESR_X2_PLAN_GROWTH_W16_INFER = 32
 };
 
 size_t resr_generator_param_count(const ResrGeneratorDesc* d);

@@ -18,8 +18,10 @@ CONV_AUX_BEFORE_MASK, CONV_AUX_BEFORE_RES = 64, 128
 CONV_WRITE_SIGNBITS = 1 << 8
 CONV_MASK_BITS = 1 << 9
 CONV_OUT_SINGLE = 1 << 10
+CONV_SINGLE_W16 = 1 << 11
 X2_PLAN_GROWTH_F16_INFER, X2_PLAN_GROWTH_GRAD_F16, X2_PLAN_GROWTH_GRAD_STORE_F16, X2_PLAN_GROWTH_ACT_F16_WGRAD = 1, 2, 4, 8
 X2_PLAN_GROWTH_ACT_G_HI_WGRAD = 16
+X2_PLAN_GROWTH_W16_INFER = 32
 RESR_VERSION = 2   # include/resr.h: the structures below mirror THIS version of the header
 
 

@@ -33,6 +33,7 @@ struct ConvArgs {
     // RESR_F16X2: the first pair_chunks 32-channel input chunks are hi/lo pairs (three stages each), the chunks behind them single
     // f16 tensors (two stages: x W0 + x W1); >= cin / 32 = every chunk a pair (ResrConvDesc.x2_pair_chunks)
     int pair_chunks, out_single;
+    int single_stages;               // RESR_F16X2: 1 = the single chunks take ONE stage (x W0 alone: RESR_CONV_SINGLE_W16), else two
     // sparse taps of a 4x4 / stride-2 convolution run over the space-to-depth image (conv3x3_ws.h, SP): channels per
     // sub-position of the input (forward), sub-position of this launch's output group (backward-data)
     int s2d_c, tap_c;

@@ -340,7 +340,7 @@ static int conv3x3_args(const ResrConvDesc* d, const void* in0, const void* in1,
     a.in0_chunk_b = (size_t)chunk(d->in0_chunk_stride) * es; a.in1_chunk_b = (size_t)chunk(d->in1_chunk_stride) * es;
     a.out_chunk = chunk(d->out_chunk_stride); a.res0_chunk = chunk(d->res0_chunk_stride);
     a.res1_chunk = chunk(d->res1_chunk_stride); a.mask_chunk = chunk(d->mask_chunk_stride);
-    a.flags = d->flags & ~RESR_CONV_OUT_SINGLE; a.s0 = d->s0; a.t0 = d->t0; a.s1 = d->s1; a.t1 = d->t1; a.slope = d->slope;
+    a.flags = d->flags & ~(RESR_CONV_OUT_SINGLE | RESR_CONV_SINGLE_W16); a.s0 = d->s0; a.t0 = d->t0; a.s1 = d->s1; a.t1 = d->t1; a.slope = d->slope;
     a.s2d_c = 0; a.tap_c = 0; a.ngroups = 1; a.w_group_b = 0;
     // RESR_F16X2: leading pair chunks / a single-f16 output (kept out of a.flags: the kernels and the chain checks never see the bit)
     a.pair_chunks = d->cin / 32; a.out_single = 0;
@@ -350,6 +350,7 @@ static int conv3x3_args(const ResrConvDesc* d, const void* in0, const void* in1,
         if (d->x2_pair_chunks < 0 || d->x2_pair_chunks > d->cin / 32)
             return fail(RESR_ERR_ARG, "conv3x3: x2_pair_chunks=%d of %d chunks", d->x2_pair_chunks, d->cin / 32);
         if (d->x2_pair_chunks > 0) a.pair_chunks = d->x2_pair_chunks;
+        if ((d->flags & RESR_CONV_SINGLE_W16) && a.pair_chunks * 32 < d->cin) a.single_stages = 1;
         if (d->flags & RESR_CONV_OUT_SINGLE) {
             if (d->flags & RESR_CONV_OUT_NCHW_F32) return fail(RESR_ERR_ARG, "conv3x3: OUT_SINGLE is an NHWC f16 output");
             a.out_single = 1;
@@ -475,7 +476,7 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
     const int chain_pairs = eff_pairs(b);
     for (int j = 0; ok && j < njobs; ++j) {
         const ConvArgs& c = a[j];
-        ok = d[j].dtype == d[0].dtype && (!x2 || eff_pairs(c) == chain_pairs || c.cin <= chain_pairs * 32) && c.out_single == b.out_single && d[j].cout_pad == 32 && c.cout == 32 && c.in0_lo_b == b.in0_lo_b && c.in1_lo_b == b.in1_lo_b && (c.flags == fwd_flags || c.flags == bwd_flags || c.flags == inf_flags) &&
+        ok = d[j].dtype == d[0].dtype && (!x2 || eff_pairs(c) == chain_pairs || c.cin <= chain_pairs * 32) && c.out_single == b.out_single && (c.single_stages == b.single_stages || c.pair_chunks * 32 >= c.cin) && d[j].cout_pad == 32 && c.cout == 32 && c.in0_lo_b == b.in0_lo_b && c.in1_lo_b == b.in1_lo_b && (c.flags == fwd_flags || c.flags == bwd_flags || c.flags == inf_flags) &&
              c.flags == b.flags && c.n == b.n && c.h == b.h && c.w_ == b.w_ && c.hs == c.h && c.ws == c.w_ &&
              (c.n % 8) == 0 && (c.w_ % 2) == 0 && c.slope == b.slope &&
              c.in0_stride_b == 64 && c.in0_chunk_b == b.in0_chunk_b && c.out_stride == 32 &&
@@ -505,7 +506,7 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
         const int c0 = c.cin - 32;
         const bool seg1 = c0 >= c.cin0;
         const char* last = seg1 ? c.in1 + (size_t)((c0 - c.cin0) >> 5) * c.in1_chunk_b : c.in0 + (size_t)(c0 >> 5) * c.in0_chunk_b;
-        with5 = with5 && d5->dtype == d[0].dtype && (!x2 || eff_pairs(c) == chain_pairs) && !c.out_single && c.in0_lo_b == b.in0_lo_b && c.in1_lo_b == b.in1_lo_b && d5->cout_pad == 64 && c.cout == 64 && c.cin == b.cin + 32 && last == b.out &&
+        with5 = with5 && d5->dtype == d[0].dtype && (!x2 || eff_pairs(c) == chain_pairs) && !c.out_single && c.single_stages == b.single_stages && c.in0_lo_b == b.in0_lo_b && c.in1_lo_b == b.in1_lo_b && d5->cout_pad == 64 && c.cout == 64 && c.cin == b.cin + 32 && last == b.out &&
                 (c.flags & ~RESR_CONV_NO_BIAS) == 0 && ((c.flags & RESR_CONV_NO_BIAS) != 0) == ((b.flags & RESR_CONV_NO_BIAS) != 0) &&
                 c.n == b.n && c.h == b.h && c.w_ == b.w_ && c.hs == c.h && c.ws == c.w_ &&
                 c.in0_stride_b == 64 && c.in0_chunk_b == b.in0_chunk_b &&

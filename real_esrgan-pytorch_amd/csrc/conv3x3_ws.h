@@ -271,14 +271,18 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         }
     }
     // X2 stage map: the first a.pair_chunks real chunks are hi/lo pairs -- three stages (x_hi W0, x_hi W1, x_lo W2) --, the chunks
-    // behind them single f16 tensors -- two stages (x W0, x W1).  Packed weights keep three blocks per real chunk whatever its
-    // kind (block = chunk * 3 + part; a single chunk never reads its third).
+    // behind them single f16 tensors -- two stages (x W0, x W1), or ONE (x W0: a.single_stages = 1, the growth planes of an inference
+    // forward against f16 weights).  Packed weights keep three blocks per real chunk whatever its kind (block = chunk * 3 + part; a
+    // single chunk never reads its third, a one-stage chunk only its first).
     const int x2_p = X2 ? a.pair_chunks : 0, x2_p3 = 3 * x2_p;
-    auto stages_of = [&](int cin) { const int c = cin >> 5; return !X2 ? c : (c <= x2_p ? 3 * c : x2_p3 + 2 * (c - x2_p)); };
-    auto st_chunk = [&](int ck) { return !X2 ? ck : (ck < x2_p3 ? ck / 3 : x2_p + ((ck - x2_p3) >> 1)); };      // real chunk of stage ck
-    auto st_part = [&](int ck) { return !X2 ? 0 : (ck < x2_p3 ? ck % 3 : ((ck - x2_p3) & 1)); };               // its part: 0 / 1 on x (hi), 2 on x_lo
+    const bool x2_one = X2 && a.single_stages == 1;
+    auto stages_of = [&](int cin) { const int c = cin >> 5; return !X2 ? c : (c <= x2_p ? 3 * c : x2_p3 + (x2_one ? c - x2_p : 2 * (c - x2_p))); };
+    auto st_chunk = [&](int ck) { return !X2 ? ck : (ck < x2_p3 ? ck / 3 : x2_p + (x2_one ? ck - x2_p3 : ((ck - x2_p3) >> 1))); };      // real chunk of stage ck
+    auto st_part = [&](int ck) { return !X2 ? 0 : (ck < x2_p3 ? ck % 3 : (x2_one ? 0 : ((ck - x2_p3) & 1))); };               // its part: 0 / 1 on x (hi), 2 on x_lo
     auto st_wblock = [&](int ck) { return !X2 ? ck : st_chunk(ck) * 3 + st_part(ck); };                        // its packed weight block
-    auto last_stages = [&](int cin) { return !X2 ? 1 : ((cin >> 5) <= x2_p ? 3 : 2); };                        // stages of a job's LAST real chunk
+    auto last_stages = [&](int cin) { return !X2 ? 1 : ((cin >> 5) <= x2_p ? 3 : (x2_one ? 1 : 2)); };         // stages of a job's LAST real chunk
+    // does the NEXT stage multiply the halo of stage ck again (part 0 of a chunk that has a part 1)?
+    auto st_keeps_halo = [&](int ck) { return X2 && st_part(ck) == 0 && !(x2_one && ck >= x2_p3); };
     int nchunks = stages_of(a.cin);   // stages per tile (CH: of the current job)
     if constexpr (CH) nchunks = stages_of(cj.job[CH == 3 ? pin_job : 0].cin);
     int tk = 0;
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     else if (nstage < nchunks) stage_weights(tile, ck, ck);    // resident: buffer = chunk, first tile only
                 }
                 par ^= 1;
-                if (!X2 || cpart != 0) hpar ^= 1;   // X2 part 0: the next stage stays on this buffer
+                if (!st_keeps_halo(ck)) hpar ^= 1;   // X2 part 0 of a multi-stage chunk: the next stage stays on this buffer
                 ++nstage;
                 stamp(0);
                 // the next tile's index math runs while this tile's last chunk is in flight
@@ -947,7 +951,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     default: sparse_stage(I1{}, I1{}); break;
                 }
                 par ^= 1;
-                if (!X2 || st_part(ck) != 0) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
+                if (!st_keeps_halo(ck)) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
                 if (wave == 0) stamp(1);
                 continue;
             }
@@ -979,7 +983,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 }
             }
             par ^= 1;
-            if (!X2 || st_part(ck) != 0) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
+            if (!st_keeps_halo(ck)) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
             if (wave == 0) stamp(1);
             if constexpr (CH) publish();
         }

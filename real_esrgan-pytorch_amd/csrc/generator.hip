@@ -442,6 +442,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
     // exact16 inference with single-f16 growth planes (RESR_X2_PLAN_GROWTH_F16_INFER): o1..o4 are stored without a lo tensor and
     // read as two-stage chunks; a training forward keeps every pre-activation fp32-class (a rounded input flips LeakyReLU masks)
     const bool growth_single = x2 && !d->training && (d->x2_plan & RESR_X2_PLAN_GROWTH_F16_INFER);
+    const bool growth_w16 = growth_single && (d->x2_plan & RESR_X2_PLAN_GROWTH_W16_INFER);   // ... and meet f16 weights: one stage per growth chunk
     // RESR_F16X2: element offset hi -> lo of a buffer holding `planes` 32-channel planes of `pl` elements
     auto LO = [&](long planes, long pl) -> int64_t { return x2 ? planes * pl : 0; };
     const int64_t lo_ws = LO(6, plane), lo_t = LO(2, plane), lo_xin = x2 ? (int64_t)N * h * w * p.ci_pad : 0;
@@ -474,7 +475,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
                 ResrConvDesc cd = conv_desc(p, N, h, w, c.cin, c.cin, 32, 0, 32, 32, 32, RESR_CONV_LRELU);
                 cd.in0_chunk_stride = plane;
                 cd.in0_lo_offset = lo_ws; cd.out_lo_offset = lo_ws;
-                if (growth_single) { cd.x2_pair_chunks = 2; cd.flags |= RESR_CONV_OUT_SINGLE; }
+                if (growth_single) { cd.x2_pair_chunks = 2; cd.flags |= RESR_CONV_OUT_SINGLE | (growth_w16 ? RESR_CONV_SINGLE_W16 : 0); }
                 char* signs = nullptr;
                 if (d->training) {   // the backward pass reads the 1-bit mask, not the activation
                     cd.flags |= RESR_CONV_WRITE_SIGNBITS;
@@ -491,7 +492,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
             cd.in0_chunk_stride = plane;
             cd.out_chunk_stride = plane;
             cd.in0_lo_offset = lo_ws; cd.out_lo_offset = last ? lo_t : lo_ws;
-            if (growth_single) cd.x2_pair_chunks = 2;
+            if (growth_single) { cd.x2_pair_chunks = 2; if (growth_w16) cd.flags |= RESR_CONV_SINGLE_W16; }
             cd.s0 = 0.2f; cd.t0 = 1.f; cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.res0_lo_offset = lo_ws;  // model.py:95-96
             const char* res1 = nullptr;
             if (r % 3 == 2) {  // model.py:129-130

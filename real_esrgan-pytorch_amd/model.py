@@ -214,14 +214,15 @@ class Generator(nn.Module):
     MFMAs per product, fp32 accumulate: meets the 1e-3 parity tolerance vs the fp32 CPU path at about a third
     of fast mode's throughput), "strict" = f32 operands on v_mfma_f32_32x32x2_f32 (bit-for-bit fp32 FMA chains).
     Default from $RESR_PRECISION, else "fast".
-    `x2_plan` (exact16 only; bit set of _lib.X2_PLAN_*, default from $RESR_X2_PLAN, else 27 = bits 0, 1, 3, 4): which tensors of the dense
+    `x2_plan` (exact16 only; bit set of _lib.X2_PLAN_*, default from $RESR_X2_PLAN, else 59 = bits 0, 1, 3, 4, 5): which tensors of the dense
     blocks are single f16 instead of hi/lo pairs -- bit 0: the growth planes o1..o4 of an INFERENCE forward (50 instead of 60
     stages per block; forward ~1e-6 at the reference's init scale, gate 2e-4), bit 1: the growth-plane gradients of the backward
     pass are READ as single f16 (two stages / two tap-products on their chunks; the bias sums still take hi + lo; worst gradient
     tensor 3-5e-4 vs float64, gate 1e-3), bit 2 (opt-in, with bit 1): they are stored single as well (~4 % faster, worst bias tensor
     6.7e-4), bit 3: the weight products read the growth planes (the X chunks of conv2..conv5 behind the residual stream) as their
     hi tensor (54 instead of 68 tap-products per block; the worst tensor does not move), bit 4 (with bit 3): conv5's products of the
-    growth planes also take g_y's hi tensor alone (46 per block).  x2_plan=0 = pairs everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
+    growth planes also take g_y's hi tensor alone (46 per block), bit 5 (with bit 0): the growth chunks of an inference forward meet
+    the f16 weights W0 alone -- one stage each, 40 per block (forward 2.3e-6 at the init scale, 2.9e-5 at dense weights x 4).  x2_plan=0 = pairs everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
     The backward pass of the 16-bit modes (exact16, fast) does not depend on the caller's loss scale: an incoming gradient whose largest element is below 2^6 is
     lifted by a power of two inside the native pass and the results are handed back unscaled (bit-identical gradients at loss scale
     1 and 2^20; csrc/generator.hip, $RESR_X2_GRAD_PRESCALE_LOG2 / RESR_X2_NO_GRAD_PRESCALE=1).
@@ -238,10 +239,10 @@ class Generator(nn.Module):
         self.in_channels, self.out_channels, self.upscale_factor = in_channels, out_channels, upscale_factor
         self.precision = precision or os.environ.get("RESR_PRECISION", "fast")
         self._dtype = _precision_to_dtype(self.precision)
-        self.x2_plan = int(os.environ.get("RESR_X2_PLAN", "27")) if x2_plan is None else int(x2_plan)
-        if not 0 <= self.x2_plan <= 31:
+        self.x2_plan = int(os.environ.get("RESR_X2_PLAN", "59")) if x2_plan is None else int(x2_plan)
+        if not 0 <= self.x2_plan <= 63:
             raise ValueError(f"x2_plan must be a bit set of X2_PLAN_GROWTH_F16_INFER (1) | X2_PLAN_GROWTH_GRAD_F16 (2) | "
-                             f"X2_PLAN_GROWTH_GRAD_STORE_F16 (4) | X2_PLAN_GROWTH_ACT_F16_WGRAD (8) | X2_PLAN_GROWTH_ACT_G_HI_WGRAD (16), got {self.x2_plan}")
+                             f"X2_PLAN_GROWTH_GRAD_STORE_F16 (4) | X2_PLAN_GROWTH_ACT_F16_WGRAD (8) | X2_PLAN_GROWTH_ACT_G_HI_WGRAD (16) | X2_PLAN_GROWTH_W16_INFER (32), got {self.x2_plan}")
         self.n_blocks = n_blocks or self.N_BLOCKS
         if upscale_factor == 2:
             conv_in, downscale_factor = in_channels * 4, 2

@@ -197,18 +197,23 @@ def test_inference_plan_forward_vs_oracle(n, h, w, wscale, diag_dir):
     from real_esrgan_pytorch_amd import _lib as L
     g1, sd, M = _setup(23, 11, 1, wscale)
     g0, _, _ = _setup(23, 11, 0, wscale)
+    g33, _, _ = _setup(23, 11, 33, wscale)      # + bit 5: the growth chunks take ONE stage (f16 weights): 40 stages per block
     x = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(5))
     with torch.no_grad():
         y1 = g1.eval()(x.cuda()).cpu()
         y0 = g0.eval()(x.cuda()).cpu()
+        y33 = g33.eval()(x.cuda()).cpu()
     yo = M.generator_forward(x, sd, 4, 23)
     yo64 = M.generator_forward(x.double(), {k: v.double() for k, v in sd.items()}, 4, 23)
     rep = {"plan1_vs_f32_oracle": (y1 - yo).abs().max().item(), "plan0_vs_f32_oracle": (y0 - yo).abs().max().item(),
            "plan1_vs_f64": (y1.double() - yo64).abs().max().item(), "plan0_vs_f64": (y0.double() - yo64).abs().max().item(),
+           "plan33_vs_f32_oracle": (y33 - yo).abs().max().item(), "plan33_vs_f64": (y33.double() - yo64).abs().max().item(),
+           "plan33_vs_plan1": (y33 - y1).abs().max().item(),
            "frac_unclamped": ((yo > 0) & (yo < 1)).float().mean().item()}
     with open(os.path.join(diag_dir, f"x2_plan_infer_{n}x{h}x{w}_w{wscale}.json"), "w") as f:
         json.dump(rep, f, indent=1)
     assert rep["plan1_vs_f32_oracle"] < 2e-4 and rep["plan1_vs_f64"] < 2e-4, rep
+    assert rep["plan33_vs_f32_oracle"] < 2e-4 and rep["plan33_vs_f64"] < 2e-4 and rep["plan33_vs_plan1"] > 0, rep
     assert rep["plan0_vs_f64"] < 5e-5, rep
     assert int(L.lib().resr_debug_chain_errors()) == 0
 
@@ -230,17 +235,17 @@ def test_inference_plan_after_training_steps(diag_dir):
     assert losses[-1] < 0.5 * losses[0]
     sd = {k: v.detach().float().cpu().clone() for k, v in g.state_dict().items()}
     ys = {}
-    for plan in (0, 1):
+    for plan in (0, 1, 33):
         ge = R.Generator(3, 3, 4, precision="exact16", x2_plan=plan)
         ge.load_state_dict(sd)
         with torch.no_grad():
             ys[plan] = ge.cuda().eval()(lr[:1]).cpu()
     yo = M.generator_forward(lr[:1].cpu(), sd, 4, 23)
     rep = {"plan1_vs_f32_oracle": (ys[1] - yo).abs().max().item(), "plan0_vs_f32_oracle": (ys[0] - yo).abs().max().item(),
-           "plan1_vs_plan0": (ys[1] - ys[0]).abs().max().item()}
+           "plan1_vs_plan0": (ys[1] - ys[0]).abs().max().item(), "plan33_vs_f32_oracle": (ys[33] - yo).abs().max().item()}
     with open(os.path.join(diag_dir, "x2_plan_infer_trained.json"), "w") as f:
         json.dump(rep, f, indent=1)
-    assert rep["plan1_vs_f32_oracle"] < 2e-4, rep
+    assert rep["plan1_vs_f32_oracle"] < 2e-4 and rep["plan33_vs_f32_oracle"] < 2e-4, rep
 
 
 @pytest.mark.parametrize("n,h,w,n_blocks,seed", [(1, 24, 24, 23, 11), (1, 24, 24, 23, 12), (1, 24, 24, 23, 13), (8, 32, 32, 3, 11), (2, 33, 17, 2, 13)])
@@ -328,7 +333,7 @@ def test_plan_bits_are_honoured_and_ignored_outside_exact16():
     with torch.no_grad():
         assert torch.equal(f0(x), f3(x))
     with pytest.raises(ValueError):
-        R.Generator(3, 3, 4, precision="exact16", x2_plan=32)
+        R.Generator(3, 3, 4, precision="exact16", x2_plan=64)
     # bit 3: the weight products read the growth planes (X chunks 2..) as their hi tensor -- conv2's gradient changes, conv1's
     # (stream chunks only) and the backward-data path (the input gradient) do not
     g11 = R.Generator(3, 3, 4, precision="exact16", n_blocks=2, x2_plan=11).cuda()
@@ -458,14 +463,15 @@ def test_exact16_backward_keeps_a_non_finite_gradient_visible():
     assert all(torch.equal(again[k], clean[k]) for k in clean), "the next pass is clean again"
 
 
+@pytest.mark.parametrize("plan", [3, 35])
 @pytest.mark.parametrize("n,h,w", [(8, 24, 40), (16, 64, 64), (16, 128, 128)])
-def test_single_plane_chains_equal_separate_launches(n, h, w):
+def test_single_plane_chains_equal_separate_launches(n, h, w, plan):
     """Chained dense-block launches with two-stage chunks (the dependent chunk of a job is its last TWO stages): inference forward
     (x2_plan bit 0, conv5 inside the chain on the small launches) and training backward (bit 1) bit-equal to one launch per pass."""
     import real_esrgan_pytorch_amd as R
     L = R._lib
     torch.manual_seed(3)
-    g = R.Generator(3, 3, 4, precision="exact16", n_blocks=1, x2_plan=3).cuda()
+    g = R.Generator(3, 3, 4, precision="exact16", n_blocks=1, x2_plan=plan).cuda()     # 35: the growth chunks of the inference forward take ONE stage
     with torch.no_grad():
         g.conv4.bias.add_(0.5)
     gen = torch.Generator(device="cuda").manual_seed(7)

@@ -105,8 +105,10 @@ class Conv(torch.autograd.Function):
     f16 separately from the data path (exact16's hi-only weight gradients)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, fw, fwg, fwb, gread="pair", wx_from=None, wxg_hi=False):
+    def forward(ctx, x, w, b, fw, fwg, fwb, gread="pair", wx_from=None, wxg_hi=False, w16_from=None):
         wq = q16(w) if fw == "f16" else w
+        if w16_from is not None:     # forward only: the input chunks from w16_from on (the growth planes) meet f16 weights -- ONE stage, x W0
+            wq = torch.cat([wq[:, :w16_from], q16(wq[:, w16_from:])], 1)
         ctx.save_for_backward(x, w)
         ctx.fwg, ctx.fwb, ctx.gread, ctx.wx_from, ctx.wxg_hi = fwg, fwb, gread, wx_from, wxg_hi
         return F.conv2d(x, wq, b, padding=1)
@@ -129,7 +131,7 @@ class Conv(torch.autograd.Function):
                             torch.nn.grad.conv2d_weight(xw[:, k:], (w.shape[0], w.shape[1] - k, 3, 3), q16(gq), padding=1)], 1)
         else:
             gw = torch.nn.grad.conv2d_weight(xw, w.shape, gq, padding=1)
-        return gx, gw, g.sum((0, 2, 3)), None, None, None, None, None, None
+        return gx, gw, g.sum((0, 2, 3)), None, None, None, None, None, None, None
 
 
 def generator(x, sd, cfg, upscale=4, n_blocks=23):
@@ -144,7 +146,8 @@ def generator(x, sd, cfg, upscale=4, n_blocks=23):
         wx_from = 64 if (".rdb" in key and ((cfg.get("wx5_growth") == "hi" and key.endswith("conv5")) or
                                              (cfg.get("wx_growth") == "hi" and not key.endswith("conv1")))) else None
         return Conv.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["w"], wg, cfg.get("wb", cfg["w"]),
-                          cfg.get("gread_growth", "pair") if growth else "pair", wx_from, bool(cfg.get("wxg5_hi")) and key.endswith("conv5"))
+                          cfg.get("gread_growth", "pair") if growth else "pair", wx_from, bool(cfg.get("wxg5_hi")) and key.endswith("conv5"),
+                          64 if (cfg.get("w_growth_fwd") == "f16" and ".rdb" in key and not key.endswith("conv1")) else None)
 
     x = S(x, "in")
     out1 = S(conv(x, "conv1"), "stream")
@@ -200,6 +203,7 @@ _EXACT = mk("pair", "pair", "pair", "split", "pair")
 # round 5: the two rungs that get built, as they are built, + fp8 (MX e4m3) operands for the 2^-12-weighted correction products
 RUNGS5 = {
     "INFER: stream+tail pair, growth planes f16, W split":           mk("pair", "f16", "pair", "split", "pair"),
+    "INFER40: INFER + the growth chunks meet f16 weights (ONE stage each: 40 stages per block)": _with(mk("pair", "f16", "pair", "split", "pair"), w_growth_fwd="f16"),
     "TRAIN: fwd exact; growth-plane gradients f16 (bwd-data 2 stages, wgrad conv1-4 2 products)": mk("pair", "pair", "pair", "split", "pair", g_dense="f16"),
     "TRAIN2: growth-plane gradients stored as pairs, READ as hi only by backward-data and the weight products; bias sums from hi + lo": _with(_EXACT, gread_growth="hi"),
     "TRAIN3: TRAIN2 + conv5's weight products read the growth planes o1..o4 as their hi tensor": _with(_EXACT, gread_growth="hi", wx5_growth="hi"),

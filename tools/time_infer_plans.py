@@ -1,0 +1,15 @@
+import sys, time, torch
+sys.path.insert(0, '/root/repo')
+import real_esrgan_pytorch_amd as R
+torch.manual_seed(0)
+x = torch.rand(16, 3, 256, 256, device="cuda")
+for rep in range(2):
+    for plan in (27, 59):
+        g = R.Generator(3, 3, 4, precision="exact16", x2_plan=plan).cuda().eval()
+        with torch.no_grad():
+            for _ in range(3): g(x)
+            torch.cuda.synchronize(); t = time.time()
+            for _ in range(10): g(x)
+            torch.cuda.synchronize(); dt = (time.time() - t) / 10
+        print("plan", plan, "%.2f ms  %.1f images/s" % (dt * 1e3, 16 / dt), flush=True)
+        del g
