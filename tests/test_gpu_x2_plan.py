@@ -4,6 +4,8 @@ ResrGeneratorDesc.x2_plan -- DESIGN.md section 2, round 5).
 The residual stream of a dense block stays a (hi, lo) pair; the four growth planes (inference) and their gradients (backward) are
 single f16 tensors: their chunks take two MFMA stages (x W0 + x W1) instead of three, conv1..conv4's weight gradients two
 tap-products instead of three.  Reference arithmetic: /root/reference/model.py:87-98,255-272 (fp32 on the CPU, inference.py:52-53).
+Later bits of the plan: the weight products read the growth planes as their hi tensor (bit 3), conv5's such products with g_y's hi tensor
+(bit 4), and at inference the growth chunks meet the f16 weights alone -- one stage (bit 5, RESR_CONV_SINGLE_W16).  Default plan 59.
 Gates: inference forward <= 2e-4 vs the fp32 oracle at 23 blocks for weights x 1, x 4 and after 60
 training steps; every gradient tensor <= 1e-3 relative L2 vs the float64 evaluation of the oracle (shipped because the emulation
 of tools/precision_ladder_sim.py keeps the worst tensor <= 5e-4 at three geometries and five seeds)."""

@@ -145,7 +145,8 @@ def generator(x, sd, cfg, upscale=4, n_blocks=23):
         wg = cfg.get("wg_growth", cfg["wg"]) if growth else cfg["wg"]
         wx_from = 64 if (".rdb" in key and ((cfg.get("wx5_growth") == "hi" and key.endswith("conv5")) or
                                              (cfg.get("wx_growth") == "hi" and not key.endswith("conv1")))) else None
-        return Conv.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["w"], wg, cfg.get("wb", cfg["w"]),
+        wb = cfg.get("wb_growth", cfg.get("wb", cfg["w"])) if growth else cfg.get("wb", cfg["w"])   # backward-data weights of conv1..4: their G is the single chunk of the mirrored passes
+        return Conv.apply(t, sd[key + ".weight"], sd[key + ".bias"], cfg["w"], wg, wb,
                           cfg.get("gread_growth", "pair") if growth else "pair", wx_from, bool(cfg.get("wxg5_hi")) and key.endswith("conv5"),
                           64 if (cfg.get("w_growth_fwd") == "f16" and ".rdb" in key and not key.endswith("conv1")) else None)
 
@@ -209,6 +210,7 @@ RUNGS5 = {
     "TRAIN3: TRAIN2 + conv5's weight products read the growth planes o1..o4 as their hi tensor": _with(_EXACT, gread_growth="hi", wx5_growth="hi"),
     "TRAIN4: TRAIN2 + EVERY weight product reads the growth planes o1..o4 as their hi tensor (conv2..conv5)": _with(_EXACT, gread_growth="hi", wx_growth="hi"),
     "TRAIN5: TRAIN4 + conv5's growth-plane products take g_y's hi tensor too (one tap-product per growth chunk)": _with(_EXACT, gread_growth="hi", wx_growth="hi", wxg5_hi=True),
+    "TRAIN6: TRAIN5 + backward-data multiplies the growth-plane gradients with f16 weights (ONE stage per single chunk: 40 stages)": _with(_EXACT, gread_growth="hi", wx_growth="hi", wxg5_hi=True, wb_growth="f16"),
     "TRAIN + hi-only wgrad on conv1-4 only":                         _with(mk("pair", "pair", "pair", "split", "pair", g_dense="f16"), wg_growth="f16"),
     "fp8 corrections: weight gradients only":                        _with(_EXACT, fp8="w"),
     "fp8 corrections: backward-data + weight gradients":             _with(_EXACT, fp8="dw"),

@@ -1,5 +1,10 @@
+"""exact16 inference at 16 x 256^2 under two x2_plan values, alternated twice on one box (default: 27 = 50 stages per dense block against
+59 = 40 stages, the growth chunks against f16 weights).
+
+    python tools/time_infer_plans.py
+"""
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import real_esrgan_pytorch_amd as R
 torch.manual_seed(0)
 x = torch.rand(16, 3, 256, 256, device="cuda")
