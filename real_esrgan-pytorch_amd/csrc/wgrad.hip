@@ -46,7 +46,8 @@ struct WgradJob {
     const char* g;        // G base + channel offset of the job's 32-channel tile
     unsigned xstride_b, gstride_b;
     unsigned slab_off;    // float offset of this job's [splits][kSlab] slabs in `partial`
-    unsigned want_bias;   // 1: also produce sum_p G[p][co] (one job per co tile does)
+    unsigned want_bias;   // bit 0: also produce sum_p G[p][co] (one job per co tile does); bit 1: ONLY that -- the quad kernel skips the job's tap
+                          // products (its dW slabs are zeros): the (x_hi chunk 0, g_lo) job of WgradConv.g_lo_bias_only
     unsigned xsub;        // 0..3: X chunk lies in sub-position (i*2+j) of a space-to-depth image -- only 2x2 of the 9 taps of the
                           // virtual kernel of a 4x4 / stride-2 conv are non-zero there; 4: all taps
 };
@@ -399,7 +400,7 @@ struct WgradQuad {
     const char* g[2];
     unsigned xstride_b[2], gstride_b[2];
     unsigned slab_off[4];   // float offset of product p's [splits][kSlab] slabs, ~0u = product not wanted
-    unsigned bias_mask;     // bit p: product p also yields sum_p G (one product per G tile does)
+    unsigned bias_mask;     // bit p: product p also yields sum_p G (one product per G tile does); bit 4 + p: product p yields ONLY that (no taps)
     unsigned xsub;          // byte xi: tap pattern of X chunk xi (WgradJob::xsub)
 };
 
@@ -587,8 +588,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
     // instantiations: every one executes the same staging instructions and one barrier per tile.
     auto tile_loop = [&](auto mode_c) {
         constexpr int MODE = decltype(mode_c)::value;
-        auto vdy = [](int dy) { return MODE == 4 || (MODE >> 1 == 0 ? dy >= 1 : dy <= 1); };
-        auto vdx = [](int dx) { return MODE == 4 || ((MODE & 1) == 0 ? dx >= 1 : dx <= 1); };
+        // MODE 5: no taps at all -- a product nobody wants (a quad's empty slot) or one that exists for its bias sum alone: the wave
+        // stages, reads its G fragments (the sum) and keeps the barriers, its accumulators stay zero
+        auto vdy = [](int dy) { return MODE != 5 && (MODE == 4 || (MODE >> 1 == 0 ? dy >= 1 : dy <= 1)); };
+        auto vdx = [](int dx) { return MODE != 5 && (MODE == 4 || ((MODE & 1) == 0 ? dx >= 1 : dx <= 1)); };
         int it = 0;
         for (; tile < a.ntiles; tile += a.splits, ++it) {
             const int next = tile + a.splits;
@@ -652,7 +655,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
     using M2 = std::integral_constant<int, 2>;
     using M3 = std::integral_constant<int, 3>;
     using M4 = std::integral_constant<int, 4>;
-    switch ((j_xsub >> (8 * xi)) & 0xffu) {   // wave-uniform
+    using M5 = std::integral_constant<int, 5>;
+    const bool no_taps = slab_of(prod) == ~0u || ((j_bias_mask >> (4 + prod)) & 1u);   // wave-uniform
+    if (no_taps) tile_loop(M5{});
+    else switch ((j_xsub >> (8 * xi)) & 0xffu) {   // wave-uniform
         case 0: tile_loop(M0{}); break;
         case 1: tile_loop(M1{}); break;
         case 2: tile_loop(M2{}); break;
@@ -871,7 +877,8 @@ static int build_quads(const WgradArgs& a, int nj, WgradQuadArgs& q) {
             if (qi.prod[p] < 0) continue;
             const WgradJob& j = a.jobs[qi.prod[p]];
             w.slab_off[p] = j.slab_off;
-            if (j.want_bias) w.bias_mask |= 1u << p;
+            if (j.want_bias & 1u) w.bias_mask |= 1u << p;
+            if (j.want_bias & 2u) w.bias_mask |= 16u << p;
         }
     }
     return nq;
@@ -1138,6 +1145,7 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
                     j.gstride_b = (unsigned)(c.g_stride * es);
                     j.slab_off = off;
                     j.want_bias = part < 2 ? want_bias : 0;
+                    if (part == 1 && c.g_lo_bias_only && !getenv("RESR_WGRAD_BIAS_JOBS_FULL")) j.want_bias |= 2u;   // this job exists for the bias sum alone (A/B knob, read per call)
                     j.xsub = (c.x_s2d_c > 0 && dtype != RESR_F32) ? (unsigned)((ck * 32) / c.x_s2d_c) : 4u;
                     if (part == 1) q.slab_b = off;
                     if (part == 2) q.slab_c = off;
