@@ -1145,7 +1145,9 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
                     j.gstride_b = (unsigned)(c.g_stride * es);
                     j.slab_off = off;
                     j.want_bias = part < 2 ? want_bias : 0;
-                    if (part == 1 && c.g_lo_bias_only && !getenv("RESR_WGRAD_BIAS_JOBS_FULL")) j.want_bias |= 2u;   // this job exists for the bias sum alone (A/B knob, read per call)
+                    // (x_hi chunk 0, g_lo) carries the bias sum AND a real term of dW: skipping its taps was measured (+1 % on the exact16 step)
+                    // and rejected -- the worst gradient tensor against the all-pairs plan rises by a fifth (32 x 64^2: 5.1e-4 -> 6.3e-4)
+                    if (part == 1 && c.g_lo_bias_only && getenv("RESR_WGRAD_BIAS_JOBS_NO_TAPS")) j.want_bias |= 2u;   // experiment knob, read per call
                     j.xsub = (c.x_s2d_c > 0 && dtype != RESR_F32) ? (unsigned)((ck * 32) / c.x_s2d_c) : 4u;
                     if (part == 1) q.slab_b = off;
                     if (part == 2) q.slab_c = off;
