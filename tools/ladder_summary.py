@@ -11,9 +11,9 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 out = {}
-for path in sorted(glob.glob(os.path.join(src, "r5_*x*_w*.json")) + glob.glob(os.path.join(src, "r5_bf8_*.json")) + glob.glob(os.path.join(src, "r5t2_*x*_w*.json")) + glob.glob(os.path.join(src, "r5t4_*x*_w*.json")) + glob.glob(os.path.join(src, "r5t5_*x*_w*.json")) + glob.glob(os.path.join(src, "r5i40_*x*_w*.json"))):
+for path in sorted(glob.glob(os.path.join(src, "r5_*x*_w*.json")) + glob.glob(os.path.join(src, "r5_bf8_*.json")) + glob.glob(os.path.join(src, "r5t2_*x*_w*.json")) + glob.glob(os.path.join(src, "r5t4_*x*_w*.json")) + glob.glob(os.path.join(src, "r5t5_*x*_w*.json")) + glob.glob(os.path.join(src, "r5i40_*x*_w*.json")) + glob.glob(os.path.join(src, "r5t6_*x*_w*.json"))):
     base = os.path.basename(path)
-    tag = base[5:-5] if base.startswith(("r5t2_", "r5t4_", "r5t5_")) else base[6:-5] if base.startswith("r5i40_") else base[3:-5]      # r5t2_* / r5t4_*: the TRAIN2 / TRAIN4 rungs, run separately, merged into their geometry
+    tag = base[5:-5] if base.startswith(("r5t2_", "r5t4_", "r5t5_", "r5t6_")) else base[6:-5] if base.startswith("r5i40_") else base[3:-5]      # r5t2_* / r5t4_*: the TRAIN2 / TRAIN4 rungs, run separately, merged into their geometry
     for seed, rows in json.load(open(path)).items():
         out.setdefault(tag, {}).setdefault(seed, {}).update(rows)
 for path in sorted(glob.glob(os.path.join(src, "r5l1_*x*_w*.json"))):   # --loss l1: the train step's own loss, kept as separate geometries
