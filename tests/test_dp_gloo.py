@@ -239,3 +239,23 @@ def test_loss_helpers_call_a_non_stock_criterion():
     assert torch.allclose(losses.bce_with_logits_const(torch.nn.BCEWithLogitsLoss(), x, 1.0, 0.1), want)
     summed = losses.bce_with_logits_const(torch.nn.BCEWithLogitsLoss(reduction="sum"), x, 0.0)
     assert torch.allclose(summed, torch.nn.functional.binary_cross_entropy_with_logits(x, torch.zeros_like(x), reduction="sum"))
+
+
+def test_bench_plain_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment: the parent starts two ranks through torch.distributed.run
+    (children, never an exec) and hands back their exit code.  Without a GPU each rank refuses loudly (the hot path has no CPU
+    fallback), so here the relayed code is non-zero and the refusal is what stderr shows -- the launch path itself is what runs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert "starting 2 ranks" in r.stderr and "--nproc-per-node=2" in r.stderr
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs an MI355X" in r.stderr
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # a launcher whose world disagrees with --gpus is still an error, not a second launch
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, cwd=root, capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "disagree" in r2.stderr and "starting" not in r2.stderr

@@ -210,22 +210,27 @@ def test_bench_two_ranks_prints_one_line():
     assert out["host"]["enqueue_ms_per_step"] > 0 and out["host"]["cpus_in_affinity"] >= 1
 
 
-def test_bench_gan_two_ranks_prints_one_line():
-    """The driver's launch line with --gan (BASELINE config 4): two ranks, generator + discriminator exchanges, one JSON line."""
+def test_bench_gan_two_ranks_plain_launch_prints_one_line():
+    """PLAIN `python bench.py --gpus 2 --gan` -- no launcher, no WORLD_SIZE in the environment (BASELINE config 4): bench.py starts
+    its two ranks itself as children of a process that never touches the GPU (`self_launch`), generator + discriminator exchanges
+    run, and exactly one JSON line with `dist.nranks == 2` comes back through the parent's stdout with the children's exit code."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RESR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--batch", "2", "--lr-size", "32", "--gan"]   # (LR 16: a resize1 factor of 0.15 leaves 9 pixels for the 21-tap blur, which reflect padding refuses -- as F.pad does)
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "starting 2 ranks" in r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["dist"]["nranks"] == 2 and out["dist"]["world"] == 2
     assert out["value"] > 0 and "GAN" in out["metric"] and set(out["losses"]) >= {"pixel_loss", "adversarial_loss", "d_loss_hr", "d_loss_sr", "content_loss"}
     assert "roofline" in out and "error" not in out["roofline"], out.get("roofline")
 
