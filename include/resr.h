@@ -32,7 +32,9 @@ extern "C" {
  * ResrGeneratorDesc gained x2_plan.  A caller built against an older header passes shorter structs: compare resr_version() with the RESR_VERSION it was
  * compiled with and refuse on a mismatch.  New fields are appended (or replace reserved ones) and mean "as before" when zero, so
  * zero-initialise every descriptor (memset / = {0}) before filling it. */
-#define RESR_VERSION 2
+/* 3 (round 6): ResrConvDesc gained in0_q_offset / in1_q_offset / out_q_offset / w_mx_offset (RESR_CONV_MX_PAIRS), ChainJob-level
+ * counterparts follow from the per-job descriptors; resr_pack_weights_mx; RESR_X2_PLAN_MX_INFER. */
+#define RESR_VERSION 3
 
 typedef enum {
     RESR_OK = 0,
@@ -72,7 +74,16 @@ enum {
     /* RESR_F16X2 with x2_pair_chunks: the single chunks meet the f16 weights W0 alone -- ONE stage (x W0) instead of two (x W0 + x W1).
      * For operands that are the small ones of the sum (the growth planes of an inference forward next to the residual stream: forward
      * 1.4-2.1e-6 instead of 1.0-1.4e-6 at the reference's init, 2.4-2.9e-5 instead of 1.6-2.9e-5 with the dense weights x 4). */
-    RESR_CONV_SINGLE_W16 = 1 << 11
+    RESR_CONV_SINGLE_W16 = 1 << 11,
+    /* RESR_F16X2 only: the PAIR chunks take TWO stages instead of three -- the main product x_hi W0 on the f16 matrix pipe, and BOTH
+     * 2^-12-weighted corrections (x_hi W1 + x_lo W2) as ONE stage of nine v_mfma_scale_f32_32x32x64_f8f6f4 per output row on 8-bit
+     * operands: B = the pixel's "q record" [bf8(x_hi) x 32 | bf8(x_lo) x 32] (64 B per pixel and chunk, K = 64 per tap), A = the
+     * packed block [bf8(W1) | bf8(W2)] of resr_pack_weights_mx, unit scales (bf8 = e5m2 has f16's exponent range; the remainders
+     * are stored times 2^12).  Every pair operand then needs its q tensor (in0_q_offset / in1_q_offset), the weights their MX blocks
+     * (w_mx_offset); out_q_offset != 0 makes a pass EMIT the q tensor of its (pair) output for the passes behind it.  The
+     * corrections need ~4 good bits, not 11: forward 0.8-1.2e-4 of the fp32 result over 23 blocks, 2/3 of the
+     * matrix time of a pair chunk.  Inference epilogues only (bias / LeakyReLU / residuals). */
+    RESR_CONV_MX_PAIRS = 1 << 12
 };
 
 /* One 3x3, stride 1, pad 1 convolution pass (forward conv or backward-data conv):
@@ -126,6 +137,12 @@ typedef struct {
      * "not positive"; the mask may then be any f16 tensor, e.g. a view of a larger batch). */
     int32_t reserved2_;
     int64_t mask_lo_offset;
+    /* RESR_F16X2, RESR_CONV_MX_PAIRS (version 3): ELEMENT offsets (2 bytes each, like the lo offsets) from the hi tensor of a pair
+     * operand to its q tensor -- same pixel / chunk strides as the hi tensor, 64 bytes per pixel and 32-channel chunk: byte c = bf8
+     * (e5m2, round to nearest even) of hi[c], byte 32 + c = bf8 of lo[c].  out_q_offset != 0 (any pass with a pair output and a lean
+     * epilogue): also write out's q tensor.  w_mx_offset: BYTE offset from w_packed to this convolution's MX blocks, one block of
+     * 9 x cout_pad x 64 bytes per 32-channel input chunk in chunk order (resr_pack_weights_mx). */
+    int64_t in0_q_offset, in1_q_offset, out_q_offset, w_mx_offset;
 } ResrConvDesc;
 
 int resr_conv3x3(const ResrConvDesc* d, const void* in0, const void* in1, const void* w_packed,
@@ -206,6 +223,12 @@ typedef struct {
 
 int resr_pack_weights(const ResrPackChunk* chunks_dev, int32_t n_chunks, const float* arena,
                       void* packed, int32_t dtype, void* stream);
+/* The MX blocks of RESR_CONV_MX_PAIRS from the SAME chunk table: chunk i becomes one block of 9 x (32 mt) x 64 bytes at
+ * packed_mx + 2 * dst_off bytes (dst_off counts elements of the plain f16 layout, so the MX region mirrors a plain f16 packing byte for
+ * byte): per tap and output row the bytes [bf8(W1[k]), k = 0..31 | bf8(W2[k])] of the exact16 split of resr_pack_weights (W0 =
+ * f16(w 2^12), W1 = f16(w 2^12 - W0), W2 = f16(W0 2^-12)), in the A-fragment order of v_mfma_scale_f32_32x32x64_f8f6f4 (lane (row,
+ * half h): K = 16 h .. 16 h + 15 of either block). */
+int resr_pack_weights_mx(const ResrPackChunk* chunks_dev, int32_t n_chunks, const float* arena, void* packed_mx, void* stream);
 
 /* Layout helpers around the generator (model.py:257 PixelUnshuffle, NCHW fp32 module surface). */
 int resr_nchw_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w,
@@ -258,14 +281,23 @@ enum {
     RESR_X2_PLAN_GROWTH_ACT_G_HI_WGRAD = 16,
     /* with GROWTH_F16_INFER: the growth chunks of an inference forward take ONE stage (RESR_CONV_SINGLE_W16): 40 instead of 50 stages per
      * dense block */
-    RESR_X2_PLAN_GROWTH_W16_INFER = 32
+    RESR_X2_PLAN_GROWTH_W16_INFER = 32,
+    /* inference forward (training = 0) only, with GROWTH_F16_INFER + GROWTH_W16_INFER: the pair chunks (residual stream, HR tail) take
+     * one f16 stage + one MX-fp8 stage (RESR_CONV_MX_PAIRS) instead of three f16 stages: 30 stage-equivalents per dense block
+     * instead of 40.  The workspace grows by the q tensors, the packed weights by their MX region (resr_generator_packed_bytes,
+     * resr_generator_mx_offset).  Forward 0.8-1.2e-4 of the fp32 oracle instead of 2e-6 (gate 2e-4). */
+    RESR_X2_PLAN_MX_INFER = 64
 };
 
 size_t resr_generator_param_count(const ResrGeneratorDesc* d);
 size_t resr_generator_packed_bytes(const ResrGeneratorDesc* d, int32_t backward);
+/* RESR_F16X2: byte offset of the MX region (resr_pack_weights_mx; RESR_X2_PLAN_MX_INFER) inside a packed buffer of
+ * resr_generator_packed_bytes(d, *) bytes: pack the same chunk table there after resr_pack_weights.  0 for other dtypes. */
+size_t resr_generator_mx_offset(const ResrGeneratorDesc* d);
 size_t resr_generator_workspace_bytes(const ResrGeneratorDesc* d);
 /* The first resr_generator_chain_state_bytes(d) bytes of a generator workspace are the chain state of its dense-block
- * launches (resr_conv3x3_chain): the caller fills them with zeros once, when the workspace is allocated. */
+ * launches (resr_conv3x3_chain) and, behind it, the 256-byte slot of the backward pass's gradient pre-scale (below): the caller
+ * fills them with zeros once, when the workspace is allocated. */
 size_t resr_generator_chain_state_bytes(const ResrGeneratorDesc* d);
 /* fills `chunks` (host memory, capacity in elements) and returns the count; forward table first,
  * then (if backward) the backward-data table; dst offsets are relative to one packed buffer */
@@ -283,7 +315,12 @@ int resr_generator_forward(const ResrGeneratorDesc* d, const float* x_nchw, cons
  * stream wait on them and all-reduces each range while the rest of the backward pass still runs.
  * RESR_F16 / RESR_F16X2: the pass does not depend on the scale of gy -- when max |gy| < 2^6 it runs on gy * 2^k (max in [2^6, 2^7)) and hands
  * grad / gx out times 2^-k, both exact, so its f16 tensors never see subnormals at small loss scales; an inf / NaN in gy turns the
- * lift off and reaches grad (resr_discriminator_backward does the same).  $RESR_X2_GRAD_PRESCALE_LOG2, RESR_X2_NO_GRAD_PRESCALE=1. */
+ * lift off and reaches grad (resr_discriminator_backward does the same).  $RESR_X2_GRAD_PRESCALE_LOG2, RESR_X2_NO_GRAD_PRESCALE=1.
+ * The lift leaves 2^9 of headroom to f16's maximum.  A gradient that grows by more than that on its way back overflows whatever the
+ * caller's loss scale is -- a GradScaler halving its scale cannot cure an overflow the lift re-creates every step (the symptom would
+ * be found_inf on every step and a scale decaying to nothing) -- so the pass backs off by itself: a lifted pass that writes a non-finite
+ * weight gradient sets a flag in the workspace's pre-scale slot, and every later pass on that workspace aims 2^4 lower per such event
+ * (sticky, up to 2^40 = lift off: the caller's scale rules again).  The overflowed step is the GradScaler's to skip, as ever. */
 int resr_generator_backward(const ResrGeneratorDesc* d, const float* gy_nchw, const float* params,
                             const void* packed, void* workspace, size_t workspace_bytes,
                             float* grad_params, float* gx_nchw, void* stream,
@@ -427,6 +464,8 @@ typedef struct {
 } ResrDiscriminatorDesc;
 size_t resr_discriminator_param_count(void);
 size_t resr_discriminator_uv_count(void);
+/* The first 256 bytes of a discriminator workspace (1 / sigma of the normalised layers + the gradient pre-scale slot of
+ * resr_discriminator_backward, see resr_generator_backward) are filled with zeros by the caller once, when the workspace is allocated. */
 size_t resr_discriminator_workspace_bytes(const ResrDiscriminatorDesc* d);
 /* chunk table for the pack launch inside resr_discriminator_forward (host memory; returns the count, `chunks` may be NULL to
  * query it).  1/sigma of the normalised layers is read on the device from the head of `workspace`: one table per workspace. */

@@ -22,7 +22,9 @@ CONV_SINGLE_W16 = 1 << 11
 X2_PLAN_GROWTH_F16_INFER, X2_PLAN_GROWTH_GRAD_F16, X2_PLAN_GROWTH_GRAD_STORE_F16, X2_PLAN_GROWTH_ACT_F16_WGRAD = 1, 2, 4, 8
 X2_PLAN_GROWTH_ACT_G_HI_WGRAD = 16
 X2_PLAN_GROWTH_W16_INFER = 32
-RESR_VERSION = 2   # include/resr.h: the structures below mirror THIS version of the header
+X2_PLAN_MX_INFER = 64
+CONV_MX_PAIRS = 1 << 12
+RESR_VERSION = 3   # include/resr.h: the structures below mirror THIS version of the header
 
 
 class ConvDesc(C.Structure):
@@ -37,7 +39,8 @@ class ConvDesc(C.Structure):
                 ("in0_lo_offset", C.c_int64), ("in1_lo_offset", C.c_int64), ("out_lo_offset", C.c_int64),
                 ("res0_lo_offset", C.c_int64), ("res1_lo_offset", C.c_int64),
                 ("s2d_in_channels", C.c_int32), ("s2d_out_channels", C.c_int32), ("cout_groups", C.c_int32),
-                ("x2_pair_chunks", C.c_int32), ("reserved2_", C.c_int32), ("mask_lo_offset", C.c_int64)]
+                ("x2_pair_chunks", C.c_int32), ("reserved2_", C.c_int32), ("mask_lo_offset", C.c_int64),
+                ("in0_q_offset", C.c_int64), ("in1_q_offset", C.c_int64), ("out_q_offset", C.c_int64), ("w_mx_offset", C.c_int64)]
 
 
 class WgradDesc(C.Structure):
@@ -90,6 +93,8 @@ _PROTOS = {
     "resr_wgrad_partial_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "resr_conv3x3_wgrad": (C.c_int, [C.POINTER(WgradDesc), _P, _P, _P, _P, _P, _P, _P]),
     "resr_pack_weights": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P]),
+    "resr_pack_weights_mx": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
+    "resr_generator_mx_offset": (C.c_size_t, [C.POINTER(GeneratorDesc)]),
     "resr_nchw_to_nhwc": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, _P, _P]),
     "resr_nhwc_to_nchw": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -81,6 +81,8 @@ size_t wgrad_partial_bytes(const ResrWgradDesc*);
 int wgrad_debug_plan(const int*, const int*, int, int*, int);
 int wgrad_debug_dense_blocks(int, const void* const*, const void* const*, int, int, int, int, float*, size_t, float*, hipStream_t);
 int pack_dispatch(const ResrPackChunk*, int, const float*, void*, int, hipStream_t);
+int pack_mx_dispatch(const ResrPackChunk*, int, const float*, void*, hipStream_t);
+size_t generator_mx_offset(const ResrGeneratorDesc*);
 int ema_dispatch(float*, const float*, long, double, hipStream_t);
 int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long);
 int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t, long);
@@ -197,6 +199,11 @@ int resr_pack_weights(const ResrPackChunk* chunks_dev, int32_t n_chunks, const f
     return pack_dispatch(chunks_dev, n_chunks, arena, packed, dtype, (hipStream_t)stream);
 }
 
+int resr_pack_weights_mx(const ResrPackChunk* chunks_dev, int32_t n_chunks, const float* arena, void* packed_mx, void* stream) {
+    RESR_DEVICE_SCOPE(stream);
+    return pack_mx_dispatch(chunks_dev, n_chunks, arena, packed_mx, (hipStream_t)stream);
+}
+
 int resr_nchw_to_nhwc(const float* src, void* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t unshuffle,
                       int32_t c_pad, int32_t dtype, const uint8_t* mask, void* stream) {
     RESR_DEVICE_SCOPE(stream);
@@ -217,6 +224,7 @@ int resr_sumpool2x2(const void* src, void* dst, const void* mask, int32_t n, int
 
 size_t resr_generator_param_count(const ResrGeneratorDesc* d) { return generator_param_count(d); }
 size_t resr_generator_packed_bytes(const ResrGeneratorDesc* d, int32_t backward) { return generator_packed_bytes(d, backward); }
+size_t resr_generator_mx_offset(const ResrGeneratorDesc* d) { return generator_mx_offset(d); }
 size_t resr_generator_workspace_bytes(const ResrGeneratorDesc* d) { return generator_workspace_bytes(d); }
 size_t resr_generator_chain_state_bytes(const ResrGeneratorDesc* d) { return generator_chain_state_bytes(d); }
 int64_t resr_generator_pack_table(const ResrGeneratorDesc* d, int32_t backward, ResrPackChunk* chunks, int64_t capacity) {

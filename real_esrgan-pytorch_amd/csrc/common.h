@@ -45,6 +45,19 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // normal range however small the caller's loss scale is -- and every result leaves through * 1/s.  Both factors are exact.  Gradients
 // that are large enough already (m >= 1) are left alone (s = 1): a GradScaler that keeps doubling its scale still meets f16's
 // overflow and settles below it, as it does without the pre-scale.  Zero, denormal or non-finite maxima give s = 1.
+// The slot is a block of words in memory the caller zero-fills once (the head of a generator / discriminator workspace):
+//   [0] the bits of m, rewritten by every pass (absmax_dispatch)
+//   [1] back-off b (sticky): the lift aims 2^b lower -- m is stored times 2^b -- once a LIFTED pass has produced a non-finite weight
+//       gradient: a gradient that grows by more than the 2^9 of headroom on its way back overflows f16 at EVERY loss scale when the lift
+//       re-raises it each step, so a GradScaler backing off could no longer cure it (found_inf would fire until its scale decays to
+//       nothing).  Every such pass lowers the target by 2^4 (up to 2^40: then the lift is effectively off and the caller's scale rules,
+//       as before round 5); the pass that overflowed is the GradScaler's to skip, the next one runs with headroom.
+//   [2] flag: set by the weight-gradient reductions of a lifted pass that wrote a non-finite value; consumed by the next absmax_dispatch
+constexpr int kPrescaleBackoffStep = 4, kPrescaleBackoffMax = 40;
+__host__ __device__ __forceinline__ bool grad_prescale_lifted(unsigned amax_bits) {
+    const unsigned e = (amax_bits >> 23) & 0xffu;
+    return e != 0u && e < 127u;
+}
 __host__ __device__ __forceinline__ float grad_prescale(unsigned amax_bits, bool inverse) {
     const unsigned e = (amax_bits >> 23) & 0xffu;          // biased exponent of m
     if (e == 0u || e >= 127u) return 1.f;

@@ -34,6 +34,13 @@ struct ConvArgs {
     // f16 tensors (two stages: x W0 + x W1); >= cin / 32 = every chunk a pair (ResrConvDesc.x2_pair_chunks)
     int pair_chunks, out_single;
     int single_stages;               // RESR_F16X2: 1 = the single chunks take ONE stage (x W0 alone: RESR_CONV_SINGLE_W16), else two
+    // RESR_CONV_MX_PAIRS (kernel instantiations X2 = 2): a pair chunk is an f16 stage (x_hi W0) + an MX stage on 8-bit operands
+    // (conv3x3_ws.h).  Byte offsets hi tensor -> q tensor of the two input segments (same strides as the hi tensor), element offset
+    // hi -> q of the output (0: no q tensor is written), this convolution's MX weight blocks (one WBUF-sized block per real chunk)
+    int mx;
+    size_t in0_q_b, in1_q_b;
+    long out_q;
+    const char* w_mx;
     // sparse taps of a 4x4 / stride-2 convolution run over the space-to-depth image (conv3x3_ws.h, SP): channels per
     // sub-position of the input (forward), sub-position of this launch's output group (backward-data)
     int s2d_c, tap_c;
@@ -64,6 +71,8 @@ struct ChainJob {
     const char* res1;     // or null
     float s0, t0, s1, t1;
     long out_lo, res0_lo, res1_lo;   // RESR_F16X2: element offsets hi -> lo tensor of out / res0 / res1
+    const char* w_mx;     // RESR_CONV_MX_PAIRS: the job's MX weight blocks (laid out for w_mt tiles like w)
+    long out_q;           // ... and the element offset hi -> q tensor of its output (0: none)
 };
 constexpr int kMaxChain = 6;
 constexpr int kMaxBiasGroups = 8;   // output-group launches WITH a bias keep <= 8 x 64 bias values in LDS (conv3x3_ws.h, GB_OFF)
@@ -101,6 +110,7 @@ inline double conv_algorithmic_bytes(const ConvArgs& a, size_t es) {
     if (a.flags & RESR_CONV_MASK) b += px_out * ((a.flags & RESR_CONV_MASK_BITS) ? ((a.cout + 31) / 32) * 4.0 : a.cout * (double)es);
     if (a.res0) b += px_out * a.cout * es;
     if (a.res1) b += px_out * a.cout * es;
+    if (a.out_q) b += px_out * a.cout * 2.0;   // the q tensor of a pair output: one byte per hi and per lo value
     if (a.aux) b += px_out * ((a.flags & RESR_CONV_WRITE_SIGNBITS) ? ((a.cout + 31) / 32) * 4.0 : nchw ? a.cout : a.cout * (double)es);
     return b;
 }

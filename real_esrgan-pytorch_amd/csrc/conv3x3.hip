@@ -340,7 +340,7 @@ static int conv3x3_args(const ResrConvDesc* d, const void* in0, const void* in1,
     a.in0_chunk_b = (size_t)chunk(d->in0_chunk_stride) * es; a.in1_chunk_b = (size_t)chunk(d->in1_chunk_stride) * es;
     a.out_chunk = chunk(d->out_chunk_stride); a.res0_chunk = chunk(d->res0_chunk_stride);
     a.res1_chunk = chunk(d->res1_chunk_stride); a.mask_chunk = chunk(d->mask_chunk_stride);
-    a.flags = d->flags & ~(RESR_CONV_OUT_SINGLE | RESR_CONV_SINGLE_W16); a.s0 = d->s0; a.t0 = d->t0; a.s1 = d->s1; a.t1 = d->t1; a.slope = d->slope;
+    a.flags = d->flags & ~(RESR_CONV_OUT_SINGLE | RESR_CONV_SINGLE_W16 | RESR_CONV_MX_PAIRS); a.s0 = d->s0; a.t0 = d->t0; a.s1 = d->s1; a.t1 = d->t1; a.slope = d->slope;
     a.s2d_c = 0; a.tap_c = 0; a.ngroups = 1; a.w_group_b = 0;
     // RESR_F16X2: leading pair chunks / a single-f16 output (kept out of a.flags: the kernels and the chain checks never see the bit)
     a.pair_chunks = d->cin / 32; a.out_single = 0;
@@ -355,6 +355,26 @@ static int conv3x3_args(const ResrConvDesc* d, const void* in0, const void* in1,
             if (d->flags & RESR_CONV_OUT_NCHW_F32) return fail(RESR_ERR_ARG, "conv3x3: OUT_SINGLE is an NHWC f16 output");
             a.out_single = 1;
         }
+        // MX stages for the pair chunks (RESR_CONV_MX_PAIRS) and / or a q tensor next to a pair output
+        if (d->in0_q_offset < 0 || d->in1_q_offset < 0 || d->out_q_offset < 0 || d->w_mx_offset < 0)
+            return fail(RESR_ERR_ARG, "conv3x3: negative q / MX offset");
+        if (d->flags & RESR_CONV_MX_PAIRS) {
+            const bool in1_pairs = in1 && d->cin0 < d->cin && a.pair_chunks * 32 > d->cin0;
+            if (d->in0_q_offset == 0 || (in1_pairs && d->in1_q_offset == 0) || d->w_mx_offset == 0)
+                return fail(RESR_ERR_ARG, "conv3x3: RESR_CONV_MX_PAIRS needs the q offset of every pair operand and w_mx_offset");
+            if (d->cout_groups > 1 || d->s2d_in_channels > 0 || d->s2d_out_channels > 0)
+                return fail(RESR_ERR_ARG, "conv3x3: RESR_CONV_MX_PAIRS is a dense 3x3 pass of one output group");
+            a.mx = 1;
+            a.in0_q_b = (size_t)d->in0_q_offset * 2; a.in1_q_b = (size_t)d->in1_q_offset * 2;
+            a.w_mx = (const char*)w + d->w_mx_offset;
+        }
+        if (d->out_q_offset != 0) {
+            if (a.out_single || (d->flags & RESR_CONV_OUT_NCHW_F32) || !(d->flags & RESR_CONV_MX_PAIRS))
+                return fail(RESR_ERR_ARG, "conv3x3: out_q_offset goes with a pair NHWC output of an RESR_CONV_MX_PAIRS pass");
+            a.out_q = (long)d->out_q_offset;
+        }
+    } else if (d->flags & RESR_CONV_MX_PAIRS) {
+        return fail(RESR_ERR_ARG, "conv3x3: RESR_CONV_MX_PAIRS is an RESR_F16X2 mode");
     }
     const int groups = d->cout_groups > 1 ? d->cout_groups : 1;
     if (groups > 1) {
@@ -407,6 +427,7 @@ static int conv3x3_route(const ResrConvDesc* d, ConvArgs& a, bool have_bias, boo
         a.out_lo = a.out_single ? 0L : (long)d->out_lo_offset; a.res0_lo = (long)d->res0_lo_offset; a.res1_lo = (long)d->res1_lo_offset;
         if (!conv3x3_ws_supported(a))
             return fail(RESR_ERR_ARG, "conv3x3: RESR_F16X2 needs tensors below 4 GB / 2^24 pixels and cout %% 8 == 0");
+        if (a.mx && (a.s2d_c > 0 || a.tap_c > 0)) return fail(RESR_ERR_ARG, "conv3x3: RESR_CONV_MX_PAIRS with sparse taps");
         return conv3x3_ws_f16(a, mt, true, stream);
     }
     // 16-row tiles only when that still yields enough workgroups to fill 256 CUs twice over
@@ -459,6 +480,7 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
             if (d[j].dtype != RESR_F16X2 || d[j].in0_lo_offset == 0 || (d[j].out_lo_offset == 0 && !a[j].out_single) || (in1_pairs && d[j].in1_lo_offset == 0)) { ok = false; break; }
             a[j].in0_lo_b = (size_t)d[j].in0_lo_offset * es2; a[j].in1_lo_b = (size_t)d[j].in1_lo_offset * es2;
             a[j].out_lo = a[j].out_single ? 0L : (long)d[j].out_lo_offset;
+            if (a[j].mx != a[0].mx || a[j].in0_q_b != a[0].in0_q_b || a[j].in1_q_b != a[0].in1_q_b) { ok = false; break; }   // one stage map per chain
         }
         if (ok && d5) {
             if (d5->dtype != RESR_F16X2 || d5->in0_lo_offset == 0 || d5->out_lo_offset == 0 || (res0_5 && d5->res0_lo_offset == 0) ||
@@ -506,7 +528,7 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
         const int c0 = c.cin - 32;
         const bool seg1 = c0 >= c.cin0;
         const char* last = seg1 ? c.in1 + (size_t)((c0 - c.cin0) >> 5) * c.in1_chunk_b : c.in0 + (size_t)(c0 >> 5) * c.in0_chunk_b;
-        with5 = with5 && d5->dtype == d[0].dtype && (!x2 || eff_pairs(c) == chain_pairs) && !c.out_single && c.single_stages == b.single_stages && c.in0_lo_b == b.in0_lo_b && c.in1_lo_b == b.in1_lo_b && d5->cout_pad == 64 && c.cout == 64 && c.cin == b.cin + 32 && last == b.out &&
+        with5 = with5 && d5->dtype == d[0].dtype && c.mx == b.mx && c.in0_q_b == b.in0_q_b && c.in1_q_b == b.in1_q_b && (!x2 || eff_pairs(c) == chain_pairs) && !c.out_single && c.single_stages == b.single_stages && c.in0_lo_b == b.in0_lo_b && c.in1_lo_b == b.in1_lo_b && d5->cout_pad == 64 && c.cout == 64 && c.cin == b.cin + 32 && last == b.out &&
                 (c.flags & ~RESR_CONV_NO_BIAS) == 0 && ((c.flags & RESR_CONV_NO_BIAS) != 0) == ((b.flags & RESR_CONV_NO_BIAS) != 0) &&
                 c.n == b.n && c.h == b.h && c.w_ == b.w_ && c.hs == c.h && c.ws == c.w_ &&
                 c.in0_stride_b == 64 && c.in0_chunk_b == b.in0_chunk_b &&
@@ -530,6 +552,7 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
         jobs[j].aux = (a[j].flags == bwd_flags) ? (void*)a[j].mask : (void*)a[j].aux;
         jobs[j].cin = a[j].cin; jobs[j].dep = j - 1; jobs[j].kind = 0; jobs[j].w_mt = 1; jobs[j].w_m = 0;
         jobs[j].out_lo = a[j].out_lo;
+        jobs[j].w_mx = a[j].w_mx; jobs[j].out_q = a[j].out_q;
         flop[j] = 2.0 * 9 * a[j].cin * a[j].cout * (double)a[j].n * a[j].h * a[j].w_;
         bytes[j] = conv_algorithmic_bytes(a[j], x2 ? 4 : 2);
     }
@@ -542,6 +565,7 @@ int conv3x3_block_dispatch(int njobs, const ResrConvDesc* d, const void* in0, co
             ChainJob& q = jobs[4 + m];
             q.w = a5.w; q.w_mt = 2; q.w_m = m;
             q.out_lo = a5.out_lo; q.res0_lo = a5.res0_lo; q.res1_lo = a5.res1_lo;
+            q.w_mx = a5.w_mx; q.out_q = a5.out_q;
             q.bias = a5.bias ? a5.bias + 32 * m : nullptr;
             q.out = a5.out + (size_t)m * a5.out_chunk * 2;
             q.aux = nullptr; q.cin = a5.cin; q.dep = 3; q.kind = 3;

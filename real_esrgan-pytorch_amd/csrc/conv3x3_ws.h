@@ -213,10 +213,20 @@ __device__ __forceinline__ unsigned signs4_x128(unsigned d0, unsigned d1, unsign
 // L2: plain stores and loads are coherent there, and the flags only order them.  Deadlock-free with all workgroups
 // resident: a tile of job j never waits for anything of job j+1, consumers publish a tile one stage after its epilogue
 // without waiting for their producers, and producers only poll (for stage s+2) after barrier s.
-template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0, int CH = 0>
+//
+// X2 = 2 (MX, RESR_CONV_MX_PAIRS): a pair chunk is TWO stages -- part 0 (x_hi, W0) as above, and part 3: BOTH corrections
+// x_hi W1 + x_lo W2 as nine v_mfma_scale_f32_32x32x64_f8f6f4 per output row on 8-bit operands with unit scales.  B = the pixel's q
+// record [bf8(x_hi) x 32 | bf8(x_lo) x 32] -- 64 B per pixel and chunk, the f16 record's size, so halo buffers, slot maps and the
+// LDS-DMA pipeline are the f16 stage's; a lane (pixel, half h) wants K = 16 h .. 16 h + 15 of either 32-wide block, i.e. the 16-byte
+// pieces h and 2 + h of the record: exactly the two k-step reads of an f16 stage.  A = [bf8(W1) | bf8(W2)] per (tap, output row) in
+// the same fragment order (resr_pack_weights_mx), one WBUF-sized block per chunk.  bf8 = e5m2 shares f16's exponent range and both
+// remainders are stored times 2^12: no scale bytes anywhere.  The corrections carry ~3 good bits of a 2^-11-weighted term.
+template <typename T, int MT, int NT, int NWC, int EPI, int X2 = 0, int SP = 0, int CH = 0>
 __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCfg<T, MT, NT, NWC>::NP) / 4) void conv3x3_ws_kernel(const ConvArgs a, const std::conditional_t<CH != 0, ChainArgs, ChainNone> cj) {
     static_assert(!CH || (MT == 1 && SP == 0 && (EPI == 0 || EPI == 16 || EPI == 33) && WsCfg<T, MT, NT, NWC>::NHB == 3), "chain: cout-32 dense-block passes only");
     static_assert(!(CH == 3 && X2), "the pinned-pipeline experiment is fast mode only");
+    constexpr bool MX = X2 == 2;
+    static_assert(!MX || (sizeof(T) == 2 && SP == 0), "MX stages: f16 storage, dense taps");
     using C = WsCfg<T, MT, NT, NWC>;
     constexpr int SPP = C::SPP, KS = C::KS, PB = C::PB, TH = C::TH, TW = C::TW, HW = C::HW, BUF = C::BUF;
     constexpr int NI = C::NI, NG = C::NG, NP = C::NP, NIP = C::NIP;
@@ -274,15 +284,17 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     // behind them single f16 tensors -- two stages (x W0, x W1), or ONE (x W0: a.single_stages = 1, the growth planes of an inference
     // forward against f16 weights).  Packed weights keep three blocks per real chunk whatever its kind (block = chunk * 3 + part; a
     // single chunk never reads its third, a one-stage chunk only its first).
-    const int x2_p = X2 ? a.pair_chunks : 0, x2_p3 = 3 * x2_p;
+    // MX: a pair chunk is two stages -- part 0 (x_hi, W0) and part 3 (the q record against the chunk's MX block).
+    constexpr int PS = MX ? 2 : 3;   // stages of a pair chunk
+    const int x2_p = X2 ? a.pair_chunks : 0, x2_p3 = PS * x2_p;
     const bool x2_one = X2 && a.single_stages == 1;
-    auto stages_of = [&](int cin) { const int c = cin >> 5; return !X2 ? c : (c <= x2_p ? 3 * c : x2_p3 + (x2_one ? c - x2_p : 2 * (c - x2_p))); };
-    auto st_chunk = [&](int ck) { return !X2 ? ck : (ck < x2_p3 ? ck / 3 : x2_p + (x2_one ? ck - x2_p3 : ((ck - x2_p3) >> 1))); };      // real chunk of stage ck
-    auto st_part = [&](int ck) { return !X2 ? 0 : (ck < x2_p3 ? ck % 3 : (x2_one ? 0 : ((ck - x2_p3) & 1))); };               // its part: 0 / 1 on x (hi), 2 on x_lo
-    auto st_wblock = [&](int ck) { return !X2 ? ck : st_chunk(ck) * 3 + st_part(ck); };                        // its packed weight block
-    auto last_stages = [&](int cin) { return !X2 ? 1 : ((cin >> 5) <= x2_p ? 3 : (x2_one ? 1 : 2)); };         // stages of a job's LAST real chunk
+    auto stages_of = [&](int cin) { const int c = cin >> 5; return !X2 ? c : (c <= x2_p ? PS * c : x2_p3 + (x2_one ? c - x2_p : 2 * (c - x2_p))); };
+    auto st_chunk = [&](int ck) { return !X2 ? ck : (ck < x2_p3 ? ck / PS : x2_p + (x2_one ? ck - x2_p3 : ((ck - x2_p3) >> 1))); };      // real chunk of stage ck
+    auto st_part = [&](int ck) { return !X2 ? 0 : (ck < x2_p3 ? (MX ? 3 * (ck & 1) : ck % 3) : (x2_one ? 0 : ((ck - x2_p3) & 1))); };   // its part: 0 / 1 on x (hi), 2 on x_lo, 3 on the q record
+    auto st_wblock = [&](int ck) { return !X2 ? ck : st_chunk(ck) * 3 + st_part(ck); };                        // its packed weight block (parts 0..2)
+    auto last_stages = [&](int cin) { return !X2 ? 1 : ((cin >> 5) <= x2_p ? PS : (x2_one ? 1 : 2)); };        // stages of a job's LAST real chunk
     // does the NEXT stage multiply the halo of stage ck again (part 0 of a chunk that has a part 1)?
-    auto st_keeps_halo = [&](int ck) { return X2 && st_part(ck) == 0 && !(x2_one && ck >= x2_p3); };
+    auto st_keeps_halo = [&](int ck) { return X2 && st_part(ck) == 0 && !(x2_one && ck >= x2_p3) && !(MX && ck < x2_p3); };
     int nchunks = stages_of(a.cin);   // stages per tile (CH: of the current job)
     if constexpr (CH) nchunks = stages_of(cj.job[CH == 3 ? pin_job : 0].cin);
     int tk = 0;
@@ -411,6 +423,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 const bool seg1 = c0 >= a.cin0;
                 const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
                 if (X2 && st_part(ck) == 2) base += seg1 ? a.in1_lo_b : a.in0_lo_b;
+                if (MX && st_part(ck) == 3) base += seg1 ? a.in1_q_b : a.in0_q_b;
                 const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
                 if (stride_b != voff_stride) {
 #pragma unroll
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 }
             };
             auto issue_w = [&](int ck, int par) {   // stage ck's packed weights, lane-linear = fragment order
-                const char* wbase = a.w + (size_t)st_wblock(ck) * C::WBUF;
+                const char* wbase = (MX && st_part(ck) == 3) ? a.w_mx + (size_t)st_chunk(ck) * C::WBUF : a.w + (size_t)st_wblock(ck) * C::WBUF;
 #pragma unroll
                 for (int i = 0; i < C::NWIP; ++i) {
                     const int idx = i * NP + pw;
@@ -465,7 +478,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 auto issue_wj = [&](int jb, int ck, int par) {
                     int wmt = 1, wm = 0;
                     if constexpr (CH == 2) { wmt = cj.job[jb].w_mt; wm = cj.job[jb].w_m; }
-                    const char* wbase = cj.job[jb].w + (size_t)st_wblock(ck) * C::WBUF * wmt + (size_t)wm * 1024;
+                    const char* wbase = (MX && st_part(ck) == 3) ? cj.job[jb].w_mx + (size_t)st_chunk(ck) * C::WBUF * wmt + (size_t)wm * 1024
+                                                                 : cj.job[jb].w + (size_t)st_wblock(ck) * C::WBUF * wmt + (size_t)wm * 1024;
 #pragma unroll
                     for (int i = 0; i < C::NWIP; ++i) {
                         const int idx = i * NP + pw;
@@ -675,7 +689,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         }
         const unsigned wdst0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + C::WOFF);
         auto stage_weights = [&](int tile, int ck, int par) {   // stage ck's packed weights of the tile's output group, lane-linear = fragment order
-            const char* wbase = a.w + (size_t)(tile / ntiles_sp) * a.w_group_b + (size_t)st_wblock(ck) * C::WBUF;
+            const char* wbase = (MX && st_part(ck) == 3) ? a.w_mx + (size_t)st_chunk(ck) * C::WBUF   // (MX launches have one output group: host-checked)
+                                                         : a.w + (size_t)(tile / ntiles_sp) * a.w_group_b + (size_t)st_wblock(ck) * C::WBUF;
 #pragma unroll
             for (int i = 0; i < C::NWIP; ++i) {
                 const int idx = i * NP + pw;
@@ -712,6 +727,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 const bool seg1 = c0 >= a.cin0;
                 const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
                 if (X2 && cpart == 2) base += seg1 ? a.in1_lo_b : a.in0_lo_b;
+                if (MX && cpart == 3) base += seg1 ? a.in1_q_b : a.in0_q_b;
                 const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
                 const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + hpar * BUF);
                 const bool new_halo = !X2 || cpart != 1;   // X2 part 1: the x_hi halo of part 0 again, second weight block
@@ -885,7 +901,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 }
             }
         }
-        for (int ck = 0; ck < nchunks; ++ck) {
+        // One stage.  An MX kernel runs its pair chunks as (f16 stage, MX stage) PAIRS of straight-line code (is_mx_c = the second of the
+        // two): with the two stage bodies as alternatives of one branch inside the stage loop the register allocator splits the
+        // accumulators' live ranges around the branch and spills them (217 registers of the cout-64 shape).
+        auto run_stage = [&](int ck, auto is_mx_c) {
+            constexpr bool IS_MX = decltype(is_mx_c)::value;
             // consumers only read LDS: a bare barrier (no vmcnt drain of the weight ring) is enough
             if (wave == 0) stamp(1);
             asm volatile("s_barrier" ::: "memory");
@@ -901,6 +921,51 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
 #pragma unroll
                 for (int r = 0; r < NT + 2; ++r) rowf[slot][r] = *reinterpret_cast<const uint4*>(bp + r * (HW * PB));
             };
+            if constexpr (IS_MX) {
+                {
+                    // ---- MX stage: both corrections of the chunk, K = 64 per tap -- nine scaled 8-bit MFMAs per output row ----
+                    // B fragment of (row r, dx) = pieces h and 2 + h of the pixel's q record = the two k-step reads of an f16 stage;
+                    // A fragment of tap (dy, dx) = the two 1 KB fragments (tap * 2 + {0, 1}) * MT + m of the chunk's MX block.
+                    static_assert(KS == 2, "MX stage: 64-byte pixel records");
+                    typedef int v8i __attribute__((ext_vector_type(8)));
+                    const char* wl = wlds + wsel * C::WBUF;
+                    const int one = 0x7f7f7f7f;   // e8m0 1.0 for every block: bf8 operands carry their own exponents
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        uint4 q0[NT + 2], q1[NT + 2];
+                        __builtin_amdgcn_sched_barrier(0);   // (one dx group's fragments live at a time: the 8-wave shapes have 128 registers)
+#pragma unroll
+                        for (int r = 0; r < NT + 2; ++r) {
+                            q0[r] = *reinterpret_cast<const uint4*>(lbuf + boff[dx][0] + r * (HW * PB));
+                            q1[r] = *reinterpret_cast<const uint4*>(lbuf + boff[dx][1] + r * (HW * PB));
+                        }
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            uint4 w0[MT], w1[MT];
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                w0[m] = *reinterpret_cast<const uint4*>(wl + (((dy * 3 + dx) * 2 + 0) * MT + m) * 1024);
+                                w1[m] = *reinterpret_cast<const uint4*>(wl + (((dy * 3 + dx) * 2 + 1) * MT + m) * 1024);
+                            }
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                for (int m = 0; m < MT; ++m) {
+                                    const v8i av = {(int)w0[m].x, (int)w0[m].y, (int)w0[m].z, (int)w0[m].w, (int)w1[m].x, (int)w1[m].y, (int)w1[m].z, (int)w1[m].w};
+                                    const v8i bv = {(int)q0[t + dy].x, (int)q0[t + dy].y, (int)q0[t + dy].z, (int)q0[t + dy].w,
+                                                    (int)q1[t + dy].x, (int)q1[t + dy].y, (int)q1[t + dy].z, (int)q1[t + dy].w};
+                                    acc[m][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[m][t], 1, 1, 0, one, 0, one);   // cbsz / blgp 1: bf8
+                                }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    par ^= 1;
+                    hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;
+                    if (wave == 0) stamp(1);
+                    if constexpr (CH) publish();
+                    return;
+                }
+            }
             if constexpr (SP != 0) {
                 // ---- sparse taps: valid dy in {dy0, dy0+1}, valid dx in {dx0, dx0+1}; rows dy0 .. dy0+NT; 2*KS groups ----
                 const int sub = SP == 1 ? (st_chunk(ck) * 32) / a.s2d_c : ((tile / ntiles_sp) * 64) / a.tap_c;   // wave-uniform
@@ -953,7 +1018,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 par ^= 1;
                 if (!st_keeps_halo(ck)) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
                 if (wave == 0) stamp(1);
-                continue;
+                return;
             }
             // the stage's weights are in LDS once the barrier is passed: no prefetch across stages
 #pragma unroll
@@ -986,6 +1051,17 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             if (!st_keeps_halo(ck)) hbc = hbc + 1 == C::NHB ? 0 : hbc + 1;   // X2 part 0: part 1 multiplies the same halo
             if (wave == 0) stamp(1);
             if constexpr (CH) publish();
+        };
+        {
+            int ck = 0;
+            if constexpr (MX) {
+                const int npair = nchunks < x2_p3 ? nchunks : x2_p3;   // the pair chunks' stages: (part 0, part 3) per chunk
+                for (; ck < npair; ck += 2) {
+                    run_stage(ck, std::false_type{});
+                    run_stage(ck + 1, std::true_type{});
+                }
+            }
+            for (; ck < nchunks; ++ck) run_stage(ck, std::false_type{});
         }
 
         if constexpr (FAST) {
@@ -1011,7 +1087,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 int out_chunk, res0_chunk, res1_chunk;
                 float s0, t0, s1, t1, slope;
                 long out_lo, res0_lo, res1_lo;   // X2: element offsets hi -> lo tensor
+                long out_q;                      // MX: element offset hi -> q tensor of the output (0: none)
             } e;
+            e.out_q = 0;
+            if constexpr (MX) e.out_q = ep->out_q;
+            if constexpr (CH && MX) e.out_q = cj.job[job].out_q;
             e.out = ep->out; e.h = ep->h; e.w_ = ep->w_; e.cout = ep->cout; e.out_stride = ep->out_stride;
             e.out_chunk = ep->out_chunk; e.flags = ep->flags; e.slope = ep->slope;
             if constexpr (X2) e.out_lo = ep->out_lo;
@@ -1163,6 +1243,28 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             }
                             if (in_img && piece_ok(m, j))
                                 *reinterpret_cast<uint4v*>(orow + ((size_t)m * e.out_chunk + j * 16 + e.out_lo) * 2) = dl;
+                            if constexpr (MX) {
+                                if (e.out_q != 0) {
+                                    // the q record of the pixel's chunk m: byte c = bf8(hi[c]), byte 32 + c = bf8(lo[c]) -- e5m2 of the f16 values
+                                    // just stored, round to nearest even, unit scale; this lane's 8 channels start at (2 j + kh) * 8
+                                    // (scalar copies first: __builtin_bit_cast on a vector-element lvalue reads element 0 in this toolchain)
+                                    const unsigned dh0 = d[0], dh1 = d[1], dh2 = d[2], dh3 = d[3], dl0 = dl[0], dl1 = dl[1], dl2 = dl[2], dl3 = dl[3];
+                                    short2v h01 = {0, 0}, h23 = {0, 0}, l01 = {0, 0}, l23 = {0, 0};
+                                    h01 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(h01, __builtin_bit_cast(half2v, dh0), 1.f, false);
+                                    h01 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(h01, __builtin_bit_cast(half2v, dh1), 1.f, true);
+                                    h23 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(h23, __builtin_bit_cast(half2v, dh2), 1.f, false);
+                                    h23 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(h23, __builtin_bit_cast(half2v, dh3), 1.f, true);
+                                    l01 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(l01, __builtin_bit_cast(half2v, dl0), 1.f, false);
+                                    l01 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(l01, __builtin_bit_cast(half2v, dl1), 1.f, true);
+                                    l23 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(l23, __builtin_bit_cast(half2v, dl2), 1.f, false);
+                                    l23 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(l23, __builtin_bit_cast(half2v, dl3), 1.f, true);
+                                    char* const qrec = e.out + ((size_t)p * e.out_stride + (size_t)m * e.out_chunk + e.out_q) * 2 + (2 * j + kh_e) * 8;
+                                    if (in_img && piece_ok(m, j)) {
+                                        *reinterpret_cast<uint2v*>(qrec) = uint2v{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+                                        *reinterpret_cast<uint2v*>(qrec + 32) = uint2v{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+                                    }
+                                }
+                            }
                         }
                         if (ESB && own) {
                             if constexpr (X2) {
@@ -1469,7 +1571,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
     }
 }
 
-template <typename T, int MT, int NT, int NWC, int EPI, bool X2 = false, int SP = 0>
+template <typename T, int MT, int NT, int NWC, int EPI, int X2 = 0, int SP = 0>
 static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     using C = WsCfg<T, MT, NT, NWC>;
     ConvArgs args = a;
@@ -1517,8 +1619,17 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
     return RESR_OK;
 }
 
-template <typename T, int MT, int NT, int NWC, bool X2 = false>
+template <typename T, int MT, int NT, int NWC, int X2 = 0>
 static int launch_ws(const ConvArgs& a, hipStream_t stream) {
+    if constexpr (X2 == 2) {   // MX stages (RESR_CONV_MX_PAIRS): the inference epilogues -- bias / LeakyReLU / residuals, all lean
+        const bool lean_ok = !a.aux && !a.mask && !(a.flags & ~(RESR_CONV_LRELU | RESR_CONV_NO_BIAS | RESR_CONV_UPSAMPLE_IN)) &&
+                             !((a.flags & RESR_CONV_LRELU) && !(a.slope >= 0.f && a.slope <= 1.f)) && !((a.res0 || a.res1) && (a.cout & 15));
+        if (!lean_ok) return fail(RESR_ERR_ARG, "conv3x3: RESR_CONV_MX_PAIRS supports bias / LeakyReLU (0 <= slope <= 1) / residual epilogues only");
+        if (a.res0 && a.res1) return launch_ws_epi<T, MT, NT, NWC, 6, X2>(a, stream);
+        if (a.res0) return launch_ws_epi<T, MT, NT, NWC, 2, X2>(a, stream);
+        if (a.res1) return fail(RESR_ERR_ARG, "conv3x3: res1 without res0");
+        return launch_ws_epi<T, MT, NT, NWC, 0, X2>(a, stream);
+    } else {
     const int combo = ((a.flags & RESR_CONV_MASK) ? 1 : 0) | (a.res0 ? 2 : 0) | (a.res1 ? 4 : 0);
     if (a.flags & RESR_CONV_WRITE_SIGNBITS) {   // forward conv + LeakyReLU that also emits its 1-bit mask (checked by the caller)
         if (!X2 && (a.flags & RESR_CONV_LRELU) && !(a.slope >= 0.f && a.slope <= 1.f)) return fail(RESR_ERR_ARG, "conv3x3: sign-bit output needs 0 <= slope <= 1");
@@ -1546,6 +1657,7 @@ static int launch_ws(const ConvArgs& a, hipStream_t stream) {
         default: break;
     }
     return launch_ws_epi<T, MT, NT, NWC, 15, X2>(a, stream);
+    }
 }
 
 

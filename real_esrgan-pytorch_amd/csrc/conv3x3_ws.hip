@@ -15,6 +15,8 @@ int conv3x3_ws_mt1(const ConvArgs& a, int tile_rows, hipStream_t stream);
 int conv3x3_ws_mt2(const ConvArgs& a, int tile_rows, hipStream_t stream);
 int conv3x3_ws_x2_mt1(const ConvArgs& a, int tile_rows, hipStream_t stream);   // RESR_F16X2 instantiations
 int conv3x3_ws_x2_mt2(const ConvArgs& a, int tile_rows, hipStream_t stream);
+int conv3x3_ws_mx_mt1(const ConvArgs& a, int tile_rows, hipStream_t stream);   // RESR_CONV_MX_PAIRS instantiations (conv3x3_ws_mx.hip)
+int conv3x3_ws_mx_mt2(const ConvArgs& a, int tile_rows, hipStream_t stream);
 
 // Preconditions of the producer's 24 x 24-bit offsets and of the 8-channel epilogue; otherwise the caller uses the
 // one-role kernel.
@@ -179,6 +181,10 @@ int conv3x3_ws_f16(const ConvArgs& a, int mt, bool x2, hipStream_t stream) {
     if (mt == 2 && (a.s2d_c > 0 || a.tap_c > 0) && !a.res0 && !a.res1 && !a.mask && !a.aux &&
         !(a.flags & ~(RESR_CONV_LRELU | RESR_CONV_NO_BIAS)) && a.cin0 == a.cin && (!(a.flags & RESR_CONV_LRELU) || (a.slope >= 0.f && a.slope <= 1.f)))
         return conv3x3_ws_sparse(a, 8, a.s2d_c > 0 ? 1 : 2, x2, stream);   // 8-row tiles: the 16-row shape of this variant spills
+    if (x2 && a.mx) {
+        if (mt == 1) return conv3x3_ws_mx_mt1(a, pick_rows(a, rows1, 2), stream);
+        return conv3x3_ws_mx_mt2(a, pick_rows(a, rows2, 2), stream);
+    }
     if (x2) {
         if (mt == 1) return conv3x3_ws_x2_mt1(a, pick_rows(a, rows1, 2), stream);
         return conv3x3_ws_x2_mt2(a, pick_rows(a, rows2, 2), stream);

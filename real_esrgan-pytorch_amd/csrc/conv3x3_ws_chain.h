@@ -6,7 +6,7 @@
 
 namespace resr {
 
-template <int NT, int EPI, int CH, bool X2>
+template <int NT, int EPI, int CH, int X2>
 static int launch_chain(const ConvArgs& a, const ChainArgs& cj, double flop, double bytes, hipStream_t stream) {
     using C = WsCfg<half_t, 1, NT, 8>;
     auto kern = conv3x3_ws_kernel<half_t, 1, NT, 8, EPI, X2, 0, CH>;
@@ -57,27 +57,32 @@ static int launch_chain(const ConvArgs& a, const ChainArgs& cj, double flop, dou
 
 // kind: 0 = forward at inference (LeakyReLU), 1 = forward in training (LeakyReLU + sign words), 2 = mirrored backward-data;
 // jobs of kind "residual half" (the closing convolution inside the chain) take the instantiation with the per-job switches
-template <int NT, int CH, bool X2>
+template <int NT, int CH, int X2>
 static int launch_chain_kind(const ConvArgs& a, const ChainArgs& cj, int kind, double flop, double bytes, hipStream_t stream) {
-    if (kind == 2) return launch_chain<NT, 33, CH, X2>(a, cj, flop, bytes, stream);
-    return kind == 1 ? launch_chain<NT, 16, CH, X2>(a, cj, flop, bytes, stream) : launch_chain<NT, 0, CH, X2>(a, cj, flop, bytes, stream);
+    if constexpr (X2 == 2) {   // MX stages: inference chains only (LeakyReLU; the closing convolution's halves through CH 2)
+        if (kind != 0) return fail(RESR_ERR_ARG, "conv3x3_chain: RESR_CONV_MX_PAIRS chains are inference forward passes");
+        return launch_chain<NT, 0, CH, X2>(a, cj, flop, bytes, stream);
+    } else {
+        if (kind == 2) return launch_chain<NT, 33, CH, X2>(a, cj, flop, bytes, stream);
+        return kind == 1 ? launch_chain<NT, 16, CH, X2>(a, cj, flop, bytes, stream) : launch_chain<NT, 0, CH, X2>(a, cj, flop, bytes, stream);
+    }
 }
 
-template <bool X2>
+template <int X2>
 static int chain_launch_t(const ConvArgs& a, const ChainArgs& cj, int tile_rows, int kind, double flop, double bytes, hipStream_t stream) {
     if constexpr (!X2) {
-        if (cj.split[1] > 0) return launch_chain_kind<1, 3, false>(a, cj, kind, flop, bytes, stream);   // pinned pipeline (experiment): 8-row tiles
+        if (cj.split[1] > 0) return launch_chain_kind<1, 3, 0>(a, cj, kind, flop, bytes, stream);   // pinned pipeline (experiment): 8-row tiles
     }
     bool mixed = false;
     for (int j = 0; j < cj.njobs; ++j) mixed = mixed || cj.job[j].kind == 3;
     if constexpr (X2) {   // exact16 with the closing convolution's halves: the 16-row shape exceeds its 128-register budget (it spills)
-        if (mixed) return launch_chain_kind<1, 2, true>(a, cj, kind, flop, bytes, stream);
-        if (tile_rows >= 16) return launch_chain_kind<2, 1, true>(a, cj, kind, flop, bytes, stream);
-        return launch_chain_kind<1, 1, true>(a, cj, kind, flop, bytes, stream);
+        if (mixed) return launch_chain_kind<1, 2, X2>(a, cj, kind, flop, bytes, stream);
+        if (tile_rows >= 16) return launch_chain_kind<2, 1, X2>(a, cj, kind, flop, bytes, stream);
+        return launch_chain_kind<1, 1, X2>(a, cj, kind, flop, bytes, stream);
     } else {
         if (tile_rows >= 16)
-            return mixed ? launch_chain_kind<2, 2, false>(a, cj, kind, flop, bytes, stream) : launch_chain_kind<2, 1, false>(a, cj, kind, flop, bytes, stream);
-        return mixed ? launch_chain_kind<1, 2, false>(a, cj, kind, flop, bytes, stream) : launch_chain_kind<1, 1, false>(a, cj, kind, flop, bytes, stream);
+            return mixed ? launch_chain_kind<2, 2, 0>(a, cj, kind, flop, bytes, stream) : launch_chain_kind<2, 1, 0>(a, cj, kind, flop, bytes, stream);
+        return mixed ? launch_chain_kind<1, 2, 0>(a, cj, kind, flop, bytes, stream) : launch_chain_kind<1, 1, 0>(a, cj, kind, flop, bytes, stream);
     }
 }
 

@@ -4,7 +4,7 @@
 namespace resr {
 
 int conv3x3_ws_chain_launch_x2(const ConvArgs& a, const ChainArgs& cj, int tile_rows, int kind, double flop, double bytes, hipStream_t stream) {
-    return chain_launch_t<true>(a, cj, tile_rows, kind, flop, bytes, stream);
+    return chain_launch_t<1>(a, cj, tile_rows, kind, flop, bytes, stream);
 }
 
 }  // namespace resr

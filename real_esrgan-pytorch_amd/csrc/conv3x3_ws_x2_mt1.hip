@@ -5,8 +5,8 @@
 namespace resr {
 
 int conv3x3_ws_x2_mt1(const ConvArgs& a, int tile_rows, hipStream_t stream) {
-    if (tile_rows >= 16) return launch_ws<half_t, 1, 2, 8, true>(a, stream);
-    return launch_ws<half_t, 1, 1, 8, true>(a, stream);
+    if (tile_rows >= 16) return launch_ws<half_t, 1, 2, 8, 1>(a, stream);
+    return launch_ws<half_t, 1, 1, 8, 1>(a, stream);
 }
 
 }  // namespace resr

@@ -163,7 +163,8 @@ void carve(const DPlan& p, char* base, DBufs& b) {
     const size_t px = (size_t)p.d.n * p.d.h * p.d.w;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += align_up(bytes, 256); return q; };
-    b.sigma = (float*)take(kLayers * 2 * sizeof(float));
+    b.sigma = (float*)take(kLayers * 2 * sizeof(float));   // (64 of the slot's 256 bytes)
+    b.gscale = base ? reinterpret_cast<unsigned*>(base + 128) : nullptr;   // the gradient pre-scale slot (common.h): inside the head the caller zero-fills once
     b.uv = (float*)take(p.n_uv * sizeof(float));
     b.packed = take(p.pk_elems * elem_size(p.d.dtype) * (p.d.dtype == RESR_F16X2 ? 3 : 1) + 16384);
     {   // spectral-norm scratch of every normalised layer (all layers iterate in the same four launches): rows + ceil(rows / 32) * cols floats each
@@ -192,7 +193,6 @@ void carve(const DPlan& p, char* base, DBufs& b) {
         b.G2 = take(px / 16 * 256 * es); b.g_s2 = take(px / 16 * 512 * es);
         b.G1 = take(px / 4 * 128 * es); b.g_s1 = take(px / 4 * 256 * es);
         b.G0 = take(px * 64 * es); b.gxin = take(px * 32 * es);
-        b.gscale = (unsigned*)take(256);
         b.raw = (float*)take((size_t)512 * 1024 * 9 * sizeof(float));
         b.folded = (float*)take((size_t)512 * 256 * 16 * sizeof(float));
         b.tmp1 = (float*)take(8 * 512 * sizeof(float));   // block partials of the spectral-norm backward's <G, W>, all layers

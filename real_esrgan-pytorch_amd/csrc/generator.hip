@@ -51,6 +51,7 @@ int nchw_to_nhwc_dispatch(const float*, void*, int, int, int, int, int, int, int
 int nhwc_to_nchw_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t, long);
 int absmax_dispatch(const float*, long, unsigned*, int, hipStream_t);
 int nchw_to_nhwc_scaled_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long, const unsigned*);
+int nchw_to_nhwc_q_dispatch(const float*, void*, int, int, int, int, int, int, int, const uint8_t*, hipStream_t, long, const unsigned*, long);
 int nhwc_to_nchw_scaled_dispatch(const void*, float*, int, int, int, int, int, int, int, hipStream_t, long, const unsigned*);
 int sumpool2x2_dispatch(const void*, void*, const void*, int, int, int, int, int, float, hipStream_t, long, long);
 int add_inplace_dispatch(void*, const void*, long, int, hipStream_t, long, long);
@@ -80,6 +81,14 @@ struct Plan {
 };
 
 int round32(int v) { return (v + 31) / 32 * 32; }
+
+// RESR_X2_PLAN_MX_INFER: an exact16 INFERENCE forward whose pair chunks take one f16 stage + one MX stage (RESR_CONV_MX_PAIRS).  Rides
+// on the single-f16 growth planes against f16 weights (bits 0 + 5): every activation buffer then holds THREE tensors -- hi, lo and the
+// q tensor (bf8 of both, 2 bytes per element) -- and the packed weights an MX region behind the f16 blocks (generator_mx_offset).
+bool plan_mx(const ResrGeneratorDesc& d) {
+    const int need = RESR_X2_PLAN_GROWTH_F16_INFER | RESR_X2_PLAN_GROWTH_W16_INFER | RESR_X2_PLAN_MX_INFER;
+    return d.dtype == RESR_F16X2 && !d.training && (d.x2_plan & need) == need;
+}
 
 bool build_plan(const ResrGeneratorDesc* d, Plan& p) {
     if (!d) return false;
@@ -205,7 +214,7 @@ int splits_for(const Plan& p, int npairs, int h, int w, int nquads = 0) {
 }
 
 void carve(const Plan& p, char* base, Bufs& b) {
-    const size_t es = elem_size(p.d.dtype) * act_tensors(p.d.dtype);   // bytes per activation element (hi + lo)
+    const size_t es = elem_size(p.d.dtype) * (act_tensors(p.d.dtype) + (plan_mx(p.d) ? 1 : 0));   // bytes per activation element (hi + lo [+ q])
     const int wm = p.d.dtype == RESR_F16X2 ? 3 : 1;                     // weight-gradient jobs per product (upper bound: sizes the slab buffer)
     const size_t px = (size_t)p.d.n * p.h * p.w;
     size_t off = 0;
@@ -214,9 +223,9 @@ void carve(const Plan& p, char* base, Bufs& b) {
         off += align_up(bytes, 256);
         return ptr;
     };
-    b.gscale = nullptr;
     b.chain_bytes = conv3x3_chain_state_bytes(p.d.n, p.h, p.w);
     b.chain = take(b.chain_bytes);
+    b.gscale = (unsigned*)take(256);   // with the chain state: the zero-filled head of the workspace (its words 1, 2 are sticky: common.h)
     b.x_in = take(px * p.ci_pad * es);
     const int nws = p.d.training ? p.nrdb : 3;
     b.ws.resize(nws);
@@ -243,7 +252,6 @@ void carve(const Plan& p, char* base, Bufs& b) {
         for (int i = 0; i < 4; ++i) b.gT[i] = take(px * 64 * es);
         for (int i = 0; i < 3; ++i) b.gS[i] = take(px * 128 * es);
         b.gxin = take(px * p.ci_pad * es);
-        b.gscale = (unsigned*)take(256);
         // wgrad slabs: largest batch (an RRDB = 78 products, a dense block = 26 at LR; single 64->64 convs = 4 jobs at 1x/2x/4x)
         const size_t slab = (9 * 1024 + 32) * sizeof(float);
         size_t pb = 0;
@@ -303,16 +311,26 @@ size_t generator_param_count(const ResrGeneratorDesc* d) {
     return build_plan(d, p) ? p.n_params : 0;
 }
 
+// Byte offset of the MX region inside the packed buffer (RESR_F16X2): behind the f16 blocks of the forward AND backward-data tables
+// whatever the pass, so that one buffer serves every use; the region mirrors a plain f16 packing (2 bytes per plain element).
+size_t generator_mx_offset(const ResrGeneratorDesc* d) {
+    Plan p;
+    if (!build_plan(d, p) || d->dtype != RESR_F16X2) return 0;
+    return align_up(p.pk_total_elems * 2 * 3 + 16384, 256);
+}
+
 size_t generator_packed_bytes(const ResrGeneratorDesc* d, int backward) {
     Plan p;
     if (!build_plan(d, p)) return 0;
+    if (d->dtype == RESR_F16X2 && (d->x2_plan & RESR_X2_PLAN_MX_INFER)) return generator_mx_offset(d) + p.pk_total_elems * 2 + 16384;
     // + two dummy (chunk,tap) of slack: conv3x3_kernel prefetches two taps past the end
     return (backward ? p.pk_total_elems : p.pk_fwd_elems) * elem_size(d->dtype) * (d->dtype == RESR_F16X2 ? 3 : 1) + 16384;
 }
 
+// the zero-filled head of a workspace: the chain state of the dense-block launches + the gradient pre-scale slot behind it
 size_t generator_chain_state_bytes(const ResrGeneratorDesc* d) {
     Plan p;
-    return build_plan(d, p) ? conv3x3_chain_state_bytes(p.d.n, p.h, p.w) : 0;
+    return build_plan(d, p) ? align_up(conv3x3_chain_state_bytes(p.d.n, p.h, p.w), 256) + 256 : 0;
 }
 
 size_t generator_workspace_bytes(const ResrGeneratorDesc* d) {
@@ -449,16 +467,29 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
     const int64_t lo_out1 = b.out1 == b.ws[0] ? lo_ws : LO(2, plane);
     auto W = [&](const ConvSpec& c) { return pk + c.pk_fwd * wes; };
     auto Bias = [&](const ConvSpec& c) { return params + c.b_off; };
+    // RESR_X2_PLAN_MX_INFER: the q tensor of a buffer follows its lo tensor (element offset hi -> q = twice hi -> lo); a pass whose
+    // pair chunks take the MX stage says so (in_q = its input's hi -> q offset), names its convolution's MX blocks, and emits the q
+    // tensor of its own output when a later pass reads that output through an MX stage (out_q; 0: none)
+    const bool mx = plan_mx(*d);
+    const char* pk_mx = mx ? pk + generator_mx_offset(d) : nullptr;
+    auto MXP = [&](ResrConvDesc& cd, const ConvSpec& c, int64_t in_q, int64_t out_q) {
+        if (!mx) return;
+        cd.flags |= RESR_CONV_MX_PAIRS;
+        cd.in0_q_offset = in_q; cd.out_q_offset = out_q;
+        cd.w_mx_offset = (int64_t)((pk_mx + c.pk_fwd * 2) - W(c));
+    };
 
-    RUN(nchw_to_nhwc_dispatch(x, b.x_in, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, nullptr, st, (long)lo_xin));
+    RUN(nchw_to_nhwc_q_dispatch(x, b.x_in, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, nullptr, st, (long)lo_xin, nullptr, mx ? 2L * (long)lo_xin : 0L));
     {   // conv1 -> ws[0][0:64]                                           model.py:259
         const ConvSpec& c = p.convs[p.i_conv1];
         ResrConvDesc cd = conv_desc(p, N, h, w, p.ci_pad, p.ci_pad, p.ci_pad, 0, 64, 64, 32, 0);
         cd.out_chunk_stride = plane;
         cd.in0_lo_offset = lo_xin; cd.out_lo_offset = lo_ws;
+        MXP(cd, c, 2 * lo_xin, 2 * lo_ws);
         RUN(conv3x3_dispatch(&cd, b.x_in, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.ws[0], nullptr, st));
         if (b.out1 != b.ws[0]) {  // inference: second copy of out1 (0.01 % of the FLOPs) instead of a pinned workspace
             cd.out_stride = b.out1_stride; cd.out_chunk_stride = 0; cd.out_lo_offset = lo_out1;
+            cd.out_q_offset = 0;   // (read as a residual only)
             RUN(conv3x3_dispatch(&cd, b.x_in, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.out1, nullptr, st));
         }
     }
@@ -476,6 +507,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
                 cd.in0_chunk_stride = plane;
                 cd.in0_lo_offset = lo_ws; cd.out_lo_offset = lo_ws;
                 if (growth_single) { cd.x2_pair_chunks = 2; cd.flags |= RESR_CONV_OUT_SINGLE | (growth_w16 ? RESR_CONV_SINGLE_W16 : 0); }
+                MXP(cd, c, 2 * lo_ws, 0);
                 char* signs = nullptr;
                 if (d->training) {   // the backward pass reads the 1-bit mask, not the activation
                     cd.flags |= RESR_CONV_WRITE_SIGNBITS;
@@ -493,6 +525,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
             cd.out_chunk_stride = plane;
             cd.in0_lo_offset = lo_ws; cd.out_lo_offset = last ? lo_t : lo_ws;
             if (growth_single) { cd.x2_pair_chunks = 2; if (growth_w16) cd.flags |= RESR_CONV_SINGLE_W16; }
+            MXP(cd, c, 2 * lo_ws, last ? 2 * lo_t : 2 * lo_ws);
             cd.s0 = 0.2f; cd.t0 = 1.f; cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.res0_lo_offset = lo_ws;  // model.py:95-96
             const char* res1 = nullptr;
             if (r % 3 == 2) {  // model.py:129-130
@@ -510,6 +543,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         cd.res0_chunk_stride = b.out1 == b.ws[0] ? plane : 0;
         cd.out_stride = 32; cd.out_chunk_stride = plane;        // feat and the whole HR tail are chunk-planar [2][N,H,W,32] too
         cd.in0_lo_offset = lo_t; cd.res0_lo_offset = lo_out1; cd.out_lo_offset = lo_t;
+        MXP(cd, c, 2 * lo_t, 2 * lo_t);
         RUN(conv3x3_dispatch(&cd, b.trunk_out, nullptr, W(c), Bias(c), b.out1, nullptr, nullptr, b.feat, nullptr, st));
     }
     {   // model.py:264
@@ -517,6 +551,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         ResrConvDesc cd = conv_desc(p, N, 2 * h, 2 * w, 64, 64, 32, 0, 64, 64, 32, RESR_CONV_LRELU | RESR_CONV_UPSAMPLE_IN);
         cd.in0_chunk_stride = plane; cd.out_chunk_stride = 4 * plane;
         cd.in0_lo_offset = lo_t; cd.out_lo_offset = LO(2, 4L * plane);
+        MXP(cd, c, 2 * lo_t, 2 * LO(2, 4L * plane));
         RUN(conv3x3_dispatch(&cd, b.feat, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.u1, nullptr, st));
     }
     {   // model.py:265
@@ -525,6 +560,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         cd.in0_chunk_stride = 4 * plane; cd.out_chunk_stride = 16 * plane;
         cd.in0_lo_offset = LO(2, 4L * plane); cd.out_lo_offset = LO(2, 16L * plane);
         if (d->training) cd.flags |= RESR_CONV_WRITE_SIGNBITS;
+        MXP(cd, c, 2 * LO(2, 4L * plane), 2 * LO(2, 16L * plane));
         RUN(conv3x3_dispatch(&cd, b.u1, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.u2, b.bits_u2, st));
     }
     {   // model.py:267
@@ -533,6 +569,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         cd.in0_chunk_stride = 16 * plane; cd.out_chunk_stride = 16 * plane;
         cd.in0_lo_offset = LO(2, 16L * plane); cd.out_lo_offset = LO(2, 16L * plane);
         if (d->training) cd.flags |= RESR_CONV_WRITE_SIGNBITS;
+        MXP(cd, c, 2 * LO(2, 16L * plane), 0);   // (conv4 -- 0.15 % of the FLOPs, the fp32 NCHW epilogue -- keeps its three f16 stages: no q tensor of c3)
         RUN(conv3x3_dispatch(&cd, b.u2, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.c3, b.bits_c3, st));
     }
     {   // model.py:268-270

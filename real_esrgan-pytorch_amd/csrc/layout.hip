@@ -25,7 +25,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
                                                            int n, int c, int h, int w, int r, int c_pad,
                                                            const uint8_t* __restrict__ mask, long lo_off,
-                                                           const unsigned* __restrict__ amax) {
+                                                           const unsigned* __restrict__ amax, long q_off) {
     // output pixel grid is (h/r) x (w/r); output channel = ch*r*r + i*r + j  (torch pixel_unshuffle).
     // One thread per 16-byte piece of an output pixel: consecutive threads write consecutive 16 bytes.
     // Rows and images come from blockIdx.y / blockIdx.z, (pixel, piece) inside the row from one 32-bit division: decoded from one flat
@@ -65,6 +65,24 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         }
         *reinterpret_cast<uint4*>(dst + p * c_pad + piece * E) = out;
         if (sizeof(T) == 2 && lo_off) *reinterpret_cast<uint4*>(dst + lo_off + p * c_pad + piece * E) = outl;
+        if constexpr (sizeof(T) == 2) {
+            if (lo_off && q_off) {
+                // the q tensor of RESR_CONV_MX_PAIRS (include/resr.h): per pixel and 32-channel chunk 64 bytes, byte c = bf8(hi[c]), byte
+                // 32 + c = bf8(lo[c]) (e5m2 = the f16 pattern rounded to its upper byte, nearest even); this thread owns 8 channels
+                const unsigned short* hs = reinterpret_cast<const unsigned short*>(&out);
+                const unsigned short* ls = reinterpret_cast<const unsigned short*>(&outl);
+                unsigned long long qh = 0ull, ql = 0ull;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned a = hs[e], b2 = ls[e];
+                    qh |= (unsigned long long)(((a + 0x7fu + ((a >> 8) & 1u)) >> 8) & 0xffu) << (8 * e);
+                    ql |= (unsigned long long)(((b2 + 0x7fu + ((b2 >> 8) & 1u)) >> 8) & 0xffu) << (8 * e);
+                }
+                char* rec = reinterpret_cast<char*>(dst + q_off + p * c_pad + (piece >> 2) * 32) + (piece & 3) * 8;
+                *reinterpret_cast<unsigned long long*>(rec) = qh;
+                *reinterpret_cast<unsigned long long*>(rec + 32) = ql;
+            }
+        }
     }
 }
 
@@ -229,6 +247,22 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ dst, c
 static unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
 
 // RESR_F16X2: lo_off < 0 selects the C-ABI default -- the lo tensor directly follows the hi tensor
+// The sticky half of the slot (common.h): a non-finite result of the previous lifted pass lowers the target; m leaves times 2^back-off.
+__global__ void absmax_backoff_kernel(unsigned* __restrict__ slot) {
+    unsigned b = slot[1];
+    if (b > (unsigned)kPrescaleBackoffMax) b = (unsigned)kPrescaleBackoffMax;
+    if (slot[2]) {
+        b = b + kPrescaleBackoffStep > (unsigned)kPrescaleBackoffMax ? (unsigned)kPrescaleBackoffMax : b + kPrescaleBackoffStep;
+        slot[2] = 0u;
+    }
+    slot[1] = b;
+    const unsigned m = slot[0], e = (m >> 23) & 0xffu;
+    if (b && e != 0u && e < 255u) {
+        const unsigned e2 = e + b > 254u ? 254u : e + b;
+        slot[0] = (m & 0x807fffffu) | (e2 << 23);
+    }
+}
+
 int absmax_dispatch(const float* src, long count, unsigned* slot, int target_log2, hipStream_t stream) {
     if (!src || !slot || count <= 0 || target_log2 < -64 || target_log2 > 64) return fail(RESR_ERR_ARG, "absmax: bad argument");
     if (hipMemsetAsync(slot, 0, sizeof(unsigned), stream) != hipSuccess) return fail(RESR_ERR_LAUNCH, "absmax: memset");
@@ -236,9 +270,13 @@ int absmax_dispatch(const float* src, long count, unsigned* slot, int target_log
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(want < 1 ? 1 : want > 2048 ? 2048 : want)), dim3(256), 0, stream, src, count, slot,
                        ((size_t)src & 15) ? 0 : 1, ldexpf(1.f, -target_log2));
     RESR_CHECK_LAUNCH("absmax_kernel");
+    hipLaunchKernelGGL(absmax_backoff_kernel, dim3(1), dim3(1), 0, stream, slot);
+    RESR_CHECK_LAUNCH("absmax_backoff_kernel");
     return RESR_OK;
 }
 
+int nchw_to_nhwc_q_dispatch(const float* src, void* dst, int n, int c, int h, int w, int r, int c_pad, int dtype,
+                            const uint8_t* mask, hipStream_t stream, long lo_off, const unsigned* amax, long q_off);
 int nchw_to_nhwc_scaled_dispatch(const float* src, void* dst, int n, int c, int h, int w, int r, int c_pad, int dtype,
                                  const uint8_t* mask, hipStream_t stream, long lo_off, const unsigned* amax);
 int nchw_to_nhwc_dispatch(const float* src, void* dst, int n, int c, int h, int w, int r, int c_pad, int dtype,
@@ -249,15 +287,22 @@ int nchw_to_nhwc_dispatch(const float* src, void* dst, int n, int c, int h, int 
 // amax: device pointer to the bits of max |src| (absmax_dispatch) -- src is read times grad_prescale(*amax) -- or nullptr
 int nchw_to_nhwc_scaled_dispatch(const float* src, void* dst, int n, int c, int h, int w, int r, int c_pad, int dtype,
                                  const uint8_t* mask, hipStream_t stream, long lo_off, const unsigned* amax) {
+    return nchw_to_nhwc_q_dispatch(src, dst, n, c, h, w, r, c_pad, dtype, mask, stream, lo_off, amax, 0L);
+}
+
+// q_off != 0 (RESR_F16X2): also write the q tensor (bf8 of hi and lo, RESR_CONV_MX_PAIRS) at that element offset behind dst
+int nchw_to_nhwc_q_dispatch(const float* src, void* dst, int n, int c, int h, int w, int r, int c_pad, int dtype,
+                            const uint8_t* mask, hipStream_t stream, long lo_off, const unsigned* amax, long q_off) {
+    if (q_off != 0 && (dtype != RESR_F16X2 || (c_pad & 31))) return fail(RESR_ERR_ARG, "nchw_to_nhwc: a q tensor goes with RESR_F16X2 and c_pad %% 32 == 0");
     if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || r <= 0 || (h % r) || (w % r) || c * r * r > c_pad || (c_pad & 7))
         return fail(RESR_ERR_ARG, "nchw_to_nhwc: bad argument (c=%d r=%d c_pad=%d h=%d w=%d)", c, r, c_pad, h, w);
     const dim3 grid(blocks_for((long)(w / r) * (c_pad / (dtype != RESR_F32 ? 8 : 4))), (unsigned)(h / r > 65535 ? 65535 : h / r), (unsigned)(n > 65535 ? 65535 : n));
     if (dtype == RESR_F16X2 && lo_off < 0) lo_off = (long)n * (h / r) * (w / r) * c_pad;
     if (dtype != RESR_F16X2) lo_off = 0;
     if (dtype != RESR_F32)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, grid, dim3(256), 0, stream, src, (half_t*)dst, n, c, h, w, r, c_pad, mask, lo_off, amax);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, grid, dim3(256), 0, stream, src, (half_t*)dst, n, c, h, w, r, c_pad, mask, lo_off, amax, q_off);
     else
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, stream, src, (float*)dst, n, c, h, w, r, c_pad, mask, 0L, amax);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, stream, src, (float*)dst, n, c, h, w, r, c_pad, mask, 0L, amax, 0L);
     RESR_CHECK_LAUNCH("nchw_to_nhwc_kernel");
     return RESR_OK;
 }

@@ -77,6 +77,62 @@ int pack_dispatch(const ResrPackChunk* chunks_dev, int n_chunks, const float* ar
     return RESR_OK;
 }
 
+// f16 -> bf8 (e5m2), round to nearest even: e5m2 is f16's sign, exponent and two leading significand bits, so the conversion rounds
+// the 16-bit pattern to its upper byte (carries run into the exponent as they should; f16 subnormals become e5m2 subnormals).
+// The conv epilogue makes its q records with v_cvt_scalef32_pk_bf8_f16 at unit scale: the same function (tests/test_gpu_mx.py).
+__host__ __device__ __forceinline__ unsigned f16_bits_to_bf8(unsigned h) {
+    return ((h + 0x7fu + ((h >> 8) & 1u)) >> 8) & 0xffu;
+}
+
+// resr_pack_weights_mx: the MX block of a chunk (RESR_CONV_MX_PAIRS; conv3x3_ws.h, X2 = 2) -- per tap and output row 64 bytes
+// [bf8(W1[k]) k = 0..31 | bf8(W2[k])] of the exact16 split above, as A fragments of v_mfma_scale_f32_32x32x64_f8f6f4: 16-byte piece
+// ((tap * 2 + p) * mt + tile) * 64 + h * 32 + row holds K = 16 h .. 16 h + 15 of block p (0: W1, 1: W2).  One block = 9 x mt x 2 KB
+// = the bytes of one plain f16 block, at packed_mx + 2 * dst_off.
+__global__ __launch_bounds__(256) void pack_mx_kernel(const ResrPackChunk* __restrict__ chunks, const float* __restrict__ arena,
+                                                      unsigned char* __restrict__ packed) {
+    const ResrPackChunk c = chunks[blockIdx.x];
+    const int total = 9 * c.mt * 2048;   // bytes
+    unsigned char* dst = packed + c.dst_off * 2;
+    const float* src = arena + c.src_off;
+    const float sc = c.scale * (c.scale_ptr ? *c.scale_ptr : 1.f);
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        int r = idx;
+        const int e = r % 16; r /= 16;
+        const int m = r % 32; r /= 32;
+        const int kh = r % 2; r /= 2;
+        const int mt = r % c.mt; r /= c.mt;
+        const int part = r % 2; r /= 2;
+        const int tap = r;
+        const int k = kh * 16 + e;
+        const int mm = mt * 32 + m;
+        float v = 0.f;
+        if (mm < c.m_count && k < c.k_count) {
+            const int co = c.transposed ? c.k_off + k : c.m_off + mm;
+            const int ci = c.transposed ? c.m_off + mm : c.k_off + k;
+            const int t = c.transposed ? 8 - tap : tap;
+            if (!c.virtual4x4) {
+                v = src[((size_t)co * c.src_cin + ci) * 9 + t];
+            } else {
+                const int C = c.src_cin, sub = ci / C, ch = ci % C;
+                const int ky = 2 * (t / 3) + (sub >> 1) - 1, kx = 2 * (t % 3) + (sub & 1) - 1;
+                if (ky >= 0 && ky < 4 && kx >= 0 && kx < 4) v = src[((size_t)co * C + ch) * 16 + ky * 4 + kx];
+            }
+            v *= sc;
+        }
+        const float t = v * kLoScale;
+        const half_t w0 = (half_t)t;
+        const half_t q = part == 0 ? (half_t)(t - (float)w0) : (half_t)((float)w0 * kLoInv);
+        dst[idx] = (unsigned char)f16_bits_to_bf8((unsigned)__builtin_bit_cast(unsigned short, q));
+    }
+}
+
+int pack_mx_dispatch(const ResrPackChunk* chunks_dev, int n_chunks, const float* arena, void* packed_mx, hipStream_t stream) {
+    if (!chunks_dev || !arena || !packed_mx || n_chunks <= 0) return fail(RESR_ERR_ARG, "pack_weights_mx: bad argument");
+    hipLaunchKernelGGL(pack_mx_kernel, dim3(n_chunks), dim3(256), 0, stream, chunks_dev, arena, (unsigned char*)packed_mx);
+    RESR_CHECK_LAUNCH("pack_mx_kernel");
+    return RESR_OK;
+}
+
 // two rounded products, one rounded sum: the empty asm makes the products opaque so the compiler
 // cannot contract them into an FMA (HIP's default -ffp-contract=fast would)
 __device__ __forceinline__ float ema_step(float one_minus, float p, float decay, float s) {

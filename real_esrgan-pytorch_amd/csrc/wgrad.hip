@@ -375,7 +375,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const ReduceArgs
         s = __builtin_fmaf(s2, kLoInv, s);
     }
     s *= job.scale;
-    if (a.unscale) s *= grad_prescale(*a.unscale, true);
+    if (a.unscale) {
+        const unsigned mb = *a.unscale;
+        s *= grad_prescale(mb, true);
+        // a LIFTED pass that overflowed: tell the next pass to aim lower (common.h: the slot's sticky words)
+        if (grad_prescale_lifted(mb) && !(__builtin_fabsf(s) <= 3.0e38f)) const_cast<unsigned*>(a.unscale)[2] = 1u;
+    }
     if (e < 9 * 1024) {
         const int tap = e >> 10, co = job.co_base + ((e >> 5) & 31), ci = job.ci_base + (e & 31);
         if (co < job.cout && ci < job.cin_real) job.dw[((size_t)co * job.cin_real + ci) * 9 + tap] = s;
@@ -741,7 +746,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     __syncthreads();
     if (g != 0 || e >= kSlab) return;
     s = (((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) + ((red[4][lane] + red[5][lane]) + (red[6][lane] + red[7][lane]))) * job.scale;
-    if (a.unscale) s *= grad_prescale(*a.unscale, true);
+    if (a.unscale) {
+        const unsigned mb = *a.unscale;
+        s *= grad_prescale(mb, true);
+        // a LIFTED pass that overflowed: tell the next pass to aim lower (common.h: the slot's sticky words)
+        if (grad_prescale_lifted(mb) && !(__builtin_fabsf(s) <= 3.0e38f)) const_cast<unsigned*>(a.unscale)[2] = 1u;
+    }
     if (e < 9 * 1024) {
         const int tap = e >> 10, co = job.co_base + ((e >> 5) & 31), ci = job.ci_base + (e & 31);
         if (co < job.cout && ci < job.cin_real) job.dw[((size_t)co * job.cin_real + ci) * 9 + tap] = s;

@@ -34,6 +34,7 @@ class _DWorkspace:
     def __init__(self, nbytes: int, device, desc) -> None:
         L = _lib.lib()
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.buf[:256].zero_()     # 1 / sigma + the gradient pre-scale slot with its sticky back-off words: zero once (include/resr.h)
         n = int(L.resr_discriminator_pack_table(C.byref(desc), _lib.ptr(self.buf), None, 0))
         host = (_lib.PackChunk * n)()
         got = int(L.resr_discriminator_pack_table(C.byref(desc), _lib.ptr(self.buf), C.cast(host, C.c_void_p), n))

@@ -222,7 +222,10 @@ class Generator(nn.Module):
     6.7e-4), bit 3: the weight products read the growth planes (the X chunks of conv2..conv5 behind the residual stream) as their
     hi tensor (54 instead of 68 tap-products per block; the worst tensor does not move), bit 4 (with bit 3): conv5's products of the
     growth planes also take g_y's hi tensor alone (46 per block), bit 5 (with bit 0): the growth chunks of an inference forward meet
-    the f16 weights W0 alone -- one stage each, 40 per block (forward 2.3e-6 at the init scale, 2.9e-5 at dense weights x 4).  x2_plan=0 = pairs everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
+    the f16 weights W0 alone -- one stage each, 40 per block (forward 2.3e-6 at the init scale, 2.9e-5 at dense weights x 4), bit 6 (with bits 0 + 5): the PAIR
+    chunks of an inference forward take one f16 stage + one MX stage -- both 2^-12-weighted correction products as nine
+    v_mfma_scale_f32_32x32x64_f8f6f4 per output row on unscaled bf8 operands ([bf8(x_hi) | bf8(x_lo)] records written by the producing
+    epilogues, [bf8(W1) | bf8(W2)] blocks from the packer): 30 stage-equivalents per block, forward ~1e-4 (gate 2e-4).  x2_plan=0 = pairs everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
     The backward pass of the 16-bit modes (exact16, fast) does not depend on the caller's loss scale: an incoming gradient whose largest element is below 2^6 is
     lifted by a power of two inside the native pass and the results are handed back unscaled (bit-identical gradients at loss scale
     1 and 2^20; csrc/generator.hip, $RESR_X2_GRAD_PRESCALE_LOG2 / RESR_X2_NO_GRAD_PRESCALE=1).
@@ -240,9 +243,15 @@ class Generator(nn.Module):
         self.precision = precision or os.environ.get("RESR_PRECISION", "fast")
         self._dtype = _precision_to_dtype(self.precision)
         self.x2_plan = int(os.environ.get("RESR_X2_PLAN", "59")) if x2_plan is None else int(x2_plan)
-        if not 0 <= self.x2_plan <= 63:
+        if not 0 <= self.x2_plan <= 127:
             raise ValueError(f"x2_plan must be a bit set of X2_PLAN_GROWTH_F16_INFER (1) | X2_PLAN_GROWTH_GRAD_F16 (2) | "
-                             f"X2_PLAN_GROWTH_GRAD_STORE_F16 (4) | X2_PLAN_GROWTH_ACT_F16_WGRAD (8) | X2_PLAN_GROWTH_ACT_G_HI_WGRAD (16) | X2_PLAN_GROWTH_W16_INFER (32), got {self.x2_plan}")
+                             f"X2_PLAN_GROWTH_GRAD_STORE_F16 (4) | X2_PLAN_GROWTH_ACT_F16_WGRAD (8) | X2_PLAN_GROWTH_ACT_G_HI_WGRAD (16) | X2_PLAN_GROWTH_W16_INFER (32) | "
+                             f"X2_PLAN_MX_INFER (64), got {self.x2_plan}")
+        # a bit that only refines another one means nothing without it: refuse instead of silently ignoring it
+        for bit, needs, name in ((4, 2, "GROWTH_GRAD_STORE_F16 (4) refines GROWTH_GRAD_F16 (2)"), (16, 8, "GROWTH_ACT_G_HI_WGRAD (16) refines GROWTH_ACT_F16_WGRAD (8)"),
+                                 (32, 1, "GROWTH_W16_INFER (32) refines GROWTH_F16_INFER (1)"), (64, 33, "MX_INFER (64) rides on GROWTH_F16_INFER (1) + GROWTH_W16_INFER (32)")):
+            if (self.x2_plan & bit) and (self.x2_plan & needs) != needs:
+                raise ValueError(f"x2_plan={self.x2_plan}: {name}")
         self.n_blocks = n_blocks or self.N_BLOCKS
         if upscale_factor == 2:
             conv_in, downscale_factor = in_channels * 4, 2
@@ -377,6 +386,11 @@ class Generator(nn.Module):
         raw, n = self._table_dev[key]
         _lib.check(L.resr_pack_weights(_lib.ptr(raw), n, _lib.ptr(flat), _lib.ptr(self._packed), self._dtype,
                                        _lib.stream_ptr(flat)), "resr_pack_weights")
+        if self._dtype == _lib.RESR_F16X2 and (desc.x2_plan & _lib.X2_PLAN_MX_INFER) and not desc.training:
+            # the MX blocks of the same table ([bf8(W1) | bf8(W2)] per tap and row), behind the f16 blocks of the packed buffer
+            mx_off = int(L.resr_generator_mx_offset(C.byref(desc)))
+            _lib.check(L.resr_pack_weights_mx(_lib.ptr(raw), n, _lib.ptr(flat), C.c_void_p(self._packed.data_ptr() + mx_off),
+                                              _lib.stream_ptr(flat)), "resr_pack_weights_mx")
 
     def _workspace(self, desc: _lib.GeneratorDesc, device) -> _Workspace:
         L = _lib.lib()

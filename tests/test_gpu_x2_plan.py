@@ -466,6 +466,42 @@ def test_exact16_backward_keeps_a_non_finite_gradient_visible():
     assert all(torch.equal(again[k], clean[k]) for k in clean), "the next pass is clean again"
 
 
+@pytest.mark.parametrize("precision", ["fast", "exact16"])
+def test_lifted_backward_backs_off_when_the_gradient_outgrows_its_headroom(precision):
+    """the lift re-raises max |g_y| to [2^6, 2^7) on every step, so a gradient that grows by more than f16's
+    remaining 2^9 on its way back would overflow at EVERY loss scale -- a GradScaler halving its scale could not cure it.  Here the
+    backward gain of the HR tail is 2^11 by construction (conv4's weights x 2^11, conv3's weights and bias x 2^-11: LeakyReLU is
+    positively homogeneous, so the forward pass is the same function): the first lifted pass overflows, sets the flag in the
+    workspace's pre-scale slot, and the next pass aims 2^4 lower (common.h) -- after at most three skipped steps the GradScaler's scale
+    stops decaying and the weights move.  Without the back-off every step of the loop below is skipped."""
+    import real_esrgan_pytorch_amd as R
+    torch.manual_seed(2)
+    g = R.Generator(3, 3, 4, precision=precision, n_blocks=1).cuda().train()
+    with torch.no_grad():
+        g.conv4.bias.add_(0.5)
+        g.conv4.weight.mul_(2.0 ** 11)
+        g.conv3[0].weight.mul_(2.0 ** -11)
+        g.conv3[0].bias.mul_(2.0 ** -11)
+    opt = torch.optim.Adam(g.parameters(), 1e-6, (0.9, 0.99))
+    scaler = torch.amp.GradScaler("cuda")
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.rand(4, 3, 32, 32, device="cuda", generator=gen)
+    target = torch.rand(4, 3, 128, 128, device="cuda", generator=gen)
+    w0 = g.conv1.weight.detach().clone()
+    scales, finite = [], []
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        scaler.scale((g(x) - target).abs().mean()).backward()
+        finite.append(all(torch.isfinite(p.grad).all().item() for p in g.parameters()))
+        scaler.step(opt)
+        scaler.update()
+        scales.append(scaler.get_scale())
+    assert not finite[0], "the case does not overflow the lifted pass: no back-off exercised"
+    assert all(finite[3:]), (finite, scales)
+    assert scales[-1] >= 65536.0 / 8, (finite, scales)      # at most three skipped steps; without the back-off: 65536 / 2^8
+    assert not torch.equal(g.conv1.weight.detach(), w0), "no optimizer step was taken"
+
+
 @pytest.mark.parametrize("plan", [3, 35])
 @pytest.mark.parametrize("n,h,w", [(8, 24, 40), (16, 64, 64), (16, 128, 128)])
 def test_single_plane_chains_equal_separate_launches(n, h, w, plan):

@@ -34,12 +34,12 @@ def test_library_exports_every_declared_symbol(built):
             assert hasattr(lib, name), f"{name} declared in include/{h} but not exported"
         declared += names
     assert set(built._lib.exported_symbols()) <= set(declared)
-    assert lib.resr_version() == built._lib.RESR_VERSION == 2
+    assert lib.resr_version() == built._lib.RESR_VERSION == 3
 
 
 def test_struct_layouts_match_header(built):
     L = built._lib
-    assert ctypes.sizeof(L.ConvDesc) == 26 * 4 + 5 * 8 + 4 * 4 + 4 + 4 + 8   # 20 original fields + 6 chunk strides + 5 hi->lo offsets (RESR_F16X2) + sparse-tap / group fields + x2_pair_chunks slot, padding, mask_lo_offset
+    assert ctypes.sizeof(L.ConvDesc) == 26 * 4 + 5 * 8 + 4 * 4 + 4 + 4 + 8 + 4 * 8   # (+ the four q / MX offsets of ABI version 3) 20 original fields + 6 chunk strides + 5 hi->lo offsets (RESR_F16X2) + sparse-tap / group fields + x2_pair_chunks slot, padding, mask_lo_offset
     assert ctypes.sizeof(L.WgradDesc) == 16 * 4 + 4 * 8   # 15 fields + padding + 2 hi->lo offsets + 2 chunk strides
     assert ctypes.sizeof(L.PackChunk) == 64
     assert ctypes.sizeof(L.GeneratorDesc) == 12 * 4   # + x2_plan, reserved_ (ABI version 2)
@@ -55,6 +55,16 @@ def test_host_planning_calls_need_no_gpu(built):
     # (conv4^T 1 + four 64->64 convs x 2 + conv1^T 2 + 69 x 20)
     assert n == 2 * (1 + 69 * 20 + 5 * 2)
     assert lib.resr_generator_workspace_bytes(ctypes.byref(d)) > 30e9
+    # RESR_X2_PLAN_MX_INFER: the packed buffer grows by the MX region (one plain-f16-sized block per chunk) behind the f16 blocks, and
+    # an inference workspace by the q tensors (2 more bytes per activation element)
+    dx = L.GeneratorDesc(16, 256, 256, 3, 3, 4, 23, L.RESR_F16X2, 0, 0, 33, 0)
+    dm = L.GeneratorDesc(16, 256, 256, 3, 3, 4, 23, L.RESR_F16X2, 0, 0, 97, 0)
+    plain = (lib.resr_generator_packed_bytes(ctypes.byref(dx), 1) - 16384) // 6
+    off = lib.resr_generator_mx_offset(ctypes.byref(dm))
+    assert off >= plain * 6 + 16384 and off % 256 == 0 and lib.resr_generator_packed_bytes(ctypes.byref(dm), 0) == off + plain * 2 + 16384
+    assert lib.resr_generator_mx_offset(ctypes.byref(d)) == 0
+    wx, wm = lib.resr_generator_workspace_bytes(ctypes.byref(dx)), lib.resr_generator_workspace_bytes(ctypes.byref(dm))
+    assert 1.45 * wx < wm < 1.55 * wx
     bad = L.GeneratorDesc(1, 7, 8, 3, 3, 2, 23, L.RESR_F16, 0, 0)                # 7 not divisible by 2
     assert lib.resr_generator_workspace_bytes(ctypes.byref(bad)) == 0
 

@@ -55,6 +55,26 @@ def split16(t):
     return hi, t - hi
 
 
+def q8_bf8s(t):
+    """bf8 (e5m2, unit scales) of a REMAINDER operand as the HIP path stores it: times 2^12 (f16's range again), rounded, descaled."""
+    return (t * 4096.0).to(torch.float32).to(torch.float8_e5m2).to(t.dtype) / 4096.0
+
+
+def q8_row(t, kdim):
+    """e4m3 WEIGHTS with ONE power-of-two scale per (output row of the product, 32-wide K chunk, all nine taps): what the packer emits
+    for an MX stage.  `kdim` = the weight dimension the product contracts over (1: forward, 0: backward-data)."""
+    tt = t.movedim(kdim, -1)                      # (rows, 3, 3, K)
+    shp = tt.shape
+    pad = (-shp[-1]) % 32
+    tp = F.pad(tt, (0, pad)) if pad else tt
+    b = tp.reshape(shp[0], 9, -1, 32).permute(0, 2, 1, 3)    # (rows, chunks, taps, 32)
+    amax = b.abs().amax((-1, -2), keepdim=True).clamp_min(2.0 ** -120)
+    sc = torch.exp2(torch.floor(torch.log2(amax)) - 7.0)
+    q = (b / sc).to(torch.float32).to(torch.float8_e4m3fn).to(t.dtype) * sc
+    q = q.permute(0, 2, 1, 3).reshape(tp.shape)[..., :shp[-1]]
+    return q.movedim(-1, kdim)
+
+
 class Conv8(torch.autograd.Function):
     """3x3 conv on split operands whose two 2^-12-weighted correction products take fp8 (MX e4m3) operands:
     x w ~ x_hi w_hi + q8(x_hi) q8(w_lo) + q8(x_lo) q8(w_hi), per pass selected by `where` ("f" forward, "d" backward-data,
@@ -69,6 +89,10 @@ class Conv8(torch.autograd.Function):
             return F.conv2d(x, w, b, padding=1)
         xh, xl = split16(x)
         wh, wl = split16(w)
+        if "6" in where:    # round 6: unscaled bf8 activations (lo times 2^12), row-scaled e4m3 weights
+            return F.conv2d(xh, wh, b, padding=1) + F.conv2d(q8_e5m2(xh), q8_row(wl, 1), None, padding=1) + F.conv2d(q8_bf8s(xl), q8_row(wh, 1), None, padding=1)
+        if "7" in where:    # round 6, as built: unscaled bf8 on BOTH operands (remainders times 2^12) -- no scale bytes anywhere
+            return F.conv2d(xh, wh, b, padding=1) + F.conv2d(q8_e5m2(xh), q8_bf8s(wl), None, padding=1) + F.conv2d(q8_bf8s(xl), q8_e5m2(wh), None, padding=1)
         return F.conv2d(xh, wh, b, padding=1) + F.conv2d(q8(xh, 1), q8(wl, 1), None, padding=1) + F.conv2d(q8(xl, 1), q8(wh, 1), None, padding=1)
 
     @staticmethod
@@ -81,6 +105,14 @@ class Conv8(torch.autograd.Function):
         ci = lambda gg, ww: torch.nn.grad.conv2d_input(x.shape, ww, gg, padding=1)    # noqa: E731
         cw = lambda xx, gg: torch.nn.grad.conv2d_weight(xx, w.shape, gg, padding=1)   # noqa: E731
         # backward-data contracts over the OUTPUT channels (dim 1 of g, dim 0 of w)
+        if "7" in ctx.where:
+            gx = ci(gh, wh) + ci(q8_e5m2(gh), q8_bf8s(wl)) + ci(q8_bf8s(gl), q8_e5m2(wh)) if "d" in ctx.where else ci(g, w)
+            gw = cw(xh, gh) + cw(q8_e5m2(xh), q8_bf8s(gl)) + cw(q8_bf8s(xl), q8_e5m2(gh)) if "w" in ctx.where else cw(x, g)
+            return gx, gw, g.sum((0, 2, 3)), None
+        if "6" in ctx.where:
+            gx = ci(gh, wh) + ci(q8_e5m2(gh), q8_row(wl, 0)) + ci(q8_bf8s(gl), q8_row(wh, 0)) if "d" in ctx.where else ci(g, w)
+            gw = cw(xh, gh) + cw(q8_e5m2(xh), q8_bf8s(gl)) + cw(q8_bf8s(xl), q8_e5m2(gh)) if "w" in ctx.where else cw(x, g)
+            return gx, gw, g.sum((0, 2, 3)), None
         gx = ci(gh, wh) + ci(q8(gh, 1), q8(wl, 0)) + ci(q8(gl, 1), q8(wh, 0)) if "d" in ctx.where else ci(g, w)
         # the weight gradients contract over pixels: blocks of 32 along a row
         gw = cw(xh, gh) + cw(q8(xh, 3), q8(gl, 3)) + cw(q8(xl, 3), q8(gh, 3)) if "w" in ctx.where else cw(x, g)
@@ -219,6 +251,11 @@ RUNGS5 = {
     "bf8 (e5m2, unit scales) corrections: weight gradients only":    _with(_EXACT, fp8="w5"),
     "bf8 (e5m2, unit scales) corrections: backward-data only":       _with(_EXACT, fp8="d5"),
     "bf8 (e5m2, unit scales) corrections: backward-data + weight gradients": _with(_EXACT, fp8="dw5"),
+    "bf8x4096 acts + row-scaled e4m3 weights (round 6): backward-data only":            _with(_EXACT, fp8="d6"),
+    "bf8x4096 acts (round 6): weight gradients only":                                   _with(_EXACT, fp8="w6"),
+    "bf8x4096 acts + row-scaled e4m3 weights (round 6): backward-data + weight gradients": _with(_EXACT, fp8="dw6"),
+    "bf8x4096 on both operands (round 6, as built): backward-data only":                 _with(_EXACT, fp8="d7"),
+    "bf8x4096 on both operands (round 6, as built): backward-data + weight gradients":   _with(_EXACT, fp8="dw7"),
     "exact16x3 (all pair, W split, wgrad pairs)":                    _EXACT,
 }
 
