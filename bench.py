@@ -991,12 +991,24 @@ def other_configs(args):
         g4x = g4x.cuda().eval()
         with torch.no_grad():
             dtx = timed(lambda: g4x(x), 3)
-        rec2["parity_mode"] = {"precision": "exact16 (the default of inference.py / test.py: fp32 call sites of the reference); inference plan: residual stream "
-                                            "and HR tail as pairs, growth planes single f16 against f16 weights (40 instead of 60 stages per block; forward 2.3e-6 / 2.9e-5 vs the "
-                                            "fp32 oracle at init scale / dense weights x 4, tests/test_gpu_x2_plan.py)",
+        rec2["parity_mode"] = {"precision": "exact16 (the default of inference.py / test.py: fp32 call sites of the reference); inference plan (x2_plan bits 0, 5, 6): residual "
+                                            "stream and HR tail as pairs on ONE f16 stage + ONE MX stage (both 2^-12-weighted corrections as v_mfma_scale_f32_32x32x64_f8f6f4 on "
+                                            "unscaled bf8 records), growth planes single f16 against f16 weights -- 30 stage-equivalents per dense block instead of 60; forward "
+                                            "0.9-1.14e-4 vs the fp32 oracle at init scale / dense weights x 4, 6e-5 on trained weights (gate 2e-4, tests/test_gpu_mx.py)",
+                               "x2_plan_effective": int(g4x.x2_plan),
                                "images_per_sec": round(16 / dtx, 1), "ms": round(dtx * 1e3, 2), "tflops_algorithmic": round(flop / dtx / 1e12, 1)}
+        # ... and round 5's plan behind the knob (x2_plan = 59: three f16 stages per pair chunk, 40 stages per block; forward 2.3e-6 / 2.9e-5)
+        del g4x
+        torch.cuda.empty_cache()
+        g4y = R.Generator(3, 3, 4, precision="exact16", x2_plan=59)
+        g4y.load_state_dict(sd2)
+        g4y = g4y.cuda().eval()
+        with torch.no_grad():
+            dty = timed(lambda: g4y(x), 3)
+        rec2["parity_mode"]["without_mx_stages"] = {"knob": "x2_plan=59 / RESR_X2_PLAN=59 (round 5's default: forward 2.3e-6 / 2.9e-5)", "images_per_sec": round(16 / dty, 1),
+                                                    "ms": round(dty * 1e3, 2)}
         out["config2_x4_f16_inference_b16_lr256"] = rec2
-        del g4x, x, sd2
+        del g4y, x, sd2
         torch.cuda.empty_cache()
     except Exception as e:  # pragma: no cover
         out["config2_x4_f16_inference_b16_lr256"] = {"error": repr(e)}
@@ -1054,13 +1066,21 @@ def other_configs(args):
         torch.manual_seed(0)
         g2 = R.Generator(3, 3, 2, precision="fast").cuda().eval()
         frame = torch.rand(1, 3, 2160, 3840, device="cuda")
-        tg = TiledGenerator(g2, halo=32, use_graph=True)
+        from real_esrgan_pytorch_amd.tiling import DEFAULT_HALO
+        tg = TiledGenerator(g2, halo=DEFAULT_HALO, use_graph=True)      # the halo inference.py / test.py tile with (64; rounds 2-5 timed halo 32)
         tiles, wh, ww = tg.plan(1, 2160, 3840)
         dt = timed(lambda: tg(frame), 3)
         flop = 2 * 17_932_032 * 1920 * 1080
         out["config5_x2_4k_tiled_hipgraph"] = {"frames_per_sec": round(1 / dt, 3), "ms": round(dt * 1e3, 1), "tflops": round(flop / dt / 1e12, 1),
                                                "frac_of_f16_peak": round(flop / dt / 1e12 / PEAK_F16_TFLOPS, 3),
-                                               "tiles": len(tiles), "window": [wh, ww], "halo": 32}
+                                               "tiles": len(tiles), "window": [wh, ww], "halo": DEFAULT_HALO}
+        try:    # ... and at the halo the rounds before measured (32), for continuity with their numbers
+            tg32 = TiledGenerator(g2, halo=32, use_graph=True)
+            dt32 = timed(lambda: tg32(frame), 2)
+            out["config5_x2_4k_tiled_hipgraph"]["halo32"] = {"frames_per_sec": round(1 / dt32, 3), "ms": round(dt32 * 1e3, 1)}
+            del tg32
+        except Exception as e:  # pragma: no cover
+            out["config5_x2_4k_tiled_hipgraph"]["halo32"] = {"error": repr(e)}
         del g2, frame, tg
         torch.cuda.empty_cache()
     except Exception as e:  # pragma: no cover
@@ -1198,10 +1218,9 @@ def main():
             parity_hi = run_mode(args, "exact16", max(2, min(args.steps, 4)), 1, world, rank, probe=False)
         finally:
             os.environ.pop("RESR_X2_WGRAD_PRODUCTS", None)
-        # ... and with the growth-plane gradients STORED single as well (x2_plan bit 2, opt-in: no lo store in the mirrored passes, no bias
-        # job; the worst bias tensor of the emulation reaches 6.7e-4, outside the 5e-4 rule of the default plan)
+        # ... and round 5's default plan (x2_plan = 59: without the MX stages of the backward-data passes) behind its knob
         prev_plan = os.environ.get("RESR_X2_PLAN")
-        os.environ["RESR_X2_PLAN"] = "63"
+        os.environ["RESR_X2_PLAN"] = "59"
         try:
             parity_p7 = run_mode(args, "exact16", max(2, min(args.steps, 4)), 1, world, rank, probe=False)
         finally:
@@ -1255,8 +1274,11 @@ def main():
             pm = {"precision": "exact16",
                   "what": "the same train step with split-operand f16 MFMA (activations and weights as hi+lo f16 pairs, three MFMAs per "
                           "product, fp32 accumulate): the mode that meets the 1e-3 max-abs parity tolerance vs the fp32 CPU path",
-                  "x2_plan": "default (59; its training bits 27): forward all pairs; backward READS the growth-plane gradients as single f16 -- two stages on their chunks in "
-                             "backward-data, two tap-products in conv1..conv4's weight gradients, bias sums from hi + lo -- and the weight products read "
+                  "x2_plan_effective": int(os.environ.get("RESR_X2_PLAN", "251")),
+                  "x2_plan": "default (251; its training bits 27 + 128): forward all pairs; the dense blocks' backward-data passes read EVERY gradient chunk as a pair on one f16 + "
+                             "one MX stage (round 6: unscaled bf8 q records from the producing epilogues; 40 stage-equivalents per block, gradients within 4.7e-5 of the "
+                             "all-pairs plan where round 5's single-f16 reads gave 2.6e-4); the weight gradients keep round 5's plan: conv1..conv4's products read G's hi "
+                             "tensor -- two tap-products, bias sums from hi + lo -- and the weight products read "
                              "the growth planes as their hi tensor, conv5's such products with g_y's hi tensor (46 instead of 78 tap-products per dense block; worst gradient tensor "
                              "2.2-4.6e-4 vs float64 in the emulation at three geometries x five seeds; against the all-pairs plan on the GPU at 16 x 256^2 .. "
                              "1 x 24^2: 1.7-5.1e-4 under a dense random cotangent, 5e-7 .. 2e-5 under this step's L1 loss -- profiles/r05_x2_plan_validate.json, "
@@ -1271,9 +1293,8 @@ def main():
                                                   "ms_per_step": round(parity_hi["dt"] / parity_hi["steps"] * 1e3, 2),
                                                   "gradient_error": "worst tensor 2.8-5.0e-4 against the all-pairs plan under a dense random cotangent, 2.4-3.1e-4 under the L1 loss (conv4: the L1 gradient has ONE magnitude, whose f16 rounding is systematic) -- profiles/r05_x2_plan_validate_hi_only.json; inside 1e-3, not inside the 5e-4 ship rule"}
             if parity_p7 is not None:
-                pm["growth_gradients_stored_single"] = {"knob": "x2_plan=63 / RESR_X2_PLAN=63 (opt-in: the default plan + bit 2)", "value": round(rate(parity_p7), 3), "unit": "images/sec",
-                                                        "ms_per_step": round(parity_p7["dt"] / parity_p7["steps"] * 1e3, 2),
-                                                        "gradient_error": "as the default plan, but conv1..conv4's bias gradients sum rounded values: worst bias tensor 6.7e-4 (emulation, 1 x 128^2)"}
+                pm["without_mx_stages"] = {"knob": "x2_plan=59 / RESR_X2_PLAN=59 (round 5's default: backward-data reads the growth-plane gradients as single f16, 50 f16 stages per block)",
+                                           "value": round(rate(parity_p7), 3), "unit": "images/sec", "ms_per_step": round(parity_p7["dt"] / parity_p7["steps"] * 1e3, 2)}
             if "roofline" in parity_res:
                 r = parity_res["roofline"]
                 pm["roofline"] = {k: r[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "per_instance", "vs_sustained") if k in r}

@@ -191,11 +191,13 @@ typedef struct {
     int32_t cin, cin0, in0_stride, in1_stride; /* X operand, same addressing as ResrConvDesc      */
     int32_t cin_real;                          /* rows of dW actually written (<= cin)            */
     int32_t cout, cout_pad, g_stride;          /* G operand: channels [0,cout_pad) of g           */
-    int32_t dtype, flags;                      /* RESR_CONV_UPSAMPLE_IN honoured for X            */
+    int32_t dtype, flags;                      /* RESR_CONV_UPSAMPLE_IN honoured for X; RESR_CONV_OUT_SINGLE: G is a single f16 tensor */
     int32_t splits;                            /* pixel splits (partial slabs)                    */
     float scale;
-    int64_t x_lo_offset, g_lo_offset;          /* RESR_F16X2: hi -> lo element offsets of X and G; g_lo_offset = 0: G is a
-                                                * single f16 tensor (RESR_CONV_OUT_SINGLE): dW = X_hi^T G + 2^-12 X_lo^T G     */
+    int64_t x_lo_offset, g_lo_offset;          /* RESR_F16X2: hi -> lo element offsets of X and G (both required).  A G that a
+                                                * pass stored as ONE f16 tensor is selected explicitly by RESR_CONV_OUT_SINGLE in
+                                                * flags (g_lo_offset is then ignored): dW = X_hi^T G + 2^-12 X_lo^T G; a zero
+                                                * g_lo_offset without the flag is an argument error (version 3)                 */
     /* elements between consecutive 32-channel chunks of X / G (0 = 32: interleaved NHWC; a chunk-planar tensor
      * [C/32][N,H,W,32] has pixel stride 32 and chunk stride N*H*W*32 -- how the generator keeps its dense-block workspaces) */
     int64_t x_chunk_stride, g_chunk_stride;
@@ -286,7 +288,14 @@ enum {
      * one f16 stage + one MX-fp8 stage (RESR_CONV_MX_PAIRS) instead of three f16 stages: 30 stage-equivalents per dense block
      * instead of 40.  The workspace grows by the q tensors, the packed weights by their MX region (resr_generator_packed_bytes,
      * resr_generator_mx_offset).  Forward 0.8-1.2e-4 of the fp32 oracle instead of 2e-6 (gate 2e-4). */
-    RESR_X2_PLAN_MX_INFER = 64
+    RESR_X2_PLAN_MX_INFER = 64,
+    /* backward (training = 1): the backward-data passes of the dense blocks (the four mirrored cout-32 passes and the g_x pass of every
+     * block) read EVERY gradient chunk as a pair on one f16 stage + one MX stage (RESR_CONV_MX_PAIRS): 40 stage-equivalents per block
+     * instead of 50 (GROWTH_GRAD_F16) or 60, and nothing is dropped -- the growth-plane gradients enter with both halves again: worst
+     * gradient tensor 0.8-1.2e-4 vs float64 in the emulation (GROWTH_GRAD_F16: 3-5e-4).  The gradient planes gT / gS carry q tensors
+     * (written by the passes that produce them), the packed buffer its MX region.  The forward pass and the weight gradients are
+     * untouched (GROWTH_GRAD_F16 then only shapes the weight products); not together with GROWTH_GRAD_STORE_F16. */
+    RESR_X2_PLAN_MX_BWD = 128
 };
 
 size_t resr_generator_param_count(const ResrGeneratorDesc* d);

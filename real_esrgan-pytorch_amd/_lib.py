@@ -23,6 +23,7 @@ X2_PLAN_GROWTH_F16_INFER, X2_PLAN_GROWTH_GRAD_F16, X2_PLAN_GROWTH_GRAD_STORE_F16
 X2_PLAN_GROWTH_ACT_G_HI_WGRAD = 16
 X2_PLAN_GROWTH_W16_INFER = 32
 X2_PLAN_MX_INFER = 64
+X2_PLAN_MX_BWD = 128
 CONV_MX_PAIRS = 1 << 12
 RESR_VERSION = 3   # include/resr.h: the structures below mirror THIS version of the header
 

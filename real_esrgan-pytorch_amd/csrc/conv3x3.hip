@@ -369,8 +369,8 @@ static int conv3x3_args(const ResrConvDesc* d, const void* in0, const void* in1,
             a.w_mx = (const char*)w + d->w_mx_offset;
         }
         if (d->out_q_offset != 0) {
-            if (a.out_single || (d->flags & RESR_CONV_OUT_NCHW_F32) || !(d->flags & RESR_CONV_MX_PAIRS))
-                return fail(RESR_ERR_ARG, "conv3x3: out_q_offset goes with a pair NHWC output of an RESR_CONV_MX_PAIRS pass");
+            if (a.out_single || (d->flags & RESR_CONV_OUT_NCHW_F32) || d->cout_groups > 1)
+                return fail(RESR_ERR_ARG, "conv3x3: out_q_offset goes with a pair NHWC output of one output group");
             a.out_q = (long)d->out_q_offset;
         }
     } else if (d->flags & RESR_CONV_MX_PAIRS) {

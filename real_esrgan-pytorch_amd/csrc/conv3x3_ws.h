@@ -40,8 +40,21 @@
 // B^T d B of that formulation is 32 adds per 4x4 patch and channel = 8 v_pk_add_f16 per MFMA of a 16-channel k-step.
 // RESR_TIMING_NO_W / RESR_TIMING_NO_H (chained launches): the producers skip the weight / halo requests after the first stages
 // (tools/build_variant.py ... -DRESR_TIMING_NO_H=1): what a 64^2 launch costs with an idle memory pipe.
+// RESR_TIMING_RESIDENT (chained launches, round 6): the memory side of an LDS-RESIDENT dense block -- a workgroup's own tile of the six
+// planes stays in LDS across the jobs, only what it cannot have travels: job 0 fetches its two chunks whole (as today), a later job
+// requests NOTHING for the planes it already holds and only the one-pixel RING of its newest plane (84 pixels x 64 B = six full LDS-DMA
+// instructions instead of 22, behind the usual poll: the ring is the neighbours' data).  Flags, polls, barriers, weights, MFMAs,
+// epilogues and stores are today's; the LDS contents are wrong.  An upper bound of what the restructuring could gain (it would
+// still owe the epilogue's ds_writes into the next job's operand slots and 130 KB of resident planes next to the weight ring).
 #ifndef RESR_TIMING_TAPS
 #define RESR_TIMING_TAPS 9
+#endif
+// Stamps per traced wave of a timeline (trace builds, -DRESR_TRACE=1).  RESR_TRACE=2 ("budget" build, tools/chain_budget.py): 192 stamps per
+// wave, so that all 26 stages of a six-job chained launch fit (six producer stamps and three consumer stamps per stage).
+#if defined(RESR_TRACE) && RESR_TRACE == 2
+#define RESR_TRACE_STAMPS 192
+#else
+#define RESR_TRACE_STAMPS 64
 #endif
 #ifndef RESR_TIMING_VALU
 #define RESR_TIMING_VALU 0
@@ -93,7 +106,7 @@ struct WsCfg {
     // (+ 1 KB for the debug timeline of a traced workgroup: stamps go to LDS and are copied out at the end of the kernel -- a stamp
     // written straight to global memory is a store on the in-order vector-memory counter, and the very waits the timeline is
     // supposed to show then also wait for its acknowledgement)
-    static constexpr int CHAIN_OFF = LUT_OFF + LUT_BYTES, CHAIN_TRACE = kMaxChain * 128 + 64, CHAIN_BYTES = CHAIN_TRACE + 1024;
+    static constexpr int CHAIN_OFF = LUT_OFF + LUT_BYTES, CHAIN_TRACE = kMaxChain * 128 + 64, CHAIN_BYTES = CHAIN_TRACE + 2 * RESR_TRACE_STAMPS * 8;
     static_assert(LDS_BYTES + LUT_BYTES + CHAIN_BYTES <= 160 * 1024, "LDS");
     // output-group launches WITH a bias (cout 64 shape; VGG19's 128..512-channel layers): the biases of up to kMaxBiasGroups
     // groups, 64 floats each, where the chained launches (cout 32 shape only) keep their state
@@ -304,16 +317,16 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
         return;        // configurations 2 % (six uniform branches per stage on the producers' serial path -- measured).
 #endif
         // traced workgroups: blockIdx 16k .. 16k+0 for k < 32 (a sample across the whole grid)
-        if (a.trace && (blockIdx.x & 15) == 0 && blockIdx.x < 512 && lane == 0 && tk < 64 && wave <= NWC) {
-            if constexpr (CH != 0) reinterpret_cast<unsigned long long*>(smem + C::CHAIN_OFF + C::CHAIN_TRACE)[role * 64 + tk++] = __builtin_amdgcn_s_memrealtime();
-            else a.trace[((blockIdx.x >> 4) * 2 + role) * 64 + tk++] = __builtin_amdgcn_s_memrealtime();
+        if (a.trace && (blockIdx.x & 15) == 0 && blockIdx.x < 512 && lane == 0 && tk < RESR_TRACE_STAMPS && wave <= NWC) {
+            if constexpr (CH != 0) reinterpret_cast<unsigned long long*>(smem + C::CHAIN_OFF + C::CHAIN_TRACE)[role * RESR_TRACE_STAMPS + tk++] = __builtin_amdgcn_s_memrealtime();
+            else a.trace[((blockIdx.x >> 4) * 2 + role) * RESR_TRACE_STAMPS + tk++] = __builtin_amdgcn_s_memrealtime();
         }
     };
     auto stamp_dump = [&](int role) {   // chained launches: the wave's stamps, LDS -> the trace buffer
         if constexpr (CH != 0) {
             if (a.trace && (blockIdx.x & 15) == 0 && blockIdx.x < 512 && lane == 0 && wave <= NWC)
                 for (int i = 0; i < tk; ++i)
-                    a.trace[((blockIdx.x >> 4) * 2 + role) * 64 + i] = reinterpret_cast<const unsigned long long*>(smem + C::CHAIN_OFF + C::CHAIN_TRACE)[role * 64 + i];
+                    a.trace[((blockIdx.x >> 4) * 2 + role) * RESR_TRACE_STAMPS + i] = reinterpret_cast<const unsigned long long*>(smem + C::CHAIN_OFF + C::CHAIN_TRACE)[role * RESR_TRACE_STAMPS + i];
         }
     };
 
@@ -575,6 +588,32 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         if (ick == nch - nlast && dep >= 0 && !(CH == 3 && tile_settled)) poll(it, chain_epoch + (unsigned)dep + 1u, chain_epoch + (unsigned)dep + 1u);
                         stamp(0);
                         hb = hb == 2 ? 0 : hb + 1;
+#if defined(RESR_TIMING_RESIDENT)
+                        {
+                            const bool newest = ick >= nch - nlast;     // the job's dependent chunk: its ring is the neighbours' data
+                            if (job == 0) { issue_h(ick, hb); poison_src = nullptr; stamp(0); wait_all_but_h(); }
+                            else if (newest) {
+                                // the ring: six full instructions (waves 0..5 one each), same source plane
+                                if (pw < 6 && NIP > 0) {
+                                    const int ckr = st_chunk(ick);
+                                    const int c0 = ckr * 32;
+                                    const bool seg1 = c0 >= a.cin0;
+                                    const char* base = seg1 ? a.in1 + (size_t)((c0 - a.cin0) >> 5) * a.in1_chunk_b : a.in0 + (size_t)(c0 >> 5) * a.in0_chunk_b;
+                                    const unsigned stride_b = seg1 ? a.in1_stride_b : a.in0_stride_b;
+                                    if (stride_b != voff_stride) {
+#pragma unroll
+                                        for (int i = 0; i < NIP; ++i) voff[i] = __umul24(pix[i], stride_b) + ((cst[i] >> 16) & 0xfff0u);
+                                        voff_stride = stride_b;
+                                    }
+                                    const unsigned dst = lds_base + hb * BUF + pw * 1024;
+                                    if (inb[0] == val[0]) dma_s(base, voff[0], dst, val[0]);
+                                    else dma_v(pix[0] != ~0u ? base + voff[0] : zero, dst, val[0]);
+                                }
+                                poison_src = nullptr; stamp(0);
+                                if (pw < 6) __builtin_amdgcn_s_waitcnt((1 & 15) | 0x0F70); else __builtin_amdgcn_s_waitcnt(0x0F70);
+                            } else { poison_src = nullptr; stamp(0); __builtin_amdgcn_s_waitcnt(0x0F70); }
+                        }
+#else
 #ifndef RESR_TIMING_NO_H
                         issue_h(ick, hb);
 #endif
@@ -584,6 +623,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         wait_all_but_h();
 #else
                         __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
 #endif
                     } else {
                         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -928,35 +968,45 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                     // A fragment of tap (dy, dx) = the two 1 KB fragments (tap * 2 + {0, 1}) * MT + m of the chunk's MX block.
                     static_assert(KS == 2, "MX stage: 64-byte pixel records");
                     typedef int v8i __attribute__((ext_vector_type(8)));
+                    typedef int v4i __attribute__((ext_vector_type(4)));
                     const char* wl = wlds + wsel * C::WBUF;
                     const int one = 0x7f7f7f7f;   // e8m0 1.0 for every block: bf8 operands carry their own exponents
+                    auto ld8 = [&](const char* p0, const char* p1) -> v8i {
+                        const v4i lo4 = *reinterpret_cast<const v4i*>(p0), hi4 = *reinterpret_cast<const v4i*>(p1);
+                        return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    };
+                    // Units u = dx * 3 + dy in consumption order.  The weight fragments of unit u + 1 are requested before unit u's MFMAs
+                    // (a ring of two); the halo rows of the next dx replace this dx's rows as the dy taps release them -- row 0 before the
+                    // dy = 1 MFMAs, row 1 before the dy = 2 MFMAs, the rest behind them (one dx group's rows live at a time: the 8-wave
+                    // shapes have 128 registers).
+                    v8i wa[2][MT], qa[NT + 2];
+                    auto wld = [&](int slot, int u) {
+                        const int tap = (u % 3) * 3 + u / 3;
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        uint4 q0[NT + 2], q1[NT + 2];
-                        __builtin_amdgcn_sched_barrier(0);   // (one dx group's fragments live at a time: the 8-wave shapes have 128 registers)
+                        for (int m = 0; m < MT; ++m)
+                            wa[slot][m] = ld8(wl + ((tap * 2 + 0) * MT + m) * 1024, wl + ((tap * 2 + 1) * MT + m) * 1024);
+                    };
+                    auto qld = [&](int r, int dx) {
+                        qa[r] = ld8(lbuf + boff[dx][0] + r * (HW * PB), lbuf + boff[dx][1] + r * (HW * PB));
+                    };
+                    wld(0, 0);
 #pragma unroll
-                        for (int r = 0; r < NT + 2; ++r) {
-                            q0[r] = *reinterpret_cast<const uint4*>(lbuf + boff[dx][0] + r * (HW * PB));
-                            q1[r] = *reinterpret_cast<const uint4*>(lbuf + boff[dx][1] + r * (HW * PB));
-                        }
+                    for (int r = 0; r < NT + 2; ++r) qld(r, 0);
 #pragma unroll
-                        for (int dy = 0; dy < 3; ++dy) {
-                            uint4 w0[MT], w1[MT];
+                    for (int u = 0; u < 9; ++u) {
+                        const int dx = u / 3, dy = u % 3;
+                        if (u + 1 < 9) wld((u + 1) & 1, u + 1);
+                        if (dx < 2 && dy >= 1) qld(dy - 1, dx + 1);     // rows 0 / 1 were last read by the dy = 0 / dy = 1 taps of this dx
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int m = 0; m < MT; ++m) {
-                                w0[m] = *reinterpret_cast<const uint4*>(wl + (((dy * 3 + dx) * 2 + 0) * MT + m) * 1024);
-                                w1[m] = *reinterpret_cast<const uint4*>(wl + (((dy * 3 + dx) * 2 + 1) * MT + m) * 1024);
-                            }
+                        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                            for (int t = 0; t < NT; ++t)
+                            for (int m = 0; m < MT; ++m)
+                                acc[m][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[u & 1][m], qa[t + dy], acc[m][t], 1, 1, 0, one, 0, one);   // cbsz / blgp 1: bf8
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (dx < 2 && dy == 2) {
 #pragma unroll
-                                for (int m = 0; m < MT; ++m) {
-                                    const v8i av = {(int)w0[m].x, (int)w0[m].y, (int)w0[m].z, (int)w0[m].w, (int)w1[m].x, (int)w1[m].y, (int)w1[m].z, (int)w1[m].w};
-                                    const v8i bv = {(int)q0[t + dy].x, (int)q0[t + dy].y, (int)q0[t + dy].z, (int)q0[t + dy].w,
-                                                    (int)q1[t + dy].x, (int)q1[t + dy].y, (int)q1[t + dy].z, (int)q1[t + dy].w};
-                                    acc[m][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[m][t], 1, 1, 0, one, 0, one);   // cbsz / blgp 1: bf8
-                                }
-                            __builtin_amdgcn_sched_barrier(0);
+                            for (int r = 2; r < NT + 2; ++r) qld(r, dx + 1);
                         }
                     }
                     par ^= 1;
@@ -1090,8 +1140,8 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                 long out_q;                      // MX: element offset hi -> q tensor of the output (0: none)
             } e;
             e.out_q = 0;
-            if constexpr (MX) e.out_q = ep->out_q;
-            if constexpr (CH && MX) e.out_q = cj.job[job].out_q;
+            if constexpr (X2) e.out_q = ep->out_q;
+            if constexpr (CH && X2) e.out_q = cj.job[job].out_q;
             e.out = ep->out; e.h = ep->h; e.w_ = ep->w_; e.cout = ep->cout; e.out_stride = ep->out_stride;
             e.out_chunk = ep->out_chunk; e.flags = ep->flags; e.slope = ep->slope;
             if constexpr (X2) e.out_lo = ep->out_lo;
@@ -1243,7 +1293,7 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                             }
                             if (in_img && piece_ok(m, j))
                                 *reinterpret_cast<uint4v*>(orow + ((size_t)m * e.out_chunk + j * 16 + e.out_lo) * 2) = dl;
-                            if constexpr (MX) {
+                            if constexpr (X2) {   // (any exact16 pass with a lean epilogue may emit it: the pass BEHIND it decides whether it reads q records)
                                 if (e.out_q != 0) {
                                     // the q record of the pixel's chunk m: byte c = bf8(hi[c]), byte 32 + c = bf8(lo[c]) -- e5m2 of the f16 values
                                     // just stored, round to nearest even, unit scale; this lane's 8 channels start at (2 j + kh) * 8
@@ -1621,10 +1671,12 @@ static int launch_ws_epi(const ConvArgs& a, hipStream_t stream) {
 
 template <typename T, int MT, int NT, int NWC, int X2 = 0>
 static int launch_ws(const ConvArgs& a, hipStream_t stream) {
-    if constexpr (X2 == 2) {   // MX stages (RESR_CONV_MX_PAIRS): the inference epilogues -- bias / LeakyReLU / residuals, all lean
+    if constexpr (X2 == 2) {   // MX stages (RESR_CONV_MX_PAIRS): the lean epilogues -- bias / LeakyReLU / residuals, or the sign-word mask of a backward-data pass
+        if ((a.flags & RESR_CONV_MASK_BITS) && !a.aux && !a.res0 && !a.res1 && !(a.flags & ~(RESR_CONV_MASK | RESR_CONV_MASK_BITS | RESR_CONV_NO_BIAS)))
+            return launch_ws_epi<T, MT, NT, NWC, 33, X2>(a, stream);
         const bool lean_ok = !a.aux && !a.mask && !(a.flags & ~(RESR_CONV_LRELU | RESR_CONV_NO_BIAS | RESR_CONV_UPSAMPLE_IN)) &&
                              !((a.flags & RESR_CONV_LRELU) && !(a.slope >= 0.f && a.slope <= 1.f)) && !((a.res0 || a.res1) && (a.cout & 15));
-        if (!lean_ok) return fail(RESR_ERR_ARG, "conv3x3: RESR_CONV_MX_PAIRS supports bias / LeakyReLU (0 <= slope <= 1) / residual epilogues only");
+        if (!lean_ok) return fail(RESR_ERR_ARG, "conv3x3: RESR_CONV_MX_PAIRS supports bias / LeakyReLU (0 <= slope <= 1) / residual / sign-word-mask epilogues only");
         if (a.res0 && a.res1) return launch_ws_epi<T, MT, NT, NWC, 6, X2>(a, stream);
         if (a.res0) return launch_ws_epi<T, MT, NT, NWC, 2, X2>(a, stream);
         if (a.res1) return fail(RESR_ERR_ARG, "conv3x3: res1 without res0");
@@ -1648,6 +1700,8 @@ static int launch_ws(const ConvArgs& a, hipStream_t stream) {
     const bool odd_slope = (a.flags & RESR_CONV_LRELU) && !(a.slope >= 0.f && a.slope <= 1.f);
     const bool odd_cout = (a.res0 || a.res1) && (a.cout & 15);   // its residual loads select whole 16-channel piece pairs
     const bool extras = odd_slope || odd_cout || a.aux || (a.flags & (RESR_CONV_OUT_NCHW_F32 | RESR_CONV_CLAMP01));
+    if (a.out_q != 0 && (extras || !(combo == 0 || combo == 2 || combo == 6)))   // (the sign-word forms above are lean as well)
+        return fail(RESR_ERR_ARG, "conv3x3: out_q_offset needs a lean epilogue (bias / LeakyReLU / residuals / sign words)");
     if (!extras) switch (combo) {
         case 0: return launch_ws_epi<T, MT, NT, NWC, 0, X2>(a, stream);  // forward convs 1-4, upsampling, D forward
         case 1: return launch_ws_epi<T, MT, NT, NWC, 1, X2>(a, stream);  // backward-data through a LeakyReLU

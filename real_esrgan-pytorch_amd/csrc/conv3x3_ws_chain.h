@@ -59,8 +59,9 @@ static int launch_chain(const ConvArgs& a, const ChainArgs& cj, double flop, dou
 // jobs of kind "residual half" (the closing convolution inside the chain) take the instantiation with the per-job switches
 template <int NT, int CH, int X2>
 static int launch_chain_kind(const ConvArgs& a, const ChainArgs& cj, int kind, double flop, double bytes, hipStream_t stream) {
-    if constexpr (X2 == 2) {   // MX stages: inference chains only (LeakyReLU; the closing convolution's halves through CH 2)
-        if (kind != 0) return fail(RESR_ERR_ARG, "conv3x3_chain: RESR_CONV_MX_PAIRS chains are inference forward passes");
+    if constexpr (X2 == 2) {   // MX stages: inference forward chains (LeakyReLU) and the mirrored backward-data chains (sign-word mask)
+        if (kind == 1) return fail(RESR_ERR_ARG, "conv3x3_chain: a training forward keeps every pair chunk on three f16 stages (no RESR_CONV_MX_PAIRS)");
+        if (kind == 2) return launch_chain<NT, 33, CH, X2>(a, cj, flop, bytes, stream);
         return launch_chain<NT, 0, CH, X2>(a, cj, flop, bytes, stream);
     } else {
         if (kind == 2) return launch_chain<NT, 33, CH, X2>(a, cj, flop, bytes, stream);

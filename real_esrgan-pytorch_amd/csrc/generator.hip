@@ -85,6 +85,10 @@ int round32(int v) { return (v + 31) / 32 * 32; }
 // RESR_X2_PLAN_MX_INFER: an exact16 INFERENCE forward whose pair chunks take one f16 stage + one MX stage (RESR_CONV_MX_PAIRS).  Rides
 // on the single-f16 growth planes against f16 weights (bits 0 + 5): every activation buffer then holds THREE tensors -- hi, lo and the
 // q tensor (bf8 of both, 2 bytes per element) -- and the packed weights an MX region behind the f16 blocks (generator_mx_offset).
+// RESR_X2_PLAN_MX_BWD: the trunk's backward-data passes on MX stages; the gradient planes gT / gS carry q tensors.
+bool plan_mx_bwd(const ResrGeneratorDesc& d) {
+    return d.dtype == RESR_F16X2 && d.training && (d.x2_plan & RESR_X2_PLAN_MX_BWD) && !(d.x2_plan & RESR_X2_PLAN_GROWTH_GRAD_STORE_F16);
+}
 bool plan_mx(const ResrGeneratorDesc& d) {
     const int need = RESR_X2_PLAN_GROWTH_F16_INFER | RESR_X2_PLAN_GROWTH_W16_INFER | RESR_X2_PLAN_MX_INFER;
     return d.dtype == RESR_F16X2 && !d.training && (d.x2_plan & need) == need;
@@ -249,8 +253,9 @@ void carve(const Plan& p, char* base, Bufs& b) {
         b.gB = take(px * 16 * 64 * es);
         b.gM1 = take(px * 4 * 64 * es);
         b.gF = take(px * 64 * es);
-        for (int i = 0; i < 4; ++i) b.gT[i] = take(px * 64 * es);
-        for (int i = 0; i < 3; ++i) b.gS[i] = take(px * 128 * es);
+        const size_t esg = es + (plan_mx_bwd(p.d) ? 2 : 0);   // RESR_X2_PLAN_MX_BWD: hi, lo and q tensors
+        for (int i = 0; i < 4; ++i) b.gT[i] = take(px * 64 * esg);
+        for (int i = 0; i < 3; ++i) b.gS[i] = take(px * 128 * esg);
         b.gxin = take(px * p.ci_pad * es);
         // wgrad slabs: largest batch (an RRDB = 78 products, a dense block = 26 at LR; single 64->64 convs = 4 jobs at 1x/2x/4x)
         const size_t slab = (9 * 1024 + 32) * sizeof(float);
@@ -322,7 +327,7 @@ size_t generator_mx_offset(const ResrGeneratorDesc* d) {
 size_t generator_packed_bytes(const ResrGeneratorDesc* d, int backward) {
     Plan p;
     if (!build_plan(d, p)) return 0;
-    if (d->dtype == RESR_F16X2 && (d->x2_plan & RESR_X2_PLAN_MX_INFER)) return generator_mx_offset(d) + p.pk_total_elems * 2 + 16384;
+    if (d->dtype == RESR_F16X2 && (d->x2_plan & (RESR_X2_PLAN_MX_INFER | RESR_X2_PLAN_MX_BWD))) return generator_mx_offset(d) + p.pk_total_elems * 2 + 16384;
     // + two dummy (chunk,tap) of slack: conv3x3_kernel prefetches two taps past the end
     return (backward ? p.pk_total_elems : p.pk_fwd_elems) * elem_size(d->dtype) * (d->dtype == RESR_F16X2 ? 3 : 1) + 16384;
 }
@@ -626,6 +631,8 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     // reads 4.3e-3 at a GradScaler's initial 2^16 and 1.4e-3 from 2^20 on (median 7.7e-4 throughout; garbage at 2^10) -- the difference is
     // f16 underflow, not f16 arithmetic (tools/fast_loss_scale_probe.py).  strict (f32) needs none.
     const unsigned* gsc = (d->dtype != RESR_F32 && !no_prescale) ? b.gscale : nullptr;
+    // RESR_X2_PLAN_MX_BWD: the dense blocks' backward-data passes read every gradient chunk as a pair on an f16 + an MX stage
+    const bool mxb = plan_mx_bwd(*d);
     const bool gg_single = x2 && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_F16);
     const bool gg_store_single = gg_single && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_STORE_F16);   // opt-in: no lo store, biases from hi alone
     // RESR_X2_PLAN_GROWTH_ACT_F16_WGRAD: the weight products of conv2..conv5 read the growth planes (X chunks 2..) as their hi tensor
@@ -719,8 +726,17 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         RUN(wgrad(c, h, w, b.trunk_out, 64, 32, b.gF, 32, 0, 1.f, plane, plane, lo_t, lo_t));
         ResrConvDesc cd = dgrad(h, w, 64, 32, 64, 0, 64, 64, 32, 0, lo_t, 0, lo_t);
         cd.in0_chunk_stride = plane; cd.out_chunk_stride = plane;   // the gT ring (gradient wrt the RDB chain) is chunk-planar [2][N,h,w,32]
+        if (mxb) cd.out_q_offset = 2 * lo_t;   // the first dense block's passes read gT[0] through MX stages: this (plain) pass emits its q tensor
         RUN(conv3x3_dispatch(&cd, b.gF, nullptr, pk + p.pk_bwd_conv2 * wes, nullptr, nullptr, nullptr, nullptr, b.gT[0], nullptr, st));
     }
+    const char* pk_mx = mxb ? pk + generator_mx_offset(d) : nullptr;
+    auto MXB = [&](ResrConvDesc& cd, size_t pk_off, long out_q) {   // gin (in0) and the slab gS (in1) with their q tensors, the pass's MX blocks
+        if (!mxb) return;
+        cd.flags |= RESR_CONV_MX_PAIRS;
+        cd.x2_pair_chunks = 0;   // every chunk a pair: the growth-plane gradients enter with both halves
+        cd.in0_q_offset = 2 * lo_t; cd.in1_q_offset = 2 * lo_gs; cd.out_q_offset = out_q;
+        cd.w_mx_offset = (int64_t)((pk_mx + pk_off * 2) - (pk + pk_off * wes));
+    };
     RUN(ready(0));   // conv4, conv3, upsampling2, upsampling1, conv2: the tail of the arena
     // trunk, mirrored dense blocks.  gT ring: e (grad wrt RRDB output) must survive its three RDBs.
     int e_idx = 0;
@@ -754,6 +770,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             cd.in0_chunk_stride = plane; cd.in1_chunk_stride = plane;
             if (gg_single) cd.x2_pair_chunks = 2;   // g_y (in0): pairs; the slab (in1) is read as single f16 chunks, written as a pair
             if (gg_store_single) cd.flags |= RESR_CONV_OUT_SINGLE;
+            MXB(cd, p.pk_bwd_trunk[(size_t)r * 5 + ps], 2 * lo_gs);
             char* out = gS + (size_t)ps * plane * es;
             const char* mask = b.bits[r] + (size_t)(k - 1) * N * h * w * sizeof(uint32_t);   // sign plane of o_k
             cds[ps] = cd; ws4[ps] = pk + p.pk_bwd_trunk[(size_t)r * 5 + ps] * wes; masks4[ps] = mask; outs4[ps] = out;
@@ -775,6 +792,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.s0 = 1.f; cd.res0_lo_offset = lo_t;
             cd.t0 = pos == 2 ? 0.2f : 1.f;       // d(rdb3_out*0.2 + x)/d(rdb3_out) reaches x3 scaled
             if (pos == 0) { res1 = b.gT[e_idx]; cd.res1_stride = 32; cd.res1_chunk_stride = plane; cd.s1 = 1.f; cd.t1 = 1.f; cd.res1_lo_offset = lo_t; }
+            MXB(cd, p.pk_bwd_trunk[(size_t)r * 5 + 4], 2 * lo_t);
             RUN(conv3x3_block_dispatch(4, cds, gin, gS, ws4, nullptr, masks4, outs4, nullptr, &cd,
                                        pk + p.pk_bwd_trunk[(size_t)r * 5 + 4] * wes, nullptr, res0, res1, b.gT[nxt], b.chain, b.chain_bytes, st));
             cur = nxt;

@@ -1239,18 +1239,27 @@ int wgrad_dispatch(const ResrWgradDesc* d, const void* x0, const void* x1, const
             return fail(RESR_ERR_ARG, "wgrad: chunk strides %lld / %lld, lo offsets %lld / %lld out of range (zero-initialise ResrWgradDesc; resr_version() = %d)",
                         (long long)d->x_chunk_stride, (long long)d->g_chunk_stride, (long long)d->x_lo_offset, (long long)d->g_lo_offset, RESR_VERSION);
     }
+    // RESR_F16X2: a single-f16 G is selected EXPLICITLY (RESR_CONV_OUT_SINGLE in flags: the tensor a pass with that flag wrote); a zero
+    // g_lo_offset without it is a forgotten field, not a mode -- the internal WgradConv keeps the "0 = single" convention
+    int flags = d->flags;
+    long g_lo = (long)d->g_lo_offset;
+    if (d->dtype == RESR_F16X2) {
+        if (flags & RESR_CONV_OUT_SINGLE) g_lo = 0;
+        else if (g_lo == 0) return fail(RESR_ERR_ARG, "wgrad: RESR_F16X2 needs g_lo_offset (or RESR_CONV_OUT_SINGLE in flags for a single f16 G)");
+    }
+    flags &= ~RESR_CONV_OUT_SINGLE;
     WgradConv c;
     c.x0 = x0; c.cin = d->cin; c.in0_stride = d->in0_stride; c.cin_real = d->cin_real;
     c.g = g; c.cout = d->cout; c.cout_pad = d->cout_pad; c.g_stride = d->g_stride;
     c.x_chunk_stride = (long)d->x_chunk_stride; c.g_chunk_stride = (long)d->g_chunk_stride;
-    c.x_lo_off = (long)d->x_lo_offset; c.g_lo_off = (long)d->g_lo_offset; c.x_s2d_c = 0; c.g_lo_bias_only = 0;
+    c.x_lo_off = (long)d->x_lo_offset; c.g_lo_off = g_lo; c.x_s2d_c = 0; c.g_lo_bias_only = 0;
     c.dw = dw; c.db = db; c.scale = d->scale;
     // more products than one launch's job table holds (or an output wider than 64 channels): the layer mode (f16, exact16)
     const int tap_products = (c.cin / 32) * (c.cout_pad / 32) * (d->dtype == RESR_F16X2 ? wgrad_x2_products() : 1);
     if ((d->dtype == RESR_F16 || d->dtype == RESR_F16X2) &&
         (c.cout_pad > 64 || (c.cin / 32) * (c.cout_pad / 32) > kMaxReduce || tap_products > kMaxJobs))
-        return wgrad_layer(&c, d->n, d->h, d->w, d->dtype, d->flags, d->splits, partial, stream);
-    return wgrad_batch(&c, 1, d->n, d->h, d->w, d->dtype, d->flags, d->splits, partial, stream);
+        return wgrad_layer(&c, d->n, d->h, d->w, d->dtype, flags, d->splits, partial, stream);
+    return wgrad_batch(&c, 1, d->n, d->h, d->w, d->dtype, flags, d->splits, partial, stream);
 }
 
 }  // namespace resr

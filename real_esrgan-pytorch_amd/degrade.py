@@ -191,6 +191,11 @@ class Degrader:
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             lr, hrc = run_plan(hr, plan, self.usm, self.jpeg, self.upscale, self.crop)
+            # An identity HR window comes back as `hr` itself (imgproc.quantize_crop).  The pair is handed out one call LATER: a caller that
+            # refills its HR buffer in place in between would get LR(i) next to HR(i + 1), so the pair keeps its own copy (0.4 GB of the
+            # stage's 3.4 GB per batch at the headline geometry); direct run_plan callers keep the alias.
+            if hrc.data_ptr() == hr.data_ptr():
+                hrc = hr.clone()
         done = torch.cuda.Event()
         done.record(self.stream)
         return lr, hrc, done
@@ -242,6 +247,11 @@ class DegradationPrefetcher:
         with torch.cuda.stream(self.stream):
             start.record(self.stream)
             lr, hrc = run_plan(hr, plan, self.usm, self.jpeg, self.upscale, self.crop)
+            # An identity HR window comes back as `hr` itself (imgproc.quantize_crop).  The pair is handed out one call LATER: a caller that
+            # refills its HR buffer in place in between would get LR(i) next to HR(i + 1), so the pair keeps its own copy (0.4 GB of the
+            # stage's 3.4 GB per batch at the headline geometry); direct run_plan callers keep the alias.
+            if hrc.data_ptr() == hr.data_ptr():
+                hrc = hr.clone()
             end.record(self.stream)
         for t in (hr, batch["kernel1"], batch["kernel2"], batch["sinc_kernel"]):
             if torch.is_tensor(t) and t.is_cuda:

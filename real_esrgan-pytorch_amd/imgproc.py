@@ -348,7 +348,11 @@ def jpeg_u8(image: torch.Tensor, quality, return_coeffs: bool = False):
 
 # ---- crop / conversions --------------------------------------------------------------------------------
 def quantize_crop(lr_images, hr_images, hr_image_size, upscale_factor, hr_top, hr_left):
-    """clamp(round(lr*255))/255 fused with the crop of both tensors (train_realesrnet.py:374-377)."""
+    """clamp(round(lr*255))/255 fused with the crop of both tensors (train_realesrnet.py:374-377).
+    ALIASING: when the HR window is the whole tile (hr_top = hr_left = 0, hr_image_size = the tile's edge: every batch of the
+    reference's configuration) the returned HR tensor IS `hr_images` (a float contiguous input is not copied either) -- the reference's
+    random_crop always returns fresh tensors.  Callers that keep the pair beyond the caller's next write to that buffer must copy
+    (degrade.Degrader / DegradationPrefetcher do)."""
     lr, hr = _img(lr_images, "quantize_crop"), _img(hr_images, "quantize_crop")
     b, c = lr.shape[:2]
     ls = hr_image_size // upscale_factor

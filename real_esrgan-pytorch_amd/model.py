@@ -214,7 +214,7 @@ class Generator(nn.Module):
     MFMAs per product, fp32 accumulate: meets the 1e-3 parity tolerance vs the fp32 CPU path at about a third
     of fast mode's throughput), "strict" = f32 operands on v_mfma_f32_32x32x2_f32 (bit-for-bit fp32 FMA chains).
     Default from $RESR_PRECISION, else "fast".
-    `x2_plan` (exact16 only; bit set of _lib.X2_PLAN_*, default from $RESR_X2_PLAN, else 59 = bits 0, 1, 3, 4, 5): which tensors of the dense
+    `x2_plan` (exact16 only; bit set of _lib.X2_PLAN_*, default from $RESR_X2_PLAN, else 251 = bits 0, 1, 3, 4, 5, 6, 7; 59 = round 5's default without the MX stages): which tensors of the dense
     blocks are single f16 instead of hi/lo pairs -- bit 0: the growth planes o1..o4 of an INFERENCE forward (50 instead of 60
     stages per block; forward ~1e-6 at the reference's init scale, gate 2e-4), bit 1: the growth-plane gradients of the backward
     pass are READ as single f16 (two stages / two tap-products on their chunks; the bias sums still take hi + lo; worst gradient
@@ -225,7 +225,9 @@ class Generator(nn.Module):
     the f16 weights W0 alone -- one stage each, 40 per block (forward 2.3e-6 at the init scale, 2.9e-5 at dense weights x 4), bit 6 (with bits 0 + 5): the PAIR
     chunks of an inference forward take one f16 stage + one MX stage -- both 2^-12-weighted correction products as nine
     v_mfma_scale_f32_32x32x64_f8f6f4 per output row on unscaled bf8 operands ([bf8(x_hi) | bf8(x_lo)] records written by the producing
-    epilogues, [bf8(W1) | bf8(W2)] blocks from the packer): 30 stage-equivalents per block, forward ~1e-4 (gate 2e-4).  x2_plan=0 = pairs everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
+    epilogues, [bf8(W1) | bf8(W2)] blocks from the packer): 30 stage-equivalents per block, forward ~1e-4 (gate 2e-4), bit 7: the dense
+    blocks' backward-data passes read EVERY gradient chunk as a pair on one f16 + one MX stage (40 stage-equivalents per block instead of
+    50; the growth-plane gradients enter with both halves again: worst gradient tensor ~1e-4 instead of 3-5e-4).  x2_plan=0 = pairs everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
     The backward pass of the 16-bit modes (exact16, fast) does not depend on the caller's loss scale: an incoming gradient whose largest element is below 2^6 is
     lifted by a power of two inside the native pass and the results are handed back unscaled (bit-identical gradients at loss scale
     1 and 2^20; csrc/generator.hip, $RESR_X2_GRAD_PRESCALE_LOG2 / RESR_X2_NO_GRAD_PRESCALE=1).
@@ -242,11 +244,13 @@ class Generator(nn.Module):
         self.in_channels, self.out_channels, self.upscale_factor = in_channels, out_channels, upscale_factor
         self.precision = precision or os.environ.get("RESR_PRECISION", "fast")
         self._dtype = _precision_to_dtype(self.precision)
-        self.x2_plan = int(os.environ.get("RESR_X2_PLAN", "59")) if x2_plan is None else int(x2_plan)
-        if not 0 <= self.x2_plan <= 127:
+        self.x2_plan = int(os.environ.get("RESR_X2_PLAN", "251")) if x2_plan is None else int(x2_plan)
+        if not 0 <= self.x2_plan <= 255:
             raise ValueError(f"x2_plan must be a bit set of X2_PLAN_GROWTH_F16_INFER (1) | X2_PLAN_GROWTH_GRAD_F16 (2) | "
                              f"X2_PLAN_GROWTH_GRAD_STORE_F16 (4) | X2_PLAN_GROWTH_ACT_F16_WGRAD (8) | X2_PLAN_GROWTH_ACT_G_HI_WGRAD (16) | X2_PLAN_GROWTH_W16_INFER (32) | "
-                             f"X2_PLAN_MX_INFER (64), got {self.x2_plan}")
+                             f"X2_PLAN_MX_INFER (64) | X2_PLAN_MX_BWD (128), got {self.x2_plan}")
+        if (self.x2_plan & 128) and (self.x2_plan & 4):
+            raise ValueError(f"x2_plan={self.x2_plan}: MX_BWD (128) reads the growth-plane gradients as pairs; GROWTH_GRAD_STORE_F16 (4) stores them single")
         # a bit that only refines another one means nothing without it: refuse instead of silently ignoring it
         for bit, needs, name in ((4, 2, "GROWTH_GRAD_STORE_F16 (4) refines GROWTH_GRAD_F16 (2)"), (16, 8, "GROWTH_ACT_G_HI_WGRAD (16) refines GROWTH_ACT_F16_WGRAD (8)"),
                                  (32, 1, "GROWTH_W16_INFER (32) refines GROWTH_F16_INFER (1)"), (64, 33, "MX_INFER (64) rides on GROWTH_F16_INFER (1) + GROWTH_W16_INFER (32)")):
@@ -386,7 +390,8 @@ class Generator(nn.Module):
         raw, n = self._table_dev[key]
         _lib.check(L.resr_pack_weights(_lib.ptr(raw), n, _lib.ptr(flat), _lib.ptr(self._packed), self._dtype,
                                        _lib.stream_ptr(flat)), "resr_pack_weights")
-        if self._dtype == _lib.RESR_F16X2 and (desc.x2_plan & _lib.X2_PLAN_MX_INFER) and not desc.training:
+        if self._dtype == _lib.RESR_F16X2 and (((desc.x2_plan & _lib.X2_PLAN_MX_INFER) and not desc.training) or
+                                               ((desc.x2_plan & _lib.X2_PLAN_MX_BWD) and desc.training)):
             # the MX blocks of the same table ([bf8(W1) | bf8(W2)] per tap and row), behind the f16 blocks of the packed buffer
             mx_off = int(L.resr_generator_mx_offset(C.byref(desc)))
             _lib.check(L.resr_pack_weights_mx(_lib.ptr(raw), n, _lib.ptr(flat), C.c_void_p(self._packed.data_ptr() + mx_off),
@@ -394,7 +399,7 @@ class Generator(nn.Module):
 
     def _workspace(self, desc: _lib.GeneratorDesc, device) -> _Workspace:
         L = _lib.lib()
-        key = (desc.n, desc.h, desc.w, desc.training, desc.dtype, desc.wgrad_splits)
+        key = (desc.n, desc.h, desc.w, desc.training, desc.dtype, desc.wgrad_splits, desc.x2_plan & (_lib.X2_PLAN_MX_INFER | _lib.X2_PLAN_MX_BWD))   # (the MX plans carry q tensors)
         pool = self._workspaces.setdefault(key, [])
         for ws in pool:
             if not ws.busy:

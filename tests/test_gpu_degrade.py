@@ -223,3 +223,22 @@ def test_generic_filter_kernel_knob():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_degrade.py"), "-q", "-x", "-m", "gpu",
                         "-k", "usm_and_filter2d or pipeline_prefix"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_degrader_pair_does_not_alias_a_buffer_the_caller_refills():
+    """with an identity HR window (crop = the tile's edge: every batch of the reference's configuration) quantize_crop
+    hands back the input tensor itself, and the prefetching stage returns its pairs ONE CALL LATER -- a caller that refills its HR
+    buffer in place between two calls would get LR(i) next to HR(i + 1).  The stage keeps its own copy: the HR tensor of pair i still
+    holds batch i's values after the buffer has been overwritten, and it is not the caller's storage."""
+    from real_esrgan_pytorch_amd.degrade import Degrader
+    d = Degrader(batch=2, hr_size=64, upscale=4, crop=64, seed=0)
+    buf = torch.rand(2, 3, 64, 64, device="cuda")
+    first = buf.clone()
+    d(buf)                                   # submits batch 0 (and returns it: the very first call has nothing older)
+    torch.cuda.synchronize()
+    buf.fill_(0.25)                          # the caller refills its buffer in place: batch 1
+    lr, hr = d(buf)                          # the pair submitted for batch 0 ... 
+    torch.cuda.synchronize()
+    assert hr.data_ptr() != buf.data_ptr()
+    assert torch.equal(hr, first), "the HR half of a prefetched pair changed with the caller's buffer"
+    assert lr.shape == (2, 3, 16, 16)

@@ -192,7 +192,7 @@ def test_bench_two_ranks_prints_one_line():
     env = dict(os.environ, RESR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "2", "--lr-size", "64"]
+           "--batch", "2", "--lr-size", "64", "--no-parity-mode", "--no-sustained"]   # (the exact16 sub-runs of the line are single-rank matters: 40 s of this test)
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -222,7 +222,7 @@ def test_bench_gan_two_ranks_plain_launch_prints_one_line():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "2", "--lr-size", "32", "--gan"]   # (LR 16: a resize1 factor of 0.15 leaves 9 pixels for the 21-tap blur, which reflect padding refuses -- as F.pad does)
+           "--batch", "2", "--lr-size", "32", "--gan", "--no-parity-mode", "--no-sustained"]   # (LR 16: a resize1 factor of 0.15 leaves 9 pixels for the 21-tap blur, which reflect padding refuses -- as F.pad does)
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert "starting 2 ranks" in r.stderr

@@ -158,18 +158,22 @@ def test_wgrad_single_g_equals_pair_g_with_zero_lo(U, cin, cout, n, h, w, splits
     xb, x_lo = pair(x)
     gb, g_lo = pair(gy, zero_lo=True)
 
-    def run(g_lo_offset):
-        d = L.WgradDesc(n, h, w, cin, cin, cin, 0, cin, cout, cout, cout, L.RESR_F16X2, 0, splits, 1.0)
+    def run(g_lo_offset, flags=0, expect=0):
+        d = L.WgradDesc(n, h, w, cin, cin, cin, 0, cin, cout, cout, cout, L.RESR_F16X2, flags, splits, 1.0)
         d.x_lo_offset, d.g_lo_offset = x_lo, g_lo_offset
         partial = torch.zeros(L.lib().resr_wgrad_partial_bytes(C.byref(d)) // 4, device="cuda")
         dw = torch.full((cout, cin, 3, 3), -7.0, device="cuda")
         db = torch.full((cout,), -7.0, device="cuda")
-        L.check(L.lib().resr_conv3x3_wgrad(C.byref(d), L.ptr(xb), None, L.ptr(gb), L.ptr(partial), L.ptr(dw), L.ptr(db), L.stream_ptr()),
-                "resr_conv3x3_wgrad")
+        rc = L.lib().resr_conv3x3_wgrad(C.byref(d), L.ptr(xb), None, L.ptr(gb), L.ptr(partial), L.ptr(dw), L.ptr(db), L.stream_ptr())
+        if expect != 0:
+            assert rc == expect
+            return None, None
+        L.check(rc, "resr_conv3x3_wgrad")
         torch.cuda.synchronize()
         return dw, db
     dw3, db3 = run(g_lo)
-    dw2, db2 = run(0)
+    dw2, db2 = run(0, flags=L.CONV_OUT_SINGLE)       # the single-G mode is selected explicitly ...
+    run(0, expect=L.ERR_ARG)                        # ... a zero offset alone is a forgotten field
     assert torch.equal(dw3, dw2) and torch.equal(db3, db2)
     wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
     bs = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
@@ -190,8 +194,7 @@ def _setup(n_blocks, seed, x2_plan, wscale=1.0, upscale=4):
     return g.cuda(), sd, M
 
 
-@pytest.mark.parametrize("wscale", [1.0, 4.0])
-@pytest.mark.parametrize("n,h,w", [(1, 24, 24), (8, 32, 32)])
+@pytest.mark.parametrize("n,h,w,wscale", [(1, 24, 24, 1.0), (8, 32, 32, 4.0)])
 def test_inference_plan_forward_vs_oracle(n, h, w, wscale, diag_dir):
     """23 blocks, eval: growth planes single f16 (50 stages per block) against the fp32 CPU oracle and against the all-pairs plan;
     weights at the reference's init scale and dense-block weights x 4 (activations grow, the dense branch is no longer small);
@@ -250,7 +253,7 @@ def test_inference_plan_after_training_steps(diag_dir):
     assert rep["plan1_vs_f32_oracle"] < 2e-4 and rep["plan33_vs_f32_oracle"] < 2e-4, rep
 
 
-@pytest.mark.parametrize("n,h,w,n_blocks,seed", [(1, 24, 24, 23, 11), (1, 24, 24, 23, 12), (1, 24, 24, 23, 13), (8, 32, 32, 3, 11), (2, 33, 17, 2, 13)])
+@pytest.mark.parametrize("n,h,w,n_blocks,seed", [(1, 24, 24, 23, 11), (8, 32, 32, 3, 11), (2, 33, 17, 2, 13)])   # (seeds 12, 13 at full depth: tools/x2_plan_validate.py)
 def test_training_plan_gradients_vs_float64_oracle(n, h, w, n_blocks, seed, diag_dir):
     """Backward with single-f16 growth-plane gradients (x2_plan bit 1) and weight products that read the growth planes as their hi
     tensor (bits 3, 4) -- the default plan, 27; the forward pass keeps every pair: all gradient tensors
@@ -470,18 +473,22 @@ def test_exact16_backward_keeps_a_non_finite_gradient_visible():
 def test_lifted_backward_backs_off_when_the_gradient_outgrows_its_headroom(precision):
     """the lift re-raises max |g_y| to [2^6, 2^7) on every step, so a gradient that grows by more than f16's
     remaining 2^9 on its way back would overflow at EVERY loss scale -- a GradScaler halving its scale could not cure it.  Here the
-    backward gain of the HR tail is 2^11 by construction (conv4's weights x 2^11, conv3's weights and bias x 2^-11: LeakyReLU is
-    positively homogeneous, so the forward pass is the same function): the first lifted pass overflows, sets the flag in the
-    workspace's pre-scale slot, and the next pass aims 2^4 lower (common.h) -- after at most three skipped steps the GradScaler's scale
-    stops decaying and the weights move.  Without the back-off every step of the loop below is skipped."""
+    backward gain of the HR tail is 2^18 by construction (conv4's and conv3's weights x 2^9 each -- below exact16's |w| < 16 --,
+    upsampling2's weights and bias x 2^-18: LeakyReLU is positively homogeneous, so the forward pass is the same function): the first
+    lifted passes overflow, set the flag in the workspace's pre-scale slot, and every later pass aims 2^4 lower (common.h) -- after at
+    most five skipped steps the GradScaler's scale stops decaying and the weights move.  Without the back-off every step of the loop
+    below is skipped."""
     import real_esrgan_pytorch_amd as R
     torch.manual_seed(2)
     g = R.Generator(3, 3, 4, precision=precision, n_blocks=1).cuda().train()
     with torch.no_grad():
         g.conv4.bias.add_(0.5)
-        g.conv4.weight.mul_(2.0 ** 11)
-        g.conv3[0].weight.mul_(2.0 ** -11)
-        g.conv3[0].bias.mul_(2.0 ** -11)
+        g.conv4.weight.mul_(2.0 ** 9)
+        g.conv3[0].weight.mul_(2.0 ** 9)
+        g.conv3[0].bias.mul_(2.0 ** -9)
+        g.upsampling2[0].weight.mul_(2.0 ** -18)
+        g.upsampling2[0].bias.mul_(2.0 ** -18)
+        assert g.conv4.weight.abs().max() < 16 and g.conv3[0].weight.abs().max() < 16
     opt = torch.optim.Adam(g.parameters(), 1e-6, (0.9, 0.99))
     scaler = torch.amp.GradScaler("cuda")
     gen = torch.Generator(device="cuda").manual_seed(9)
@@ -489,7 +496,7 @@ def test_lifted_backward_backs_off_when_the_gradient_outgrows_its_headroom(preci
     target = torch.rand(4, 3, 128, 128, device="cuda", generator=gen)
     w0 = g.conv1.weight.detach().clone()
     scales, finite = [], []
-    for _ in range(8):
+    for _ in range(10):
         opt.zero_grad(set_to_none=True)
         scaler.scale((g(x) - target).abs().mean()).backward()
         finite.append(all(torch.isfinite(p.grad).all().item() for p in g.parameters()))
@@ -497,8 +504,8 @@ def test_lifted_backward_backs_off_when_the_gradient_outgrows_its_headroom(preci
         scaler.update()
         scales.append(scaler.get_scale())
     assert not finite[0], "the case does not overflow the lifted pass: no back-off exercised"
-    assert all(finite[3:]), (finite, scales)
-    assert scales[-1] >= 65536.0 / 8, (finite, scales)      # at most three skipped steps; without the back-off: 65536 / 2^8
+    assert all(finite[5:]), (finite, scales)
+    assert scales[-1] >= 65536.0 / 32, (finite, scales)     # at most five skipped steps; without the back-off: 65536 / 2^10
     assert not torch.equal(g.conv1.weight.detach(), w0), "no optimizer step was taken"
 
 
@@ -549,7 +556,10 @@ def _oracle_grads(M, sd, x, gw, n_blocks, dt=torch.float64):
     return yo.detach(), {k: v.grad for k, v in sdo.items()}, xo.grad
 
 
-@pytest.mark.parametrize("precision,plan", [("exact16", 27), ("exact16", 0), ("fast", 0)])
+_OFF_INIT_ORACLE = {}
+
+
+@pytest.mark.parametrize("precision,plan", [("exact16", 27 + 128), ("exact16", 0), ("fast", 0)])
 @pytest.mark.parametrize("case", ["dense_x4", "stream_x40", "stream_x0p01"])
 def test_generator_parity_off_the_init_scale(precision, plan, case, diag_dir):
     """Forward + backward of a 6-block generator against the float64 oracle with (a) the dense-block weights x 4 (the branches are
@@ -578,7 +588,9 @@ def test_generator_parity_off_the_init_scale(precision, plan, case, diag_dir):
     gen = torch.Generator().manual_seed(5)
     x = torch.rand(2, 3, 24, 28, generator=gen)
     gw = torch.randn(2, 3, 96, 112, generator=gen)
-    yo, go, gxo = _oracle_grads(M, sd, x, gw, nb)
+    if case not in _OFF_INIT_ORACLE:      # (one float64 evaluation per case: the three precision / plan rows share it)
+        _OFF_INIT_ORACLE[case] = _oracle_grads(M, sd, x, gw, nb)
+    yo, go, gxo = _OFF_INIT_ORACLE[case]
     with torch.no_grad():      # the stream's magnitude, for the record
         f = torch.nn.functional.conv2d(x.double(), sd["conv1.weight"].double(), sd["conv1.bias"].double(), padding=1)
     scale = 256.0
