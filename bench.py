@@ -1274,11 +1274,12 @@ def main():
             pm = {"precision": "exact16",
                   "what": "the same train step with split-operand f16 MFMA (activations and weights as hi+lo f16 pairs, three MFMAs per "
                           "product, fp32 accumulate): the mode that meets the 1e-3 max-abs parity tolerance vs the fp32 CPU path",
-                  "x2_plan_effective": int(os.environ.get("RESR_X2_PLAN", "251")),
-                  "x2_plan": "default (251; its training bits 27 + 128): forward all pairs; the dense blocks' backward-data passes read EVERY gradient chunk as a pair on one f16 + "
-                             "one MX stage (round 6: unscaled bf8 q records from the producing epilogues; 40 stage-equivalents per block, gradients within 4.7e-5 of the "
-                             "all-pairs plan where round 5's single-f16 reads gave 2.6e-4); the weight gradients keep round 5's plan: conv1..conv4's products read G's hi "
-                             "tensor -- two tap-products, bias sums from hi + lo -- and the weight products read "
+                  "x2_plan_effective": int(os.environ.get("RESR_X2_PLAN", "763")),
+                  "x2_plan": "default (763; its training bits 27 + 128 + 512): forward all pairs; the dense blocks' backward-data passes read EVERY gradient chunk as a pair on one f16 + "
+                             "one MX stage (round 6: unscaled bf8 q records from the producing epilogues; 40 stage-equivalents per block); their weight gradients take both "
+                             "2^-12-weighted tap-products of every stream chunk as ONE MX job (8-bit transpose reads, K = 32 pixels twice per v_mfma_scale_f32_32x32x64_f8f6f4) -- "
+                             "worst gradient tensor 5.6-6.5e-5 against the all-pairs plan on the GPU (round 5's plan 27: 2.2-2.6e-4); for the growth chunks round 5's plan stays: "
+                             "conv1..conv4's products read G's hi tensor and the weight products read "
                              "the growth planes as their hi tensor, conv5's such products with g_y's hi tensor (46 instead of 78 tap-products per dense block; worst gradient tensor "
                              "2.2-4.6e-4 vs float64 in the emulation at three geometries x five seeds; against the all-pairs plan on the GPU at 16 x 256^2 .. "
                              "1 x 24^2: 1.7-5.1e-4 under a dense random cotangent, 5e-7 .. 2e-5 under this step's L1 loss -- profiles/r05_x2_plan_validate.json, "

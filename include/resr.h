@@ -295,7 +295,19 @@ enum {
      * gradient tensor 0.8-1.2e-4 vs float64 in the emulation (GROWTH_GRAD_F16: 3-5e-4).  The gradient planes gT / gS carry q tensors
      * (written by the passes that produce them), the packed buffer its MX region.  The forward pass and the weight gradients are
      * untouched (GROWTH_GRAD_F16 then only shapes the weight products); not together with GROWTH_GRAD_STORE_F16. */
-    RESR_X2_PLAN_MX_BWD = 128
+    RESR_X2_PLAN_MX_BWD = 128,
+    /* opt-in: the exact16 forward (all pairs: reference-exact masks, fp32-class losses) followed by FAST mode's backward pass -- plain f16
+     * on the hi tensors, f16 weights: resr_generator_backward then takes a RESR_F16 packing of the same table as `packed`.  Most of fast
+     * mode's gradient error is its own forward's mask flips, not its backward pass's roundings (emulation: median 4-6e-3 -> 5-7e-4 under the
+     * L1 loss): a third operating point between fast and exact16.  Overrides the other backward bits. */
+    RESR_X2_PLAN_F16_BACKWARD = 256,
+    /* with MX_BWD: the weight gradients of the dense blocks take the two 2^-12-weighted tap-products (x_hi, g_lo) + (x_lo, g_hi) of every
+     * STREAM chunk as ONE MX job -- K is pixels there: 8-bit transpose reads (ds_read_b64_tr_b8) of the staged q records feed one
+     * v_mfma_scale_f32_32x32x64_f8f6f4 per output row and tap, block 0 = (g_lo, x_hi), block 1 = (g_hi, x_lo) -- half the staged bytes
+     * and half the matrix time of the two f16 tap-products, and conv1..conv4 get their (x_hi, g_lo) term back (GROWTH_GRAD_F16 drops it).
+     * The training forward then emits the q tensor of the residual stream (conv1 and every closing convolution: + 2 of 12 plane stores
+     * per dense block), the workspace holds it, and the bias sums of g_lo come from tap-free jobs. */
+    RESR_X2_PLAN_MX_WGRAD = 512
 };
 
 size_t resr_generator_param_count(const ResrGeneratorDesc* d);

@@ -24,6 +24,8 @@ X2_PLAN_GROWTH_ACT_G_HI_WGRAD = 16
 X2_PLAN_GROWTH_W16_INFER = 32
 X2_PLAN_MX_INFER = 64
 X2_PLAN_MX_BWD = 128
+X2_PLAN_F16_BACKWARD = 256
+X2_PLAN_MX_WGRAD = 512
 CONV_MX_PAIRS = 1 << 12
 RESR_VERSION = 3   # include/resr.h: the structures below mirror THIS version of the header
 

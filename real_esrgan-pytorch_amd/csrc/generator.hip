@@ -89,6 +89,11 @@ int round32(int v) { return (v + 31) / 32 * 32; }
 bool plan_mx_bwd(const ResrGeneratorDesc& d) {
     return d.dtype == RESR_F16X2 && d.training && (d.x2_plan & RESR_X2_PLAN_MX_BWD) && !(d.x2_plan & RESR_X2_PLAN_GROWTH_GRAD_STORE_F16);
 }
+// RESR_X2_PLAN_MX_WGRAD: the stream chunks' correction tap-products of the dense blocks' weight gradients as MX jobs; the residual stream
+// (planes 0, 1 of every dense-block workspace) carries a q tensor written by the training forward
+bool plan_mx_wgrad(const ResrGeneratorDesc& d) {
+    return plan_mx_bwd(d) && (d.x2_plan & RESR_X2_PLAN_MX_WGRAD) && !(d.x2_plan & RESR_X2_PLAN_F16_BACKWARD);
+}
 bool plan_mx(const ResrGeneratorDesc& d) {
     const int need = RESR_X2_PLAN_GROWTH_F16_INFER | RESR_X2_PLAN_GROWTH_W16_INFER | RESR_X2_PLAN_MX_INFER;
     return d.dtype == RESR_F16X2 && !d.training && (d.x2_plan & need) == need;
@@ -233,7 +238,7 @@ void carve(const Plan& p, char* base, Bufs& b) {
     b.x_in = take(px * p.ci_pad * es);
     const int nws = p.d.training ? p.nrdb : 3;
     b.ws.resize(nws);
-    for (int i = 0; i < nws; ++i) b.ws[i] = take(px * 192 * es);
+    for (int i = 0; i < nws; ++i) b.ws[i] = take(px * 192 * (es + (plan_mx_wgrad(p.d) ? 2 : 0)));   // (MX_WGRAD: hi, lo and q tensors)
     b.bits.clear();
     if (p.d.training)
         for (int i = 0; i < p.nrdb; ++i) b.bits.push_back(take(px * 4 * sizeof(uint32_t)));
@@ -327,7 +332,7 @@ size_t generator_mx_offset(const ResrGeneratorDesc* d) {
 size_t generator_packed_bytes(const ResrGeneratorDesc* d, int backward) {
     Plan p;
     if (!build_plan(d, p)) return 0;
-    if (d->dtype == RESR_F16X2 && (d->x2_plan & (RESR_X2_PLAN_MX_INFER | RESR_X2_PLAN_MX_BWD))) return generator_mx_offset(d) + p.pk_total_elems * 2 + 16384;
+    if (d->dtype == RESR_F16X2 && (d->x2_plan & (RESR_X2_PLAN_MX_INFER | RESR_X2_PLAN_MX_BWD | RESR_X2_PLAN_MX_WGRAD))) return generator_mx_offset(d) + p.pk_total_elems * 2 + 16384;
     // + two dummy (chunk,tap) of slack: conv3x3_kernel prefetches two taps past the end
     return (backward ? p.pk_total_elems : p.pk_fwd_elems) * elem_size(d->dtype) * (d->dtype == RESR_F16X2 ? 3 : 1) + 16384;
 }
@@ -476,6 +481,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
     // pair chunks take the MX stage says so (in_q = its input's hi -> q offset), names its convolution's MX blocks, and emits the q
     // tensor of its own output when a later pass reads that output through an MX stage (out_q; 0: none)
     const bool mx = plan_mx(*d);
+    const bool mxw = plan_mx_wgrad(*d);
     const char* pk_mx = mx ? pk + generator_mx_offset(d) : nullptr;
     auto MXP = [&](ResrConvDesc& cd, const ConvSpec& c, int64_t in_q, int64_t out_q) {
         if (!mx) return;
@@ -491,6 +497,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         cd.out_chunk_stride = plane;
         cd.in0_lo_offset = lo_xin; cd.out_lo_offset = lo_ws;
         MXP(cd, c, 2 * lo_xin, 2 * lo_ws);
+        if (mxw) cd.out_q_offset = 2 * lo_ws;    // training, MX_WGRAD: the stream's q tensor for the weight gradients' MX jobs (a plain three-stage pass emits it)
         RUN(conv3x3_dispatch(&cd, b.x_in, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.ws[0], nullptr, st));
         if (b.out1 != b.ws[0]) {  // inference: second copy of out1 (0.01 % of the FLOPs) instead of a pinned workspace
             cd.out_stride = b.out1_stride; cd.out_chunk_stride = 0; cd.out_lo_offset = lo_out1;
@@ -531,6 +538,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
             cd.in0_lo_offset = lo_ws; cd.out_lo_offset = last ? lo_t : lo_ws;
             if (growth_single) { cd.x2_pair_chunks = 2; if (growth_w16) cd.flags |= RESR_CONV_SINGLE_W16; }
             MXP(cd, c, 2 * lo_ws, last ? 2 * lo_t : 2 * lo_ws);
+            if (mxw && !last) cd.out_q_offset = 2 * lo_ws;   // (the next block's stream planes; the trunk's output is no dense block's X)
             cd.s0 = 0.2f; cd.t0 = 1.f; cd.res0_stride = 32; cd.res0_chunk_stride = plane; cd.res0_lo_offset = lo_ws;  // model.py:95-96
             const char* res1 = nullptr;
             if (r % 3 == 2) {  // model.py:129-130
@@ -608,8 +616,16 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     Bufs b;
     carve(p, (char*)workspace, b);
     if (b.total > workspace_bytes) return fail(RESR_ERR_WORKSPACE, "generator_backward: workspace %zu < %zu", workspace_bytes, b.total);
-    const size_t es = elem_size(d->dtype);
-    const bool x2 = d->dtype == RESR_F16X2;
+    // RESR_X2_PLAN_F16_BACKWARD (opt-in): an exact16 FORWARD (every pre-activation fp32-class: reference-exact LeakyReLU masks, losses at
+    // 2e-6) followed by fast mode's backward pass -- plain f16 on the hi tensors of the saved activations, the sign words the forward
+    // wrote, single f16 gradient planes, f16 packed weights (`packed` is then a RESR_F16 packing of the same table).  The workspace is
+    // the exact16 one (carve below keeps the caller's descriptor); every descriptor of the pass says `dt`.
+    const bool f16bwd = d->dtype == RESR_F16X2 && (d->x2_plan & RESR_X2_PLAN_F16_BACKWARD);
+    const int dt = f16bwd ? (int)RESR_F16 : d->dtype;
+    Plan pb = p;
+    pb.d.dtype = dt;
+    const size_t es = elem_size(dt);
+    const bool x2 = dt == RESR_F16X2;
     const size_t wes = es * (x2 ? 3 : 1);
     const int wm = x2 ? wgrad_x2_products() : 1;
     // exact16, RESR_X2_PLAN_GROWTH_GRAD_F16: the growth-plane gradients g_o1..g_o4 are READ as single f16 tensors -- two stages on
@@ -630,9 +646,10 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     // fast mode (plain f16) takes the same lift: under the L1 loss at 16 x 256^2 its worst gradient tensor against exact16's all-pairs plan
     // reads 4.3e-3 at a GradScaler's initial 2^16 and 1.4e-3 from 2^20 on (median 7.7e-4 throughout; garbage at 2^10) -- the difference is
     // f16 underflow, not f16 arithmetic (tools/fast_loss_scale_probe.py).  strict (f32) needs none.
-    const unsigned* gsc = (d->dtype != RESR_F32 && !no_prescale) ? b.gscale : nullptr;
+    const unsigned* gsc = (dt != RESR_F32 && !no_prescale) ? b.gscale : nullptr;
     // RESR_X2_PLAN_MX_BWD: the dense blocks' backward-data passes read every gradient chunk as a pair on an f16 + an MX stage
-    const bool mxb = plan_mx_bwd(*d);
+    const bool mxb = plan_mx_bwd(*d) && !f16bwd;
+    const bool mxw = plan_mx_wgrad(*d) && mxb;
     const bool gg_single = x2 && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_F16);
     const bool gg_store_single = gg_single && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_STORE_F16);   // opt-in: no lo store, biases from hi alone
     // RESR_X2_PLAN_GROWTH_ACT_F16_WGRAD: the weight products of conv2..conv5 read the growth planes (X chunks 2..) as their hi tensor
@@ -660,11 +677,11 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         return wc;
     };
     auto wgrad_run = [&](const WgradConv* wc, int nconv, int hh, int ww, int flags) -> int {
-        const int njobs = wgrad_batch_jobs(wc, nconv, d->dtype);   // tap-products: fewer than wm per product where G or an X chunk is read single
-        const int splits = splits_for(p, njobs, hh, ww, x2 ? wgrad_batch_quads(wc, nconv, d->dtype) : 0);
-        if (wgrad_batch_partial_bytes(wc, nconv, splits, d->dtype) > b.partial_bytes)
+        const int njobs = wgrad_batch_jobs(wc, nconv, dt);   // tap-products: fewer than wm per product where G or an X chunk is read single
+        const int splits = splits_for(pb, njobs, hh, ww, x2 ? wgrad_batch_quads(wc, nconv, dt) : 0);
+        if (wgrad_batch_partial_bytes(wc, nconv, splits, dt) > b.partial_bytes)
             return fail(RESR_ERR_WORKSPACE, "wgrad slab buffer too small");
-        return wgrad_batch(wc, nconv, N, hh, ww, d->dtype, flags, splits, b.partial, st);
+        return wgrad_batch(wc, nconv, N, hh, ww, dt, flags, splits, b.partial, st);
     };
     auto wgrad = [&](const ConvSpec& c, int hh, int ww, const void* x0, int cin, int s0, const void* g, int gstride,
                      int flags, float scale, long x_chunk, long g_chunk, long x_lo, long g_lo) -> int {
@@ -675,14 +692,14 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     // backward-data pass descriptor: in0 (cin0 channels, lo offset lo0) [+ in1 (lo offset lo1)] -> out (lo offset lo_out)
     auto dgrad = [&](int hh, int ww, int cin0, int s0, int cin, int s1, int cout, int cout_pad, int out_stride, int flags,
                      long lo0, long lo1, long lo_out) {
-        ResrConvDesc cd = conv_desc(p, N, hh, ww, cin, cin0, s0, s1, cout, cout_pad, out_stride, flags | RESR_CONV_NO_BIAS);
+        ResrConvDesc cd = conv_desc(pb, N, hh, ww, cin, cin0, s0, s1, cout, cout_pad, out_stride, flags | RESR_CONV_NO_BIAS);
         cd.in0_lo_offset = lo0; cd.in1_lo_offset = lo1; cd.out_lo_offset = lo_out;
         return cd;
     };
 
     // clamp_ backward + layout                                              model.py:270
     if (gsc) RUN(absmax_dispatch(gy, (long)N * d->out_channels * H4 * W4, b.gscale, pre_log2, st));
-    RUN(nchw_to_nhwc_scaled_dispatch(gy, b.g4, N, d->out_channels, H4, W4, 1, 32, d->dtype, b.ymask, st, lo_g4, gsc));
+    RUN(nchw_to_nhwc_scaled_dispatch(gy, b.g4, N, d->out_channels, H4, W4, 1, 32, dt, b.ymask, st, lo_g4, gsc));
     {   // conv4                                                            model.py:268
         const ConvSpec& c = p.convs[p.i_conv4];
         RUN(wgrad(c, H4, W4, b.c3, 64, 32, b.g4, 32, 0, 1.f, pl4, 0, lo_4, lo_g4));
@@ -706,7 +723,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         RUN(conv3x3_dispatch(&cd, b.gB, nullptr, pk + p.pk_bwd_up2 * wes, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
         for (int q = 0; q < 2; ++q)   // per 32-channel plane
             RUN(sumpool2x2_dispatch(b.gA + (size_t)q * pl4 * es, b.gM1 + (size_t)q * pl2 * es, b.u1 + (size_t)q * pl2 * es,
-                                    N, H2, W2, 32, d->dtype, 0.2f, st, lo_4, lo_2));
+                                    N, H2, W2, 32, dt, 0.2f, st, lo_4, lo_2));
     }
     if (debug_stop() == 2) return RESR_OK;
     {   // upsampling1                                                      model.py:264
@@ -716,7 +733,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         cd.in0_chunk_stride = pl2; cd.out_chunk_stride = pl2;
         RUN(conv3x3_dispatch(&cd, b.gM1, nullptr, pk + p.pk_bwd_up1 * wes, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
         for (int q = 0; q < 2; ++q)
-            RUN(sumpool2x2_dispatch(b.gA + (size_t)q * pl2 * es, b.gF + (size_t)q * plane * es, nullptr, N, h, w, 32, d->dtype, 0.2f, st,
+            RUN(sumpool2x2_dispatch(b.gA + (size_t)q * pl2 * es, b.gF + (size_t)q * plane * es, nullptr, N, h, w, 32, dt, 0.2f, st,
                                     lo_2, lo_t));
     }
     if (debug_stop() == 3) return RESR_OK;
@@ -759,6 +776,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         wcb[4].x_chunk_stride = plane; wcb[4].g_chunk_stride = plane;
         wcb[4].x_pair_chunks = wx_pairs;
         wcb[4].x_single_g_hi = (wx_pairs && (d->x2_plan & RESR_X2_PLAN_GROWTH_ACT_G_HI_WGRAD)) ? 1 : 0;
+        if (mxw) { wcb[4].x_q_off = 2 * lo_ws; wcb[4].g_q_off = 2 * lo_t; }   // MX jobs for the stream chunks' corrections (X: ws planes 0, 1; G: gin)
         ResrConvDesc cds[4];
         const void* ws4[4];
         const void* masks4[4];
@@ -779,6 +797,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             wcb[k - 1].x_chunk_stride = plane;
             wcb[k - 1].g_lo_bias_only = (gg_single && !gg_store_single) ? 1 : 0;
             wcb[k - 1].x_pair_chunks = wx_pairs;
+            if (mxw) { wcb[k - 1].x_q_off = 2 * lo_ws; wcb[k - 1].g_q_off = 2 * lo_gs; }   // (the stream chunks' MX job carries (x_hi, g_lo) too; the growth chunks keep the plan's reads)
         }
         {   // the four mirrored cout-32 passes, then g_x = convT(all) + (skip terms): one chained launch where the kernel supports
             // it (g_x joins on small launches), else one launch per pass
@@ -803,7 +822,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     }
     if (debug_stop() == 4) return RESR_OK;
     // gradient wrt out1 = trunk path + skip (model.py:262)
-    RUN(add_inplace_dispatch(b.gT[cur], b.gF, (long)N * h * w * 64, d->dtype, st, lo_t, lo_t));   // both chunk-planar [2][N,h,w,32]
+    RUN(add_inplace_dispatch(b.gT[cur], b.gF, (long)N * h * w * 64, dt, st, lo_t, lo_t));   // both chunk-planar [2][N,h,w,32]
     {   // conv1                                                            model.py:259
         const ConvSpec& c = p.convs[p.i_conv1];
         RUN(wgrad(c, h, w, b.x_in, p.ci_pad, p.ci_pad, b.gT[cur], 32, 0, 1.f, 0, plane, lo_xin, lo_t));
@@ -812,7 +831,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
             ResrConvDesc cd = dgrad(h, w, 64, 32, 64, 0, p.ci_pad, p.ci_pad, p.ci_pad, 0, lo_t, 0, lo_xin);
             cd.in0_chunk_stride = plane;
             RUN(conv3x3_dispatch(&cd, b.gT[cur], nullptr, pk + p.pk_bwd_conv1 * wes, nullptr, nullptr, nullptr, nullptr, b.gxin, nullptr, st));
-            RUN(nhwc_to_nchw_scaled_dispatch(b.gxin, gx, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, d->dtype, st, lo_xin, gsc));
+            RUN(nhwc_to_nchw_scaled_dispatch(b.gxin, gx, N, d->in_channels, d->h, d->w, p.r, p.ci_pad, dt, st, lo_xin, gsc));
         }
     }
     return RESR_OK;

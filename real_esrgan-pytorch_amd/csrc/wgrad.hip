@@ -50,6 +50,7 @@ struct WgradJob {
                           // products (its dW slabs are zeros): the (x_hi chunk 0, g_lo) job of WgradConv.g_lo_bias_only
     unsigned xsub;        // 0..3: X chunk lies in sub-position (i*2+j) of a space-to-depth image -- only 2x2 of the 9 taps of the
                           // virtual kernel of a 4x4 / stride-2 conv are non-zero there; 4: all taps
+    unsigned mx;          // 1: an MX job -- x and g are q tensors (bf8 records); the job yields (x_hi, g_lo) + (x_lo, g_hi) in one slab (quad kernel only)
 };
 
 struct WgradArgs {
@@ -58,6 +59,7 @@ struct WgradArgs {
     const char* zero;     // 16 zero bytes in global memory
     int n, h, w_, hs, ws;
     int up, splits, njobs;
+    int splits_mx;        // pixel splits of the MX jobs' launch (a multiple of splits)
     int fast_addr;        // 1: every operand < 4 GB and < 2^24 pixels -> 32-bit lane offsets + uniform base (see stage())
     int tiles_x, tiles_y, ntiles;
 };
@@ -83,6 +85,7 @@ struct ReduceArgs {
     int layer_nck;   // > 0: layer mode (WgradLayer) -- workgroup row b reduces product (b / nck, b % nck) of the convolution jobs[0] describes
     unsigned layer_part_stride;   // layer mode, RESR_F16X2 with three tap-products: floats from a product's (hi, hi) slabs to its (hi, lo) and on to its (lo, hi) slabs; else 0
     const unsigned* unscale;      // pre-scaled backward pass (common.h: grad_prescale): results leave times the inverse factor; else nullptr
+    int splits_c;                 // slabs per slab_c region when it differs from `splits` (the MX jobs' launch has its own pixel splits); 0: = splits
 };
 
 static_assert(sizeof(ReduceArgs) <= 4096, "kernel arguments");
@@ -405,7 +408,8 @@ struct WgradQuad {
     const char* g[2];
     unsigned xstride_b[2], gstride_b[2];
     unsigned slab_off[4];   // float offset of product p's [splits][kSlab] slabs, ~0u = product not wanted
-    unsigned bias_mask;     // bit p: product p also yields sum_p G (one product per G tile does); bit 4 + p: product p yields ONLY that (no taps)
+    unsigned bias_mask;     // bit p: product p also yields sum_p G (one product per G tile does); bit 4 + p: product p yields ONLY that (no taps);
+                            // bit 8 + p: product p is an MX job (q records, 8-bit MFMAs)
     unsigned xsub;          // byte xi: tap pattern of X chunk xi (WgradJob::xsub)
 };
 
@@ -444,7 +448,10 @@ constexpr int kQXCH = kQXW * 1024;                // bytes per X chunk image in 
 constexpr int kQGT = 16 * 1024;                   // bytes per G tile image (8 x 32 px x 64 B)
 constexpr int kQBUF = 2 * kQXCH + 2 * kQGT;       // one stage: 77,824 B; two stages = 152 KB of the 160 KB LDS
 
-__global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs a) {
+// MXK: the MX instantiation (x2_plan bit 9) -- every product of every quad of the launch is an MX job (or empty); its own kernel, because the
+// two tile loops as alternatives of one branch make the register allocator spill the 144 accumulator registers (252 spilled VGPRs).
+template <bool MXK>
+__global__ __launch_bounds__(512, 1) void wgrad_quad_kernel_t(const WgradQuadArgs a) {
     constexpr int PB = 64, HW = 34;
     constexpr int NSX = 6, NSG = 4;               // LDS-DMA instructions per wave per tile: 44 X waves / 8, 32 G waves / 8
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -661,14 +668,75 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
     using M3 = std::integral_constant<int, 3>;
     using M4 = std::integral_constant<int, 4>;
     using M5 = std::integral_constant<int, 5>;
+    // An MX job (x2_plan bit 9): the staged records are q records -- per pixel 32 bytes bf8(hi) | 32 bytes bf8(lo) -- and the wave computes
+    // BOTH 2^-12-weighted tap-products of its product in one pass: per output row and tap ONE v_mfma_scale_f32_32x32x64_f8f6f4 whose K = 64
+    // is the row's 32 pixels twice, block 0 = (g_lo, x_hi), block 1 = (g_hi, x_lo), unit scales.  Fragments come from 8-bit transpose
+    // reads: ds_read_b64_tr_b8 hands lane n of a 16-lane group column n of an 8 x 16 byte block, i.e. 8 consecutive pixels of one channel
+    // (tools/micro/tr8_probe.hip); four reads make a 32-byte operand.  Any permutation of K inside a block is harmless as long as both
+    // operands share it, which they do (same read pattern on both tiles).  Same staging instructions and barriers as the f16 loop.
+    auto tile_loop_mx = [&]() {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        typedef int v8i __attribute__((ext_vector_type(8)));
+        auto tr8 = [&](const char* p) -> v2i {
+            return __builtin_amdgcn_ds_read_tr8_b64_v2i32(reinterpret_cast<__attribute__((address_space(3))) v2i*>((__attribute__((address_space(3))) char*)p));
+        };
+        // lane -> its 8-byte piece of an 8-pixel x 16-byte block: pixel (a16 >> 1), piece (a16 & 1); channel group (lane >> 4) & 1; pixel half kh
+        const int lane_off = ((kh << 4) + (a16 >> 1)) * PB + (((lane >> 4) & 1) << 4) + ((a16 & 1) << 3);
+        // operand of one pixel row: [first part: 16 pixels | second part: 16 pixels] of this lane's channel
+        auto frag = [&](const char* row, int first_part_off, int second_part_off) -> v8i {
+            const v2i a0 = tr8(row + first_part_off), a1 = tr8(row + first_part_off + 8 * PB);
+            const v2i b0 = tr8(row + second_part_off), b1 = tr8(row + second_part_off + 8 * PB);
+            return v8i{a0.x, a0.y, a1.x, a1.y, b0.x, b0.y, b1.x, b1.y};
+        };
+        const int one = 0x7f7f7f7f;
+        int it = 0;
+        for (; tile < a.ntiles; tile += a.splits, ++it) {
+            const int next = tile + a.splits;
+            const bool has_next = next < a.ntiles;
+            const TileAt tn = tile_at(has_next ? next : tile);
+            const int nb = (it + 1) & 1;
+            const char* gb = smem + (it & 1) * kQBUF + 2 * kQXCH + gi * kQGT + (khalf * 4 * 32) * PB + lane_off;
+            const char* xb = smem + (it & 1) * kQBUF + xi * kQXCH + (khalf * 4 * HW) * PB + lane_off;
+            // the next tile's ten LDS-DMA requests go out up front (between the MFMA groups, as the f16 loop spreads them, their address
+            // selects became branches inside the unrolled loop and the accumulators spilled -- 158 to 504 registers in three placements
+            // tried); they land under the 36 MFMAs, the wave pays their issue back-pressure before its first MFMA of the tile
+#pragma unroll
+            for (int k = 0; k < NSX + NSG; ++k) stage_slot(k, tn, nb, has_next);
+            __builtin_amdgcn_sched_barrier(0);
+            v8i fgm[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fgm[r] = frag(gb + r * 32 * PB, 32, 0);          // A = [g_lo | g_hi]
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {          // halo row j of the wave's six serves output rows j (dy 0), j - 1 (dy 1), j - 2 (dy 2)
+                v8i fx[3];
+                __builtin_amdgcn_sched_barrier(0);   // (one halo row's fragments live at a time: 144 accumulator + 32 G registers leave room for no more)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) fx[dx] = frag(xb + (j * HW + dx) * PB, 0, 32);   // B = [x_hi | x_lo]
+#pragma unroll
+                for (int dy = 2; dy >= 0; --dy) {
+                    const int r = j - dy;
+                    if (r < 0 || r > 3) continue;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+                        acc[dy * 3 + dx] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fgm[r], fx[dx], acc[dy * 3 + dx], 1, 1, 0, one, 0, one);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's asm LDS-DMA has landed
+            __syncthreads();
+        }
+    };
     const bool no_taps = slab_of(prod) == ~0u || ((j_bias_mask >> (4 + prod)) & 1u);   // wave-uniform
-    if (no_taps) tile_loop(M5{});
-    else switch ((j_xsub >> (8 * xi)) & 0xffu) {   // wave-uniform
-        case 0: tile_loop(M0{}); break;
-        case 1: tile_loop(M1{}); break;
-        case 2: tile_loop(M2{}); break;
-        case 3: tile_loop(M3{}); break;
-        default: tile_loop(M4{}); break;
+    if constexpr (MXK) {
+        tile_loop_mx();     // (an empty product slot multiplies whatever its LDS region holds and is not written: one loop body, no spills)
+    } else {
+        if (no_taps) tile_loop(M5{});
+        else switch ((j_xsub >> (8 * xi)) & 0xffu) {   // wave-uniform
+            case 0: tile_loop(M0{}); break;
+            case 1: tile_loop(M1{}); break;
+            case 2: tile_loop(M2{}); break;
+            case 3: tile_loop(M3{}); break;
+            default: tile_loop(M4{}); break;
+        }
     }
 
     // ---- sum the two row-halves of every product through LDS, write the slabs ---------------------------------
@@ -701,6 +769,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel(const WgradQuadArgs 
     }
 }
 
+#define wgrad_quad_kernel wgrad_quad_kernel_t<false>
+
 // deterministic slab reduction -> OIHW fp32 gradient (+ bias gradient).  32 slab elements per workgroup, the splits dealt
 // to eight thread groups (a thread sums splits/8 slabs: the launch is latency-bound at small images -- 19 us with four
 // groups of 64 elements -- and the slabs of a full-size dense block are 69 MB) and combined in a fixed order.
@@ -719,26 +789,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     float s = 0.f;
     // a thread's slabs k = g, g + 8, ... are requested eight at a time and then added in that order: the plain loop waited
     // for every load before issuing the next (4-9 dependent memory round trips at the 36-72 splits of a training launch)
-    auto sum_splits = [&](const float* p, float acc) {
+    auto sum_splits = [&](const float* p, float acc, int nsplits) {
         constexpr int U = 8;
-        for (int k0 = g; k0 < a.splits; k0 += 8 * U) {
+        for (int k0 = g; k0 < nsplits; k0 += 8 * U) {
             float v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int k = k0 + 8 * u;
-                v[u] = k < a.splits ? p[(size_t)k * kSlab] : 0.f;
+                v[u] = k < nsplits ? p[(size_t)k * kSlab] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (k0 + 8 * u < a.splits) acc += v[u];
+                if (k0 + 8 * u < nsplits) acc += v[u];
         }
         return acc;
     };
     if (e < kSlab) {
-        s = sum_splits(a.partial + job.slab_off + e, 0.f);
+        s = sum_splits(a.partial + job.slab_off + e, 0.f, a.splits);
         if (job.slab_b != ~0u || job.slab_c != ~0u) {   // RESR_F16X2: the cross products (bias sums: only the g_lo one; a single-f16 G has none)
-            float s2 = job.slab_b != ~0u ? sum_splits(a.partial + job.slab_b + e, 0.f) : 0.f;
-            if (job.slab_c != ~0u && e < 9 * 1024) s2 = sum_splits(a.partial + job.slab_c + e, s2);
+            float s2 = job.slab_b != ~0u ? sum_splits(a.partial + job.slab_b + e, 0.f, a.splits) : 0.f;
+            if (job.slab_c != ~0u && e < 9 * 1024) s2 = sum_splits(a.partial + job.slab_c + e, s2, a.splits_c > 0 ? a.splits_c : a.splits);
             s = __builtin_fmaf(s2, kLoInv, s);
         }
     }
@@ -858,19 +928,23 @@ static const std::vector<QuadIdx>* plan_quads(const int* jx, const int* jg, int 
     return &out;
 }
 
-static int build_quads(const WgradArgs& a, int nj, WgradQuadArgs& q) {
+// quads of the jobs of one kind (mx = 0: the f16 tap-products, 1: the MX jobs -- their operands are q tensors, so the two kinds never share
+// an operand, and they run as two launches of two kernel instantiations); 0 when there is no job of the kind
+static int build_quads(const WgradArgs& a, int nj_all, WgradQuadArgs& q, unsigned mx = 0) {
     const char* xs[kMaxJobs]; const char* gs[kMaxJobs];
     unsigned xstr[kMaxJobs], gstr[kMaxJobs], xsub[kMaxJobs];
-    int nx = 0, ng = 0;
-    int jx[kMaxJobs], jg[kMaxJobs];
-    for (int i = 0; i < nj; ++i) {
+    int nx = 0, ng = 0, nj = 0;
+    int jx[kMaxJobs], jg[kMaxJobs], jid[kMaxJobs];
+    for (int i = 0; i < nj_all; ++i) {
+        if (a.jobs[i].mx != mx) continue;
         int xi = 0, gi = 0;
         while (xi < nx && xs[xi] != a.jobs[i].x) ++xi;
         if (xi == nx) { xs[nx] = a.jobs[i].x; xstr[nx] = a.jobs[i].xstride_b; xsub[nx] = a.jobs[i].xsub; ++nx; }
         while (gi < ng && gs[gi] != a.jobs[i].g) ++gi;
         if (gi == ng) { gs[ng] = a.jobs[i].g; gstr[ng] = a.jobs[i].gstride_b; ++ng; }
-        jx[i] = xi; jg[i] = gi;
+        jx[nj] = xi; jg[nj] = gi; jid[nj] = i; ++nj;
     }
+    if (nj == 0) return 0;
     const std::vector<QuadIdx>* plan = plan_quads(jx, jg, nj, nx, ng);
     if (!plan) return -1;
     int nq = 0;
@@ -885,29 +959,43 @@ static int build_quads(const WgradArgs& a, int nj, WgradQuadArgs& q) {
         for (int p = 0; p < 4; ++p) {
             w.slab_off[p] = ~0u;
             if (qi.prod[p] < 0) continue;
-            const WgradJob& j = a.jobs[qi.prod[p]];
+            const WgradJob& j = a.jobs[jid[qi.prod[p]]];
             w.slab_off[p] = j.slab_off;
             if (j.want_bias & 1u) w.bias_mask |= 1u << p;
             if (j.want_bias & 2u) w.bias_mask |= 16u << p;
+            if (j.mx) w.bias_mask |= 256u << p;
         }
     }
     return nq;
 }
 
+template <bool MXK>
+static int launch_wgrad_quad_kind(const WgradArgs& a, int nj, int nprod, hipStream_t stream, bool* done);
+
 static int launch_wgrad_quad(const WgradArgs& a, int nj, int nprod, hipStream_t stream, bool* done) {
+    bool any_mx = false;
+    for (int i = 0; i < nj; ++i) any_mx = any_mx || a.jobs[i].mx;
+    const int rc = launch_wgrad_quad_kind<false>(a, nj, nprod, stream, done);
+    if (rc || !*done || !any_mx) return rc;
+    *done = false;     // the MX jobs' quads: a second launch (wgrad_quad_kernel_t<true>); no pair-kernel fallback exists for them
+    return launch_wgrad_quad_kind<true>(a, nj, nprod, stream, done);
+}
+
+template <bool MXK>
+static int launch_wgrad_quad_kind(const WgradArgs& a, int nj, int nprod, hipStream_t stream, bool* done) {
     static thread_local WgradQuadArgs q;
     *done = false;
-    const int nq = build_quads(a, nj, q);
+    const int nq = build_quads(a, nj, q, MXK ? 1u : 0u);
     if (nq <= 0) return RESR_OK;
     q.partial = a.partial;
-    q.n = a.n; q.h = a.h; q.w_ = a.w_; q.hs = a.hs; q.ws = a.ws; q.up = a.up; q.splits = a.splits; q.njobs = nq;
+    q.n = a.n; q.h = a.h; q.w_ = a.w_; q.hs = a.hs; q.ws = a.ws; q.up = a.up; q.splits = MXK ? a.splits_mx : a.splits; q.njobs = nq;
     q.tiles_x = (a.w_ + 31) / 32;
     q.tiles_y = (a.h + 7) / 8;
     q.ntiles = q.tiles_x * q.tiles_y * a.n;
     const size_t lds = 2 * kQBUF;
-    static bool attr_done = false;
+    static bool attr_done = false;     // (one flag per instantiation of this function template)
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_quad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_quad_kernel_t<MXK>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return fail(RESR_ERR_LAUNCH, "wgrad: cannot reserve %zu B of LDS", lds);
         attr_done = true;
@@ -915,13 +1003,14 @@ static int launch_wgrad_quad(const WgradArgs& a, int nj, int nprod, hipStream_t 
     void* zp = nullptr;
     if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess || !zp) return fail(RESR_ERR_LAUNCH, "wgrad: zero page");
     q.zero = (const char*)zp;
-    const int splits8 = (a.splits + 7) / 8 * 8;
+    const int splits8 = (q.splits + 7) / 8 * 8;
     double staged = 0;
     for (int i = 0; i < nq; ++i) staged += 1 + (q.jobs[i].x[1] != nullptr) + 1 + (q.jobs[i].g[1] != nullptr);
     prof_before(stream);
-    hipLaunchKernelGGL(wgrad_quad_kernel, dim3(nq * splits8), dim3(512), lds, stream, q);
+    hipLaunchKernelGGL(wgrad_quad_kernel_t<MXK>, dim3(nq * splits8), dim3(512), lds, stream, q);
     // algorithmic bytes: every quad's X chunks and G tiles once (quads that share an operand find it in their XCD's L2)
-    prof_after(stream, nprod != nj ? 50500 : 50200, 2.0 * 9 * 32 * 32 * nprod * (double)a.n * a.h * a.w_, staged * 64.0 * (double)a.n * a.h * a.w_);
+    // (the MX launch: kernel id 50600, no algorithmic FLOPs of its own -- the products are counted with the f16 launch)
+    prof_after(stream, MXK ? 50600 : (nprod != nj ? 50500 : 50200), MXK ? 0.0 : 2.0 * 9 * 32 * 32 * nprod * (double)a.n * a.h * a.w_, staged * 64.0 * (double)a.n * a.h * a.w_);
     RESR_CHECK_LAUNCH("wgrad_quad_kernel");
     *done = true;
     return RESR_OK;
@@ -974,18 +1063,37 @@ int wgrad_x2_products() {
     return kX2WgradProductsDefault;
 }
 
-// tap-products of one algorithmic product: RESR_F16X2 takes wgrad_x2_products() of them -- two of the three where G is a single f16
-// tensor (g_lo_off = 0: no (x_hi, g_lo) product)
+// The jobs (kernel launches' slab regions) of ONE algorithmic product (G tile ct, X chunk ck): part 0 (x_hi, g_hi) always; RESR_F16X2 with
+// three tap-products adds 1 = (x_hi, g_lo) and 2 = (x_lo, g_hi) as the plan bits allow -- or, where both operands carry q tensors and the
+// X chunk is a pair (WgradConv.x_q_off / g_q_off, x2_plan bit 9), ONE job 3 = "MX" for both corrections, plus 4 = the tap-free (x_hi chunk 0,
+// g_lo) job that sums the bias of g_lo where a bias is wanted.  One definition for the job count, the quad count and the job table.
+static int product_parts(const WgradConv& c, int dtype, int nparts, int ck, int parts[4]) {
+    int n = 0;
+    parts[n++] = 0;
+    if (dtype != RESR_F16X2 || nparts == 1) return n;
+    const bool g_single = c.g_lo_off == 0;
+    const bool single_chunk = c.x_pair_chunks > 0 && ck >= c.x_pair_chunks;
+    if (nparts == 3 && c.x_q_off != 0 && c.g_q_off != 0 && !g_single && !single_chunk) {
+        parts[n++] = 3;
+        if (ck == 0 && c.db) parts[n++] = 4;
+        return n;
+    }
+    for (int part = 1; part < nparts; ++part) {
+        if (part == 1 && g_single) continue;   // no g_lo: dW = X_hi^T G + 2^-12 X_lo^T G
+        if (part == 1 && c.g_lo_bias_only && ck != 0) continue;   // g_lo only where the bias is summed (X chunk 0)
+        if (single_chunk && (part == 2 || c.x_single_g_hi)) continue;   // this X chunk enters as its hi tensor: dW = X_hi^T G (x_single_g_hi: X_hi^T G_hi)
+        parts[n++] = part;
+    }
+    return n;
+}
+
+// tap-products of one convolution
 static size_t wgrad_conv_jobs(const WgradConv& c, int dtype) {
-    const size_t prod = (size_t)(c.cin / 32) * (c.cout_pad / 32);
-    if (dtype != RESR_F16X2) return prod;
-    const int n = wgrad_x2_products();
-    if (n != 3) return prod * n;
-    // per (G tile, X chunk): (x_hi, g_hi); (x_hi, g_lo) unless G is single / only for chunk 0 (the bias job); (x_lo, g_hi) unless the chunk is read single
-    const size_t nck = (size_t)(c.cin / 32), nct = (size_t)(c.cout_pad / 32);
-    const size_t xpairs = (c.x_pair_chunks > 0 && (size_t)c.x_pair_chunks < nck) ? (size_t)c.x_pair_chunks : nck;
-    const size_t part1 = c.g_lo_off == 0 ? 0 : (c.g_lo_bias_only ? 1 : (c.x_single_g_hi ? xpairs : nck));
-    return nct * (nck + part1 + xpairs);
+    const int nparts = dtype == RESR_F16X2 ? wgrad_x2_products() : 1;
+    size_t jobs = 0;
+    int parts[4];
+    for (int ck = 0; ck < c.cin / 32; ++ck) jobs += (size_t)product_parts(c, dtype, nparts, ck, parts);
+    return jobs * (size_t)(c.cout_pad / 32);
 }
 
 // Quad jobs (workgroups per pixel split) the batched launch of `convs` will run: the planners size their pixel splits by it --
@@ -999,16 +1107,17 @@ int wgrad_batch_quads(const WgradConv* convs, int nconv, int dtype) {
     int jx[kMaxJobs], jg[kMaxJobs], nx = 0, ng = 0, nj = 0, total = 0;
     for (int i = 0; i < nconv; ++i) {
         const WgradConv& c = convs[i];
-        const bool g_single = x2 && c.g_lo_off == 0;
         for (int ct = 0; ct < c.cout_pad / 32; ++ct)
-            for (int ck = 0; ck < c.cin / 32; ++ck)
-                for (int part = 0; part < nparts; ++part) {
-                    if (part == 1 && (g_single || (c.g_lo_bias_only && ck != 0))) continue;
-                    if (part != 0 && c.x_pair_chunks > 0 && ck >= c.x_pair_chunks && (part == 2 || c.x_single_g_hi)) continue;
+            for (int ck = 0; ck < c.cin / 32; ++ck) {
+                int parts[4];
+                const int np = product_parts(c, dtype, nparts, ck, parts);
+                for (int pi = 0; pi < np; ++pi) {
+                    const int part = parts[pi];
+                    if (part == 3) continue;     // (the MX jobs run as their own launch with their own pixel splits: mx_split_factor)
                     ++total;
                     if (nj >= kMaxJobs) continue;
-                    const char* xp = (const char*)c.x0 + (size_t)ck * (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * es + (part == 2 ? (size_t)c.x_lo_off * es : 0);
-                    const char* gp = (const char*)c.g + (size_t)ct * (c.g_chunk_stride > 0 ? c.g_chunk_stride : 32) * es + (part == 1 ? (size_t)c.g_lo_off * es : 0);
+                    const char* xp = (const char*)c.x0 + (size_t)ck * (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * es + (part == 2 ? (size_t)c.x_lo_off * es : part == 3 ? (size_t)c.x_q_off * es : 0);
+                    const char* gp = (const char*)c.g + (size_t)ct * (c.g_chunk_stride > 0 ? c.g_chunk_stride : 32) * es + ((part == 1 || part == 4) ? (size_t)c.g_lo_off * es : part == 3 ? (size_t)c.g_q_off * es : 0);
                     int xi = 0, gi = 0;
                     while (xi < nx && xs[xi] != xp) ++xi;
                     if (xi == nx) xs[nx++] = xp;
@@ -1016,6 +1125,7 @@ int wgrad_batch_quads(const WgradConv* convs, int nconv, int dtype) {
                     if (gi == ng) gs[ng++] = gp;
                     jx[nj] = xi; jg[nj] = gi; ++nj;
                 }
+            }
     }
     if (total > kMaxJobs || dtype == RESR_F32) return (total + 3) / 4;
     const std::vector<QuadIdx>* plan = plan_quads(jx, jg, nj, nx, ng);
@@ -1029,9 +1139,30 @@ int wgrad_batch_jobs(const WgradConv* convs, int nconv, int dtype) {
     return (int)jobs;
 }
 
+// MX jobs of a batch, and the factor their launch's pixel splits take over the f16 launch's: a dense block has 12 of them = three quads,
+// and 3 x 32 workgroups would leave two thirds of the CUs idle -- k x splits with 3 quads x k x splits ~ one residency round (256)
+static int wgrad_mx_jobs(const WgradConv* convs, int nconv, int dtype) {
+    const int nparts = dtype == RESR_F16X2 ? wgrad_x2_products() : 1;
+    int n = 0, parts[4];
+    for (int i = 0; i < nconv; ++i)
+        for (int ck = 0; ck < convs[i].cin / 32; ++ck) {
+            const int np = product_parts(convs[i], dtype, nparts, ck, parts);
+            for (int pi = 0; pi < np; ++pi) n += parts[pi] == 3 ? convs[i].cout_pad / 32 : 0;
+        }
+    return n;
+}
+static int mx_split_factor(int n_mx, int splits) {
+    if (n_mx <= 0) return 1;
+    const int nq = (n_mx + 3) / 4, s8 = (splits + 7) / 8 * 8;
+    int k = 256 / (nq * s8);
+    return k < 1 ? 1 : (k > 4 ? 4 : k);
+}
+
 size_t wgrad_batch_partial_bytes(const WgradConv* convs, int nconv, int splits, int dtype) {
     size_t jobs = 0;
     for (int i = 0; i < nconv; ++i) jobs += wgrad_conv_jobs(convs[i], dtype);
+    const int n_mx = wgrad_mx_jobs(convs, nconv, dtype);
+    jobs += (size_t)n_mx * (mx_split_factor(n_mx, splits) - 1);
     return jobs * splits * kSlab * sizeof(float);
 }
 
@@ -1123,19 +1254,26 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
     memset(&r, 0, sizeof(r));
     int nj = 0, nr = 0;
     unsigned off = 0;
+    bool any_mx = false;
     const bool x2 = dtype == RESR_F16X2;
     const int nparts = x2 ? wgrad_x2_products() : 1;
+    int splits_mx = splits;   // the MX launch's own pixel splits: a multiple of `splits`, at least two tiles per workgroup (the size check above assumes the uncapped factor)
+    {
+        const long tiles = (long)((w + 31) / 32) * ((h + 7) / 8) * n;
+        int k = mx_split_factor(wgrad_mx_jobs(convs, nconv, dtype), splits);
+        while (k > 1 && (long)splits * k > tiles / 2) --k;
+        splits_mx = splits * k;
+    }
     for (int i = 0; i < nconv; ++i) {
         const WgradConv& c = convs[i];
         if (!c.x0 || !c.g || !c.dw) return fail(RESR_ERR_ARG, "wgrad: null tensor");
         if (x2 && (c.x_lo_off <= 0 || c.g_lo_off < 0)) return fail(RESR_ERR_ARG, "wgrad: RESR_F16X2 needs the hi -> lo offsets of X and G (g_lo_offset = 0: G is a single f16 tensor)");
-        const bool g_single = x2 && c.g_lo_off == 0;
         if (c.cin <= 0 || (c.cin & 31) || (c.cout_pad != 32 && c.cout_pad != 64) || c.cout <= 0 || c.cout > c.cout_pad ||
             c.cin_real <= 0 || c.cin_real > c.cin)
             return fail(RESR_ERR_ARG, "wgrad: cin=%d cin_real=%d cout=%d cout_pad=%d", c.cin, c.cin_real, c.cout, c.cout_pad);
         for (int ct = 0; ct < c.cout_pad / 32; ++ct)
             for (int ck = 0; ck < c.cin / 32; ++ck) {
-                if (nj + nparts > kMaxJobs || nr >= kMaxReduce) return fail(RESR_ERR_ARG, "wgrad: more than %d jobs in one batch", kMaxJobs);
+                if (nr >= kMaxReduce) return fail(RESR_ERR_ARG, "wgrad: more than %d products in one batch", kMaxReduce);
                 const char* xh = (const char*)c.x0 + (size_t)ck * (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * es;
                 const char* gh = (const char*)c.g + (size_t)ct * (c.g_chunk_stride > 0 ? c.g_chunk_stride : 32) * es;
                 const int want_bias = (ck == 0 && c.db) ? 1 : 0;
@@ -1143,29 +1281,36 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
                 q.dw = c.dw; q.db = c.db; q.slab_off = off; q.slab_b = q.slab_c = ~0u;
                 q.co_base = (short)(ct * 32); q.ci_base = (short)(ck * 32);
                 q.cout = c.cout; q.cin_real = c.cin_real; q.scale = c.scale; q.want_bias = (short)want_bias; q.pad_ = 0;
-                // parts: (x_hi, g_hi); RESR_F16X2 adds (x_hi, g_lo) and (x_lo, g_hi)
-                for (int part = 0; part < nparts; ++part) {
-                    if (part == 1 && g_single) continue;   // no g_lo: dW = X_hi^T G + 2^-12 X_lo^T G
-                    if (part == 1 && c.g_lo_bias_only && ck != 0) continue;   // g_lo only where the bias is summed (X chunk 0)
-                    if (part != 0 && c.x_pair_chunks > 0 && ck >= c.x_pair_chunks && (part == 2 || c.x_single_g_hi)) continue;   // this X chunk enters as its hi tensor: dW = X_hi^T G (x_single_g_hi: X_hi^T G_hi)
+                // parts: (x_hi, g_hi); RESR_F16X2 adds (x_hi, g_lo) and (x_lo, g_hi) -- or the MX job for both (+ the tap-free bias job): product_parts
+                int parts[4];
+                const int np = product_parts(c, dtype, nparts, ck, parts);
+                if (nj + np > kMaxJobs) return fail(RESR_ERR_ARG, "wgrad: more than %d jobs in one batch", kMaxJobs);
+                for (int pi = 0; pi < np; ++pi) {
+                    const int part = parts[pi];
                     WgradJob& j = a.jobs[nj++];
-                    j.x = xh + (part == 2 ? (size_t)c.x_lo_off * es : 0);
-                    j.g = gh + (part == 1 ? (size_t)c.g_lo_off * es : 0);
+                    j.x = xh + (part == 2 ? (size_t)c.x_lo_off * es : part == 3 ? (size_t)c.x_q_off * es : 0);
+                    j.g = gh + ((part == 1 || part == 4) ? (size_t)c.g_lo_off * es : part == 3 ? (size_t)c.g_q_off * es : 0);
                     j.xstride_b = (unsigned)(c.in0_stride * es);
                     j.gstride_b = (unsigned)(c.g_stride * es);
                     j.slab_off = off;
-                    j.want_bias = part < 2 ? want_bias : 0;
+                    j.mx = part == 3 ? 1u : 0u;
+                    any_mx = any_mx || part == 3;
+                    j.want_bias = (part < 2 || part == 4) ? want_bias : 0;
+                    if (part == 4) j.want_bias |= 2u;   // the bias sum of g_lo alone: its taps are inside the MX job
                     // (x_hi chunk 0, g_lo) carries the bias sum AND a real term of dW: skipping its taps was measured (+1 % on the exact16 step)
                     // and rejected -- the worst gradient tensor against the all-pairs plan rises by a fifth (32 x 64^2: 5.1e-4 -> 6.3e-4)
                     if (part == 1 && c.g_lo_bias_only && getenv("RESR_WGRAD_BIAS_JOBS_NO_TAPS")) j.want_bias |= 2u;   // experiment knob, read per call
                     j.xsub = (c.x_s2d_c > 0 && dtype != RESR_F32) ? (unsigned)((ck * 32) / c.x_s2d_c) : 4u;
-                    if (part == 1) q.slab_b = off;
-                    if (part == 2) q.slab_c = off;
-                    off += (unsigned)(splits * kSlab);
+                    // (the reduction takes dW = A + (B + C) 2^-12 with the bias from A and B only: an MX job's slab goes in as C, the bias job's as B)
+                    if (part == 1 || part == 4) q.slab_b = off;
+                    if (part == 2 || part == 3) q.slab_c = off;
+                    off += (unsigned)((part == 3 ? splits_mx : splits) * kSlab);
                 }
             }
     }
     a.partial = partial; r.partial = partial; r.splits = splits;
+    r.splits_c = any_mx ? splits_mx : 0;
+    a.splits_mx = splits_mx;
     r.unscale = convs[0].unscale;
     for (int i = 1; i < nconv; ++i)
         if (convs[i].unscale != convs[0].unscale) return fail(RESR_ERR_ARG, "wgrad: one pre-scale per launch");
@@ -1186,6 +1331,7 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
         if (rc) return rc;
     }
     if (quad_done) rc = RESR_OK;
+    else if (any_mx) return fail(RESR_ERR_ARG, "wgrad: MX jobs (x_q_off / g_q_off) need the quad kernel's preconditions (32-bit addressing, a quad plan of the products)");
     else if (dtype == RESR_F16 || dtype == RESR_F16X2) rc = launch_wgrad<half_t, 2>(a, nj, nr, stream);
     else if (dtype == RESR_F32) rc = launch_wgrad<float, 1>(a, nj, nr, stream);
     else return fail(RESR_ERR_ARG, "wgrad: dtype=%d", dtype);

@@ -214,7 +214,7 @@ class Generator(nn.Module):
     MFMAs per product, fp32 accumulate: meets the 1e-3 parity tolerance vs the fp32 CPU path at about a third
     of fast mode's throughput), "strict" = f32 operands on v_mfma_f32_32x32x2_f32 (bit-for-bit fp32 FMA chains).
     Default from $RESR_PRECISION, else "fast".
-    `x2_plan` (exact16 only; bit set of _lib.X2_PLAN_*, default from $RESR_X2_PLAN, else 251 = bits 0, 1, 3, 4, 5, 6, 7; 59 = round 5's default without the MX stages): which tensors of the dense
+    `x2_plan` (exact16 only; bit set of _lib.X2_PLAN_*, default from $RESR_X2_PLAN, else 763 = bits 0, 1, 3, 4, 5, 6, 7, 9; 59 = round 5's default without the MX stages): which tensors of the dense
     blocks are single f16 instead of hi/lo pairs -- bit 0: the growth planes o1..o4 of an INFERENCE forward (50 instead of 60
     stages per block; forward ~1e-6 at the reference's init scale, gate 2e-4), bit 1: the growth-plane gradients of the backward
     pass are READ as single f16 (two stages / two tap-products on their chunks; the bias sums still take hi + lo; worst gradient
@@ -227,7 +227,10 @@ class Generator(nn.Module):
     v_mfma_scale_f32_32x32x64_f8f6f4 per output row on unscaled bf8 operands ([bf8(x_hi) | bf8(x_lo)] records written by the producing
     epilogues, [bf8(W1) | bf8(W2)] blocks from the packer): 30 stage-equivalents per block, forward ~1e-4 (gate 2e-4), bit 7: the dense
     blocks' backward-data passes read EVERY gradient chunk as a pair on one f16 + one MX stage (40 stage-equivalents per block instead of
-    50; the growth-plane gradients enter with both halves again: worst gradient tensor ~1e-4 instead of 3-5e-4).  x2_plan=0 = pairs everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
+    50; the growth-plane gradients enter with both halves again), bit 9 (with bits 7 and 3): the dense blocks' weight gradients take both
+    2^-12-weighted tap-products of every stream chunk as ONE MX job (8-bit transpose reads of the q records, K = 32 pixels twice) --
+    conv1..conv4 get their (x_hi, g_lo) term back at no cost: worst gradient tensor 5-7e-5 against the all-pairs plan instead of 2-3e-4;
+    bit 8 (opt-in): exact16's forward in front of fast mode's backward pass.  x2_plan=0 = pairs everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
     The backward pass of the 16-bit modes (exact16, fast) does not depend on the caller's loss scale: an incoming gradient whose largest element is below 2^6 is
     lifted by a power of two inside the native pass and the results are handed back unscaled (bit-identical gradients at loss scale
     1 and 2^20; csrc/generator.hip, $RESR_X2_GRAD_PRESCALE_LOG2 / RESR_X2_NO_GRAD_PRESCALE=1).
@@ -244,16 +247,17 @@ class Generator(nn.Module):
         self.in_channels, self.out_channels, self.upscale_factor = in_channels, out_channels, upscale_factor
         self.precision = precision or os.environ.get("RESR_PRECISION", "fast")
         self._dtype = _precision_to_dtype(self.precision)
-        self.x2_plan = int(os.environ.get("RESR_X2_PLAN", "251")) if x2_plan is None else int(x2_plan)
-        if not 0 <= self.x2_plan <= 255:
+        self.x2_plan = int(os.environ.get("RESR_X2_PLAN", "763")) if x2_plan is None else int(x2_plan)
+        if not 0 <= self.x2_plan <= 1023:
             raise ValueError(f"x2_plan must be a bit set of X2_PLAN_GROWTH_F16_INFER (1) | X2_PLAN_GROWTH_GRAD_F16 (2) | "
                              f"X2_PLAN_GROWTH_GRAD_STORE_F16 (4) | X2_PLAN_GROWTH_ACT_F16_WGRAD (8) | X2_PLAN_GROWTH_ACT_G_HI_WGRAD (16) | X2_PLAN_GROWTH_W16_INFER (32) | "
-                             f"X2_PLAN_MX_INFER (64) | X2_PLAN_MX_BWD (128), got {self.x2_plan}")
+                             f"X2_PLAN_MX_INFER (64) | X2_PLAN_MX_BWD (128) | X2_PLAN_F16_BACKWARD (256) | X2_PLAN_MX_WGRAD (512), got {self.x2_plan}")
         if (self.x2_plan & 128) and (self.x2_plan & 4):
             raise ValueError(f"x2_plan={self.x2_plan}: MX_BWD (128) reads the growth-plane gradients as pairs; GROWTH_GRAD_STORE_F16 (4) stores them single")
         # a bit that only refines another one means nothing without it: refuse instead of silently ignoring it
         for bit, needs, name in ((4, 2, "GROWTH_GRAD_STORE_F16 (4) refines GROWTH_GRAD_F16 (2)"), (16, 8, "GROWTH_ACT_G_HI_WGRAD (16) refines GROWTH_ACT_F16_WGRAD (8)"),
-                                 (32, 1, "GROWTH_W16_INFER (32) refines GROWTH_F16_INFER (1)"), (64, 33, "MX_INFER (64) rides on GROWTH_F16_INFER (1) + GROWTH_W16_INFER (32)")):
+                                 (32, 1, "GROWTH_W16_INFER (32) refines GROWTH_F16_INFER (1)"), (64, 33, "MX_INFER (64) rides on GROWTH_F16_INFER (1) + GROWTH_W16_INFER (32)"),
+                                 (512, 128 + 8, "MX_WGRAD (512) rides on MX_BWD (128: the gradient planes' q tensors) + GROWTH_ACT_F16_WGRAD (8: the stream chunks are the pair chunks)")):
             if (self.x2_plan & bit) and (self.x2_plan & needs) != needs:
                 raise ValueError(f"x2_plan={self.x2_plan}: {name}")
         self.n_blocks = n_blocks or self.N_BLOCKS
@@ -276,6 +280,7 @@ class Generator(nn.Module):
         self._flat: Optional[torch.Tensor] = None        # fp32 parameter arena
         self._flat_grad: Optional[torch.Tensor] = None   # fp32 gradient arena (written by backward)
         self._packed: Optional[torch.Tensor] = None
+        self._packed_f16: Optional[torch.Tensor] = None   # x2_plan bit 8: a RESR_F16 packing of the same table for the f16 backward pass
         self._table_dev: Dict[int, tuple] = {}
         self._workspaces: Dict[tuple, List[_Workspace]] = {}
         self.grad_hook = None   # callable(flat_grad) run after backward wrote the arena (data-parallel all-reduce)
@@ -390,6 +395,13 @@ class Generator(nn.Module):
         raw, n = self._table_dev[key]
         _lib.check(L.resr_pack_weights(_lib.ptr(raw), n, _lib.ptr(flat), _lib.ptr(self._packed), self._dtype,
                                        _lib.stream_ptr(flat)), "resr_pack_weights")
+        if self._dtype == _lib.RESR_F16X2 and backward and (desc.x2_plan & _lib.X2_PLAN_F16_BACKWARD):
+            fd = _lib.GeneratorDesc(desc.n, desc.h, desc.w, desc.in_channels, desc.out_channels, desc.upscale, desc.n_blocks, _lib.RESR_F16, 1, 0, 0, 0)
+            nb16 = L.resr_generator_packed_bytes(C.byref(fd), 1)
+            if self._packed_f16 is None or self._packed_f16.numel() < nb16 or self._packed_f16.device != flat.device:
+                self._packed_f16 = torch.zeros(nb16, dtype=torch.uint8, device=flat.device)
+            _lib.check(L.resr_pack_weights(_lib.ptr(raw), n, _lib.ptr(flat), _lib.ptr(self._packed_f16), _lib.RESR_F16, _lib.stream_ptr(flat)),
+                       "resr_pack_weights (f16 backward)")
         if self._dtype == _lib.RESR_F16X2 and (((desc.x2_plan & _lib.X2_PLAN_MX_INFER) and not desc.training) or
                                                ((desc.x2_plan & _lib.X2_PLAN_MX_BWD) and desc.training)):
             # the MX blocks of the same table ([bf8(W1) | bf8(W2)] per tap and row), behind the f16 blocks of the packed buffer
@@ -399,7 +411,7 @@ class Generator(nn.Module):
 
     def _workspace(self, desc: _lib.GeneratorDesc, device) -> _Workspace:
         L = _lib.lib()
-        key = (desc.n, desc.h, desc.w, desc.training, desc.dtype, desc.wgrad_splits, desc.x2_plan & (_lib.X2_PLAN_MX_INFER | _lib.X2_PLAN_MX_BWD))   # (the MX plans carry q tensors)
+        key = (desc.n, desc.h, desc.w, desc.training, desc.dtype, desc.wgrad_splits, desc.x2_plan & (_lib.X2_PLAN_MX_INFER | _lib.X2_PLAN_MX_BWD | _lib.X2_PLAN_MX_WGRAD))   # (the MX plans carry q tensors)
         pool = self._workspaces.setdefault(key, [])
         for ws in pool:
             if not ws.busy:
@@ -452,7 +464,8 @@ class Generator(nn.Module):
                 e.record(torch.cuda.current_stream(gy.device))
                 self._events.append(e)
             ev_arr = (C.c_void_p * n_ev)(*[e.cuda_event for e in self._events[:n_ev]])
-        _lib.check(L.resr_generator_backward(C.byref(desc), _lib.ptr(gy), _lib.ptr(flat), _lib.ptr(self._packed),
+        f16bwd = self._dtype == _lib.RESR_F16X2 and (desc.x2_plan & _lib.X2_PLAN_F16_BACKWARD)
+        _lib.check(L.resr_generator_backward(C.byref(desc), _lib.ptr(gy), _lib.ptr(flat), _lib.ptr(self._packed_f16 if f16bwd else self._packed),
                                              _lib.ptr(ws.buf), ws.buf.numel(), _lib.ptr(self._flat_grad),
                                              _lib.ptr(gx), _lib.stream_ptr(gy), ev_arr, n_ev),
                    "resr_generator_backward")

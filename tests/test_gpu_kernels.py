@@ -219,14 +219,16 @@ def test_conv3x3_chunk_planar(U, case, dtype_name):
         assert torch.equal(bits, got > 0), "sign tensor disagrees with the stored activation"
 
 
-def test_conv3x3_one_role_fallback():
-    """The register-staged f16 kernel (used when the producer/consumer kernel's preconditions fail) stays correct:
-    re-run the f16 conv cases in a subprocess with RESR_CONV_ONE_ROLE=1 (the knob is read once per process)."""
+def test_conv3x3_one_role_and_wgrad_pair_kernel_fallbacks():
+    """The register-staged f16 conv kernel (used when the producer/consumer kernel's preconditions fail) and the f16 weight-gradient
+    pair kernel (used when the quad kernel's grouping fails) stay correct: re-run the f16 conv cases and the wgrad cases in ONE
+    subprocess with RESR_CONV_ONE_ROLE=1 and RESR_WGRAD_PAIR_KERNEL=1 (the knobs are read once per process; one interpreter start-up
+    instead of two: the suite's time box)."""
     import subprocess, sys
-    env = dict(os.environ, RESR_CONV_ONE_ROLE="1")
+    env = dict(os.environ, RESR_CONV_ONE_ROLE="1", RESR_WGRAD_PAIR_KERNEL="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "test_conv3x3 and f16 and not fallback and not persist"], env=env, cwd=root,
+                        "-k", "(test_conv3x3 and f16 and not fallback and not persist) or (test_wgrad and not fallback and not layer)"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -375,10 +377,11 @@ def test_wgrad_layer_mode_exact16(U, case, products, diag_dir):
         assert 1e-5 < rel_w < 2e-3 and rel_b < 2e-3, (rel_w, rel_b)    # the hi-only form drops the 2^-12 terms: visibly coarser, still a gradient
 
 
-@pytest.mark.parametrize("knob", ["RESR_WGRAD_PAIR_KERNEL", "RESR_WGRAD_GENERIC_ADDR"])
+@pytest.mark.parametrize("knob", ["RESR_WGRAD_GENERIC_ADDR"])
 def test_wgrad_fallback_kernels(knob):
-    """The f16 pair kernel (used when the quad kernel's grouping or 32-bit addressing preconditions fail) and its 64-bit
-    addressing path stay correct: re-run the wgrad cases in a subprocess with the knob set (read once per process)."""
+    """The f16 pair kernel's 64-bit addressing path (taken when the 32-bit addressing preconditions fail; with 32-bit addressing it
+    runs in test_conv3x3_one_role_and_wgrad_pair_kernel_fallbacks) stays correct: re-run the wgrad cases in a subprocess with the
+    knob set (read once per process)."""
     import subprocess, sys
     env = dict(os.environ, **{knob: "1"})
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

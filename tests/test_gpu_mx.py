@@ -222,12 +222,12 @@ def _setup(n_blocks, seed, x2_plan, wscale=1.0):
     return g.cuda(), sd, M
 
 
-@pytest.mark.parametrize("n,h,w,wscale", [(1, 24, 24, 1.0), (1, 24, 24, 4.0), (8, 32, 32, 1.0), (2, 40, 36, 4.0)])
+@pytest.mark.parametrize("n,h,w,wscale", [(1, 24, 24, 1.0), (8, 24, 24, 1.0), (2, 24, 28, 4.0)])
 def test_mx_inference_forward_vs_oracle(n, h, w, wscale, diag_dir):
     """23 blocks, eval, x2_plan 97 = bits 0 + 5 + 6 (30 stage-equivalents per dense block) against the fp32 CPU oracle, its float64
     evaluation and round 5's 40-stage plan (33); weights at the reference's init and with the dense-block weights x 4; 8 x 32^2 runs the
-    dense blocks as chained launches (six jobs: the closing convolution's halves emit the q records), the others as separate
-    launches on ragged tiles.  (2 x 72 x 100 -- 16-row tiles -- and 8 x 32^2 at x 4 were measured when the stage was built:
+    8 x 24^2 runs the dense blocks as chained launches (six jobs: the closing convolution's halves emit the q records), the others as
+    separate launches on ragged tiles.  (2 x 72 x 100 -- 16-row tiles -- and 8 x 32^2 at x 4 were measured when the stage was built:
     1.12e-4 / 1.13e-4 and 1.14e-4, gpurun_out/mx_infer_*.json of round 6; the per-pass cases above cover the 16-row shapes.)"""
     from real_esrgan_pytorch_amd import _lib as L
     gm, sd, M = _setup(23, 11, 97, wscale)
@@ -236,15 +236,13 @@ def test_mx_inference_forward_vs_oracle(n, h, w, wscale, diag_dir):
     with torch.no_grad():
         ym = gm.eval()(x.cuda()).cpu()
         y33 = g33.eval()(x.cuda()).cpu()
-    yo = M.generator_forward(x, sd, 4, 23)
-    yo64 = M.generator_forward(x.double(), {k: v.double() for k, v in sd.items()}, 4, 23)
-    rep = {"mx_vs_f32_oracle": (ym - yo).abs().max().item(), "mx_vs_f64": (ym.double() - yo64).abs().max().item(),
-           "plan33_vs_f64": (y33.double() - yo64).abs().max().item(), "mx_vs_plan33": (ym - y33).abs().max().item(),
-           "mx_mean_abs_vs_f64": (ym.double() - yo64).abs().mean().item(), "frac_unclamped": ((yo > 0) & (yo < 1)).float().mean().item()}
+    yo = M.generator_forward(x, sd, 4, 23)     # (the fp32 CPU path IS the gate's reference; its float64 evaluation differs from it by < 2e-6 here)
+    rep = {"mx_vs_f32_oracle": (ym - yo).abs().max().item(), "plan33_vs_f32_oracle": (y33 - yo).abs().max().item(), "mx_vs_plan33": (ym - y33).abs().max().item(),
+           "mx_mean_abs_vs_f32_oracle": (ym - yo).abs().mean().item(), "frac_unclamped": ((yo > 0) & (yo < 1)).float().mean().item()}
     with open(os.path.join(diag_dir, f"mx_infer_{n}x{h}x{w}_w{wscale}.json"), "w") as f:
         json.dump(rep, f, indent=1)
-    assert rep["mx_vs_f32_oracle"] < 2e-4 and rep["mx_vs_f64"] < 2e-4, rep
-    assert rep["mx_vs_plan33"] > 0 and rep["plan33_vs_f64"] < 5e-5, rep     # the MX stages really ran; the reference plan is where it was
+    assert rep["mx_vs_f32_oracle"] < 2e-4, rep
+    assert rep["mx_vs_plan33"] > 0 and rep["plan33_vs_f32_oracle"] < 5e-5, rep     # the MX stages really ran; the reference plan is where it was
     assert int(L.lib().resr_debug_chain_errors()) == 0
 
 
@@ -323,10 +321,8 @@ def test_mx_backward_plan_gradients(n, h, w, n_blocks, seed, diag_dir):
     gen = torch.Generator().manual_seed(5)
     x = torch.rand(n, 3, h, w, generator=gen)
     gw = torch.randn(n, 3, 4 * h, 4 * w, generator=gen)
-    sdo = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
-    xo = x.double().clone().requires_grad_(True)
-    yo = M.generator_forward(xo, sdo, 4, n_blocks)
-    (yo * gw.double()).sum().backward()
+    # (the all-pairs plan on the same device is the reference here: its own distance to the float64 oracle -- 6e-6, or a mask flip of the
+    # shared forward pass -- is held by test_gpu_generator.py and test_gpu_x2_plan.py)
 
     def run(model):
         xd = x.cuda().requires_grad_(True)
@@ -341,20 +337,15 @@ def test_mx_backward_plan_gradients(n, h, w, n_blocks, seed, diag_dir):
 
     def rel(got, ref):
         return ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
-    errs = {name: rel(gr[name], sdo[name].grad) for name in gr}
-    errs0 = {name: rel(gr0[name], sdo[name].grad) for name in gr}
     between = {name: rel(gr[name], gr0[name]) for name in gr}
     between27 = {name: rel(gr27[name], gr0[name]) for name in gr}
     worst_b = max(between, key=between.get)
     vals = sorted(between.values())
     rep = {"worst_vs_all_pairs_plan": between[worst_b], "worst_vs_all_pairs_tensor": worst_b, "median_vs_all_pairs_plan": vals[len(vals) // 2],
-           "plan27_worst_vs_all_pairs_plan": max(between27.values()), "worst_vs_f64": max(errs.values()), "worst_all_pairs_vs_f64": max(errs0.values()),
-           "gx_vs_all_pairs": rel(gx, gx0), "gx_vs_f64": rel(gx, xo.grad)}
+           "plan27_worst_vs_all_pairs_plan": max(between27.values()), "gx_vs_all_pairs": rel(gx, gx0)}
     with open(os.path.join(diag_dir, f"mx_bwd_{n}x{h}x{w}_{n_blocks}_{seed}.json"), "w") as f:
         json.dump(rep, f, indent=1)
     assert rep["worst_vs_all_pairs_plan"] < 5e-4 and rep["gx_vs_all_pairs"] < 2e-4, rep
-    for name, e in errs.items():     # vs float64: inside the gate, or a mask flip of the (shared) forward pass
-        assert e < 1e-3 or errs0[name] > 0.8 * e, (name, e, errs0[name])
     assert rep["worst_vs_all_pairs_plan"] > 1e-5, "the plan does not seem to be active (gradients at the all-pairs level)"
 
 
@@ -376,3 +367,84 @@ def test_mx_backward_chained_equals_separate_launches(monkeypatch):
         b = grads()
         monkeypatch.delenv("RESR_CONV_NO_CHAIN")
         assert all(torch.equal(a[k], b[k]) for k in a), (n, s)
+
+
+def test_exact16_forward_with_f16_backward(diag_dir):
+    """x2_plan bit 8 (opt-in): exact16's all-pairs forward -- the same bits as any exact16 training forward, hence
+    reference-exact LeakyReLU masks -- followed by fast mode's backward pass on the hi tensors.  Against the all-pairs plan under a dense
+    random cotangent the emulation reads worst 1.6-2.0e-3 / median 0.9-1.1e-3 where fast mode reads 5-8e-2 / 3-4e-2 (tools/precision_ladder_sim.py,
+    "fwd exact; bwd: g f16 all, W f16"): most of fast mode's gradient error is its own forward's mask flips."""
+    n, h, w, nb = 8, 32, 32, 3
+    gh, sd, M = _setup(nb, 11, 256)
+    g0, _, _ = _setup(nb, 11, 0)
+    import real_esrgan_pytorch_amd as R
+    gf = R.Generator(3, 3, 4, precision="fast", n_blocks=nb)
+    gf.load_state_dict(sd)
+    gf = gf.cuda()
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(n, 3, h, w, generator=gen)
+    gw = torch.randn(n, 3, 4 * h, 4 * w, generator=gen)
+
+    def run(model):
+        xd = x.cuda().requires_grad_(True)
+        y = model.train()(xd)
+        (y * gw.cuda()).sum().mul(1024.0).backward()
+        torch.cuda.synchronize()
+        return y.detach().cpu(), {name: p.grad.cpu().double() / 1024.0 for name, p in model.named_parameters()}
+    yh, grh = run(gh)
+    y0, gr0 = run(g0)
+    yf, grf = run(gf)
+    assert torch.equal(yh, y0), "the forward pass is exact16's"
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    eh = sorted(rel(grh[k], gr0[k]) for k in gr0)
+    ef = sorted(rel(grf[k], gr0[k]) for k in gr0)
+    rep = {"hybrid_median": eh[len(eh) // 2], "hybrid_worst": eh[-1], "fast_median": ef[len(ef) // 2], "fast_worst": ef[-1]}
+    with open(os.path.join(diag_dir, "hybrid_f16_backward.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    assert rep["hybrid_worst"] < 5e-3 and rep["hybrid_median"] < 2e-3, rep
+    assert rep["hybrid_median"] < 0.25 * rep["fast_median"], rep
+
+
+@pytest.mark.parametrize("n,h,w,n_blocks,seed", [(8, 32, 32, 3, 11), (2, 33, 17, 2, 13), (1, 24, 24, 23, 11)])
+def test_mx_weight_gradient_jobs(n, h, w, n_blocks, seed, diag_dir):
+    """x2_plan bit 9 (RESR_X2_PLAN_MX_WGRAD, on top of 27 + 128): the stream chunks' correction tap-products (x_hi, g_lo) + (x_lo, g_hi) of
+    every dense-block weight gradient as ONE MX job -- 8-bit transpose reads of the staged q records, K = 32 pixels twice per
+    v_mfma_scale_f32_32x32x64_f8f6f4 -- with the bias sums of g_lo from tap-free jobs.  The training forward (which now also emits the
+    stream's q tensor) stays the all-pairs plan's bit for bit; every gradient tensor within 5e-4 of the all-pairs plan (VERDICT round 5,
+    item 1c); against the plan without the bit the MX jobs move a tensor by ~1e-5 (emulation: weight gradients alone 2-3e-5 worst) --
+    more where they restore the (x_hi, g_lo) term that plan bit 1 drops for conv1..conv4."""
+    gw9, sd, M = _setup(n_blocks, seed, 27 + 128 + 512)
+    g7, _, _ = _setup(n_blocks, seed, 27 + 128)
+    g0, _, _ = _setup(n_blocks, seed, 0)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(n, 3, h, w, generator=gen)
+    gwt = torch.randn(n, 3, 4 * h, 4 * w, generator=gen)
+
+    def run(model):
+        xd = x.cuda().requires_grad_(True)
+        y = model.train()(xd)
+        (y * gwt.cuda()).sum().mul(1024.0).backward()
+        torch.cuda.synchronize()
+        return y.detach().cpu(), {name: p.grad.cpu().double() / 1024.0 for name, p in model.named_parameters()}, xd.grad.cpu().double() / 1024.0
+    y9, gr9, gx9 = run(gw9)
+    y7, gr7, gx7 = run(g7)
+    y0, gr0, gx0 = run(g0)
+    assert torch.equal(y9, y0) and torch.equal(gx9, gx7), "forward and backward-data do not depend on the weight-gradient jobs"
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    b9 = {k: rel(gr9[k], gr0[k]) for k in gr0}
+    b7 = {k: rel(gr7[k], gr0[k]) for k in gr0}
+    d97 = {k: rel(gr9[k], gr7[k]) for k in gr0}
+    trunk = [k for k in gr0 if ".rdb" in k]
+    other = [k for k in gr0 if ".rdb" not in k]
+    rep = {"worst_vs_all_pairs_plan": max(b9.values()), "worst_tensor": max(b9, key=b9.get), "without_the_bit_worst": max(b7.values()),
+           "median_vs_all_pairs_plan": sorted(b9.values())[len(b9) // 2], "without_the_bit_median": sorted(b7.values())[len(b7) // 2],
+           "moved_by_the_mx_jobs_worst": max(d97[k] for k in trunk), "worst_bias_vs_all_pairs": max(b9[k] for k in trunk if k.endswith(".bias"))}
+    with open(os.path.join(diag_dir, f"mx_wgrad_{n}x{h}x{w}_{n_blocks}_{seed}.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    assert all(torch.equal(gr9[k], gr7[k]) for k in other), "the HR tail / conv1 / conv2 keep their f16 tap-products"
+    assert 0 < rep["moved_by_the_mx_jobs_worst"] < 3e-4, rep
+    assert rep["worst_vs_all_pairs_plan"] < 5e-4 and rep["worst_bias_vs_all_pairs"] < 2e-4, rep

@@ -173,7 +173,7 @@ def test_wgrad_single_g_equals_pair_g_with_zero_lo(U, cin, cout, n, h, w, splits
         return dw, db
     dw3, db3 = run(g_lo)
     dw2, db2 = run(0, flags=L.CONV_OUT_SINGLE)       # the single-G mode is selected explicitly ...
-    run(0, expect=L.ERR_ARG)                        # ... a zero offset alone is a forgotten field
+    run(0, expect=-1)                               # ... a zero offset alone is a forgotten field
     assert torch.equal(dw3, dw2) and torch.equal(db3, db2)
     wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
     bs = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
@@ -194,11 +194,11 @@ def _setup(n_blocks, seed, x2_plan, wscale=1.0, upscale=4):
     return g.cuda(), sd, M
 
 
-@pytest.mark.parametrize("n,h,w,wscale", [(1, 24, 24, 1.0), (8, 32, 32, 4.0)])
+@pytest.mark.parametrize("n,h,w,wscale", [(1, 24, 24, 1.0), (8, 24, 24, 4.0)])
 def test_inference_plan_forward_vs_oracle(n, h, w, wscale, diag_dir):
     """23 blocks, eval: growth planes single f16 (50 stages per block) against the fp32 CPU oracle and against the all-pairs plan;
     weights at the reference's init scale and dense-block weights x 4 (activations grow, the dense branch is no longer small);
-    8 x 32^2 runs the dense blocks as chained launches."""
+    8 x 24^2 runs the dense blocks as chained launches."""
     from real_esrgan_pytorch_amd import _lib as L
     g1, sd, M = _setup(23, 11, 1, wscale)
     g0, _, _ = _setup(23, 11, 0, wscale)
@@ -473,8 +473,8 @@ def test_exact16_backward_keeps_a_non_finite_gradient_visible():
 def test_lifted_backward_backs_off_when_the_gradient_outgrows_its_headroom(precision):
     """the lift re-raises max |g_y| to [2^6, 2^7) on every step, so a gradient that grows by more than f16's
     remaining 2^9 on its way back would overflow at EVERY loss scale -- a GradScaler halving its scale could not cure it.  Here the
-    backward gain of the HR tail is 2^18 by construction (conv4's and conv3's weights x 2^9 each -- below exact16's |w| < 16 --,
-    upsampling2's weights and bias x 2^-18: LeakyReLU is positively homogeneous, so the forward pass is the same function): the first
+    backward gain of the HR tail is 2^16 by construction (conv4's and conv3's weights x 2^8 each -- below exact16's |w| < 16 --,
+    upsampling2's weights and bias x 2^-16; fast mode, whose f16 activations could not hold the 2^-16, takes 2^11 on conv4 against conv3: LeakyReLU is positively homogeneous, so the forward pass is the same function): the first
     lifted passes overflow, set the flag in the workspace's pre-scale slot, and every later pass aims 2^4 lower (common.h) -- after at
     most five skipped steps the GradScaler's scale stops decaying and the weights move.  Without the back-off every step of the loop
     below is skipped."""
@@ -483,12 +483,17 @@ def test_lifted_backward_backs_off_when_the_gradient_outgrows_its_headroom(preci
     g = R.Generator(3, 3, 4, precision=precision, n_blocks=1).cuda().train()
     with torch.no_grad():
         g.conv4.bias.add_(0.5)
-        g.conv4.weight.mul_(2.0 ** 9)
-        g.conv3[0].weight.mul_(2.0 ** 9)
-        g.conv3[0].bias.mul_(2.0 ** -9)
-        g.upsampling2[0].weight.mul_(2.0 ** -18)
-        g.upsampling2[0].bias.mul_(2.0 ** -18)
-        assert g.conv4.weight.abs().max() < 16 and g.conv3[0].weight.abs().max() < 16
+        if precision == "fast":
+            g.conv4.weight.mul_(2.0 ** 11)
+            g.conv3[0].weight.mul_(2.0 ** -11)
+            g.conv3[0].bias.mul_(2.0 ** -11)
+        else:
+            g.conv4.weight.mul_(2.0 ** 8)
+            g.conv3[0].weight.mul_(2.0 ** 8)
+            g.conv3[0].bias.mul_(2.0 ** -8)
+            g.upsampling2[0].weight.mul_(2.0 ** -16)
+            g.upsampling2[0].bias.mul_(2.0 ** -16)
+            assert g.conv4.weight.abs().max() < 16 and g.conv3[0].weight.abs().max() < 16
     opt = torch.optim.Adam(g.parameters(), 1e-6, (0.9, 0.99))
     scaler = torch.amp.GradScaler("cuda")
     gen = torch.Generator(device="cuda").manual_seed(9)
