@@ -700,9 +700,44 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel_t(const WgradQuadArg
             // the next tile's ten LDS-DMA requests go out up front (between the MFMA groups, as the f16 loop spreads them, their address
             // selects became branches inside the unrolled loop and the accumulators spilled -- 158 to 504 registers in three placements
             // tried); they land under the 36 MFMAs, the wave pays their issue back-pressure before its first MFMA of the tile
+#ifndef RESR_WGRAD_MX_PREP
 #pragma unroll
             for (int k = 0; k < NSX + NSG; ++k) stage_slot(k, tn, nb, has_next);
             __builtin_amdgcn_sched_barrier(0);
+#else
+            // the next tile's requests: addresses, lane masks and LDS destinations worked out HERE (selects and all), the ten LDS-DMA
+            // instructions themselves go out as bare asm between the MFMA groups below
+            const char* ssrc[NSX + NSG];
+            unsigned long long smask[NSX + NSG];
+            unsigned sdst[NSX + NSG];
+#pragma unroll
+            for (int k = 0; k < NSX + NSG; ++k) {
+                if (k < NSX) {
+                    const unsigned c = cx[k];
+                    const int ws = k * 8 + wave;
+                    const int chunk = ws >= kQXW ? 1 : 0;
+                    const int iy = tn.y0 - 1 + (int)((c >> 8) & 0xff), ix = tn.x0 - 1 + (int)(c & 0xff);
+                    const bool in = (unsigned)iy < (unsigned)img_h && (unsigned)ix < (unsigned)img_w;
+                    const unsigned pix = tn.xn + (unsigned)(iy >> up) * src_w + (unsigned)(ix >> up);
+                    const char* src = (chunk ? jx1 : jx0) + (__umul24(pix, chunk ? sx1 : sx0) + ((c >> 16) & 0xfff));
+                    ssrc[k] = in ? src : zero;
+                    smask[k] = __ballot(has_next && c != ~0u);
+                    sdst[k] = lds0 + nb * kQBUF + ws * 1024;
+                } else {
+                    const int i = k - NSX;
+                    const unsigned c = cg[i];
+                    const int gt = i >> 1;
+                    const int iy = tn.y0 + (int)((c >> 8) & 0xff), ix = tn.x0 + (int)(c & 0xff);
+                    const bool in = iy < img_h && ix < img_w;
+                    const unsigned pix = tn.gn + (unsigned)iy * img_w + (unsigned)ix;
+                    const char* src = (gt ? jg1 : jg0) + (__umul24(pix, gt ? sg1 : sg0) + ((c >> 16) & 0xfff));
+                    ssrc[k] = in ? src : zero;
+                    smask[k] = __ballot(has_next && c != ~0u);
+                    sdst[k] = lds0 + nb * kQBUF + 2 * kQXCH + (i * 8 + wave) * 1024;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             v8i fgm[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) fgm[r] = frag(gb + r * 32 * PB, 32, 0);          // A = [g_lo | g_hi]
@@ -720,6 +755,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel_t(const WgradQuadArg
                     for (int dx = 0; dx < 3; ++dx)
                         acc[dy * 3 + dx] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fgm[r], fx[dx], acc[dy * 3 + dx], 1, 1, 0, one, 0, one);
                 }
+#ifdef RESR_WGRAD_MX_PREP
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int k = 2 * j + q2;
+                    if (k < NSX + NSG) {
+                        unsigned long long save;
+                        asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                                     "global_load_lds_dwordx4 %3, off\n\ts_mov_b64 exec, %0"
+                                     : "=&s"(save) : "s"(smask[k]), "s"(sdst[k]), "v"(ssrc[k]) : "memory", "m0");
+                    }
+                }
+#endif
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's asm LDS-DMA has landed
             __syncthreads();

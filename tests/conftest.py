@@ -9,6 +9,12 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+# The longest validation sweeps of plans that are no longer the default (rounds 4-5: their numbers are in DESIGN section 2 and in
+# tools/x2_plan_validate.py) run only with RESR_TEST_SLOW=1: the -m gpu suite has a time box.
+SLOW = os.environ.get("RESR_TEST_SLOW") == "1"
+slow = pytest.mark.skipif(not SLOW, reason="validation sweep of a non-default plan: RESR_TEST_SLOW=1 runs it")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -222,7 +222,7 @@ def test_bench_gan_two_ranks_plain_launch_prints_one_line():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "2", "--lr-size", "32", "--gan", "--no-parity-mode", "--no-sustained", "--no-probe"]   # (LR 16: a resize1 factor of 0.15 leaves 9 pixels for the 21-tap blur, which reflect padding refuses -- as F.pad does)
+           "--batch", "2", "--lr-size", "32", "--gan", "--no-parity-mode", "--no-sustained"]   # (LR 16: a resize1 factor of 0.15 leaves 9 pixels for the 21-tap blur, which reflect padding refuses -- as F.pad does)
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert "starting 2 ranks" in r.stderr

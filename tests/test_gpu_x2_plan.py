@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+from tests.conftest import slow as _slow  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -194,7 +195,7 @@ def _setup(n_blocks, seed, x2_plan, wscale=1.0, upscale=4):
     return g.cuda(), sd, M
 
 
-@pytest.mark.parametrize("n,h,w,wscale", [(1, 24, 24, 1.0), (8, 24, 24, 4.0)])
+@pytest.mark.parametrize("n,h,w,wscale", [(1, 24, 24, 1.0), pytest.param(8, 24, 24, 4.0, marks=_slow)])
 def test_inference_plan_forward_vs_oracle(n, h, w, wscale, diag_dir):
     """23 blocks, eval: growth planes single f16 (50 stages per block) against the fp32 CPU oracle and against the all-pairs plan;
     weights at the reference's init scale and dense-block weights x 4 (activations grow, the dense branch is no longer small);
@@ -223,6 +224,7 @@ def test_inference_plan_forward_vs_oracle(n, h, w, wscale, diag_dir):
     assert int(L.lib().resr_debug_chain_errors()) == 0
 
 
+@_slow
 def test_inference_plan_after_training_steps(diag_dir):
     """The same gate on weights that have left the init: 60 RealESRNet steps (fast mode, as the train scripts run) on one fixed
     batch, then exact16 inference of the trained weights, plan 1 against plan 0 and the fp32 oracle."""
@@ -253,7 +255,7 @@ def test_inference_plan_after_training_steps(diag_dir):
     assert rep["plan1_vs_f32_oracle"] < 2e-4 and rep["plan33_vs_f32_oracle"] < 2e-4, rep
 
 
-@pytest.mark.parametrize("n,h,w,n_blocks,seed", [(1, 24, 24, 23, 11), (8, 32, 32, 3, 11), (2, 33, 17, 2, 13)])   # (seeds 12, 13 at full depth: tools/x2_plan_validate.py)
+@pytest.mark.parametrize("n,h,w,n_blocks,seed", [pytest.param(1, 24, 24, 23, 11, marks=_slow), (8, 32, 32, 3, 11), (2, 33, 17, 2, 13)])   # (seeds 12, 13 at full depth: tools/x2_plan_validate.py)
 def test_training_plan_gradients_vs_float64_oracle(n, h, w, n_blocks, seed, diag_dir):
     """Backward with single-f16 growth-plane gradients (x2_plan bit 1) and weight products that read the growth planes as their hi
     tensor (bits 3, 4) -- the default plan, 27; the forward pass keeps every pair: all gradient tensors
@@ -564,7 +566,7 @@ def _oracle_grads(M, sd, x, gw, n_blocks, dt=torch.float64):
 _OFF_INIT_ORACLE = {}
 
 
-@pytest.mark.parametrize("precision,plan", [("exact16", 27 + 128), ("exact16", 0), ("fast", 0)])
+@pytest.mark.parametrize("precision,plan", [("exact16", 27 + 128 + 512), pytest.param("exact16", 0, marks=_slow), ("fast", 0)])
 @pytest.mark.parametrize("case", ["dense_x4", "stream_x40", "stream_x0p01"])
 def test_generator_parity_off_the_init_scale(precision, plan, case, diag_dir):
     """Forward + backward of a 6-block generator against the float64 oracle with (a) the dense-block weights x 4 (the branches are
