@@ -21,6 +21,9 @@ import real_esrgan_pytorch_amd as R  # noqa: E402
 
 
 def grads(g, plan, x, loss_of, scale=1024.0, products=None):
+    if g.x2_plan != plan:      # (the MX plans have their own workspaces -- 80-100 GB each at 16 x 256^2: one at a time)
+        g._workspaces.clear()
+        torch.cuda.empty_cache()
     g.x2_plan = plan
     os.environ.pop("RESR_X2_WGRAD_PRODUCTS", None)
     if products:
