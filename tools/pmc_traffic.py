@@ -12,16 +12,18 @@ import sys
 
 
 def short(name):
-    m = re.search(r"conv3x3_ws_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)ELi\d+E(Lb[01]E)?(Li\dE)?(Li\dE)?", name)  # epilogue kinds are summed
+    # conv3x3_ws_kernel<T, MT, NT, NWC, EPI, X2, SP, CH>: epilogue kinds are summed; X2 = 1 (three f16 stages per pair chunk) and X2 = 2 (one f16 +
+    # one MX stage) share bench.py's in-situ name "f16x2"; CH != 0 = the passes of a dense block as one chained launch
+    m = re.search(r"conv3x3_ws_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)ELi\d+E(?:Li(\d)E)?(?:Li(\d)E)?(?:Li(\d)E)?", name)
     if m:
-        t = "f32" if m.group(1) != "DF16_" else ("f16x2" if m.group(5) == "Lb1E" else "f16")
-        chain = ",chain" if m.group(7) in ("Li1E", "Li2E", "Li3E") else ""   # the cout-32 passes of a dense block as one launch
+        t = "f32" if m.group(1) != "DF16_" else ("f16x2" if m.group(5) not in (None, "0") else "f16")
+        chain = ",chain" if m.group(7) not in (None, "0") else ""
         return f"conv3x3_ws_kernel<{t},{m.group(2)},{m.group(3)},{m.group(4)}{chain}>"
     m = re.search(r"conv3x3_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)E", name)
     if m:
         return f"conv3x3_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'},{m.group(2)},{m.group(3)},{m.group(4)}>"
     if "wgrad_quad_kernel" in name:
-        return "wgrad_quad_kernel<f16>"
+        return "wgrad_quad_kernel<mx>" if "ILb1E" in name or "<true>" in name else "wgrad_quad_kernel<f16>"
     m = re.search(r"wgrad_kernelI(DF16_|f)Li(\d)E", name)
     if m:
         return f"wgrad_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'},{m.group(2)}>"
