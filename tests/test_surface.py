@@ -4,6 +4,7 @@ the product refuses CPU tensors instead of falling back."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -233,3 +234,35 @@ def test_precision_defaults_follow_the_reference_call_sites(built):
     assert "config.inference_precision" in inspect.getsource(dirtest.main)
     with pytest.raises(ValueError):
         built.Generator(3, 3, 4, precision="bf16")
+
+
+def test_committed_pmc_traffic_names_the_bench_lines_kernel():
+    """`roofline.traffic` of the bench line is read from the newest profiles/r*_pmc_traffic_b16.json -- but only under the in-situ name of
+    the dominant kernel and only while the file's `csrc_sha16` is the hash of the current kernel sources (bench.pmc_traffic).  Round 6's
+    first reduction parsed an older template signature and lost the `...,chain` row, and the line said `traffic: null`: whenever the
+    newest file IS from the current sources it must carry that row, and the reduction must know every conv3x3_ws_kernel signature in use."""
+    import glob
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from pmc_traffic import short
+    assert short("_ZN4resr17conv3x3_ws_kernelIDF16_Li1ELi2ELi8ELi16ELi0ELi0ELi1EEEvNS_8ConvArgsE") == "conv3x3_ws_kernel<f16,1,2,8,chain>"
+    assert short("_ZN4resr17conv3x3_ws_kernelIDF16_Li1ELi2ELi8ELi33ELi1ELi0ELi1EEEvNS_8ConvArgsE") == "conv3x3_ws_kernel<f16x2,1,2,8,chain>"
+    assert short("_ZN4resr17conv3x3_ws_kernelIDF16_Li2ELi4ELi4ELi2ELi2ELi0ELi0EEEvNS_8ConvArgsE") == "conv3x3_ws_kernel<f16x2,2,4,4>"
+    assert short("_ZN4resr17conv3x3_ws_kernelIDF16_Li2ELi4ELi4ELi0ELi0ELi0ELi0EEEvNS_8ConvArgsE") == "conv3x3_ws_kernel<f16,2,4,4>"
+    assert short("void resr::wgrad_quad_kernel_t<true>(resr::WgradQuadArgs)") == "wgrad_quad_kernel<mx>"
+    spec = importlib.util.spec_from_file_location("bench_for_surface_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_traffic_b16.json")), reverse=True)
+    assert files
+    newest = json.load(open(files[0]))
+    if newest.get("csrc_sha16") == bench.kernel_sources_sha16():
+        assert bench.kernel_name(24128) in newest, sorted(k for k in newest if "conv3x3" in k)
+        traffic, src = bench.pmc_traffic(bench.kernel_name(24128), 16)
+        assert traffic and traffic > 1e9 and src == os.path.basename(files[0])
