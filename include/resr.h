@@ -306,7 +306,8 @@ enum {
      * v_mfma_scale_f32_32x32x64_f8f6f4 per output row and tap, block 0 = (g_lo, x_hi), block 1 = (g_hi, x_lo) -- half the staged bytes
      * and half the matrix time of the two f16 tap-products, and conv1..conv4 get their (x_hi, g_lo) term back (GROWTH_GRAD_F16 drops it).
      * The training forward then emits the q tensor of the residual stream (conv1 and every closing convolution: + 2 of 12 plane stores
-     * per dense block), the workspace holds it, and the bias sums of g_lo come from tap-free jobs. */
+     * per dense block), the workspace holds it, and g_lo's share of a bias gradient is summed by the MX job itself from the bf8 bytes of
+     * its G fragments (a bias moves by 1-2e-5 against the f16 lo tensor's sum; gate 5e-5 in tests/test_gpu_mx.py). */
     RESR_X2_PLAN_MX_WGRAD = 512
 };
 

@@ -19,7 +19,7 @@ struct WgradConv {
     long x_q_off = 0, g_q_off = 0;                     // RESR_F16X2, both != 0 (x2_plan bit 9): element offsets hi -> q tensor of X / G (64 B per pixel and
                                                        // chunk: bf8 of hi | bf8 of lo).  The two 2^-12-weighted tap-products (x_hi, g_lo) and (x_lo, g_hi) of every
                                                        // PAIR X chunk then run as ONE "MX" job -- 8-bit transpose reads of the staged q records feeding
-                                                       // v_mfma_scale_f32_32x32x64_f8f6f4, K = 32 pixels twice -- and the bias sum of g_lo comes from a tap-free job
+                                                       // v_mfma_scale_f32_32x32x64_f8f6f4, K = 32 pixels twice -- and sums g_lo's share of the bias from the same fragments
     int x_s2d_c;                                       // > 0: X is a space-to-depth image with this many channels per sub-position
                                                        // (virtual kernel of a 4x4 / stride-2 conv): the zero taps are skipped
     float* dw; float* db; float scale;

@@ -73,7 +73,8 @@ struct ReduceJob {
     short co_base, ci_base;
     int cout, cin_real;
     float scale;
-    short want_bias, pad_;
+    short want_bias;
+    short c_bias;         // the slab_c job (an MX job) also carries the bias sum of g_lo: taken like slab_b's
 };
 
 static_assert(sizeof(WgradArgs) <= 4096, "kernel arguments");
@@ -741,6 +742,20 @@ __global__ __launch_bounds__(512, 1) void wgrad_quad_kernel_t(const WgradQuadArg
             v8i fgm[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) fgm[r] = frag(gb + r * 32 * PB, 32, 0);          // A = [g_lo | g_hi]
+            if ((j_bias_mask >> prod) & 1u) {     // wave-uniform: the product that carries the bias also sums g_lo's share of it -- the first
+                // four dwords of a G fragment are 16 pixels of bf8(g_lo) of this lane's channel, and a bf8 byte IS the upper byte of the f16
+                // with the same value: two bytes -> one f16 pair by a byte permute, summed in fp32 by a dot product against (1, 1)
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 ones = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned d = (unsigned)fgm[r][k];
+                        bsum = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, __builtin_amdgcn_perm(d, 0u, 0x050c040cu)), ones, bsum, false);
+                        bsum = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, __builtin_amdgcn_perm(d, 0u, 0x070c060cu)), ones, bsum, false);
+                    }
+            }
 #pragma unroll
             for (int j = 0; j < 6; ++j) {          // halo row j of the wave's six serves output rows j (dy 0), j - 1 (dy 1), j - 2 (dy 2)
                 v8i fx[3];
@@ -855,7 +870,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
         s = sum_splits(a.partial + job.slab_off + e, 0.f, a.splits);
         if (job.slab_b != ~0u || job.slab_c != ~0u) {   // RESR_F16X2: the cross products (bias sums: only the g_lo one; a single-f16 G has none)
             float s2 = job.slab_b != ~0u ? sum_splits(a.partial + job.slab_b + e, 0.f, a.splits) : 0.f;
-            if (job.slab_c != ~0u && e < 9 * 1024) s2 = sum_splits(a.partial + job.slab_c + e, s2, a.splits_c > 0 ? a.splits_c : a.splits);
+            if (job.slab_c != ~0u && (e < 9 * 1024 || job.c_bias)) s2 = sum_splits(a.partial + job.slab_c + e, s2, a.splits_c > 0 ? a.splits_c : a.splits);
             s = __builtin_fmaf(s2, kLoInv, s);
         }
     }
@@ -1112,8 +1127,11 @@ int wgrad_x2_products() {
 
 // The jobs (kernel launches' slab regions) of ONE algorithmic product (G tile ct, X chunk ck): part 0 (x_hi, g_hi) always; RESR_F16X2 with
 // three tap-products adds 1 = (x_hi, g_lo) and 2 = (x_lo, g_hi) as the plan bits allow -- or, where both operands carry q tensors and the
-// X chunk is a pair (WgradConv.x_q_off / g_q_off, x2_plan bit 9), ONE job 3 = "MX" for both corrections, plus 4 = the tap-free (x_hi chunk 0,
-// g_lo) job that sums the bias of g_lo where a bias is wanted.  One definition for the job count, the quad count and the job table.
+// X chunk is a pair (WgradConv.x_q_off / g_q_off, x2_plan bit 9), ONE job 3 = "MX" for both corrections, which also sums
+// g_lo's share of the bias (X chunk 0) from the bf8 bytes of its own G fragments.  (Until late in round 6 a tap-free f16 job (x_hi chunk 0, g_lo)
+// per G tile summed that share from the f16 lo tensor: six product slots per dense block that staged two tiles per step for 32 sums each --
+// 7.4 ms of the 262 ms exact16 step, measured by leaving them out.  The bf8 rounding of a 2^-12-weighted term is 2^-15 of the gradient.)
+// One definition for the job count, the quad count and the job table.
 static int product_parts(const WgradConv& c, int dtype, int nparts, int ck, int parts[4]) {
     int n = 0;
     parts[n++] = 0;
@@ -1121,8 +1139,7 @@ static int product_parts(const WgradConv& c, int dtype, int nparts, int ck, int 
     const bool g_single = c.g_lo_off == 0;
     const bool single_chunk = c.x_pair_chunks > 0 && ck >= c.x_pair_chunks;
     if (nparts == 3 && c.x_q_off != 0 && c.g_q_off != 0 && !g_single && !single_chunk) {
-        parts[n++] = 3;
-        if (ck == 0 && c.db) parts[n++] = 4;
+        parts[n++] = 3;     // (where a bias is wanted -- ck 0 -- the MX job also sums g_lo's share of it from its own G fragments)
         return n;
     }
     for (int part = 1; part < nparts; ++part) {
@@ -1164,7 +1181,7 @@ int wgrad_batch_quads(const WgradConv* convs, int nconv, int dtype) {
                     ++total;
                     if (nj >= kMaxJobs) continue;
                     const char* xp = (const char*)c.x0 + (size_t)ck * (c.x_chunk_stride > 0 ? c.x_chunk_stride : 32) * es + (part == 2 ? (size_t)c.x_lo_off * es : part == 3 ? (size_t)c.x_q_off * es : 0);
-                    const char* gp = (const char*)c.g + (size_t)ct * (c.g_chunk_stride > 0 ? c.g_chunk_stride : 32) * es + ((part == 1 || part == 4) ? (size_t)c.g_lo_off * es : part == 3 ? (size_t)c.g_q_off * es : 0);
+                    const char* gp = (const char*)c.g + (size_t)ct * (c.g_chunk_stride > 0 ? c.g_chunk_stride : 32) * es + (part == 1 ? (size_t)c.g_lo_off * es : part == 3 ? (size_t)c.g_q_off * es : 0);
                     int xi = 0, gi = 0;
                     while (xi < nx && xs[xi] != xp) ++xi;
                     if (xi == nx) xs[nx++] = xp;
@@ -1262,7 +1279,7 @@ static int wgrad_layer_launch(const WgradConv& c, int n, int h, int w, int flags
     RESR_CHECK_LAUNCH("wgrad_quad_kernel (layer mode)");
     ReduceJob& j = r.jobs[0];
     j.dw = c.dw; j.db = c.db; j.slab_off = 0; j.slab_b = j.slab_c = ~0u; j.co_base = j.ci_base = 0;
-    j.cout = c.cout; j.cin_real = c.cin_real; j.scale = c.scale; j.want_bias = 0; j.pad_ = 0;
+    j.cout = c.cout; j.cin_real = c.cin_real; j.scale = c.scale; j.want_bias = 0; j.c_bias = 0;
     r.partial = partial; r.splits = splits; r.layer_nck = nck; r.layer_part_stride = nparts > 1 ? L.part_slabs : 0u;
     r.unscale = c.unscale;
     if (splits <= 8) hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(nck * nct, (kSlab + 255) / 256), dim3(256), 0, stream, r);
@@ -1327,8 +1344,8 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
                 ReduceJob& q = r.jobs[nr++];
                 q.dw = c.dw; q.db = c.db; q.slab_off = off; q.slab_b = q.slab_c = ~0u;
                 q.co_base = (short)(ct * 32); q.ci_base = (short)(ck * 32);
-                q.cout = c.cout; q.cin_real = c.cin_real; q.scale = c.scale; q.want_bias = (short)want_bias; q.pad_ = 0;
-                // parts: (x_hi, g_hi); RESR_F16X2 adds (x_hi, g_lo) and (x_lo, g_hi) -- or the MX job for both (+ the tap-free bias job): product_parts
+                q.cout = c.cout; q.cin_real = c.cin_real; q.scale = c.scale; q.want_bias = (short)want_bias; q.c_bias = 0;
+                // parts: (x_hi, g_hi); RESR_F16X2 adds (x_hi, g_lo) and (x_lo, g_hi) -- or the MX job for both: product_parts
                 int parts[4];
                 const int np = product_parts(c, dtype, nparts, ck, parts);
                 if (nj + np > kMaxJobs) return fail(RESR_ERR_ARG, "wgrad: more than %d jobs in one batch", kMaxJobs);
@@ -1336,20 +1353,20 @@ int wgrad_batch(const WgradConv* convs, int nconv, int n, int h, int w, int dtyp
                     const int part = parts[pi];
                     WgradJob& j = a.jobs[nj++];
                     j.x = xh + (part == 2 ? (size_t)c.x_lo_off * es : part == 3 ? (size_t)c.x_q_off * es : 0);
-                    j.g = gh + ((part == 1 || part == 4) ? (size_t)c.g_lo_off * es : part == 3 ? (size_t)c.g_q_off * es : 0);
+                    j.g = gh + (part == 1 ? (size_t)c.g_lo_off * es : part == 3 ? (size_t)c.g_q_off * es : 0);
                     j.xstride_b = (unsigned)(c.in0_stride * es);
                     j.gstride_b = (unsigned)(c.g_stride * es);
                     j.slab_off = off;
                     j.mx = part == 3 ? 1u : 0u;
                     any_mx = any_mx || part == 3;
-                    j.want_bias = (part < 2 || part == 4) ? want_bias : 0;
-                    if (part == 4) j.want_bias |= 2u;   // the bias sum of g_lo alone: its taps are inside the MX job
+                    j.want_bias = (part < 2 || part == 3) ? want_bias : 0;   // (an MX job sums the bf8 g_lo bytes of its G fragments)
+                    if (part == 3 && want_bias) q.c_bias = 1;
                     // (x_hi chunk 0, g_lo) carries the bias sum AND a real term of dW: skipping its taps was measured (+1 % on the exact16 step)
                     // and rejected -- the worst gradient tensor against the all-pairs plan rises by a fifth (32 x 64^2: 5.1e-4 -> 6.3e-4)
                     if (part == 1 && c.g_lo_bias_only && getenv("RESR_WGRAD_BIAS_JOBS_NO_TAPS")) j.want_bias |= 2u;   // experiment knob, read per call
                     j.xsub = (c.x_s2d_c > 0 && dtype != RESR_F32) ? (unsigned)((ck * 32) / c.x_s2d_c) : 4u;
-                    // (the reduction takes dW = A + (B + C) 2^-12 with the bias from A and B only: an MX job's slab goes in as C, the bias job's as B)
-                    if (part == 1 || part == 4) q.slab_b = off;
+                    // (the reduction takes dW = A + (B + C) 2^-12 with the bias from A and B -- and from C where C is an MX job that summed g_lo: c_bias)
+                    if (part == 1) q.slab_b = off;
                     if (part == 2 || part == 3) q.slab_c = off;
                     off += (unsigned)((part == 3 ? splits_mx : splits) * kSlab);
                 }

@@ -411,7 +411,9 @@ def test_exact16_forward_with_f16_backward(diag_dir):
 def test_mx_weight_gradient_jobs(n, h, w, n_blocks, seed, diag_dir):
     """x2_plan bit 9 (RESR_X2_PLAN_MX_WGRAD, on top of 27 + 128): the stream chunks' correction tap-products (x_hi, g_lo) + (x_lo, g_hi) of
     every dense-block weight gradient as ONE MX job -- 8-bit transpose reads of the staged q records, K = 32 pixels twice per
-    v_mfma_scale_f32_32x32x64_f8f6f4 -- with the bias sums of g_lo from tap-free jobs.  The training forward (which now also emits the
+    v_mfma_scale_f32_32x32x64_f8f6f4 --, which also sums g_lo's share of the bias from the bf8 bytes of its G fragments (against the plan without
+    the bit, whose bias takes the f16 lo tensor of the SAME gradient planes, a bias moves by the bf8 rounding of a 2^-12-weighted term: 1.4-2.3e-5 measured, gate 5e-5;
+    leaving the share out, or summing the wrong bytes, reads 2^-12 ~ 2.4e-4).  The training forward (which now also emits the
     stream's q tensor) stays the all-pairs plan's bit for bit; every gradient tensor within 5e-4 of the all-pairs plan (VERDICT round 5,
     item 1c); against the plan without the bit the MX jobs move a tensor by ~1e-5 (emulation: weight gradients alone 2-3e-5 worst) --
     more where they restore the (x_hi, g_lo) term that plan bit 1 drops for conv1..conv4."""
@@ -442,9 +444,11 @@ def test_mx_weight_gradient_jobs(n, h, w, n_blocks, seed, diag_dir):
     other = [k for k in gr0 if ".rdb" not in k]
     rep = {"worst_vs_all_pairs_plan": max(b9.values()), "worst_tensor": max(b9, key=b9.get), "without_the_bit_worst": max(b7.values()),
            "median_vs_all_pairs_plan": sorted(b9.values())[len(b9) // 2], "without_the_bit_median": sorted(b7.values())[len(b7) // 2],
-           "moved_by_the_mx_jobs_worst": max(d97[k] for k in trunk), "worst_bias_vs_all_pairs": max(b9[k] for k in trunk if k.endswith(".bias"))}
+           "moved_by_the_mx_jobs_worst": max(d97[k] for k in trunk), "worst_bias_vs_all_pairs": max(b9[k] for k in trunk if k.endswith(".bias")),
+           "bias_moved_by_the_mx_jobs_worst": max(d97[k] for k in trunk if k.endswith(".bias"))}
     with open(os.path.join(diag_dir, f"mx_wgrad_{n}x{h}x{w}_{n_blocks}_{seed}.json"), "w") as f:
         json.dump(rep, f, indent=1)
     assert all(torch.equal(gr9[k], gr7[k]) for k in other), "the HR tail / conv1 / conv2 keep their f16 tap-products"
     assert 0 < rep["moved_by_the_mx_jobs_worst"] < 3e-4, rep
+    assert rep["bias_moved_by_the_mx_jobs_worst"] < 5e-5, rep
     assert rep["worst_vs_all_pairs_plan"] < 5e-4 and rep["worst_bias_vs_all_pairs"] < 2e-4, rep
