@@ -308,7 +308,13 @@ enum {
      * The training forward then emits the q tensor of the residual stream (conv1 and every closing convolution: + 2 of 12 plane stores
      * per dense block), the workspace holds it, and g_lo's share of a bias gradient is summed by the MX job itself from the bf8 bytes of
      * its G fragments (a bias moves by 1-2e-5 against the f16 lo tensor's sum; gate 5e-5 in tests/test_gpu_mx.py). */
-    RESR_X2_PLAN_MX_WGRAD = 512
+    RESR_X2_PLAN_MX_WGRAD = 512,
+    /* with MX_WGRAD: the same treatment for the 4x-resolution tail (conv3, conv4, upsampling2 -- a third of an exact16 step's weight-gradient
+     * work and a tenth of its backward-data work): the training forward emits the q tensors of u1, u2 and c3, the layout pass that brings the
+     * incoming gradient in and the two masked tail passes emit those of the gradient tensors, the three tail passes that read them run one
+     * f16 + one MX stage per chunk, and the three weight gradients take their correction tap-products as MX jobs.  upsampling1 keeps its f16
+     * form (its gradient comes out of a 2 x 2 sum-pool). */
+    RESR_X2_PLAN_MX_TAIL = 1024
 };
 
 size_t resr_generator_param_count(const ResrGeneratorDesc* d);

@@ -26,6 +26,7 @@ X2_PLAN_MX_INFER = 64
 X2_PLAN_MX_BWD = 128
 X2_PLAN_F16_BACKWARD = 256
 X2_PLAN_MX_WGRAD = 512
+X2_PLAN_MX_TAIL = 1024
 CONV_MX_PAIRS = 1 << 12
 RESR_VERSION = 3   # include/resr.h: the structures below mirror THIS version of the header
 

@@ -94,6 +94,8 @@ bool plan_mx_bwd(const ResrGeneratorDesc& d) {
 bool plan_mx_wgrad(const ResrGeneratorDesc& d) {
     return plan_mx_bwd(d) && (d.x2_plan & RESR_X2_PLAN_MX_WGRAD) && !(d.x2_plan & RESR_X2_PLAN_F16_BACKWARD);
 }
+// RESR_X2_PLAN_MX_TAIL: conv3, conv4, upsampling2 the same way; u1, u2, c3 and the tail's gradient tensors g4, gA, gB carry q tensors
+bool plan_mx_tail(const ResrGeneratorDesc& d) { return plan_mx_wgrad(d) && (d.x2_plan & RESR_X2_PLAN_MX_TAIL); }
 bool plan_mx(const ResrGeneratorDesc& d) {
     const int need = RESR_X2_PLAN_GROWTH_F16_INFER | RESR_X2_PLAN_GROWTH_W16_INFER | RESR_X2_PLAN_MX_INFER;
     return d.dtype == RESR_F16X2 && !d.training && (d.x2_plan & need) == need;
@@ -248,14 +250,15 @@ void carve(const Plan& p, char* base, Bufs& b) {
     else { b.out1 = take(px * 64 * es); b.out1_stride = 64; }  // rotating workspaces overwrite ws[0]
     b.trunk_out = take(px * 64 * es);
     b.feat = take(px * 64 * es);
-    b.u1 = take(px * 4 * 64 * es);
-    b.u2 = take(px * 16 * 64 * es);
-    b.c3 = take(px * 16 * 64 * es);
+    const size_t est = es + (plan_mx_tail(p.d) ? 2 : 0);   // RESR_X2_PLAN_MX_TAIL: hi, lo and q tensors
+    b.u1 = take(px * 4 * 64 * est);
+    b.u2 = take(px * 16 * 64 * est);
+    b.c3 = take(px * 16 * 64 * est);
     b.ymask = (uint8_t*)take(px * 16 * p.d.out_channels);
     if (p.d.training) {
-        b.g4 = take(px * 16 * 32 * es);
-        b.gA = take(px * 16 * 64 * es);
-        b.gB = take(px * 16 * 64 * es);
+        b.g4 = take(px * 16 * 32 * est);
+        b.gA = take(px * 16 * 64 * est);
+        b.gB = take(px * 16 * 64 * est);
         b.gM1 = take(px * 4 * 64 * es);
         b.gF = take(px * 64 * es);
         const size_t esg = es + (plan_mx_bwd(p.d) ? 2 : 0);   // RESR_X2_PLAN_MX_BWD: hi, lo and q tensors
@@ -270,7 +273,8 @@ void carve(const Plan& p, char* base, Bufs& b) {
             for (int m = 1; m <= 4; m *= 2) {
                 const long tiles = (long)((p.w * m + 31) / 32) * ((p.h * m + th - 1) / th) * p.d.n;
                 const long smax = tiles / 2 < 256 ? (tiles / 2 < 1 ? 1 : tiles / 2) : 256;
-                const size_t q = (size_t)(m == 1 ? 78 : 12) * (size_t)smax * slab;
+                // (a single 64 -> 64 convolution: 12 tap-products; RESR_X2_PLAN_MX_TAIL: 4 f16 jobs + 4 MX jobs whose launch takes up to 4 x the splits)
+                const size_t q = (size_t)(m == 1 ? 78 : (plan_mx_tail(p.d) ? 20 : 12)) * (size_t)smax * slab;
                 if (q > pb) pb = q;
             }
         }
@@ -482,6 +486,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
     // tensor of its own output when a later pass reads that output through an MX stage (out_q; 0: none)
     const bool mx = plan_mx(*d);
     const bool mxw = plan_mx_wgrad(*d);
+    const bool mxt = plan_mx_tail(*d);     // the training forward also emits the q tensors of u1, u2, c3
     const char* pk_mx = mx ? pk + generator_mx_offset(d) : nullptr;
     auto MXP = [&](ResrConvDesc& cd, const ConvSpec& c, int64_t in_q, int64_t out_q) {
         if (!mx) return;
@@ -565,6 +570,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         cd.in0_chunk_stride = plane; cd.out_chunk_stride = 4 * plane;
         cd.in0_lo_offset = lo_t; cd.out_lo_offset = LO(2, 4L * plane);
         MXP(cd, c, 2 * lo_t, 2 * LO(2, 4L * plane));
+        if (mxt) cd.out_q_offset = 2 * LO(2, 4L * plane);
         RUN(conv3x3_dispatch(&cd, b.feat, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.u1, nullptr, st));
     }
     {   // model.py:265
@@ -574,6 +580,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         cd.in0_lo_offset = LO(2, 4L * plane); cd.out_lo_offset = LO(2, 16L * plane);
         if (d->training) cd.flags |= RESR_CONV_WRITE_SIGNBITS;
         MXP(cd, c, 2 * LO(2, 4L * plane), 2 * LO(2, 16L * plane));
+        if (mxt) cd.out_q_offset = 2 * LO(2, 16L * plane);
         RUN(conv3x3_dispatch(&cd, b.u1, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.u2, b.bits_u2, st));
     }
     {   // model.py:267
@@ -583,6 +590,7 @@ int generator_forward(const ResrGeneratorDesc* d, const float* x, const float* p
         cd.in0_lo_offset = LO(2, 16L * plane); cd.out_lo_offset = LO(2, 16L * plane);
         if (d->training) cd.flags |= RESR_CONV_WRITE_SIGNBITS;
         MXP(cd, c, 2 * LO(2, 16L * plane), 0);   // (conv4 -- 0.15 % of the FLOPs, the fp32 NCHW epilogue -- keeps its three f16 stages: no q tensor of c3)
+        if (mxt) cd.out_q_offset = 2 * LO(2, 16L * plane);
         RUN(conv3x3_dispatch(&cd, b.u2, nullptr, W(c), Bias(c), nullptr, nullptr, nullptr, b.c3, b.bits_c3, st));
     }
     {   // model.py:268-270
@@ -650,6 +658,7 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
     // RESR_X2_PLAN_MX_BWD: the dense blocks' backward-data passes read every gradient chunk as a pair on an f16 + an MX stage
     const bool mxb = plan_mx_bwd(*d) && !f16bwd;
     const bool mxw = plan_mx_wgrad(*d) && mxb;
+    const bool mxt = plan_mx_tail(*d) && mxw;
     const bool gg_single = x2 && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_F16);
     const bool gg_store_single = gg_single && (d->x2_plan & RESR_X2_PLAN_GROWTH_GRAD_STORE_F16);   // opt-in: no lo store, biases from hi alone
     // RESR_X2_PLAN_GROWTH_ACT_F16_WGRAD: the weight products of conv2..conv5 read the growth planes (X chunks 2..) as their hi tensor
@@ -684,9 +693,10 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         return wgrad_batch(wc, nconv, N, hh, ww, dt, flags, splits, b.partial, st);
     };
     auto wgrad = [&](const ConvSpec& c, int hh, int ww, const void* x0, int cin, int s0, const void* g, int gstride,
-                     int flags, float scale, long x_chunk, long g_chunk, long x_lo, long g_lo) -> int {
+                     int flags, float scale, long x_chunk, long g_chunk, long x_lo, long g_lo, long x_q = 0, long g_q = 0) -> int {
         WgradConv wc = wconv(c, x0, cin, s0, g, gstride, scale, x_lo, g_lo);
         wc.x_chunk_stride = x_chunk; wc.g_chunk_stride = g_chunk;
+        wc.x_q_off = x_q; wc.g_q_off = g_q;     // both != 0 (RESR_X2_PLAN_MX_TAIL): the correction tap-products as MX jobs
         return wgrad_run(&wc, 1, hh, ww, flags);
     };
     // backward-data pass descriptor: in0 (cin0 channels, lo offset lo0) [+ in1 (lo offset lo1)] -> out (lo offset lo_out)
@@ -699,27 +709,37 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
 
     // clamp_ backward + layout                                              model.py:270
     if (gsc) RUN(absmax_dispatch(gy, (long)N * d->out_channels * H4 * W4, b.gscale, pre_log2, st));
-    RUN(nchw_to_nhwc_scaled_dispatch(gy, b.g4, N, d->out_channels, H4, W4, 1, 32, dt, b.ymask, st, lo_g4, gsc));
+    RUN(nchw_to_nhwc_q_dispatch(gy, b.g4, N, d->out_channels, H4, W4, 1, 32, dt, b.ymask, st, lo_g4, gsc, mxt ? 2 * lo_g4 : 0L));
+    const char* pk_mx = mxb ? pk + generator_mx_offset(d) : nullptr;
+    auto MXT = [&](ResrConvDesc& cd, size_t pk_off, long in_q, long out_q) {   // a tail pass on one f16 + one MX stage per chunk of its gradient input
+        if (!mxt) return;
+        cd.flags |= RESR_CONV_MX_PAIRS;
+        cd.in0_q_offset = in_q; cd.out_q_offset = out_q;
+        cd.w_mx_offset = (int64_t)((pk_mx + pk_off * 2) - (pk + pk_off * wes));
+    };
     {   // conv4                                                            model.py:268
         const ConvSpec& c = p.convs[p.i_conv4];
-        RUN(wgrad(c, H4, W4, b.c3, 64, 32, b.g4, 32, 0, 1.f, pl4, 0, lo_4, lo_g4));
+        RUN(wgrad(c, H4, W4, b.c3, 64, 32, b.g4, 32, 0, 1.f, pl4, 0, lo_4, lo_g4, mxt ? 2 * lo_4 : 0, mxt ? 2 * lo_g4 : 0));
         ResrConvDesc cd = dgrad(H4, W4, 32, 32, 32, 0, 64, 64, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS, lo_g4, 0, lo_4);
         cd.out_chunk_stride = pl4;
+        MXT(cd, p.pk_bwd_conv4, 2 * lo_g4, 2 * lo_4);
         RUN(conv3x3_dispatch(&cd, b.g4, nullptr, pk + p.pk_bwd_conv4 * wes, nullptr, nullptr, nullptr, b.bits_c3, b.gA, nullptr, st));
     }
     {   // conv3                                                            model.py:267
         const ConvSpec& c = p.convs[p.i_conv3];
-        RUN(wgrad(c, H4, W4, b.u2, 64, 32, b.gA, 32, 0, 1.f, pl4, pl4, lo_4, lo_4));
+        RUN(wgrad(c, H4, W4, b.u2, 64, 32, b.gA, 32, 0, 1.f, pl4, pl4, lo_4, lo_4, mxt ? 2 * lo_4 : 0, mxt ? 2 * lo_4 : 0));
         ResrConvDesc cd = dgrad(H4, W4, 64, 32, 64, 0, 64, 64, 32, RESR_CONV_MASK | RESR_CONV_MASK_BITS, lo_4, 0, lo_4);
         cd.in0_chunk_stride = pl4; cd.out_chunk_stride = pl4;
+        MXT(cd, p.pk_bwd_conv3, 2 * lo_4, 2 * lo_4);
         RUN(conv3x3_dispatch(&cd, b.gA, nullptr, pk + p.pk_bwd_conv3 * wes, nullptr, nullptr, nullptr, b.bits_u2, b.gB, nullptr, st));
     }
     if (debug_stop() == 1) return RESR_OK;
     {   // upsampling2                                                      model.py:265
         const ConvSpec& c = p.convs[p.i_up2];
-        RUN(wgrad(c, H4, W4, b.u1, 64, 32, b.gB, 32, RESR_CONV_UPSAMPLE_IN, 1.f, pl2, pl4, lo_2, lo_4));
+        RUN(wgrad(c, H4, W4, b.u1, 64, 32, b.gB, 32, RESR_CONV_UPSAMPLE_IN, 1.f, pl2, pl4, lo_2, lo_4, mxt ? 2 * lo_2 : 0, mxt ? 2 * lo_4 : 0));
         ResrConvDesc cd = dgrad(H4, W4, 64, 32, 64, 0, 64, 64, 32, 0, lo_4, 0, lo_4);
         cd.in0_chunk_stride = pl4; cd.out_chunk_stride = pl4;
+        MXT(cd, p.pk_bwd_up2, 2 * lo_4, 0);     // (its output feeds the sum-pool: no q tensor)
         RUN(conv3x3_dispatch(&cd, b.gB, nullptr, pk + p.pk_bwd_up2 * wes, nullptr, nullptr, nullptr, nullptr, b.gA, nullptr, st));
         for (int q = 0; q < 2; ++q)   // per 32-channel plane
             RUN(sumpool2x2_dispatch(b.gA + (size_t)q * pl4 * es, b.gM1 + (size_t)q * pl2 * es, b.u1 + (size_t)q * pl2 * es,
@@ -746,7 +766,6 @@ int generator_backward(const ResrGeneratorDesc* d, const float* gy, const float*
         if (mxb) cd.out_q_offset = 2 * lo_t;   // the first dense block's passes read gT[0] through MX stages: this (plain) pass emits its q tensor
         RUN(conv3x3_dispatch(&cd, b.gF, nullptr, pk + p.pk_bwd_conv2 * wes, nullptr, nullptr, nullptr, nullptr, b.gT[0], nullptr, st));
     }
-    const char* pk_mx = mxb ? pk + generator_mx_offset(d) : nullptr;
     auto MXB = [&](ResrConvDesc& cd, size_t pk_off, long out_q) {   // gin (in0) and the slab gS (in1) with their q tensors, the pass's MX blocks
         if (!mxb) return;
         cd.flags |= RESR_CONV_MX_PAIRS;

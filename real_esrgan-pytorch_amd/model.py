@@ -230,7 +230,8 @@ class Generator(nn.Module):
     50; the growth-plane gradients enter with both halves again), bit 9 (with bits 7 and 3): the dense blocks' weight gradients take both
     2^-12-weighted tap-products of every stream chunk as ONE MX job (8-bit transpose reads of the q records, K = 32 pixels twice) --
     conv1..conv4 get their (x_hi, g_lo) term back at no cost: worst gradient tensor 5-7e-5 against the all-pairs plan instead of 2-3e-4;
-    bit 8 (opt-in): exact16's forward in front of fast mode's backward pass.  x2_plan=0 = pairs everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
+    bit 8 (opt-in): exact16's forward in front of fast mode's backward pass; bit 10 (opt-in, with bit 9): the 4x-resolution tail (conv3, conv4, upsampling2)
+    on MX stages / MX jobs too -- + 0.85 % on the step, every gradient tensor still within 6-8e-5 of the all-pairs plan (median 2.6e-5 -> 4.3e-5).  x2_plan=0 = pairs everywhere: forward 1.8e-6, every gradient tensor 5.8e-6.
     The backward pass of the 16-bit modes (exact16, fast) does not depend on the caller's loss scale: an incoming gradient whose largest element is below 2^6 is
     lifted by a power of two inside the native pass and the results are handed back unscaled (bit-identical gradients at loss scale
     1 and 2^20; csrc/generator.hip, $RESR_X2_GRAD_PRESCALE_LOG2 / RESR_X2_NO_GRAD_PRESCALE=1).
@@ -248,16 +249,17 @@ class Generator(nn.Module):
         self.precision = precision or os.environ.get("RESR_PRECISION", "fast")
         self._dtype = _precision_to_dtype(self.precision)
         self.x2_plan = int(os.environ.get("RESR_X2_PLAN", "763")) if x2_plan is None else int(x2_plan)
-        if not 0 <= self.x2_plan <= 1023:
+        if not 0 <= self.x2_plan <= 2047:
             raise ValueError(f"x2_plan must be a bit set of X2_PLAN_GROWTH_F16_INFER (1) | X2_PLAN_GROWTH_GRAD_F16 (2) | "
                              f"X2_PLAN_GROWTH_GRAD_STORE_F16 (4) | X2_PLAN_GROWTH_ACT_F16_WGRAD (8) | X2_PLAN_GROWTH_ACT_G_HI_WGRAD (16) | X2_PLAN_GROWTH_W16_INFER (32) | "
-                             f"X2_PLAN_MX_INFER (64) | X2_PLAN_MX_BWD (128) | X2_PLAN_F16_BACKWARD (256) | X2_PLAN_MX_WGRAD (512), got {self.x2_plan}")
+                             f"X2_PLAN_MX_INFER (64) | X2_PLAN_MX_BWD (128) | X2_PLAN_F16_BACKWARD (256) | X2_PLAN_MX_WGRAD (512) | X2_PLAN_MX_TAIL (1024), got {self.x2_plan}")
         if (self.x2_plan & 128) and (self.x2_plan & 4):
             raise ValueError(f"x2_plan={self.x2_plan}: MX_BWD (128) reads the growth-plane gradients as pairs; GROWTH_GRAD_STORE_F16 (4) stores them single")
         # a bit that only refines another one means nothing without it: refuse instead of silently ignoring it
         for bit, needs, name in ((4, 2, "GROWTH_GRAD_STORE_F16 (4) refines GROWTH_GRAD_F16 (2)"), (16, 8, "GROWTH_ACT_G_HI_WGRAD (16) refines GROWTH_ACT_F16_WGRAD (8)"),
                                  (32, 1, "GROWTH_W16_INFER (32) refines GROWTH_F16_INFER (1)"), (64, 33, "MX_INFER (64) rides on GROWTH_F16_INFER (1) + GROWTH_W16_INFER (32)"),
-                                 (512, 128 + 8, "MX_WGRAD (512) rides on MX_BWD (128: the gradient planes' q tensors) + GROWTH_ACT_F16_WGRAD (8: the stream chunks are the pair chunks)")):
+                                 (512, 128 + 8, "MX_WGRAD (512) rides on MX_BWD (128: the gradient planes' q tensors) + GROWTH_ACT_F16_WGRAD (8: the stream chunks are the pair chunks)"),
+                                 (1024, 512 + 128 + 8, "MX_TAIL (1024) extends MX_WGRAD (512) to the 4x-resolution tail")):
             if (self.x2_plan & bit) and (self.x2_plan & needs) != needs:
                 raise ValueError(f"x2_plan={self.x2_plan}: {name}")
         self.n_blocks = n_blocks or self.N_BLOCKS
@@ -411,7 +413,7 @@ class Generator(nn.Module):
 
     def _workspace(self, desc: _lib.GeneratorDesc, device) -> _Workspace:
         L = _lib.lib()
-        key = (desc.n, desc.h, desc.w, desc.training, desc.dtype, desc.wgrad_splits, desc.x2_plan & (_lib.X2_PLAN_MX_INFER | _lib.X2_PLAN_MX_BWD | _lib.X2_PLAN_MX_WGRAD))   # (the MX plans carry q tensors)
+        key = (desc.n, desc.h, desc.w, desc.training, desc.dtype, desc.wgrad_splits, desc.x2_plan & (_lib.X2_PLAN_MX_INFER | _lib.X2_PLAN_MX_BWD | _lib.X2_PLAN_MX_WGRAD | _lib.X2_PLAN_MX_TAIL))   # (the MX plans carry q tensors)
         pool = self._workspaces.setdefault(key, [])
         for ws in pool:
             if not ws.busy:

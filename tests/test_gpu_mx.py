@@ -452,3 +452,44 @@ def test_mx_weight_gradient_jobs(n, h, w, n_blocks, seed, diag_dir):
     assert 0 < rep["moved_by_the_mx_jobs_worst"] < 3e-4, rep
     assert rep["bias_moved_by_the_mx_jobs_worst"] < 5e-5, rep
     assert rep["worst_vs_all_pairs_plan"] < 5e-4 and rep["worst_bias_vs_all_pairs"] < 2e-4, rep
+
+
+@pytest.mark.parametrize("n,h,w,n_blocks,seed", [(2, 33, 17, 1, 13), (4, 32, 32, 2, 11)])
+def test_mx_tail_plan_gradients(n, h, w, n_blocks, seed, diag_dir):
+    """x2_plan bit 10 (RESR_X2_PLAN_MX_TAIL, on top of 27 + 128 + 512): conv3, conv4 and upsampling2 -- the 4x-resolution tail -- the way the
+    dense blocks run: the training forward emits the q tensors of u1, u2 and c3 (the LeakyReLU + sign-word epilogues), the layout pass and the
+    two masked tail passes those of g4 / gA / gB, the three tail passes that read them take one f16 + one MX stage per chunk, and the three
+    weight gradients their correction tap-products as MX jobs (upsampling2's X is read through the nearest-neighbour upsampling).  The
+    training forward stays the all-pairs plan's bit for bit; every gradient tensor within 5e-4 of the all-pairs plan; against the plan
+    without the bit only what lies UPSTREAM of the tail's passes and the tail's own three weights may move."""
+    gt, sd, M = _setup(n_blocks, seed, 27 + 128 + 512 + 1024)
+    g9, _, _ = _setup(n_blocks, seed, 27 + 128 + 512)
+    g0, _, _ = _setup(n_blocks, seed, 0)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(n, 3, h, w, generator=gen)
+    gwt = torch.randn(n, 3, 4 * h, 4 * w, generator=gen)
+
+    def run(model):
+        xd = x.cuda().requires_grad_(True)
+        y = model.train()(xd)
+        (y * gwt.cuda()).sum().mul(1024.0).backward()
+        torch.cuda.synchronize()
+        return y.detach().cpu(), {name: p.grad.cpu().double() / 1024.0 for name, p in model.named_parameters()}, xd.grad.cpu().double() / 1024.0
+    yt, grt, gxt = run(gt)
+    y9, gr9, gx9 = run(g9)
+    y0, gr0, gx0 = run(g0)
+    assert torch.equal(yt, y0), "the training forward does not depend on the plan"
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    bt = {k: rel(grt[k], gr0[k]) for k in gr0}
+    b9 = {k: rel(gr9[k], gr0[k]) for k in gr0}
+    moved = {k: rel(grt[k], gr9[k]) for k in gr0}
+    rep = {"worst_vs_all_pairs_plan": max(bt.values()), "worst_tensor": max(bt, key=bt.get), "without_the_bit_worst": max(b9.values()),
+           "median_vs_all_pairs_plan": sorted(bt.values())[len(bt) // 2], "gx_vs_all_pairs": rel(gxt, gx0),
+           "tail_weights_vs_all_pairs": {k: bt[k] for k in bt if k.split(".")[0] in ("conv3", "conv4", "upsampling2")},
+           "moved_by_the_bit_worst": max(moved.values())}
+    with open(os.path.join(diag_dir, f"mx_tail_{n}x{h}x{w}_{n_blocks}_{seed}.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    assert 0 < rep["moved_by_the_bit_worst"] < 5e-4, rep       # the bit is active
+    assert rep["worst_vs_all_pairs_plan"] < 5e-4 and rep["gx_vs_all_pairs"] < 2e-4, rep
