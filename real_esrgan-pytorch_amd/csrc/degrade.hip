@@ -67,52 +67,50 @@ __global__ __launch_bounds__(256) void filter2d_kernel(const float* __restrict__
 }
 
 // 21 x 21 taps (every blur / sinc kernel of the degradation is zero-padded to 21 x 21, dataset.py:101-103): the generic
-// kernel above reads LDS once per FMA and is LDS-bound at ~28 % of the vector rate.  Here a thread owns 4 consecutive
-// outputs of one row: per tap row it reads its 24-float window (6 x ds_read_b128) and the 21 taps (broadcast reads) once
-// for 84 FMAs.  Same tile, same accumulation order (dy, then dx) as the generic kernel.
+// kernel above reads LDS once per FMA and is LDS-bound at ~28 % of the vector rate.  Here a thread owns 8 consecutive
+// outputs of one row of a 64 x 32 tile: per tap row it reads its 28-float window (7 x ds_read_b128) once for 168 FMAs, and the 21
+// taps of the row come through the SCALAR cache into SGPRs (they are uniform over the workgroup: one sample's kernel) -- as LDS
+// broadcast reads they were half of the kernel's LDS traffic, and the LDS pipe, not the vector pipe, set its rate.
+// Same accumulation order (dy, then dx) per output as the generic kernel: the results are the same bits.
 __global__ __launch_bounds__(256) void filter2d21_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                          const float* __restrict__ kern, int c, int h, int w, int per_sample) {
-    constexpr int K = 21, R = 10, TW = 32 + 2 * R, TH = 32 + 2 * R;   // 52 x 52 tile
+    constexpr int K = 21, R = 10, OW = 64, TW = OW + 2 * R, TH = 32 + 2 * R;   // 84 x 52 tile for 64 x 32 outputs
     __shared__ __attribute__((aligned(16))) float tile[TH * TW];
-    __shared__ __attribute__((aligned(16))) float taps[K * 24];        // rows padded to 24 floats (b128 reads)
     const int plane = blockIdx.z;                       // n * c + ch
-    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const int x0 = blockIdx.x * OW, y0 = blockIdx.y * 32;
     const float* sp = src + (size_t)plane * h * w;
-    const float* kp = kern + (per_sample ? (size_t)(plane / c) * K * K : 0);
+    const float* kp = kern + (per_sample ? (size_t)(plane / c) * K * K : 0);     // workgroup-uniform
     for (int i = threadIdx.x; i < TW * TH; i += 256) {
         const int ty = i / TW, tx = i - ty * TW;
         const int iy = reflect(y0 + ty - R, h), ix = reflect(x0 + tx - R, w);
         tile[i] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? sp[(size_t)iy * w + ix] : 0.f;
     }
-    for (int i = threadIdx.x; i < K * 24; i += 256) {
-        const int r = i / 24, q = i - r * 24;
-        taps[i] = q < K ? kp[r * K + q] : 0.f;
-    }
     __syncthreads();
-    const int cg = threadIdx.x & 7, row = threadIdx.x >> 3;   // 8 column groups of 4 x 32 rows
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int cg = threadIdx.x & 7, row = threadIdx.x >> 3;   // 8 column groups of 8 x 32 rows
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int dy = 0; dy < K; ++dy) {
-        float win[24], tp[24];
-        const float4* wp = reinterpret_cast<const float4*>(tile + (row + dy) * TW + cg * 4);
-        const float4* tq = reinterpret_cast<const float4*>(taps + dy * 24);
+        float win[28];
+        const float4* wp = reinterpret_cast<const float4*>(tile + (row + dy) * TW + cg * 8);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const float4 v = wp[q], t = tq[q];
+        for (int q = 0; q < 7; ++q) {
+            const float4 v = wp[q];
             win[q * 4] = v.x; win[q * 4 + 1] = v.y; win[q * 4 + 2] = v.z; win[q * 4 + 3] = v.w;
-            tp[q * 4] = t.x; tp[q * 4 + 1] = t.y; tp[q * 4 + 2] = t.z; tp[q * 4 + 3] = t.w;
         }
+        const float* tr = kp + dy * K;
 #pragma unroll
-        for (int dx = 0; dx < K; ++dx)
+        for (int dx = 0; dx < K; ++dx) {
+            const float t = tr[dx];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += tp[dx] * win[j + dx];
+            for (int j = 0; j < 8; ++j) acc[j] += t * win[j + dx];
+        }
     }
     const int y = y0 + row;
     if (y < h) {
-        float* dp = dst + ((size_t)plane * h + y) * w + x0 + cg * 4;
+        float* dp = dst + ((size_t)plane * h + y) * w + x0 + cg * 8;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (x0 + cg * 4 + j < w) dp[j] = acc[j];
+        for (int j = 0; j < 8; ++j)
+            if (x0 + cg * 8 + j < w) dp[j] = acc[j];
     }
 }
 
@@ -177,7 +175,7 @@ int filter2d_dispatch(const float* src, float* dst, const float* kern, int n, in
     if (kh / 2 >= h || kw / 2 >= w) return fail(RESR_ERR_ARG, "filter2d: reflect padding needs pad < image size");
     static const char* generic_env = getenv("RESR_FILTER_GENERIC");   // test knob: every size on the generic kernel
     if (kh == 21 && kw == 21 && !generic_env) {
-        hipLaunchKernelGGL(filter2d21_kernel, dim3((w + 31) / 32, (h + 31) / 32, n * c), dim3(256), 0, st, src, dst, kern, c, h, w,
+        hipLaunchKernelGGL(filter2d21_kernel, dim3((w + 63) / 64, (h + 31) / 32, n * c), dim3(256), 0, st, src, dst, kern, c, h, w,
                            per_sample);
         RESR_CHECK_LAUNCH("filter2d21_kernel");
         return RESR_OK;
