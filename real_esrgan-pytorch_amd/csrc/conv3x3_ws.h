@@ -411,7 +411,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
             // SIMDs' VALU port with the MFMA waves, and a stage's requests should be scalar + vector-memory instructions only.
             unsigned voff[NIP];
             unsigned voff_stride = 0;   // pixel stride the offsets were computed for (0: stale)
+            int pix_tile = -1;   // the tile pix[] / inb[] were worked out for: a chained launch of ONE tile per workgroup comes back to the same tile for
+                                 // every job, and the 39 per-lane pixel indices are the producers' own serial work (tools/chain_budget.py: "advance")
             auto tile_pix = [&](int tile) {
+                if (tile == pix_tile) return;
+                pix_tile = tile;
                 const int tx = tile % a.tiles_x;
                 const int t2 = tile / a.tiles_x;
                 const int ty = t2 % a.tiles_y;
@@ -458,6 +462,11 @@ __global__ __launch_bounds__(64 * (NWC + WsCfg<T, MT, NT, NWC>::NP), (NWC + WsCf
                         if (inb[i] == val[i]) {
                             dma_s(base, voff[i], dst, val[i]);
                         } else {
+                            // (Tried, late in round 6: the inside lanes of a group that straddles the image border in the scalar-base form and
+                            // 16 zero bytes stored by the outside lanes themselves, the zero page only for groups that lie outside entirely -- at
+                            // 64^2 every 16 x 32 tile touches the border.  Correct, and no faster: config 3 1770 -> 1794 images/s together with the
+                            // cached pixel indices above, which alone give 1788.  A timing build that simply masked the outside lanes off ran 24 %
+                            // faster -- on NaNs: stale LDS at the borders, a NaN loss, and a chip whose clocks rise when its operands stop toggling.)
                             const char* src = pix[i] != ~0u ? base + voff[i] : zero;
                             dma_v(src, dst, val[i]);
                         }
