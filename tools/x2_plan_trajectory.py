@@ -69,7 +69,7 @@ def main():
             "exact16_plan11": ("exact16", 11, None), "exact16_plan3": ("exact16", 3, None), "exact16_plan31_single_store": ("exact16", 31, None),
             "exact16_plan27_hi_only_wgrad": ("exact16", 27, 1), "fast_f16": ("fast", 0, None),
             # round 6: the default plan with the MX backward-data stages, and exact16's forward in front of fast mode's backward pass
-            "exact16_plan155_mx_backward": ("exact16", 27 + 128, None), "exact16_plan667_mx_backward_mx_wgrad": ("exact16", 27 + 128 + 512, None), "exact16_forward_f16_backward_plan256": ("exact16", 256, None)}
+            "exact16_plan155_mx_backward": ("exact16", 27 + 128, None), "exact16_plan667_mx_backward_mx_wgrad": ("exact16", 27 + 128 + 512, None), "exact16_plan1691_mx_tail": ("exact16", 27 + 128 + 512 + 1024, None), "exact16_forward_f16_backward_plan256": ("exact16", 256, None)}
     if os.environ.get("TRAJ_ONLY"):
         keep = ["exact16_plan0"] + os.environ["TRAJ_ONLY"].split(",")
         runs = {k: v for k, v in runs.items() if k in keep}
