@@ -45,8 +45,11 @@ def test_generator_forward_backward(upscale, n_blocks, n, h, w, precision, diag_
         (yo * gw.to(dt)).sum().backward()
         return yo.detach(), {k: v.grad for k, v in sdo.items()}, xo.grad
     key = (upscale, n_blocks, n, h, w)
-    if key not in _ORACLE_CACHE:      # (one pair of CPU evaluations per case: the three precisions share it -- 20 s each at 23 blocks)
-        _ORACLE_CACHE[key] = (run_oracle(torch.float32), run_oracle(torch.float64))
+    if key not in _ORACLE_CACHE:      # (one pair of CPU evaluations per case: the three precisions share it -- 20 s each at 23 blocks, side by side)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(2) as ex:
+            f32, f64 = ex.submit(run_oracle, torch.float32), ex.submit(run_oracle, torch.float64)
+            _ORACLE_CACHE[key] = (f32.result(), f64.result())
     (yo, go32, gxo32), (yo64, go64, gxo64) = _ORACLE_CACHE[key]
 
     # fast / exact16 keep activation gradients in f16 (pairs): scale the loss like the reference's GradScaler
