@@ -23,6 +23,45 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILDREN through torch.distributed.run (one rank per GPU,
+    rendezvous on 127.0.0.1 at a free port), relay their output -- rank 0's single JSON line included -- and return the launcher's exit
+    code.  Runs before this process has made any HIP call, and starts children rather than replacing itself (a process that has
+    initialised the GPU must never exec, and this one stays clean anyway)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write(f"bench.py: no launcher in the environment -- starting {n} ranks: {' '.join(cmd)}\n")
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
+
+def _gpus_from_argv(argv):
+    """--gpus N / --gpus=N without argparse (and without torch): 1 when absent or malformed (argparse reports that later)."""
+    for i, a in enumerate(argv):
+        try:
+            if a == "--gpus" and i + 1 < len(argv):
+                return int(argv[i + 1])
+            if a.startswith("--gpus="):
+                return int(a.split("=", 1)[1])
+        except ValueError:
+            return 1
+    return 1
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _gpus_from_argv(sys.argv[1:]) > 1:
+    # plain `python bench.py --gpus N`: hand over to N ranks BEFORE torch is even imported -- this process never loads HIP, and the launch
+    # costs one interpreter start-up with torch less
+    raise SystemExit(self_launch(_gpus_from_argv(sys.argv[1:])))
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -1136,26 +1175,6 @@ def gradient_probe(sd, batch, lr_edge):
         rel = sorted(((got[k] - ref[k]).norm() / ref[k].norm().clamp_min(1e-300)).item() for k in ref)
         rec[name] = {"median": float(f"{rel[len(rel) // 2]:.3e}"), "p90": float(f"{rel[int(len(rel) * 0.9)]:.3e}"), "worst": float(f"{rel[-1]:.3e}")}
     return rec
-
-
-def self_launch(n):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILDREN through torch.distributed.run (one rank per GPU,
-    rendezvous on 127.0.0.1 at a free port), relay their output -- rank 0's single JSON line included -- and return the launcher's exit
-    code.  Runs before this process has made any HIP call, and starts children rather than replacing itself (a process that has
-    initialised the GPU must never exec, and this one stays clean anyway)."""
-    import socket
-    import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.stderr.write(f"bench.py: no launcher in the environment -- starting {n} ranks: {' '.join(cmd)}\n")
-    sys.stderr.flush()
-    return subprocess.call(cmd, env=env)
 
 
 def main():
